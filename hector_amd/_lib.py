@@ -1,0 +1,80 @@
+"""ctypes loader for libhector_amd.so (the C ABI in include/hector_amd.h).
+
+The product library is the HIP build in hector_amd/lib/.  There is no CPU
+execution path: if the library is missing or reports a backend other than
+"hip" the loader raises.  (tests/ may pass an explicit path to the test-only
+host-emulation build together with allow_emulation=True.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libhector_amd.so")
+DEFAULT_SCENARIO = os.path.join(_HERE, "data", "ssp245.hxs")
+
+_cache = {}
+
+
+class HectorAmdError(RuntimeError):
+    pass
+
+
+def load(path=None, allow_emulation=False):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _cache:
+        lib = _cache[path]
+    else:
+        if not os.path.exists(path):
+            raise HectorAmdError(
+                "hector_amd: native library %s not found -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no Python/CPU fallback" % path)
+        lib = ctypes.CDLL(path)
+        _declare(lib)
+        _cache[path] = lib
+    backend = lib.hx_backend().decode()
+    if backend != "hip" and not allow_emulation:
+        raise HectorAmdError("hector_amd: library %s has backend %r; only the HIP build is a "
+                             "product path" % (path, backend))
+    return lib
+
+
+def _declare(lib):
+    c = ctypes
+    P = c.c_void_p
+    dp = c.POINTER(c.c_double)
+    lib.hx_backend.restype = c.c_char_p
+    lib.hx_last_error.restype = c.c_char_p
+    sig = {
+        "hx_newcore": [c.c_char_p, c.c_int, c.c_int, c.POINTER(P)],
+        "hx_shutdown": [P],
+        "hx_setvar": [P, c.c_char_p, dp, c.c_int, c.c_char_p],
+        "hx_getvar": [P, c.c_char_p, dp],
+        "hx_split_biome": [P, c.c_int, c.POINTER(c.c_char_p), dp, dp, dp, dp, dp],
+        "hx_set_outputs": [P, c.c_int, c.POINTER(c.c_char_p)],
+        "hx_output_capabilities": [c.POINTER(c.POINTER(c.c_char_p)), c.POINTER(c.c_int)],
+        "hx_reset": [P, c.c_double],
+        "hx_run": [P, c.c_double],
+        "hx_sync": [P],
+        "hx_fetchvars": [P, c.c_char_p, c.c_int, c.c_int, dp],
+        "hx_device_var": [P, c.c_char_p, c.POINTER(P), c.POINTER(c.c_int)],
+        "hx_stats_device": [P, c.c_char_p, c.c_int, c.c_int, P],
+        "hx_status": [P, c.POINTER(c.c_uint)],
+        "hx_spinup_steps": [P, c.c_int, c.POINTER(c.c_int)],
+        "hx_dates": [P, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
+        "hx_sizes": [P, c.POINTER(c.c_int), c.POINTER(c.c_int)],
+        "hx_last_run_ms": [P, dp],
+        "hx_last_spinup_ms": [P, dp],
+        "hx_stream": [P, c.POINTER(P)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c.c_int
+
+
+ABI_SYMBOLS = ["hx_backend", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_setvar",
+               "hx_getvar", "hx_split_biome", "hx_set_outputs", "hx_output_capabilities",
+               "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
+               "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_dates", "hx_sizes",
+               "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream"]

@@ -1,0 +1,200 @@
+"""Python face of the ensemble core, named after the reference's R API
+(R/hector.R:57-189, R/messages.R:46-140, R/biome.R:61-130): newcore(), run(),
+reset(), shutdown(), setvar(), fetchvars(), split_biome() -- with a member axis.
+Everything here is a thin ctypes veneer over the C ABI (include/hector_amd.h);
+the numerics live in the HIP kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import HectorAmdError, DEFAULT_SCENARIO
+
+# capability strings (inst/include/component_data.hpp), R-style accessors
+def ECS(): return "S"
+def DIFFUSIVITY(): return "diff"
+def Q_CO2(): return "qco2"
+def AERO_SCALE(): return "aero_scalar"
+def VOLCANIC_SCALE(): return "vol_scalar"
+def PREINDUSTRIAL_CO2(): return "C0"
+def _b(biome, v): return v if biome in ("", None, "global") else "%s.%s" % (biome, v)
+def BETA(biome=""): return _b(biome, "beta")
+def Q10_RH(biome=""): return _b(biome, "q10_rh")
+def WARMINGFACTOR(biome=""): return _b(biome, "warmingfactor")
+def NPP_FLUX0(biome=""): return _b(biome, "npp_flux0")
+def VEG_C(biome=""): return _b(biome, "veg_c")
+def CONCENTRATIONS_CO2(): return "CO2_concentration"
+def GLOBAL_TAS(): return "global_tas"
+def RF_TOTAL(): return "RF_tot"
+def RF_CO2(): return "RF_CO2"
+def SST(): return "sst"
+def LAND_TAS(): return "land_tas"
+def OCEAN_C(): return "ocean_c"
+def ATMOSPHERIC_CO2(): return "atmos_co2"
+def PH_HL(): return "HL_pH"
+def PERMAFROST_C(): return "permafrost_c"
+def HEAT_FLUX(): return "heatflux"
+
+
+class Core:
+    """An N-member ensemble core bound to one GPU."""
+
+    def __init__(self, scenario=None, n_members=1, device=0, lib_path=None,
+                 allow_emulation=False):
+        self._lib = _lib.load(lib_path, allow_emulation)
+        self._h = ctypes.c_void_p()
+        self._ck(self._lib.hx_newcore((scenario or DEFAULT_SCENARIO).encode(), int(n_members),
+                                      int(device), ctypes.byref(self._h)))
+        self.n_members = int(n_members)
+        s, e, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._ck(self._lib.hx_dates(self._h, ctypes.byref(s), ctypes.byref(e), ctypes.byref(c)))
+        self.strtdate, self.enddate = s.value, e.value
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HectorAmdError(self._lib.hx_last_error().decode())
+
+    @property
+    def backend(self):
+        return self._lib.hx_backend().decode()
+
+    @property
+    def current_date(self):
+        c = ctypes.c_int()
+        self._ck(self._lib.hx_dates(self._h, None, None, ctypes.byref(c)))
+        return c.value
+
+    def setvar(self, var, values, unit=None):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        self._ck(self._lib.hx_setvar(self._h, var.encode(),
+                                     v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), v.size,
+                                     unit.encode() if unit else None))
+        return self
+
+    def getvar(self, var):
+        out = np.empty(self.n_members)
+        self._ck(self._lib.hx_getvar(self._h, var.encode(),
+                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
+
+    def split_biome(self, names, fveg_c=None, fdetritus_c=None, fsoil_c=None,
+                    fpermafrost_c=None, fnpp_flux0=None):
+        n = len(names)
+        arr = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+
+        def f(x):
+            if x is None:
+                return None
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+            assert a.size == n
+            keep.append(a)
+            return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        keep = []
+        self._ck(self._lib.hx_split_biome(self._h, n, arr, f(fveg_c), f(fdetritus_c), f(fsoil_c),
+                                          f(fpermafrost_c), f(fnpp_flux0)))
+        return self
+
+    def set_outputs(self, variables):
+        n = len(variables)
+        arr = (ctypes.c_char_p * n)(*[s.encode() for s in variables])
+        self._ck(self._lib.hx_set_outputs(self._h, n, arr))
+        return self
+
+    def reset(self, date=0):
+        self._ck(self._lib.hx_reset(self._h, float(date)))
+        return self
+
+    def run(self, runtodate=-1, wait=True):
+        self._ck(self._lib.hx_run(self._h, float(runtodate)))
+        if wait:
+            self._ck(self._lib.hx_sync(self._h))
+        return self
+
+    def sync(self):
+        self._ck(self._lib.hx_sync(self._h))
+
+    def fetchvars(self, var, dates=None):
+        """-> ndarray [n_years, n_members] for dates = (year0, year1) inclusive."""
+        y0, y1 = (self.strtdate, self.current_date) if dates is None else \
+            (int(min(dates)), int(max(dates)))
+        out = np.empty((y1 - y0 + 1, self.n_members))
+        self._ck(self._lib.hx_fetchvars(self._h, var.encode(), y0, y1,
+                                        out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
+
+    def device_var(self, var):
+        p, npad = ctypes.c_void_p(), ctypes.c_int()
+        self._ck(self._lib.hx_device_var(self._h, var.encode(), ctypes.byref(p), ctypes.byref(npad)))
+        return p.value, npad.value
+
+    def stats_device(self, var, year0, year1, d_ptr):
+        self._ck(self._lib.hx_stats_device(self._h, var.encode(), int(year0), int(year1),
+                                           ctypes.c_void_p(d_ptr)))
+
+    def status(self):
+        out = np.zeros(self.n_members, dtype=np.uint32)
+        self._ck(self._lib.hx_status(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint))))
+        return out
+
+    def spinup_steps(self, member=0):
+        s = ctypes.c_int()
+        self._ck(self._lib.hx_spinup_steps(self._h, int(member), ctypes.byref(s)))
+        return s.value
+
+    def last_run_ms(self):
+        v = ctypes.c_double()
+        self._ck(self._lib.hx_last_run_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def last_spinup_ms(self):
+        v = ctypes.c_double()
+        self._ck(self._lib.hx_last_spinup_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def shutdown(self):
+        if self._h:
+            self._lib.hx_shutdown(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
+
+
+# R-style free functions
+def newcore(inifile=None, n_members=1, device=0, **kw):
+    return Core(inifile, n_members, device, **kw)
+
+
+def run(core, runtodate=-1):
+    return core.run(runtodate)
+
+
+def reset(core, date=0):
+    return core.reset(date)
+
+
+def shutdown(core):
+    core.shutdown()
+
+
+def setvar(core, dates, var, values, unit=None):
+    if dates is not None and not (isinstance(dates, float) and np.isnan(dates)):
+        raise HectorAmdError("setvar: dated inputs are not supported by the ensemble path")
+    return core.setvar(var, values, unit)
+
+
+def fetchvars(core, dates, variables):
+    """-> dict variable -> ndarray [n_years, n_members]"""
+    if isinstance(variables, str):
+        variables = [variables]
+    return {v: core.fetchvars(v, dates) for v in variables}
+
+
+def split_biome(core, old_biome, new_biomes, **fractions):
+    if old_biome != "global":
+        raise HectorAmdError("only the default biome can be split")
+    return core.split_biome(list(new_biomes), **fractions)

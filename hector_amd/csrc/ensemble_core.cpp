@@ -1,0 +1,579 @@
+// ensemble_core.cpp -- see ensemble_core.hpp.
+#include "ensemble_core.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+// launchers defined in hx_kernels.hip
+hipError_t hx_launch_spinup(int B, const HxBuffers &buf, const HxConst &kc, int nmem_launch,
+                            int *d_steps, hipStream_t st);
+hipError_t hx_launch_run(int B, const HxBuffers &buf, const HxConst &kc, int iy_from, int iy_to,
+                         hipStream_t st);
+hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
+hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
+hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
+                           double *stats, hipStream_t st);
+hipError_t hx_launch_doeclim_kernel(const double *diff_row, double *ker, int ns, int count,
+                                    int stride, hipStream_t st);
+
+namespace hx {
+namespace {
+
+struct ParamDef {
+  const char *name; int row; bool per_biome; const char *units; bool spinup;
+};
+// capability strings: inst/include/component_data.hpp; units: src/unitval.cpp
+const ParamDef kParams[] = {
+    {"S", HXP_S, false, "degC", false},
+    {"diff", HXP_DIFF, false, "cm2/s", false},
+    {"qco2", HXP_QCO2, false, "W/m2", false},
+    {"aero_scalar", HXP_AERO, false, "(unitless)", false},
+    {"vol_scalar", HXP_VOL, false, "(unitless)", false},
+    {"C0", HXP_C0, false, "ppmv CO2", true},
+    {"tt", HXP_TT, false, "m3/s", true},
+    {"tu", HXP_TU, false, "m3/s", true},
+    {"twi", HXP_TWI, false, "m3/s", true},
+    {"tid", HXP_TID, false, "m3/s", true},
+    {"preind_surface_c", HXP_PRE_SURF, false, "Pg C", true},
+    {"preind_interdeep_c", HXP_PRE_ID, false, "Pg C", true},
+    {"beta", HXPB_BETA, true, "(unitless)", false},
+    {"q10_rh", HXPB_Q10, true, "(unitless)", false},
+    {"warmingfactor", HXPB_WF, true, "(unitless)", false},
+    {"npp_flux0", HXPB_NPP0, true, "Pg C/yr", true},
+    {"veg_c", HXPB_VEG0, true, "Pg C", true},
+    {"detritus_c", HXPB_DET0, true, "Pg C", true},
+    {"soil_c", HXPB_SOIL0, true, "Pg C", true},
+    {"permafrost_c", HXPB_PF0, true, "Pg C", true},
+    {"f_nppv", HXPB_F_NPPV, true, "(unitless)", true},
+    {"f_nppd", HXPB_F_NPPD, true, "(unitless)", true},
+    {"f_litterd", HXPB_F_LITTERD, true, "(unitless)", true},
+    {"rh_ch4_frac", HXPB_RH_CH4_FRAC, true, "(unitless)", false},
+    {"pf_mu", HXPB_PF_MU, true, "degC", false},
+    {"pf_sigma", HXPB_PF_SIGMA, true, "degC", false},
+    {"fpf_static", HXPB_FPF_STATIC, true, "(unitless)", false},
+};
+
+struct OutDef { const char *name; int idx; };
+const OutDef kOutputs[] = {
+    {"sst", HXO_SST}, {"land_tas", HXO_TLAND}, {"CO2_concentration", HXO_CO2},
+    {"global_tas", HXO_TGAV}, {"RF_tot", HXO_RF_TOT}, {"RF_CO2", HXO_RF_CO2},
+    {"ocean_c", HXO_OCEAN_C}, {"HL_pH", HXO_HL_PH}, {"atmos_co2", HXO_ATMOS_C},
+    {"permafrost_c", HXO_PERMAFROST_C}, {"heatflux", HXO_HEATFLUX},
+    {"CH4_concentration", HXO_CH4}, {"O3_concentration", HXO_O3}, {"veg_c", HXO_VEG_C},
+    {"detritus_c", HXO_DET_C}, {"soil_c", HXO_SOIL_C}, {"thawedp_c", HXO_THAWED_C},
+    {"earth_c", HXO_EARTH_C}, {"NBP", HXO_NBP}, {"ocean_uptake", HXO_OCEAN_UPTAKE},
+    {"timesteps", HXO_NSTASH}, {"solver_steps", HXO_NSTEPS}, {"LL_pH", HXO_LL_PH},
+};
+const char *kOutputNames[HXO_NVAR];
+
+}  // namespace
+
+const char *const *EnsembleCore::output_capabilities(int *count) {
+  for (auto &o : kOutputs) kOutputNames[o.idx] = o.name;
+  if (count) *count = HXO_NVAR;
+  return kOutputNames;
+}
+
+void EnsembleCore::check(hipError_t e, const char *what) const {
+  if (e != hipSuccess)
+    throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int device)
+    : scen_(Scenario::load(scenario_path)), n_(n_members), B_(1), device_(device) {
+  if (n_members <= 0) throw std::runtime_error("n_members must be > 0");
+  npad_ = (n_ + HX_WAVE - 1) / HX_WAVE * HX_WAVE;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    throw std::runtime_error(
+        "hector_amd: no HIP device available -- the ensemble integrator has no CPU path");
+  if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
+  check(hipSetDevice(device_), "hipSetDevice");
+  check(hipStreamCreate(&stream_), "hipStreamCreate");
+  check(hipEventCreate(&ev0_), "hipEventCreate");
+  check(hipEventCreate(&ev1_), "hipEventCreate");
+  for (int v = 0; v < HXO_NVAR; ++v) { d_out_[v] = nullptr; out_enabled_[v] = false; }
+  out_enabled_[HXO_SST] = out_enabled_[HXO_TLAND] = true;
+  out_enabled_[HXO_CO2] = out_enabled_[HXO_TGAV] = true;
+  biome_names_ = {"global"};  // SNBOX_DEFAULT_BIOME
+  // parameter rows from the scenario (INI) values
+  params_.assign(HX_NPARAM(1), std::vector<double>((size_t)npad_, 0.0));
+  row_uniform_.assign(HX_NPARAM(1), true);
+  auto setrow = [&](int row, double v) { std::fill(params_[row].begin(), params_[row].end(), v); };
+  const Scenario &s = scen_;
+  setrow(HXP_S, s.scalar("temperature", "S"));
+  setrow(HXP_DIFF, s.scalar("temperature", "diff"));
+  setrow(HXP_QCO2, s.scalar("temperature", "qco2"));
+  setrow(HXP_AERO, s.scalar("forcing", "aero_scalar", 1.0));
+  setrow(HXP_VOL, s.scalar("forcing", "vol_scalar", 1.0));
+  setrow(HXP_C0, s.scalar("simpleNbox", "C0"));
+  setrow(HXP_TT, s.scalar("ocean", "tt"));
+  setrow(HXP_TU, s.scalar("ocean", "tu"));
+  setrow(HXP_TWI, s.scalar("ocean", "twi"));
+  setrow(HXP_TID, s.scalar("ocean", "tid"));
+  setrow(HXP_PRE_SURF, s.scalar("ocean", "preind_surface_c", 900));
+  setrow(HXP_PRE_ID, s.scalar("ocean", "preind_interdeep_c", 37100));
+  const int r = HXP_NGLOBAL;
+  setrow(r + HXPB_BETA, s.scalar("simpleNbox", "beta"));
+  setrow(r + HXPB_Q10, s.scalar("simpleNbox", "q10_rh"));
+  setrow(r + HXPB_WF, s.scalar("simpleNbox", "warmingfactor", 1.0));
+  setrow(r + HXPB_NPP0, s.scalar("simpleNbox", "npp_flux0"));
+  setrow(r + HXPB_VEG0, s.scalar("simpleNbox", "veg_c"));
+  setrow(r + HXPB_DET0, s.scalar("simpleNbox", "detritus_c"));
+  setrow(r + HXPB_SOIL0, s.scalar("simpleNbox", "soil_c"));
+  setrow(r + HXPB_PF0, s.scalar("simpleNbox", "permafrost_c", 0.0));
+  setrow(r + HXPB_F_NPPV, s.scalar("simpleNbox", "f_nppv"));
+  setrow(r + HXPB_F_NPPD, s.scalar("simpleNbox", "f_nppd"));
+  setrow(r + HXPB_F_LITTERD, s.scalar("simpleNbox", "f_litterd"));
+  setrow(r + HXPB_RH_CH4_FRAC, s.scalar("simpleNbox", "rh_ch4_frac", 0.023));
+  setrow(r + HXPB_PF_MU, s.scalar("simpleNbox", "pf_mu", 1.67));
+  setrow(r + HXPB_PF_SIGMA, s.scalar("simpleNbox", "pf_sigma", 0.986));
+  setrow(r + HXPB_FPF_STATIC, s.scalar("simpleNbox", "fpf_static", 0.74));
+  if (s.scalar("ocean", "spinup_chem", 0) != 0)
+    throw std::runtime_error("ocean.spinup_chem=1 is not supported by the GPU path");
+  if (s.scalar("core", "do_spinup", 1) == 0)
+    throw std::runtime_error("core.do_spinup=0 is not supported by the GPU path");
+  build_shared();
+}
+
+EnsembleCore::~EnsembleCore() {
+  free_device();
+  if (ev0_) (void)hipEventDestroy(ev0_);
+  if (ev1_) (void)hipEventDestroy(ev1_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// Member-independent per-year series: N2O, 26 halocarbons, aerosols, albedo,
+// volcanic, misc; OH/O3 emission terms; the carbon cycle's current-year fluxes.
+void EnsembleCore::build_shared() {
+  const Scenario &s = scen_;
+  const int ns = s.ns();
+  shared_.assign((size_t)ns * HXSH_STRIDE, 0.0);
+  auto ser = [&](const char *sec, const char *key) -> const std::vector<double> & {
+    return s.series(sec, key);
+  };
+  auto ser0 = [&](const char *sec, const char *key) {
+    return s.has_series(sec, key) ? s.series(sec, key) : std::vector<double>((size_t)ns, 0.0);
+  };
+  const auto &ffi = ser("simpleNbox", "ffi_emissions");
+  const auto daccs = ser0("simpleNbox", "daccs_uptake");
+  const auto &luce = ser("simpleNbox", "luc_emissions");
+  const auto lucu = ser0("simpleNbox", "luc_uptake");
+  // If no albedo data, assume constant -0.2 (simpleNbox-runtime.cpp:162-167)
+  const auto albedo = s.has_series("simpleNbox", "RF_albedo")
+                          ? s.series("simpleNbox", "RF_albedo")
+                          : std::vector<double>((size_t)ns, -0.2);
+  const auto &so2 = ser("so2", "SO2_emissions");
+  const auto sv = ser0("so2", "SV");
+  const auto &ch4n = ser("CH4", "CH4N");
+  const auto &ch4em = ser("CH4", "CH4_emissions");
+  const auto &nox_oh = ser("OH", "NOX_emissions");
+  const auto &co_oh = ser("OH", "CO_emissions");
+  const auto &nmvoc_oh = ser("OH", "NMVOC_emissions");
+  const auto &nox_o3 = ser("ozone", "NOX_emissions");
+  const auto &co_o3 = ser("ozone", "CO_emissions");
+  const auto &nmvoc_o3 = ser("ozone", "NMVOC_emissions");
+  const auto &n2o_nat = ser("N2O", "N2O_natural_emissions");
+  const auto &n2o_em = ser("N2O", "N2O_emissions");
+  const auto misc = ser0("forcing", "RF_misc");
+  const auto &bc = ser("bc", "BC_emissions");
+  const auto &oc = ser("oc", "OC_emissions");
+  const auto &nh3 = ser("nh3", "NH3_emissions");
+  const double CNOX = s.scalar("OH", "CNOX"), CCO = s.scalar("OH", "CCO"),
+               CNMVOC = s.scalar("OH", "CNMVOC");
+  const double N0 = s.scalar("N2O", "N0"), UC_N2O = s.scalar("N2O", "UC_N2O"),
+               TN2O0 = s.scalar("N2O", "TN2O0");
+  const double rho_bc = s.scalar("forcing", "rho_bc"), rho_oc = s.scalar("forcing", "rho_oc"),
+               rho_so2 = s.scalar("forcing", "rho_so2"), rho_nh3 = s.scalar("forcing", "rho_nh3");
+  // forcing_component.hpp:120-131
+  const double aci_beta = 2.279759, s_BCOC = 111.05064063;
+  const double s_SO2 = (260.34644166 * 1000) * (32.065 / 64.066);
+  std::vector<double> hconc(s.halocarbons.size());
+  for (size_t h = 0; h < hconc.size(); ++h) hconc[h] = s.halocarbons[h].H0;
+  // halocarbon forcings enter the total in std::map key order ("RF_<gas>")
+  std::vector<size_t> horder(hconc.size());
+  for (size_t h = 0; h < horder.size(); ++h) horder[h] = h;
+  std::sort(horder.begin(), horder.end(), [&](size_t a, size_t b) {
+    return s.halocarbons[a].name < s.halocarbons[b].name;
+  });
+  double n2o = N0;
+  for (int iy = 0; iy < ns; ++iy) {
+    double *row = &shared_[(size_t)iy * HXSH_STRIDE];
+    if (iy >= 1) {  // slowparameval(t = year-1): emissions of date t (runtime.cpp:951-955)
+      row[HXSH_FFI] = ffi[iy - 1]; row[HXSH_DACCS] = daccs[iy - 1];
+      row[HXSH_LUC_E] = luce[iy - 1]; row[HXSH_LUC_U] = lucu[iy - 1];
+    }
+    // oh_component.cpp:157-170
+    row[HXSH_OH_B] = CNOX * ((1.0 * nox_oh[iy]) - nox_oh[0]);
+    row[HXSH_OH_C] = CCO * ((1.0 * co_oh[iy]) - co_oh[0]);
+    row[HXSH_OH_D] = CNMVOC * ((1.0 * nmvoc_oh[iy]) - nmvoc_oh[0]);
+    row[HXSH_CH4_EM] = ch4em[iy];
+    row[HXSH_CH4N] = ch4n[iy];
+    // o3_component.cpp:136-139
+    row[HXSH_O3_NOX] = 0.125 * nox_o3[iy];
+    row[HXSH_O3_CO] = 0.0011 * co_o3[iy];
+    row[HXSH_O3_NMVOC] = 0.0033 * nmvoc_o3[iy];
+    double rf_h = 0.0;
+    if (iy >= 1) {
+      // n2o_component.cpp:152-191
+      const double tau = TN2O0 * std::pow(n2o / N0, -0.05);
+      const double em = n2o_em[iy] + n2o_nat[iy];
+      n2o = n2o + (em / UC_N2O - n2o / tau);
+      // halocarbon_component.cpp:181-229
+      for (size_t h = 0; h < hconc.size(); ++h) {
+        const Halocarbon &H = s.halocarbons[h];
+        const double alpha = 1 / H.tau;
+        const double emissMol = H.emissions[iy] / H.molarMass * 1.0;
+        const double dconc = emissMol / (0.1 * 1.8);
+        const double expfac = std::exp(-alpha);
+        hconc[h] = hconc[h] * expfac + dconc * H.tau * (1.0 - expfac);
+      }
+      for (size_t k = 0; k < horder.size(); ++k) {
+        const Halocarbon &H = s.halocarbons[horder[k]];
+        const double rf_un = H.rho * hconc[horder[k]];
+        rf_h = rf_h + (rf_un + H.delta * rf_un);
+      }
+    }
+    row[HXSH_N2O] = n2o;
+    row[HXSH_SQRT_N2O] = std::sqrt(n2o);
+    row[HXSH_RF_OTHER] = (rf_h + albedo[iy]) + misc[iy];
+    // forcing_component.cpp:430-470 for aero_scalar = 1
+    row[HXSH_RF_AERO] = (((rho_bc * bc[iy] + rho_oc * oc[iy]) + rho_so2 * so2[iy]) +
+                         rho_nh3 * nh3[iy]) +
+                        (-1 * aci_beta *
+                         std::log(1 + (so2[iy] / s_SO2) + ((bc[iy] + oc[iy]) / s_BCOC)));
+    row[HXSH_RF_VOL] = sv[iy];
+  }
+  HxConst &k = kc_;
+  k.start_year = s.start; k.ns = ns;
+  k.baseyear_idx = (int)s.scalar("forcing", "baseyear", 1750) - s.start;
+  k.max_spinup = (int)s.scalar("core", "max_spinup", 2000);
+  k.spinup_chem = 0;
+  k.eps_abs = s.scalar("carbon-cycle-solver", "eps_abs", 1e-6);
+  k.eps_rel = s.scalar("carbon-cycle-solver", "eps_rel", 1e-6);
+  k.dt0 = s.scalar("carbon-cycle-solver", "dt", 0.3);
+  k.eps_spinup = s.scalar("carbon-cycle-solver", "eps_spinup");
+  k.M0 = s.scalar("CH4", "M0"); k.lnM0 = std::log(k.M0); k.sqrtM0 = std::sqrt(k.M0);
+  k.Tsoil = s.scalar("CH4", "Tsoil"); k.Tstrat = s.scalar("CH4", "Tstrat");
+  k.UC_CH4 = s.scalar("CH4", "UC_CH4");
+  k.TOH0 = s.scalar("OH", "TOH0"); k.CCH4 = s.scalar("OH", "CCH4");
+  k.N0 = N0; k.sqrtN0 = std::sqrt(N0);
+  k.delta_co2 = s.scalar("forcing", "delta_co2"); k.delta_ch4 = s.scalar("forcing", "delta_ch4");
+  k.delta_n2o = s.scalar("forcing", "delta_n2o");
+}
+
+void EnsembleCore::free_device() {
+  auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
+  d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
+  for (int v = 0; v < HXO_NVAR; ++v) { fr(d_out_[v]); d_out_[v] = nullptr; }
+}
+
+void EnsembleCore::alloc_device() {
+  check(hipSetDevice(device_), "hipSetDevice");
+  free_device();
+  const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
+  check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
+  check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
+  check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
+  check(hipMalloc(&d_ker_, sizeof(double) * ns * np), "hipMalloc ker");
+  check(hipMalloc(&d_status_, sizeof(unsigned) * np * 2), "hipMalloc status");
+  check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
+  for (int v = 0; v < HXO_NVAR; ++v)
+    if (out_enabled_[v]) {
+      check(hipMalloc(&d_out_[v], sizeof(double) * ns * np), "hipMalloc out");
+      check(hipMemsetAsync(d_out_[v], 0, sizeof(double) * ns * np, stream_), "memset out");
+    }
+  check(hipMemcpyAsync(d_shared_, shared_.data(), sizeof(double) * shared_.size(),
+                       hipMemcpyHostToDevice, stream_), "upload shared");
+  layout_dirty_ = false;
+  params_dirty_ = true;
+  need_spinup_ = true;
+}
+
+HxBuffers EnsembleCore::buffers() const {
+  HxBuffers b;
+  b.params = d_params_; b.state = d_state_; b.status = d_status_; b.shared = d_shared_;
+  b.ker = d_ker_;
+  for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
+  b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
+  return b;
+}
+
+int EnsembleCore::resolve_param(const std::string &capability, const ParamRef **) const {
+  std::string biome, var = capability;
+  size_t dot = capability.find('.');
+  if (dot != std::string::npos) { biome = capability.substr(0, dot); var = capability.substr(dot + 1); }
+  for (const ParamDef &d : kParams) {
+    if (var != d.name) continue;
+    if (!d.per_biome) {
+      if (!biome.empty()) throw std::runtime_error("variable " + var + " takes no biome prefix");
+      return d.row;
+    }
+    int b = -1;
+    if (biome.empty()) biome = "global";
+    for (int i = 0; i < B_; ++i) if (biome_names_[i] == biome) b = i;
+    if (b < 0)
+      throw std::runtime_error("Biome '" + biome + "' missing from biome list. Hit this error "
+                               "while trying to retrieve variable: '" + capability + "'.");
+    return HXP_NGLOBAL + b * HXPB_N + d.row;
+  }
+  throw std::runtime_error("Unknown variable name while parsing: " + capability);
+}
+
+static const ParamDef &def_of(const std::string &capability) {
+  std::string var = capability;
+  size_t dot = capability.find('.');
+  if (dot != std::string::npos) var = capability.substr(dot + 1);
+  for (const ParamDef &d : kParams) if (var == d.name) return d;
+  throw std::runtime_error("Unknown variable name while parsing: " + capability);
+}
+
+void EnsembleCore::setvar(const std::string &capability, const double *values, int nvalues,
+                          const char *units) {
+  const int row = resolve_param(capability, nullptr);
+  const ParamDef &d = def_of(capability);
+  if (units && units[0] && std::string(units) != d.units)
+    throw std::runtime_error("Units: " + std::string(units) + " do not match expected: " +
+                             d.units + " for " + capability);
+  if (nvalues != 1 && nvalues != n_)
+    throw std::runtime_error("setvar: need 1 or n_members values");
+  std::vector<double> &r = params_[row];
+  bool uniform = true;
+  for (int i = 0; i < npad_; ++i) {
+    const int src = (nvalues == 1) ? 0 : std::min(i, n_ - 1);  // pad with the last member
+    r[(size_t)i] = values[src];
+    if (values[src] != values[0]) uniform = false;
+  }
+  row_uniform_[row] = uniform;
+  params_dirty_ = true;
+  // R/messages.R:107-140: a parameter change invalidates the run from date 0
+  last_iy_ = 0;
+  need_spinup_ = true;
+  (void)d;
+}
+
+void EnsembleCore::getvar(const std::string &capability, double *out) const {
+  const int row = resolve_param(capability, nullptr);
+  std::memcpy(out, params_[row].data(), sizeof(double) * (size_t)n_);
+}
+
+void EnsembleCore::split_biome(const std::vector<std::string> &names, const double *fveg,
+                               const double *fdet, const double *fsoil, const double *fpf,
+                               const double *fnpp) {
+  const int nb = (int)names.size();
+  if (B_ != 1) throw std::runtime_error("split_biome: only a single existing biome can be split");
+  if (nb < 1 || nb > HX_MAXB)
+    throw std::runtime_error("split_biome: 1.." + std::to_string(HX_MAXB) + " biomes supported");
+  std::vector<double> eq((size_t)nb, 1.0 / nb);
+  if (!fveg) fveg = eq.data();
+  if (!fdet) fdet = fveg;
+  if (!fsoil) fsoil = fveg;
+  if (!fpf) fpf = fveg;
+  if (!fnpp) fnpp = fveg;
+  std::vector<std::vector<double>> np(HX_NPARAM(nb), std::vector<double>((size_t)npad_, 0.0));
+  std::vector<bool> nu(HX_NPARAM(nb), true);
+  for (int r = 0; r < HXP_NGLOBAL; ++r) { np[r] = params_[r]; nu[r] = row_uniform_[r]; }
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < HXPB_N; ++k) {
+      const int dst = HXP_NGLOBAL + b * HXPB_N + k, src = HXP_NGLOBAL + k;
+      double f = 1.0;
+      bool scaled = true;
+      switch (k) {
+        case HXPB_VEG0: f = fveg[b]; break;
+        case HXPB_DET0: f = fdet[b]; break;
+        case HXPB_SOIL0: f = fsoil[b]; break;
+        case HXPB_PF0: f = fpf[b]; break;
+        case HXPB_NPP0: f = fnpp[b]; break;
+        default: scaled = false;
+      }
+      for (int i = 0; i < npad_; ++i)
+        np[dst][(size_t)i] = scaled ? params_[src][(size_t)i] * f : params_[src][(size_t)i];
+      nu[dst] = row_uniform_[src];
+    }
+  params_.swap(np);
+  row_uniform_.swap(nu);
+  B_ = nb;
+  biome_names_ = names;
+  layout_dirty_ = true;
+  params_dirty_ = true;
+  need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+int EnsembleCore::out_index(const std::string &capability) const {
+  for (auto &o : kOutputs) if (capability == o.name) return o.idx;
+  throw std::runtime_error("Caller is requesting unknown variable: " + capability);
+}
+
+void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
+  bool want[HXO_NVAR];
+  for (int v = 0; v < HXO_NVAR; ++v) want[v] = false;
+  want[HXO_SST] = want[HXO_TLAND] = true;
+  for (auto &c : caps) want[out_index(c)] = true;
+  bool changed = false;
+  for (int v = 0; v < HXO_NVAR; ++v) if (want[v] != out_enabled_[v]) changed = true;
+  if (!changed) return;
+  for (int v = 0; v < HXO_NVAR; ++v) out_enabled_[v] = want[v];
+  layout_dirty_ = true;
+  need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+void EnsembleCore::upload_params() {
+  const size_t np = (size_t)npad_;
+  std::vector<double> flat(np * HX_NPARAM(B_));
+  for (int r = 0; r < HX_NPARAM(B_); ++r)
+    std::memcpy(&flat[(size_t)r * np], params_[r].data(), sizeof(double) * np);
+  check(hipMemcpyAsync(d_params_, flat.data(), sizeof(double) * flat.size(),
+                       hipMemcpyHostToDevice, stream_), "upload params");
+  check(hipStreamSynchronize(stream_), "sync params");
+  // DOECLIM convolution kernel: one shared table when every member has the same
+  // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]
+  ker_per_member_ = !row_uniform_[HXP_DIFF];
+  check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
+                                 ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,
+                                 stream_), "doeclim kernel table");
+  params_dirty_ = false;
+}
+
+void EnsembleCore::prepare() {
+  check(hipSetDevice(device_), "hipSetDevice");
+  if (layout_dirty_) alloc_device();
+  if (params_dirty_) upload_params();
+  if (!need_spinup_) return;
+  // Spinup is independent of every parameter that is not in the spinup set
+  // (SURVEY 3f): if those rows are uniform, spin up one prototype wavefront and
+  // broadcast its state.
+  bool uniform = true;
+  for (const ParamDef &d : kParams) {
+    if (!d.spinup) continue;
+    if (d.per_biome) {
+      for (int b = 0; b < B_; ++b)
+        if (!row_uniform_[HXP_NGLOBAL + b * HXPB_N + d.row]) uniform = false;
+    } else if (!row_uniform_[d.row]) uniform = false;
+  }
+  const HxBuffers b = buffers();
+  check(hipEventRecord(ev0_, stream_), "event");
+  check(hx_launch_spinup(B_, b, kc_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
+  if (uniform) {
+    check(hx_launch_broadcast(d_state_, HX_NSTATE(B_), npad_, stream_), "broadcast state");
+    check(hx_launch_broadcast_u32(d_status_, npad_, stream_), "broadcast status");
+    check(hx_launch_broadcast_u32(reinterpret_cast<unsigned *>(d_spin_steps_), npad_, stream_),
+          "broadcast steps");
+    for (int v = 0; v < HXO_NVAR; ++v)
+      if (d_out_[v]) check(hx_launch_broadcast(d_out_[v], 1, npad_, stream_), "broadcast out");
+  }
+  // snapshot of the post-spinup state for reset(startDate)
+  const size_t np = (size_t)npad_;
+  check(hipMemcpyAsync(d_state_ + np * HX_NSTATE(B_), d_state_, sizeof(double) * np * HX_NSTATE(B_),
+                       hipMemcpyDeviceToDevice, stream_), "snapshot state");
+  check(hipMemcpyAsync(d_status_ + np, d_status_, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
+                       stream_), "snapshot status");
+  check(hipEventRecord(ev1_, stream_), "event");
+  check(hipEventSynchronize(ev1_), "spinup sync");
+  float ms = 0;
+  check(hipEventElapsedTime(&ms, ev0_, ev1_), "elapsed");
+  spin_ms_ = ms;
+  need_spinup_ = false;
+  last_iy_ = 0;
+}
+
+void EnsembleCore::reset(double date) {
+  if (date < scen_.start) {  // core.cpp:511-549: rerun spinup
+    need_spinup_ = true;
+    last_iy_ = 0;
+    return;
+  }
+  const int iy = (int)date - scen_.start;
+  if (iy == last_iy_ && !need_spinup_) return;
+  if (iy != 0)
+    throw std::runtime_error("reset: only reset(0), reset(startDate) and reset(current date) are "
+                             "supported (no per-year state history is kept)");
+  if (need_spinup_ || layout_dirty_ || params_dirty_) { prepare(); return; }
+  const size_t np = (size_t)npad_;
+  check(hipMemcpyAsync(d_state_, d_state_ + np * HX_NSTATE(B_), sizeof(double) * np * HX_NSTATE(B_),
+                       hipMemcpyDeviceToDevice, stream_), "restore state");
+  check(hipMemcpyAsync(d_status_, d_status_ + np, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
+                       stream_), "restore status");
+  last_iy_ = 0;
+}
+
+void EnsembleCore::run(double runtodate) {
+  prepare();
+  if (runtodate < 0.0) runtodate = scen_.end;
+  if (runtodate > scen_.end)
+    throw std::runtime_error("Requested run-to date is after the configured end date.");
+  const int target = (int)runtodate - scen_.start;
+  if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
+  const HxBuffers b = buffers();
+  check(hipEventRecord(ev0_, stream_), "event");
+  check(hx_launch_run(B_, b, kc_, last_iy_, target, stream_), "run kernel");
+  check(hipEventRecord(ev1_, stream_), "event");
+  run_timed_ = true;
+  last_iy_ = target;
+}
+
+void EnsembleCore::sync() {
+  check(hipStreamSynchronize(stream_), "stream sync");
+  if (run_timed_) {
+    float ms = 0;
+    check(hipEventElapsedTime(&ms, ev0_, ev1_), "elapsed");
+    run_ms_ = ms;
+    run_timed_ = false;
+  }
+}
+
+void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
+                             double *out_host) {
+  const int v = out_index(capability);
+  if (!d_out_[v])
+    throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");
+  if (year0 < scen_.start || year1 > last_date() || year1 < year0)
+    throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
+  sync();
+  const int iy0 = year0 - scen_.start, ny = year1 - year0 + 1;
+  check(hipMemcpy2D(out_host, sizeof(double) * (size_t)n_, d_out_[v] + (size_t)iy0 * npad_,
+                    sizeof(double) * (size_t)npad_, sizeof(double) * (size_t)n_, (size_t)ny,
+                    hipMemcpyDeviceToHost), "fetch");
+}
+
+const double *EnsembleCore::device_var(const std::string &capability, int *npad) const {
+  const int v = out_index(capability);
+  if (!d_out_[v])
+    throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");
+  if (npad) *npad = npad_;
+  return d_out_[v];
+}
+
+void EnsembleCore::stats_device(const std::string &capability, int year0, int year1,
+                                double *d_stats) {
+  const int v = out_index(capability);
+  if (!d_out_[v])
+    throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");
+  if (year0 < scen_.start || year1 > last_date() || year1 < year0)
+    throw std::runtime_error("stats: dates must lie between startDate and the current date");
+  check(hx_launch_stats(d_out_[v], n_, npad_, year0 - scen_.start, year1 - year0 + 1, d_stats,
+                        stream_), "stats kernel");
+  check(hipStreamSynchronize(stream_), "stats sync");
+}
+
+void EnsembleCore::status(unsigned *out_host) {
+  prepare();
+  sync();
+  check(hipMemcpy(out_host, d_status_, sizeof(unsigned) * (size_t)n_, hipMemcpyDeviceToHost),
+        "status");
+}
+
+int EnsembleCore::spinup_steps(int member) {
+  prepare();
+  sync();
+  int v = 0;
+  check(hipMemcpy(&v, d_spin_steps_ + member, sizeof(int), hipMemcpyDeviceToHost), "steps");
+  return v;
+}
+
+}  // namespace hx

@@ -1,0 +1,107 @@
+// ensemble_core.hpp -- host runtime for an N-member Hector ensemble on one GPU.
+//
+// Mirrors the reference's Core for the year-loop path (inst/include/core.hpp:37-114,
+// src/core.cpp:302-549): init from an INI/scenario, setData through capability
+// strings (incl. "<biome>.<var>"), prepareToRun (incl. spinup), run(runToDate)
+// callable repeatedly with increasing dates, reset(date), getData -- except that
+// every parameter and every result carries a member axis.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "hx_layout.h"
+#include "hx_scenario.hpp"
+
+namespace hx {
+
+class EnsembleCore {
+ public:
+  EnsembleCore(const std::string &scenario_path, int n_members, int device);
+  ~EnsembleCore();
+  EnsembleCore(const EnsembleCore &) = delete;
+  EnsembleCore &operator=(const EnsembleCore &) = delete;
+
+  int n_members() const { return n_; }
+  int n_biomes() const { return B_; }
+  int start_date() const { return scen_.start; }
+  int end_date() const { return scen_.end; }
+  int last_date() const { return scen_.start + last_iy_; }
+  const std::vector<std::string> &biomes() const { return biome_names_; }
+
+  // SETDATA for a model parameter: nvalues == 1 (all members) or n_members.
+  // capability = reference capability string (component_data.hpp), optionally
+  // "<biome>.<capability>".  units: "" / nullptr skips the check, otherwise it
+  // must equal the reference's unit string for that variable (unitval.cpp).
+  // Marks the core dirty from date 0 (spinup reruns if a spinup-relevant
+  // parameter changed), like R/messages.R:107-140.
+  void setvar(const std::string &capability, const double *values, int nvalues,
+              const char *units);
+  // current value of a parameter for every member (GETDATA without date)
+  void getvar(const std::string &capability, double *out) const;
+
+  // split_biome (R/biome.R:61-130): replace the single biome by n new ones,
+  // pools and npp_flux0 partitioned by the given fractions (nullptr = equal),
+  // other parameters copied; forces a re-spinup.
+  void split_biome(const std::vector<std::string> &names, const double *fveg,
+                   const double *fdet, const double *fsoil, const double *fpf,
+                   const double *fnpp);
+
+  // which output variables are recorded per year (capability strings);
+  // sst and land_tas are always recorded (the model needs their history).
+  void set_outputs(const std::vector<std::string> &capabilities);
+  static const char *const *output_capabilities(int *count);
+
+  void reset(double date);      // Core::reset: date < startDate => redo spinup
+  void run(double runtodate);   // Core::run; < 0 => endDate.  Asynchronous.
+  void sync();                  // wait for the stream
+  // GETDATA with dates: out[(year - year0) * n + member]
+  void fetchvars(const std::string &capability, int year0, int year1, double *out_host);
+  // device pointer to the [ns][npad] array of an output variable
+  const double *device_var(const std::string &capability, int *npad) const;
+  // per-year ensemble statistics {count,sum,sumsq,min,max} into a DEVICE buffer
+  // of (year1-year0+1)*5 doubles (caller-owned, e.g. a torch tensor for RCCL)
+  void stats_device(const std::string &capability, int year0, int year1, double *d_stats);
+  void status(unsigned *out_host);
+  int spinup_steps(int member);
+
+  double last_run_kernel_ms() const { return run_ms_; }
+  double last_spinup_ms() const { return spin_ms_; }
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  struct ParamRef { int row; bool per_biome; const char *units; bool affects_spinup; };
+  int resolve_param(const std::string &capability, const ParamRef **ref) const;
+  int out_index(const std::string &capability) const;
+  void build_shared();
+  void alloc_device();
+  void free_device();
+  void upload_params();
+  void prepare();  // upload + spinup when dirty
+  HxBuffers buffers() const;
+  void check(hipError_t e, const char *what) const;
+
+  Scenario scen_;
+  int n_, npad_, B_, device_;
+  std::vector<std::string> biome_names_;
+  std::vector<std::vector<double>> params_;  // [row][npad]
+  std::vector<bool> row_uniform_;
+  bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
+  int last_iy_ = 0;
+  HxConst kc_{};
+  std::vector<double> shared_, ker_;
+  bool out_enabled_[HXO_NVAR];
+  // device
+  double *d_params_ = nullptr, *d_state_ = nullptr, *d_shared_ = nullptr, *d_ker_ = nullptr;
+  double *d_out_[HXO_NVAR];
+  unsigned *d_status_ = nullptr;
+  int *d_spin_steps_ = nullptr;
+  hipStream_t stream_ = nullptr;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  bool run_timed_ = false;
+  mutable double run_ms_ = 0, spin_ms_ = 0;
+};
+
+}  // namespace hx

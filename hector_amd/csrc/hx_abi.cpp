@@ -1,0 +1,118 @@
+// hx_abi.cpp -- the extern "C" boundary declared in include/hector_amd.h.
+// Thin: argument checks, exception -> return code + hx_last_error().
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hector_amd.h"
+#include "ensemble_core.hpp"
+
+#ifndef HX_BACKEND_NAME
+#define HX_BACKEND_NAME "hip"
+#endif
+
+struct hx_core {
+  hx::EnsembleCore *core;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::exception &e) { g_err = e.what(); return 1; }
+int fail(const char *msg) { g_err = msg; return 1; }
+}  // namespace
+
+#define HX_TRY(body)                                                           \
+  if (!core || !core->core) return fail("null hx_core handle");                \
+  try { body; return 0; } catch (const std::exception &e) { return fail(e); }  \
+  catch (...) { return fail("unknown error"); }
+
+extern "C" {
+
+const char *hx_backend(void) { return HX_BACKEND_NAME; }
+const char *hx_last_error(void) { return g_err.c_str(); }
+
+int hx_newcore(const char *scenario, int n_members, int device, hx_core **out) {
+  if (!scenario || !out) return fail("hx_newcore: null argument");
+  try {
+    hx::EnsembleCore *c = new hx::EnsembleCore(scenario, n_members, device);
+    *out = new hx_core{c};
+    return 0;
+  } catch (const std::exception &e) { return fail(e); }
+  catch (...) { return fail("unknown error"); }
+}
+
+int hx_shutdown(hx_core *core) {
+  if (!core) return fail("null hx_core handle");
+  delete core->core;
+  core->core = nullptr;
+  delete core;
+  return 0;
+}
+
+int hx_setvar(hx_core *core, const char *capability, const double *values, int nvalues,
+              const char *units) {
+  if (!capability || !values) return fail("hx_setvar: null argument");
+  HX_TRY(core->core->setvar(capability, values, nvalues, units))
+}
+int hx_getvar(hx_core *core, const char *capability, double *out) {
+  if (!capability || !out) return fail("hx_getvar: null argument");
+  HX_TRY(core->core->getvar(capability, out))
+}
+int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const double *fveg,
+                   const double *fdet, const double *fsoil, const double *fpf,
+                   const double *fnpp) {
+  if (!names || n_biomes < 1) return fail("hx_split_biome: bad arguments");
+  std::vector<std::string> nm;
+  for (int i = 0; i < n_biomes; ++i) nm.push_back(names[i] ? names[i] : "");
+  HX_TRY(core->core->split_biome(nm, fveg, fdet, fsoil, fpf, fnpp))
+}
+int hx_set_outputs(hx_core *core, int nvars, const char *const *capabilities) {
+  std::vector<std::string> caps;
+  for (int i = 0; i < nvars; ++i) caps.push_back(capabilities[i]);
+  HX_TRY(core->core->set_outputs(caps))
+}
+int hx_output_capabilities(const char *const **names, int *count) {
+  if (!names) return fail("null argument");
+  *names = hx::EnsembleCore::output_capabilities(count);
+  return 0;
+}
+int hx_reset(hx_core *core, double date) { HX_TRY(core->core->reset(date)) }
+int hx_run(hx_core *core, double runtodate) { HX_TRY(core->core->run(runtodate)) }
+int hx_sync(hx_core *core) { HX_TRY(core->core->sync()) }
+int hx_fetchvars(hx_core *core, const char *capability, int year0, int year1, double *out) {
+  if (!capability || !out) return fail("hx_fetchvars: null argument");
+  HX_TRY(core->core->fetchvars(capability, year0, year1, out))
+}
+int hx_device_var(hx_core *core, const char *capability, const double **d_ptr, int *npad) {
+  if (!capability || !d_ptr) return fail("hx_device_var: null argument");
+  HX_TRY(*d_ptr = core->core->device_var(capability, npad))
+}
+int hx_stats_device(hx_core *core, const char *capability, int year0, int year1,
+                    double *d_stats) {
+  if (!capability || !d_stats) return fail("hx_stats_device: null argument");
+  HX_TRY(core->core->stats_device(capability, year0, year1, d_stats))
+}
+int hx_status(hx_core *core, unsigned *out) {
+  if (!out) return fail("hx_status: null argument");
+  HX_TRY(core->core->status(out))
+}
+int hx_spinup_steps(hx_core *core, int member, int *steps) {
+  if (!steps) return fail("null argument");
+  HX_TRY(*steps = core->core->spinup_steps(member))
+}
+int hx_dates(hx_core *core, int *start, int *end, int *current) {
+  HX_TRY(if (start) *start = core->core->start_date(); if (end) *end = core->core->end_date();
+         if (current) *current = core->core->last_date())
+}
+int hx_sizes(hx_core *core, int *n_members, int *n_biomes) {
+  HX_TRY(if (n_members) *n_members = core->core->n_members();
+         if (n_biomes) *n_biomes = core->core->n_biomes())
+}
+int hx_last_run_ms(hx_core *core, double *ms) {
+  HX_TRY(core->core->sync(); *ms = core->core->last_run_kernel_ms())
+}
+int hx_last_spinup_ms(hx_core *core, double *ms) { HX_TRY(*ms = core->core->last_spinup_ms()) }
+int hx_stream(hx_core *core, void **stream) { HX_TRY(*stream = (void *)core->core->stream()) }
+
+}  // extern "C"

@@ -1,0 +1,1206 @@
+// hx_kernels.hip -- CDNA4 (gfx950) kernels for the Hector ensemble year loop.
+//
+// One ensemble member per lane, 64-lane workgroups (one wavefront each), all
+// per-member state register-resident for the whole multi-year launch; HBM is
+// touched only for (a) the coalesced SoA parameter/state rows at entry/exit,
+// (b) one coalesced row per output variable per year and (c) DOECLIM's SST
+// history, which is re-read ONCE PER BLOCK of HX_DBLK years instead of once per
+// year (block-causal evaluation of the same ascending sum, partials parked in
+// LDS).  Shared scenario series are wave-uniform and arrive through scalar
+// loads.  No MFMA: this is elementwise fp64 ODE stepping.
+//
+// What each device function restates (reference file:line, /root/reference):
+//   year loop / component order        src/core.cpp:483-504
+//   OH, CH4, O3                         src/oh_component.cpp:137-178,
+//                                       src/ch4_component.cpp:152-199,
+//                                       src/o3_component.cpp:126-146
+//   ocean year start / stash / RHS      src/ocean_component.cpp:356-407,653-763,603-626
+//   box exchange                        src/oceanbox.cpp:203-323
+//   carbonate chemistry                 src/ocean_csys.cpp:166-396
+//   alkalinity tuning (Brent)           src/oceanbox.cpp:382-445 + Boost minima.hpp
+//   land RHS / slow params / stash      src/simpleNbox-runtime.cpp:781-934,945-1072,270-609
+//   dopri5 + controller + retry logic   src/carbon-cycle-solver.cpp:222-303 + odeint
+//   forcing                             src/forcing_component.cpp:300-532
+//   DOECLIM                             src/temperature_component.cpp:196-557
+//
+// Deliberate, tolerance-neutral departures from the reference's arithmetic
+// (all <= a few ulp, see DESIGN.md "numerics"): FMA contraction on; quintic
+// root by warm-started safeguarded Newton (same root, different path);
+// T-only equilibrium constants computed once per year per box; LUC ratio via
+// one division; 200-year Q10 window as a running sum; forcing summed in groups.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "hx_layout.h"
+
+#define HX_DBLK 16  // DOECLIM block length (years per SST-history pass)
+
+namespace {
+
+constexpr double PGC2PPM = 1.0 / 2.13;  // carbon-cycle-model.hpp:29
+constexpr double PG_C_TO_TG_CH4 = 1000.0 * 16.04 / 12.01;
+
+// ---- DOECLIM constants  inst/include/temperature_component.hpp:77-98 -------
+constexpr double D_ak = 0.31, D_bk = 1.59, D_csw = 0.13, D_earth_area = 5100656E8,
+                 D_secs = 60.0 * 60.0 * 24.0 * 365.2422, D_rlam = 1.43,
+                 D_zbot = 4000.0, D_bsi = 1.3, D_cal = 0.52, D_cas = 7.80,
+                 D_flnd = 0.29, D_fso = 0.95;
+
+// ---- ocean geometry  src/ocean_component.cpp:202-303 -----------------------
+constexpr double O_part_high = 0.15, O_part_low = 1 - 0.15;
+constexpr double O_spy = 60.0 * 60 * 24 * 365.25;
+constexpr double O_area = 3.6e14;
+constexpr double O_vLL = O_area * O_part_low * 100.0;
+constexpr double O_vHL = O_area * O_part_high * 100.0;
+constexpr double O_vI = O_area * 900.0;
+constexpr double O_vD = O_area * (3777.0 - 900.0 - 100.0);
+constexpr double O_AsHL = O_area * O_part_high, O_AsLL = O_area * O_part_low;
+constexpr double O_S = 34.5, O_U = 6.7;
+
+struct ChemK {  // T-dependent equilibrium constants of one surface box
+  double K1, K2, Kb, Kw, Kh, Tr;
+};
+
+// oceancsys::ocean_csys_run, the part that depends only on T (S = 34.5, U = 6.7)
+// src/ocean_csys.cpp:205-287, 349
+__device__ __forceinline__ void chem_constants(double Tc, ChemK &k) {
+  const double S = O_S;
+  const double sqrtS = 5.873670062235365;      // sqrt(34.5)
+  const double S15 = 202.64161714712009;       // 34.5^1.5
+  const double Tk = Tc + 273.15;
+  const double lnTk = log(Tk);
+  const double lnTk100 = log(Tk / 100);
+  double tmp1 = -58.0931 + 90.5069 * (100 / Tk) + 22.2940 * lnTk100;
+  double tmp2 = S * (0.027766 - 0.025888 * (Tk / 100) +
+                     0.0050578 * ((Tk / 100) * (Tk / 100)));
+  const double K0 = exp(tmp1 + tmp2);
+  const double Sc =
+      2073.1 - (125.62 * Tc) + (3.6276 * Tc * Tc) - (0.043219 * Tc * Tc * Tc);
+  tmp1 = -13847.26 / Tk + 148.96502 - 23.6521 * lnTk;
+  tmp2 = +(118.67 / Tk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S;
+  k.Kw = exp(tmp1 + tmp2);
+  double tmp = 9345.17 / Tk - 60.2409 + 23.3585 * lnTk100;
+  k.Kh = exp(tmp + S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk));
+  const double pK1 = 3633.86 / Tk - 61.2172 + 9.6777 * lnTk - 0.011555 * S +
+                     0.0001152 * S * S;
+  k.K1 = exp10(-pK1);
+  const double pK2 = 471.78 / Tk + 25.9290 - 3.16967 * lnTk - 0.01781 * S +
+                     0.0001122 * S * S;
+  k.K2 = exp10(-pK2);
+  tmp1 = (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 -
+          0.0996 * S * S) / Tk;
+  tmp2 = +148.0248 + 137.1942 * sqrtS + 1.62142 * S;
+  double tmp3 = +(-24.4344 - 25.085 * sqrtS - 0.2474 * S) * lnTk +
+                0.053105 * sqrtS * Tk;
+  k.Kb = exp(tmp1 + tmp2 + tmp3);
+  k.Tr = (0.585 * K0 * rsqrt(Sc) * O_U * O_U);
+}
+
+// Carbonate solve for one box: DIC + alk -> [H+] (largest real root of the
+// quintic, src/ocean_csys.cpp:289-325) and pCO2 (:328-343).  The quintic has
+// exactly one positive root (one sign change: p5,p4 < 0 < p2,p1,p0), so f > 0
+// left of it and f < 0 right of it for h > 0; Newton from the previous [H+]
+// with a sign-maintained bracket reaches the same root the reference's
+// Fujiwara-bound Newton does.  Stop rule = Boost's (|delta| <= |h| 2^-30).
+__device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
+                                             double inv_vol, double alk,
+                                             double &h_io, unsigned &status) {
+  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
+  const double dic = ((carbon * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol);
+  const double K1 = k.K1, K2 = k.K2, Kb = k.Kb, Kw = k.Kw;
+  const double p4 = -alk - Kb - K1;
+  const double p3 = dic * K1 - alk * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
+  double tmp = dic * (Kb * K1 + 2.0 * K1 * K2) - alk * (Kb * K1 + K1 * K2) +
+               Kb * bor * K1;
+  const double p2 = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
+  tmp = 2.0 * dic * Kb * K1 * K2 - alk * Kb * K1 * K2 + Kb * bor * K1 * K2;
+  const double p1 = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
+  const double p0 = Kw * Kb * K1 * K2;
+  double h = h_io;
+  double lo = 0.0, hi = 1.0;  // f(lo) > 0 > f(hi)
+  const double factor = 0x1p-30;
+  bool done = false;
+  for (int it = 0; it < 200 && !done; ++it) {
+    // Horner, top coefficient first (boost polynomial::evaluate)
+    double f = -1.0;
+    f = f * h + p4; f = f * h + p3; f = f * h + p2; f = f * h + p1; f = f * h + p0;
+    double fp = -5.0;
+    fp = fp * h + 4.0 * p4; fp = fp * h + 3.0 * p3; fp = fp * h + 2.0 * p2;
+    fp = fp * h + p1;
+    if (f == 0.0) { done = true; break; }
+    if (f > 0) lo = h; else hi = h;
+    double delta = f / fp;
+    double hn = h - delta;
+    if (!(hn > lo && hn < hi)) {  // left the bracket (or fp == 0): bisect
+      hn = 0.5 * (lo + hi);
+      delta = h - hn;
+    }
+    done = !(fabs(hn * factor) < fabs(delta));
+    h = hn;
+  }
+  if (!done) status |= HX_ERR_ROOT;
+  h_io = h;
+  const double co2st = dic / (1.0 + K1 / h + K1 * K2 / h / h);
+  return co2st * 1e6 / k.Kh;  // PCO2o, uatm
+}
+
+// calc_annual_surface_flux  src/ocean_csys.cpp:375-396
+__device__ __forceinline__ double surf_flux(double co2, double pco2, double scale,
+                                            double Tr, double As) {
+  return (((co2 - pco2 * scale) * Tr) * As * 12.0) / 1e15;
+}
+
+// ---------------------------------------------------------------------------
+template <int B>
+struct Member {
+  // parameters
+  double C0, aero, vol;
+  double beta[B], q10[B], wf[B], npp0[B], f_nppv[B], f_nppd[B], f_litterd[B],
+      rh_ch4_frac[B], pf_mu[B], pf_sigma[B], fpf_static[B];
+  double kLH, kLI, kHD, kIL, kIH, kID, kDI;  // ocean exchange, 1/yr
+  // state
+  double cHL, cLL, cIO, cDO, atmos, earth;
+  double veg[B], det[B], soil[B], pf[B], thawed[B], tempferts[B], f_frozen[B];
+  double cum_luc_va, cum_pf_ch4, masstot, eos_vegc;
+  double max_ts, lastflux_ann, sdt;
+  int ts_timeout;
+  double ch4, alkH, alkL, hH, hL;
+  unsigned status;
+  // per-year
+  double co2fert[B], tempfertd[B], f_new_thaw[B];
+  double luc_e, luc_u, ffi, daccs, npp_luc_adjust;
+  ChemK kH, kL;
+  double pco2H, pco2L;
+  double annualflux_sum, nbp;
+  int nstash, nsteps;
+  double ode_start;
+};
+
+// rhs constants that only change at a stash (pools frozen in between,
+// src/simpleNbox-runtime.cpp:809-840)
+struct Interval {
+  double P, npp, rh, v1, d2, s3, k4, k5, k7;
+  double totC, surf, inv_surf;
+};
+
+template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, int b) {
+  return (m.npp0[b] * m.co2fert[b]) * m.npp_luc_adjust;  // :622-635
+}
+template <int B> __device__ __forceinline__ double m_rh_fda(const Member<B> &m, int b) {
+  return (m.det[b] * 0.25) * m.tempfertd[b];  // :653-665
+}
+template <int B> __device__ __forceinline__ double m_rh_fsa(const Member<B> &m, int b) {
+  return (m.soil[b] * 0.02) * m.tempferts[b];  // :671-683
+}
+template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &m, int b) {
+  return ((m.thawed[b] * (1 - m.fpf_static[b])) * 0.02) * m.tempferts[b] *
+         (1.0 - m.rh_ch4_frac[b]);  // :689-701
+}
+template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, int b) {
+  return m_rh_tp_co2(m, b) / (1.0 - m.rh_ch4_frac[b]) * m.rh_ch4_frac[b];  // :707-711
+}
+
+template <int B, bool SPIN>
+__device__ __forceinline__ void prep_interval(const Member<B> &m, Interval &K) {
+  double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
+  double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const double n = m_npp(m, b);
+    npp_c += n;
+    fav += n * m.f_nppv[b];
+    fad += n * m.f_nppd[b];
+    fas += n * (1 - m.f_nppv[b] - m.f_nppd[b]);
+    fda += m_rh_fda(m, b);
+    fsa += m_rh_fsa(m, b);
+    const double co2 = m_rh_tp_co2(m, b), ch4 = m_rh_tp_ch4(m, b);
+    tpc += co2;
+    tpm += ch4;
+    const double v = m.veg[b] * 0.035;
+    litter += v;
+    lfvd += v * m.f_litterd[b];
+    lfvs += v * (1 - m.f_litterd[b]);
+    detsoil += m.det[b] * 0.6;
+    if (!SPIN) {  // compute_pf_thaw_refreeze :744-772
+      double c_thaw = m.pf[b] * m.f_new_thaw[b];
+      double r_tp = 0.0;
+      if (c_thaw < 0) {
+        const double want = -c_thaw;
+        c_thaw = 0.0;
+        r_tp = fmin(want, m.thawed[b] - co2 - ch4);
+      }
+      thaw += c_thaw;
+      refr += r_tp;
+    }
+  }
+  K.npp = npp_c;
+  K.rh = fda + fsa + tpc;
+  K.P = ((m.ffi - m.daccs) + m.luc_e) - m.luc_u;
+  K.v1 = fav - litter;
+  K.d2 = ((fad + lfvd) - detsoil) - fda;
+  K.s3 = ((fas + lfvs) + detsoil) - fsa;
+  K.k4 = -thaw + refr;
+  K.k5 = ((thaw - refr) - tpm) - tpc;
+  K.k7 = -m.ffi + m.daccs;
+  K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
+  K.surf = m.cLL + m.cHL;
+  K.inv_surf = 1.0 / K.surf;
+}
+
+// SimpleNbox::calcderivs + OceanComponent::calcderivs restricted to the five
+// pools whose derivative depends on c[] (atmos, veg, det, soil, ocean)
+template <int B, bool SPIN>
+__device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K,
+                                    const double y[5], double d[5]) {
+  const double total = y[1] + y[2] + y[3];
+  const double r = m.luc_e / total;
+  double ao;
+  if (SPIN) {
+    ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
+  } else {
+    const double scale = (K.surf + (y[4] - K.totC)) * K.inv_surf;
+    const double co2 = y[0] * PGC2PPM;
+    ao = surf_flux(co2, m.pco2H, scale, m.kH.Tr, O_AsHL) +
+         surf_flux(co2, m.pco2L, scale, m.kL.Tr, O_AsLL);
+  }
+  d[0] = ((K.P - ao) - K.npp) + K.rh;
+  d[1] = (K.v1 - r * y[1]) + m.luc_u;
+  d[2] = K.d2 - r * y[2];
+  d[3] = K.s3 - r * y[3];
+  d[4] = ao;
+}
+
+// OceanComponent::stashCValues + SimpleNbox::stashCValues for one lane
+template <int B, bool SPIN>
+__device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
+                                      double c4, double c5, double c7) {
+  const double yf = t - m.ode_start;
+  m.nstash++;
+  const bool in_partial_year = (t != floor(t));
+  const double co2 = y[0] * PGC2PPM;
+  double aH, aL;
+  if (SPIN) {
+    aH = 1.000 * yf;
+    aL = -1.000 * yf;
+  } else {
+    m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
+    m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+    aH = surf_flux(co2, m.pco2H, 1.0, m.kH.Tr, O_AsHL) * yf;
+    aL = surf_flux(co2, m.pco2L, 1.0, m.kL.Tr, O_AsLL) * yf;
+  }
+  // box-to-box transports, oceanbox.cpp:244-257 (order: HL, LL, IO, DO)
+  const double lHD = m.cHL * m.kHD * yf;
+  const double lLH = m.cLL * m.kLH * yf, lLI = m.cLL * m.kLI * yf;
+  const double lIL = m.cIO * m.kIL * yf, lIH = m.cIO * m.kIH * yf,
+               lID = m.cIO * m.kID * yf;
+  const double lDI = m.cDO * m.kDI * yf;
+  const double currentflux = aH + aL;
+  const double totC = m.cDO + m.cIO + m.cLL + m.cHL;
+  const double solver_flux = y[4] - totC;
+  double adj = 0.0;
+  if (currentflux != 0.0) adj = (solver_flux - currentflux) / 2.0;
+  aH += adj;
+  aL += adj;
+  const double cdiff = solver_flux / yf - m.lastflux_ann;
+  if (cdiff > 0.1) {  // ocean_component.cpp:703-733
+    m.max_ts = fmax(0.3, m.max_ts * 0.5);
+    m.ts_timeout = 20;
+  } else if (!in_partial_year && m.ts_timeout) {
+    m.ts_timeout = max(0, m.ts_timeout - 1);
+    if (!m.ts_timeout) {
+      m.max_ts = fmin(1.0, m.max_ts / 0.5);
+      if (m.max_ts < 1.0) m.ts_timeout = 20;
+    }
+  }
+  const double lastflux = aL + aH;
+  m.annualflux_sum += lastflux;
+  m.lastflux_ann = lastflux / yf;
+  // update_state: carbon + additions + ao - oa - subtractions (oceanbox.cpp:297-303)
+  m.cHL = ((m.cHL + (lLH + lIH)) + aH) - lHD;
+  m.cLL = ((m.cLL + lIL) + aL) - (lLH + lLI);
+  m.cIO = (m.cIO + (lLI + lDI)) - ((lIL + lIH) + lID);
+  m.cDO = (m.cDO + (lHD + lID)) - lDI;
+
+  // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
+  double npp_t = 0, rh_t = 0, pf_t = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) npp_t += m_npp(m, b);
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+    rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, b);
+#pragma unroll
+  for (int b = 0; b < B; ++b) pf_t += m.pf[b];
+  m.nbp = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
+  const double npp_rh = npp_t + rh_t;
+  double tpf = c5;
+  if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
+  if (y[0] < 0 || y[1] < 0 || y[2] < 0 || y[3] < 0 || c4 < 0 || tpf < 0)
+    m.status |= HX_ERR_NEGPOOL;
+  const double total = y[1] + y[2] + y[3];
+  m.cum_luc_va += ((m.luc_e - m.luc_u) * y[1]) / total;  // no yf: :388-393
+  const double inv_nr = 1.0 / npp_rh;
+  const double inv_pf = (pf_t > 0) ? 1.0 / pf_t : 0.0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const double wt = (B == 1) ? 1.0
+        : (m_npp(m, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, b))) * inv_nr;
+    const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
+    m.cum_pf_ch4 += m_rh_tp_ch4(m, b) * yf;  // :481
+    m.veg[b] = y[1] * wt;
+    m.det[b] = y[2] * wt;
+    m.soil[b] = y[3] * wt;
+    m.pf[b] = c4 * wt_pf;
+    m.thawed[b] = tpf * wt_pf;
+  }
+  m.earth = c7;
+  m.atmos = y[0];
+  const double sum = ((((((y[0] + y[1]) + y[2]) + y[3]) + c4) + c5) + y[4]) + c7 +
+                     m.cum_pf_ch4;
+  if (m.masstot > 0.0 && fabs(sum - m.masstot) > 0.001) m.status |= HX_ERR_MASS;
+  m.masstot = sum;
+  if (SPIN) {  // pin the atmosphere to C0, residual to the deep box :567-603
+    const double match = m.C0 / PGC2PPM;
+    const double residual = m.atmos - match;
+    m.cDO = residual + m.cDO;
+    m.atmos = m.atmos - residual;
+  }
+  m.ode_start = t;
+}
+
+// CarbonCycleSolver::run for one model year t0 -> tnew, all 64 lanes in
+// lock-step over "one try_step attempt or one stash" iterations.
+template <int B, bool SPIN>
+__device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
+                                           double t0, double tnew) {
+  // dopri5 tableau (odeint runge_kutta_dopri5)
+  constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+  constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
+                   b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
+                   b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+                   b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247,
+                   b64 = 49.0 / 176, b65 = -5103.0 / 18656;
+  constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
+                   c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+  constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
+                   dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
+                   dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+  (void)a2; (void)a3; (void)a4; (void)a5;
+
+  Interval K;
+  prep_interval<B, SPIN>(m, K);
+  // getCValues  simpleNbox-runtime.cpp:247-258
+  double y[5], l4, l5, l7;
+  auto load_pools = [&]() {
+    double v = 0, d = 0, s = 0, p = 0, th = 0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+                                   p += m.pf[b]; th += m.thawed[b]; }
+    y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = K.totC;
+    l4 = p; l5 = th; l7 = m.earth;
+  };
+  load_pools();
+  m.ode_start = t0;
+  double t = t0;            // time reached by accepted steps
+  double t_start = t0, t_target = tnew;
+  double dtl = m.sdt;       // integrate_adaptive's by-value dt
+  double dxdt[5];
+  bool first_call = true;   // fresh controlled stepper per integrate_adaptive
+  int retry = 0, fails = 0;
+  bool active = true;
+  while (__any(active)) {
+    if (active) {
+      if ((t_target - t) > 2.220446049250313e-16) {  // less_with_sign(t, t1)
+        if (first_call) { rhs<B, SPIN>(m, K, y, dxdt); first_call = false; }
+        if (((t + dtl) - t_target) > 2.220446049250313e-16) dtl = t_target - t;
+        // Every dopri5 stage time is <= t+dtl, and the model refuses any
+        // RHS evaluation beyond max_timestep (ocean_component.cpp:621-625),
+        // so the attempt throws CARBON_CYCLE_RETRY iff its last stage does.
+        if (((t + dtl) - m.ode_start) > m.max_ts) {
+          ++retry;  // carbon-cycle-solver.cpp:266-276
+          t_target = t_start + (t_target - t_start) / 2.0;
+          t = t_start;
+          m.sdt = t_target - t;
+          dtl = m.sdt;
+          load_pools();
+          first_call = true;
+          fails = 0;
+          if (retry >= 8) { m.status |= HX_ERR_RETRIES; active = false; }
+        } else {
+          double k2[5], k3[5], k4[5], k5[5], k6[5], xt[5], xn[5], dn[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
+          rhs<B, SPIN>(m, K, xt, k2);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
+          rhs<B, SPIN>(m, K, xt, k3);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
+          rhs<B, SPIN>(m, K, xt, k4);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] +
+                    dtl * b53 * k3[i] + dtl * b54 * k4[i];
+          rhs<B, SPIN>(m, K, xt, k5);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] +
+                    dtl * b63 * k3[i] + dtl * b64 * k4[i] + dtl * b65 * k5[i];
+          rhs<B, SPIN>(m, K, xt, k6);
+#pragma unroll
+          for (int i = 0; i < 5; ++i)
+            xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
+                    dtl * c5 * k5[i] + dtl * c6 * k6[i];
+          rhs<B, SPIN>(m, K, xn, dn);
+          double err = 0.0;  // default_error_checker, max norm
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
+                              dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
+                              dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
+            const double e = fabs(xe) / (kc.eps_abs +
+                             kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i])));
+            err = fmax(err, e);
+          }
+          if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
+            dtl *= fmax(0.9 * pow(err, -1.0 / 3.0), 0.2);
+            if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; active = false; }
+          } else {          // accept
+            // pools with a constant derivative over the interval advance exactly
+            l4 += dtl * K.k4; l5 += dtl * K.k5; l7 += dtl * K.k7;
+            t += dtl;
+            if (err < 0.5) {  // increase_step
+              err = fmax(0.00032, err);  // 5^-5
+              dtl *= 0.9 * pow(err, -1.0 / 5.0);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
+            fails = 0;
+            m.nsteps++;
+          }
+        }
+      } else {
+        // integrate_adaptive returned: we are at t_target -> stash
+        retry = 0;
+        stash<B, SPIN>(m, t, y, l4, l5, l7);
+        if (t < tnew) {
+          // the solver keeps integrating its own c[] (no getCValues here,
+          // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
+          prep_interval<B, SPIN>(m, K);
+          t_start = t; t_target = tnew;
+          dtl = m.sdt;
+          first_call = true;
+        } else {
+          active = false;
+        }
+      }
+    }
+  }
+}
+
+// oceanbox::chem_equilibrate: tune alkalinity so that the chemistry reproduces
+// the spinup flux at CO2 = co2 (src/oceanbox.cpp:382-445).  Boost's
+// brent_find_minima restated; the alkalinity kept is the LAST point evaluated.
+__device__ __forceinline__ double equilibrate_alk(const ChemK &k, double carbon,
+                                                  double inv_vol, double As,
+                                                  double co2, double f_target,
+                                                  double &h, unsigned &status) {
+  auto fmin_ = [&](double alk) {
+    const double p = chem_solve(k, carbon, inv_vol, alk, h, status);
+    return fabs(surf_flux(co2, p, 1.0, k.Tr, As) - f_target);
+  };
+  const double tolerance = 0x1p-25;  // bits = min(53/2, 31) = 26
+  double mn = 2100e-6, mx = 2750e-6;
+  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+  const double golden = 0.3819660f;
+  x = w = v = mx;
+  fw = fv = fx = fmin_(x);
+  delta2 = delta = 0;
+  u = x;
+  for (int count = 0; count < 1000; ++count) {
+    mid = (mn + mx) / 2;
+    fract1 = tolerance * fabs(x) + tolerance / 4;
+    fract2 = 2 * fract1;
+    if (fabs(x - mid) <= (fract2 - (mx - mn) / 2)) break;
+    if (fabs(delta2) > fract1) {
+      double r = (x - w) * (fx - fv);
+      double q = (x - v) * (fx - fw);
+      double p = (x - v) * q - (x - w) * r;
+      q = 2 * (q - r);
+      if (q > 0) p = -p;
+      q = fabs(q);
+      const double td = delta2;
+      delta2 = delta;
+      if ((fabs(p) >= fabs(q * td / 2)) || (p <= q * (mn - x)) || (p >= q * (mx - x))) {
+        delta2 = (x >= mid) ? mn - x : mx - x;
+        delta = golden * delta2;
+      } else {
+        delta = p / q;
+        u = x + delta;
+        if (((u - mn) < fract2) || ((mx - u) < fract2))
+          delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+      }
+    } else {
+      delta2 = (x >= mid) ? mn - x : mx - x;
+      delta = golden * delta2;
+    }
+    u = (fabs(delta) >= fract1) ? (x + delta)
+                                : (delta > 0 ? (x + fabs(fract1)) : (x - fabs(fract1)));
+    fu = fmin_(u);
+    if (fu <= fx) {
+      if (u >= x) mn = x; else mx = x;
+      v = w; w = x; x = u; fv = fw; fw = fx; fx = fu;
+    } else {
+      if (u < x) mn = u; else mx = u;
+      if ((fu <= fw) || (w == x)) { v = w; w = u; fv = fw; fw = fu; }
+      else if ((fu <= fv) || (v == x) || (v == w)) { v = u; fv = fu; }
+    }
+  }
+  return u;
+}
+
+// ---- SoA helpers ------------------------------------------------------------
+__device__ __forceinline__ double ldp(const HxBuffers &b, int row, int mem) {
+  return b.params[(size_t)row * b.npad + mem];
+}
+__device__ __forceinline__ double lds_(const HxBuffers &b, int row, int mem) {
+  return b.state[(size_t)row * b.npad + mem];
+}
+__device__ __forceinline__ void sts_(const HxBuffers &b, int row, int mem, double v) {
+  b.state[(size_t)row * b.npad + mem] = v;
+}
+
+template <int B>
+__device__ __forceinline__ void load_member(const HxBuffers &buf, int mem, Member<B> &m) {
+  m.C0 = ldp(buf, HXP_C0, mem);
+  m.aero = ldp(buf, HXP_AERO, mem);
+  m.vol = ldp(buf, HXP_VOL, mem);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int r = HXP_NGLOBAL + b * HXPB_N;
+    m.beta[b] = ldp(buf, r + HXPB_BETA, mem);
+    m.q10[b] = ldp(buf, r + HXPB_Q10, mem);
+    m.wf[b] = ldp(buf, r + HXPB_WF, mem);
+    m.npp0[b] = ldp(buf, r + HXPB_NPP0, mem);
+    m.f_nppv[b] = ldp(buf, r + HXPB_F_NPPV, mem);
+    m.f_nppd[b] = ldp(buf, r + HXPB_F_NPPD, mem);
+    m.f_litterd[b] = ldp(buf, r + HXPB_F_LITTERD, mem);
+    m.rh_ch4_frac[b] = ldp(buf, r + HXPB_RH_CH4_FRAC, mem);
+    m.pf_mu[b] = ldp(buf, r + HXPB_PF_MU, mem);
+    m.pf_sigma[b] = ldp(buf, r + HXPB_PF_SIGMA, mem);
+    m.fpf_static[b] = ldp(buf, r + HXPB_FPF_STATIC, mem);
+  }
+  // exchange coefficients  src/ocean_component.cpp:265-284
+  const double tt = ldp(buf, HXP_TT, mem), tu = ldp(buf, HXP_TU, mem),
+               twi = ldp(buf, HXP_TWI, mem), tid = ldp(buf, HXP_TID, mem);
+  m.kLH = (tt * O_spy) / O_vLL;
+  m.kHD = ((tt + tu) * O_spy) / O_vHL;
+  const double DO_IO = ((tt + tu) * O_spy) / O_vD;
+  m.kIH = (tu * O_spy) / O_vI;
+  const double IO_LL = (tt * O_spy) / O_vI;
+  const double IO_LLex = (twi * O_spy) / O_vI;
+  m.kLI = (twi * O_spy) / O_vLL;
+  const double DO_IOex = (tid * O_spy) / O_vD;
+  m.kID = (tid * O_spy) / O_vI;
+  m.kIL = IO_LL + IO_LLex;
+  m.kDI = DO_IO + DO_IOex;
+}
+
+template <int B>
+__device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member<B> &m) {
+  m.cHL = lds_(buf, HXS_C_HL, mem); m.cLL = lds_(buf, HXS_C_LL, mem);
+  m.cIO = lds_(buf, HXS_C_IO, mem); m.cDO = lds_(buf, HXS_C_DO, mem);
+  m.atmos = lds_(buf, HXS_ATMOS, mem); m.earth = lds_(buf, HXS_EARTH, mem);
+  m.cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem);
+  m.cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem);
+  m.masstot = lds_(buf, HXS_MASSTOT, mem);
+  m.eos_vegc = lds_(buf, HXS_EOS_VEGC, mem);
+  m.max_ts = lds_(buf, HXS_MAX_TS, mem);
+  m.ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
+  m.lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
+  m.sdt = lds_(buf, HXS_SOLVER_DT, mem);
+  m.ch4 = lds_(buf, HXS_CH4, mem);
+  m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem);
+  m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int r = HXS_NGLOBAL + b * HXSB_N;
+    m.veg[b] = lds_(buf, r + HXSB_VEG, mem); m.det[b] = lds_(buf, r + HXSB_DET, mem);
+    m.soil[b] = lds_(buf, r + HXSB_SOIL, mem); m.pf[b] = lds_(buf, r + HXSB_PF, mem);
+    m.thawed[b] = lds_(buf, r + HXSB_THAWED, mem);
+    m.tempferts[b] = lds_(buf, r + HXSB_TEMPFERTS, mem);
+    m.f_frozen[b] = lds_(buf, r + HXSB_F_FROZEN, mem);
+  }
+  m.status = buf.status[mem];
+}
+
+template <int B>
+__device__ __forceinline__ void store_state(const HxBuffers &buf, int mem,
+                                            const Member<B> &m) {
+  sts_(buf, HXS_C_HL, mem, m.cHL); sts_(buf, HXS_C_LL, mem, m.cLL);
+  sts_(buf, HXS_C_IO, mem, m.cIO); sts_(buf, HXS_C_DO, mem, m.cDO);
+  sts_(buf, HXS_ATMOS, mem, m.atmos); sts_(buf, HXS_EARTH, mem, m.earth);
+  sts_(buf, HXS_CUM_LUC_VA, mem, m.cum_luc_va);
+  sts_(buf, HXS_CUM_PF_CH4, mem, m.cum_pf_ch4);
+  sts_(buf, HXS_MASSTOT, mem, m.masstot);
+  sts_(buf, HXS_EOS_VEGC, mem, m.eos_vegc);
+  sts_(buf, HXS_MAX_TS, mem, m.max_ts);
+  sts_(buf, HXS_TS_TIMEOUT, mem, (double)m.ts_timeout);
+  sts_(buf, HXS_LASTFLUX_ANN, mem, m.lastflux_ann);
+  sts_(buf, HXS_SOLVER_DT, mem, m.sdt);
+  sts_(buf, HXS_CH4, mem, m.ch4);
+  sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
+  sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int r = HXS_NGLOBAL + b * HXSB_N;
+    sts_(buf, r + HXSB_VEG, mem, m.veg[b]); sts_(buf, r + HXSB_DET, mem, m.det[b]);
+    sts_(buf, r + HXSB_SOIL, mem, m.soil[b]); sts_(buf, r + HXSB_PF, mem, m.pf[b]);
+    sts_(buf, r + HXSB_THAWED, mem, m.thawed[b]);
+    sts_(buf, r + HXSB_TEMPFERTS, mem, m.tempferts[b]);
+    sts_(buf, r + HXSB_F_FROZEN, mem, m.f_frozen[b]);
+  }
+  buf.status[mem] = m.status;
+}
+
+}  // namespace
+
+// ===========================================================================
+// Spinup: Core::run_spinup (src/core.cpp:394-420) + CarbonCycleSolver::
+// run_spinup (src/carbon-cycle-solver.cpp:313-370).  Pseudo-years 0,1,2...
+// until max |c(step) - c(step-1)| < eps_spinup; emissions 0, all fertilisation
+// factors 1, chemistry off (spinup_chem = 0), atmosphere pinned to C0.
+// Initialises the whole state table from the parameter rows.
+// ===========================================================================
+template <int B>
+__global__ __launch_bounds__(64) void hx_spinup_kernel(HxBuffers buf, HxConst kc,
+                                                       int *spinup_steps) {
+  const int mem = blockIdx.x * 64 + threadIdx.x;
+  if (mem >= buf.npad) return;
+  Member<B> m;
+  load_member<B>(buf, mem, m);
+  // initial conditions: ocean_component.cpp:234-260, simpleNbox.cpp:45-79,
+  // simpleNbox-runtime.cpp:146-172
+  {
+    const double LLf = O_vLL / (O_vLL + O_vHL), HLf = 1 - LLf;
+    const double If = O_vI / (O_vI + O_vD), Df = 1 - If;
+    const double ps = ldp(buf, HXP_PRE_SURF, mem), pid = ldp(buf, HXP_PRE_ID, mem);
+    m.cLL = LLf * ps; m.cHL = HLf * ps; m.cIO = If * pid; m.cDO = Df * pid;
+  }
+  m.earth = 5500;
+  m.atmos = m.C0 * (1.0 / PGC2PPM);
+  m.cum_luc_va = 0; m.cum_pf_ch4 = 0; m.masstot = 0;
+  m.max_ts = 1.0; m.ts_timeout = 0; m.lastflux_ann = 0; m.sdt = kc.dt0;
+  m.ch4 = kc.M0; m.alkH = 0; m.alkL = 0; m.hH = 1e-8; m.hL = 1e-8;
+  m.status = 0;
+  double v0 = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int r = HXP_NGLOBAL + b * HXPB_N;
+    m.veg[b] = ldp(buf, r + HXPB_VEG0, mem); m.det[b] = ldp(buf, r + HXPB_DET0, mem);
+    m.soil[b] = ldp(buf, r + HXPB_SOIL0, mem); m.pf[b] = ldp(buf, r + HXPB_PF0, mem);
+    m.thawed[b] = 0; m.tempferts[b] = 1; m.f_frozen[b] = 1;
+    m.co2fert[b] = 1; m.tempfertd[b] = 1; m.f_new_thaw[b] = 0;
+    v0 += m.veg[b];
+  }
+  m.eos_vegc = v0;
+  m.luc_e = m.luc_u = m.ffi = m.daccs = 0;
+  m.npp_luc_adjust = 1.0;  // (eos - 0)/eos
+  m.pco2H = m.pco2L = 0; m.annualflux_sum = 0; m.nbp = 0; m.nsteps = 0;
+  m.kH.Tr = m.kL.Tr = 0;
+
+  bool spun = (kc.max_spinup <= 1);
+  int steps = 0;
+  for (int step = 1; step < kc.max_spinup && __any(!spun); ++step) {
+    if (!spun) {
+      const double o0 = m.atmos, oO = m.cDO + m.cIO + m.cLL + m.cHL, oE = m.earth;
+      double ov = 0, od = 0, os = 0, op = 0, ot = 0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
+                                     op += m.pf[b]; ot += m.thawed[b]; }
+      m.nstash = 0;
+      solve_year<B, true>(m, kc, (double)(step - 1), (double)step);
+      double nv = 0, nd = 0, nso = 0, np = 0, nt = 0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) { nv += m.veg[b]; nd += m.det[b]; nso += m.soil[b];
+                                     np += m.pf[b]; nt += m.thawed[b]; }
+      double mx = fabs(m.atmos - o0);
+      mx = fmax(mx, fabs(nv - ov)); mx = fmax(mx, fabs(nd - od));
+      mx = fmax(mx, fabs(nso - os)); mx = fmax(mx, fabs(np - op));
+      mx = fmax(mx, fabs(nt - ot));
+      mx = fmax(mx, fabs((m.cDO + m.cIO + m.cLL + m.cHL) - oO));
+      mx = fmax(mx, fabs(m.earth - oE));
+      steps = step;
+      spun = (mx < kc.eps_spinup) || (m.status != 0);
+    }
+  }
+  if (!spun) m.status |= HX_ERR_SPINUP;
+  // SimpleNbox::run, first call: end_of_spinup_vegc  runtime.cpp:209-213
+  double v1 = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) v1 += m.veg[b];
+  m.eos_vegc = v1;
+  store_state<B>(buf, mem, m);
+  sts_(buf, HXS_TLAND, mem, 0.0); sts_(buf, HXS_SST, mem, 0.0);
+  sts_(buf, HXS_F_PREV, mem, 0.0); sts_(buf, HXS_BASE_TOT, mem, 0.0);
+  sts_(buf, HXS_BASE_CO2, mem, 0.0);
+  sts_(buf, HXS_TL_M1, mem, 0.0); sts_(buf, HXS_TL_M2, mem, 0.0);
+  sts_(buf, HXS_TWIN, mem, 0.0);
+  // year-0 (startDate) outputs = state recorded at the end of spinup
+  const size_t o = (size_t)mem;
+  auto put = [&](int var, double v) { if (buf.out[var]) buf.out[var][o] = v; };
+  put(HXO_SST, 0.0); put(HXO_TLAND, 0.0);
+  put(HXO_CO2, m.atmos * PGC2PPM); put(HXO_TGAV, 0.0);
+  put(HXO_RF_TOT, 0.0); put(HXO_RF_CO2, 0.0);
+  put(HXO_OCEAN_C, m.cDO + m.cIO + m.cLL + m.cHL);
+  put(HXO_HL_PH, 0.0); put(HXO_LL_PH, 0.0); put(HXO_ATMOS_C, m.atmos);
+  {
+    double v = 0, d = 0, s = 0, p = 0, th = 0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+                                   p += m.pf[b]; th += m.thawed[b]; }
+    put(HXO_PERMAFROST_C, p); put(HXO_VEG_C, v); put(HXO_DET_C, d);
+    put(HXO_SOIL_C, s); put(HXO_THAWED_C, th);
+  }
+  put(HXO_HEATFLUX, 0.0); put(HXO_CH4, kc.M0); put(HXO_O3, 0.0);
+  put(HXO_EARTH_C, m.earth); put(HXO_NBP, 0.0); put(HXO_OCEAN_UPTAKE, 0.0);
+  put(HXO_NSTASH, 0.0); put(HXO_NSTEPS, 0.0);
+  if (spinup_steps) spinup_steps[mem] = steps;
+}
+
+// ===========================================================================
+// Main run: years (iy_from, iy_to] (indices relative to startDate).
+// ===========================================================================
+template <int B>
+__global__ __launch_bounds__(64) void hx_run_kernel(HxBuffers buf, HxConst kc,
+                                                    int iy_from, int iy_to) {
+  // LDS (dynamic, sized by the launcher): per-lane partial sums of the current
+  // DOECLIM block and the SSTs produced inside it
+  extern __shared__ double s_lds[];
+  double (*s_part)[64] = reinterpret_cast<double (*)[64]>(s_lds);                  // DPAST2 partials
+  double (*s_tblk)[64] = reinterpret_cast<double (*)[64]>(s_lds + HX_DBLK * 64);   // in-block SSTs
+  double (*s_part2)[64] = reinterpret_cast<double (*)[64]>(s_lds + 2 * HX_DBLK * 64);  // heat-flux partials (only if requested)
+  const int lane = threadIdx.x;
+  const int mem = blockIdx.x * 64 + lane;
+  if (mem >= buf.npad) return;
+  const int ns = kc.ns;
+  Member<B> m;
+  load_member<B>(buf, mem, m);
+  load_state<B>(buf, mem, m);
+  double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem);
+  double f_prev = lds_(buf, HXS_F_PREV, mem), base_tot = lds_(buf, HXS_BASE_TOT, mem),
+         base_co2 = lds_(buf, HXS_BASE_CO2, mem);
+  double tl_m1 = lds_(buf, HXS_TL_M1, mem), tl_m2 = lds_(buf, HXS_TL_M2, mem),
+         twin = lds_(buf, HXS_TWIN, mem);
+  double lnq10[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) lnq10[b] = log(m.q10[b]);
+
+  // ---- DOECLIM member constants  temperature_component.cpp:251-412 ---------
+  double A0, A1, A2, A3, IB0, IB1, IB2, IB3, qc1, qc2, dq1, dq2, dpscale, hfscale;
+  {
+    const double S = ldp(buf, HXP_S, mem), qco2 = ldp(buf, HXP_QCO2, mem),
+                 diff = ldp(buf, HXP_DIFF, mem);
+    const double flnd = D_flnd, bsi = D_bsi, rlam = D_rlam, ak = D_ak, bk = D_bk,
+                 cal = D_cal, cas = D_cas, fso = D_fso;
+    const double cnum = rlam * flnd + bsi * (1.0 - flnd);
+    const double cden = rlam * flnd - ak * (rlam - bsi);
+    const double cfl = flnd * cnum / cden * qco2 / S - bk * (rlam - bsi) / cden;
+    const double cfs = (rlam * flnd - ak / (1.0 - flnd) * (rlam - bsi)) * cnum / cden *
+                           qco2 / S +
+                       rlam * flnd / (1.0 - flnd) * bk * (rlam - bsi) / cden;
+    const double kls = bk * rlam * flnd / cden - ak * flnd * cnum / cden * qco2 / S;
+    const double keff = (D_secs / 10000) * diff;
+    const double taucfs = cas / cfs, taucfl = cal / cfl;
+    const double taudif = (cas * cas) / (D_csw * D_csw) * M_PI / keff;
+    const double tauksl = (1.0 - flnd) * cas / kls, taukls = flnd * cal / kls;
+    double C0_ = 1.0 / (taucfl * taucfl) + 1.0 / (taukls * taukls) +
+                 2.0 / taucfl / taukls + bsi / taukls / tauksl;
+    double C1_ = -1 * bsi / (taukls * taukls) - bsi / taucfl / taukls -
+                 bsi / taucfs / taukls - (bsi * bsi) / taukls / tauksl;
+    double C2_ = -1 * bsi / (tauksl * tauksl) - 1.0 / taucfs / tauksl -
+                 1.0 / taucfl / tauksl - 1.0 / taukls / tauksl;
+    double C3_ = 1.0 / (taucfs * taucfs) + (bsi * bsi) / (tauksl * tauksl) +
+                 2.0 * bsi / taucfs / tauksl + bsi / taukls / tauksl;
+    C0_ *= 1.0 / 12.0; C1_ *= 1.0 / 12.0; C2_ *= 1.0 / 12.0; C3_ *= 1.0 / 12.0;
+    const double sq = sqrt(1.0 / taudif);
+    const double ker_last = buf.ker_per_member ? buf.ker[(size_t)(ns - 1) * buf.npad + mem]
+                                               : buf.ker[ns - 1];
+    const double B0 = 1.0 + 1.0 / (2.0 * taucfl) + 1.0 / (2.0 * taukls) + C0_;
+    const double B1 = -1.0 / (2.0 * taukls) * bsi + C1_;
+    const double B2 = -1.0 / (2.0 * tauksl) + C2_;
+    const double B3 = 1.0 + 1.0 / (2.0 * taucfs) + 1.0 / (2.0 * tauksl) * bsi +
+                      2.0 * fso * sq + C3_;
+    A0 = 1.0 - 1.0 / (2.0 * taucfl) - 1.0 / (2.0 * taukls) + C0_;
+    A1 = 1.0 / (2.0 * taukls) * bsi + C1_;
+    A2 = 1.0 / (2.0 * tauksl) + C2_;
+    A3 = 1.0 - 1.0 / (2.0 * taucfs) - 1.0 / (2.0 * tauksl) * bsi + ker_last * fso * sq + C3_;
+    const double det = B0 * B3 - B1 * B2;
+    if (det == 0) m.status |= HX_ERR_SINGULAR;
+    const double idet = 1 / det;
+    IB0 = idet * B3; IB1 = idet * -1 * B1; IB2 = idet * -1 * B2; IB3 = idet * B0;
+    // QC1/QC2 with DelQL == DelQO (temperature_component.cpp:462-477)
+    qc1 = ((1.0 / cal) * (1.0 / taucfl + 1.0 / taukls) - bsi / cas / taukls) / 12.0;
+    qc2 = ((1.0 / cas) * (1.0 / taucfs + bsi / tauksl) - 1.0 / cal / tauksl) / 12.0;
+    dq1 = 0.5 / cal; dq2 = 0.5 / cas;
+    dpscale = fso * sq;
+    hfscale = cas * fso / sqrt(taudif);
+  }
+  const bool want_hf = buf.out[HXO_HEATFLUX] != nullptr;
+  const double *sst_hist = buf.out[HXO_SST];
+  int blk0 = -1;  // first year index of the current DOECLIM block
+
+  for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
+    const double *sh = buf.shared + (size_t)iy * HXSH_STRIDE;
+    const double year = (double)(kc.start_year + iy);
+    // ================= OH, CH4, O3 =========================================
+    const double prev_ch4 = m.ch4;
+    double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
+    if (iy > 1) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) rh_ch4 += m_rh_tp_ch4(m, b);
+    }
+    double toh = 0.0;
+    if (prev_ch4 != kc.M0)
+      toh = ((kc.CCH4 * (log(prev_ch4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
+            sh[HXSH_OH_D];
+    const double tau_oh = kc.TOH0 * exp(-toh);
+    {
+      const double emisTocon =
+          ((sh[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
+      const double dCH4 = ((emisTocon - prev_ch4 / kc.Tsoil) - prev_ch4 / kc.Tstrat) -
+                          prev_ch4 / tau_oh;
+      m.ch4 = prev_ch4 + dCH4;
+    }
+    const double o3 = ((5 * log(m.ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) +
+                      sh[HXSH_O3_NMVOC];
+    // ================= ocean: new year ======================================
+    chem_constants(sst + 18 + (-16.4), m.kH);
+    chem_constants(sst + 18 + 2.9, m.kL);
+    m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
+    if (m.alkH == 0.0) {  // first year after spinup: turn the chemistry on
+      const double co2 = m.atmos * PGC2PPM;
+      m.alkH = equilibrate_alk(m.kH, m.cHL, 1.0 / O_vHL, O_AsHL, co2, 1.000, m.hH, m.status);
+      m.alkL = equilibrate_alk(m.kL, m.cLL, 1.0 / O_vLL, O_AsLL, co2, -1.000, m.hL, m.status);
+    }
+    m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
+    m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+    // ================= slowparameval (t = year-1) ============================
+    m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
+    m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
+    m.npp_luc_adjust = (m.eos_vegc - m.cum_luc_va) / m.eos_vegc;
+    {
+      const double lnc = log((m.atmos * PGC2PPM) / m.C0);
+      // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
+      // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
+      if (iy >= 3) {
+        twin += tl_m2;  // Tland of year iy-3 enters
+        const int iold = iy - 203;
+        if (iold >= 1) twin -= buf.out[HXO_TLAND][(size_t)iold * buf.npad + mem];
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        m.co2fert[b] = 1 + m.beta[b] * lnc;
+        const double Tb = tland * m.wf[b];
+        m.tempfertd[b] = exp(lnq10[b] * (Tb / 10.0));
+        m.f_new_thaw[b] = 0.0;
+        if (m.pf[b] != 0.0) {
+          double ff = 1.0;
+          if (Tb > 0) {
+            const double d = (log(Tb) - m.pf_mu[b]) /
+                             (m.pf_sigma[b] * 1.4142135623730951);
+            ff = 1 - erfc(-d) / 2;
+          }
+          m.f_new_thaw[b] = m.f_frozen[b] - ff;
+          m.f_frozen[b] = ff;
+        }
+        const double Trm = (iy > 1) ? (twin * m.wf[b]) / 200 : 0.0;
+        double tfs = exp(lnq10[b] * (Trm / 10.0));
+        const double last = (iy > 1) ? m.tempferts[b] : 0.0;
+        m.tempferts[b] = fmax(tfs, last);  // sticky :1054-1059
+      }
+    }
+    // ================= carbon-cycle solver ==================================
+    solve_year<B, false>(m, kc, year - 1.0, year);
+    // ================= forcing ==============================================
+    const double co2c = m.atmos * PGC2PPM;
+    double rf_tot = 0, rf_co2 = 0;
+    if (iy >= kc.baseyear_idx) {
+      const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
+      const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
+      const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
+      const double sqN = sh[HXSH_SQRT_N2O], sqM = sqrt(m.ch4), sqC = sqrt(co2c);
+      const double C_alpha_max = m.C0 - (b1 / (2 * a1));
+      double alpha_prime;
+      if (co2c > C_alpha_max) alpha_prime = d1 - ((b1 * b1) / (4 * a1));
+      else if (m.C0 < co2c && co2c < C_alpha_max)
+        alpha_prime = d1 + a1 * ((co2c - m.C0) * (co2c - m.C0)) + b1 * (co2c - m.C0);
+      else alpha_prime = d1;
+      const double sarf_co2 = (alpha_prime + c1 * sqN) * log(co2c / m.C0);
+      const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
+      const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - kc.sqrtN0);
+      const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
+      const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
+      const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
+      const double fh2o = 0.0485 * ((m.ch4 - kc.M0) / (1831 - kc.M0));
+      const double fo3 = 0.042 * o3;
+      const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
+                           m.aero * sh[HXSH_RF_AERO]) + m.vol * sh[HXSH_RF_VOL];
+      if (iy == kc.baseyear_idx) { base_tot = ftot; base_co2 = fco2; }
+      rf_tot = ftot - base_tot;
+      rf_co2 = fco2 - base_co2;
+    }
+    // ================= DOECLIM ==============================================
+    if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
+      // block-causal pass: partial sums over the history BEFORE this block for
+      // each year of the block, same ascending order as the reference loop
+      // (temperature_component.cpp:488-491, 534-537)
+      blk0 = iy;
+      double acc[HX_DBLK], acc2[HX_DBLK];
+#pragma unroll
+      for (int j = 0; j < HX_DBLK; ++j) { acc[j] = 0; acc2[j] = 0; }
+      for (int i = 0; i < blk0; ++i) {
+        const double T = sst_hist[(size_t)i * buf.npad + mem];
+#pragma unroll
+        for (int j = 0; j < HX_DBLK; ++j) {
+          const int kidx = ns - (blk0 + j) + i - 1;
+          if (kidx >= 0) {
+            const double kk = buf.ker_per_member ? buf.ker[(size_t)kidx * buf.npad + mem]
+                                                 : buf.ker[kidx];
+            acc[j] += T * kk;
+            if (want_hf) {
+              const double k2 = buf.ker_per_member
+                                    ? buf.ker[(size_t)(kidx + 1) * buf.npad + mem]
+                                    : buf.ker[kidx + 1];
+              acc2[j] += T * k2;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HX_DBLK; ++j) {
+        s_part[j][lane] = acc[j];
+        if (want_hf) s_part2[j][lane] = acc2[j];
+      }
+    }
+    double tl_new, sst_new, heatflux = 0;
+    {
+      const int j = iy - blk0;
+      double dpast = s_part[j][lane];
+      double hint = want_hf ? s_part2[j][lane] : 0.0;
+      for (int i = blk0; i < iy; ++i) {
+        const double T = s_tblk[i - blk0][lane];
+        const int kidx = ns - iy + i - 1;
+        const double kk = buf.ker_per_member ? buf.ker[(size_t)kidx * buf.npad + mem]
+                                             : buf.ker[kidx];
+        dpast += T * kk;
+        if (want_hf) {
+          const double k2 = buf.ker_per_member ? buf.ker[(size_t)(kidx + 1) * buf.npad + mem]
+                                               : buf.ker[kidx + 1];
+          hint += T * k2;
+        }
+      }
+      dpast *= dpscale;
+      const double DelQ = rf_tot - f_prev;
+      const double DQ1 = dq1 * (rf_tot + f_prev) + DelQ * qc1;
+      const double DQ2 = dq2 * (rf_tot + f_prev) + DelQ * qc2;
+      const double X1 = DQ1 + (A0 * tland + A1 * sst);
+      const double X2 = (DQ2 + dpast) + (A2 * tland + A3 * sst);
+      tl_new = IB0 * X1 + IB1 * X2;
+      sst_new = IB2 * X1 + IB3 * X2;
+      if (want_hf) {
+        const double hmix = D_cas * (sst_new - sst);
+        const double hi = hfscale * (2.0 * sst_new - hint);
+        heatflux = hmix + D_fso * hi;
+      }
+      s_tblk[j][lane] = sst_new;
+    }
+    const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+    f_prev = rf_tot;
+    tl_m2 = tl_m1; tl_m1 = tland;  // Tland of years iy-2, iy-1 for the next year
+    tland = tl_new; sst = sst_new;
+    // ================= outputs ==============================================
+    const size_t o = (size_t)iy * buf.npad + mem;
+    buf.out[HXO_SST][o] = sst_new;
+    buf.out[HXO_TLAND][o] = tl_new;
+    if (buf.out[HXO_CO2]) buf.out[HXO_CO2][o] = co2c;
+    if (buf.out[HXO_TGAV]) buf.out[HXO_TGAV][o] = tgav;
+    if (buf.out[HXO_RF_TOT]) buf.out[HXO_RF_TOT][o] = rf_tot;
+    if (buf.out[HXO_RF_CO2]) buf.out[HXO_RF_CO2][o] = rf_co2;
+    if (buf.out[HXO_OCEAN_C]) buf.out[HXO_OCEAN_C][o] = m.cDO + m.cIO + m.cLL + m.cHL;
+    if (buf.out[HXO_HL_PH]) buf.out[HXO_HL_PH][o] = -log10(m.hH);
+    if (buf.out[HXO_LL_PH]) buf.out[HXO_LL_PH][o] = -log10(m.hL);
+    if (buf.out[HXO_ATMOS_C]) buf.out[HXO_ATMOS_C][o] = m.atmos;
+    if (buf.out[HXO_HEATFLUX]) buf.out[HXO_HEATFLUX][o] = heatflux;
+    if (buf.out[HXO_CH4]) buf.out[HXO_CH4][o] = m.ch4;
+    if (buf.out[HXO_O3]) buf.out[HXO_O3][o] = o3;
+    if (buf.out[HXO_EARTH_C]) buf.out[HXO_EARTH_C][o] = m.earth;
+    if (buf.out[HXO_NBP]) buf.out[HXO_NBP][o] = m.nbp;
+    if (buf.out[HXO_OCEAN_UPTAKE]) buf.out[HXO_OCEAN_UPTAKE][o] = m.annualflux_sum;
+    if (buf.out[HXO_NSTASH]) buf.out[HXO_NSTASH][o] = (double)m.nstash;
+    if (buf.out[HXO_NSTEPS]) buf.out[HXO_NSTEPS][o] = (double)m.nsteps;
+    if (buf.out[HXO_PERMAFROST_C] || buf.out[HXO_VEG_C] || buf.out[HXO_DET_C] ||
+        buf.out[HXO_SOIL_C] || buf.out[HXO_THAWED_C]) {
+      double v = 0, d = 0, s = 0, p = 0, th = 0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+                                     p += m.pf[b]; th += m.thawed[b]; }
+      if (buf.out[HXO_PERMAFROST_C]) buf.out[HXO_PERMAFROST_C][o] = p;
+      if (buf.out[HXO_VEG_C]) buf.out[HXO_VEG_C][o] = v;
+      if (buf.out[HXO_DET_C]) buf.out[HXO_DET_C][o] = d;
+      if (buf.out[HXO_SOIL_C]) buf.out[HXO_SOIL_C][o] = s;
+      if (buf.out[HXO_THAWED_C]) buf.out[HXO_THAWED_C][o] = th;
+    }
+  }
+  store_state<B>(buf, mem, m);
+  sts_(buf, HXS_TLAND, mem, tland); sts_(buf, HXS_SST, mem, sst);
+  sts_(buf, HXS_F_PREV, mem, f_prev); sts_(buf, HXS_BASE_TOT, mem, base_tot);
+  sts_(buf, HXS_BASE_CO2, mem, base_co2);
+  sts_(buf, HXS_TL_M1, mem, tl_m1); sts_(buf, HXS_TL_M2, mem, tl_m2);
+  sts_(buf, HXS_TWIN, mem, twin);
+}
+
+// ===========================================================================
+// Broadcast member 0's state/outputs row to every member (shared spinup).
+// ===========================================================================
+__global__ void hx_broadcast_rows_kernel(double *table, int nrows, int npad) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mem >= npad || mem == 0) return;
+  for (int r = 0; r < nrows; ++r) table[(size_t)r * npad + mem] = table[(size_t)r * npad];
+}
+__global__ void hx_broadcast_u32_kernel(unsigned *v, int npad) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mem >= npad || mem == 0) return;
+  v[mem] = v[0];
+}
+
+// ===========================================================================
+// Per-year ensemble statistics of one output variable over members [0, n):
+// count, sum, sum of squares, min, max -> stats[year][5].  One workgroup per
+// year; wave-level DPP/shuffle reduction, then one LDS hop across the waves.
+// ===========================================================================
+__global__ __launch_bounds__(256) void hx_stats_kernel(const double *var, int n, int npad,
+                                                       int iy0, double *stats) {
+  const int iy = iy0 + blockIdx.x;
+  const double *row = var + (size_t)iy * npad;
+  double s = 0, s2 = 0, mn = INFINITY, mx = -INFINITY, cnt = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = row[i];
+    s += v; s2 += v * v; mn = fmin(mn, v); mx = fmax(mx, v); cnt += 1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64);
+    cnt += __shfl_down(cnt, off, 64);
+    mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64));
+  }
+  __shared__ double red[4][5];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = cnt; red[w][1] = s; red[w][2] = s2;
+                                 red[w][3] = mn; red[w][4] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) { red[0][0] += red[k][0]; red[0][1] += red[k][1];
+      red[0][2] += red[k][2]; red[0][3] = fmin(red[0][3], red[k][3]);
+      red[0][4] = fmax(red[0][4], red[k][4]); }
+    double *o = stats + (size_t)blockIdx.x * 5;
+    o[0] = red[0][0]; o[1] = red[0][1]; o[2] = red[0][2]; o[3] = red[0][3]; o[4] = red[0][4];
+  }
+}
+
+// ===========================================================================
+// DOECLIM convolution kernel table Ker[i] (temperature_component.cpp:303-371)
+// for `count` diffusivities: ker[i * stride + mem].  count = 1, stride = 1 when
+// every member shares the diffusivity.
+// ===========================================================================
+__global__ __launch_bounds__(256) void hx_doeclim_table_kernel(const double *diff_row,
+                                                               double *ker, int ns, int count,
+                                                               int stride) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (mem >= count || i >= ns) return;
+  const double keff = (D_secs / 10000) * diff_row[mem];
+  const double tb = (D_zbot * D_zbot) / keff;  // taubot / dt, dt = 1
+  const double sq2 = sqrt(2.0), sqpt = sqrt(M_PI * tb);
+  double KT0, KTA1, KTB1, KTA2, KTB2, KTA3, KTB3;
+  if (i == ns - 1) {
+    KT0 = 4.0 - 2.0 * sq2;
+    KTA1 = -8.0 * exp(-tb) + 4.0 * sq2 * exp(-0.5 * tb);
+    KTB1 = 4.0 * sqpt * (1.0 + erf(sqrt(0.5 * tb)) - 2.0 * erf(sqrt(tb)));
+    KTA2 = 8.0 * exp(-4.0 * tb) - 4.0 * sq2 * exp(-2.0 * tb);
+    KTB2 = -8.0 * sqpt * (1.0 + erf(sqrt(2.0 * tb)) - 2.0 * erf(2.0 * sqrt(tb)));
+    KTA3 = -8.0 * exp(-9.0 * tb) + 4.0 * sq2 * exp(-4.5 * tb);
+    KTB3 = 12.0 * sqpt * (1.0 + erf(sqrt(4.5 * tb)) - 2.0 * erf(3.0 * sqrt(tb)));
+  } else {
+    const double a = (double)(ns - i), b = (double)(ns + 1 - i), c = (double)(ns - 1 - i);
+    const double ra = sqrt(a), rb = sqrt(b), rc = sqrt(c);
+    const double ua = sqrt(tb / a), ub = sqrt(tb / b), uc = sqrt(tb / c);
+    KT0 = 4.0 * ra - 2.0 * rb - 2.0 * rc;
+    KTA1 = -8.0 * ra * exp(-tb / a) + 4.0 * rb * exp(-tb / b) + 4.0 * rc * exp(-tb / c);
+    KTB1 = 4.0 * sqpt * (erf(uc) + erf(ub) - 2.0 * erf(ua));
+    KTA2 = 8.0 * ra * exp(-4.0 * tb / a) - 4.0 * rb * exp(-4.0 * tb / b) -
+           4.0 * rc * exp(-4.0 * tb / c);
+    KTB2 = -8.0 * sqpt * (erf(2.0 * uc) + erf(2.0 * ub) - 2.0 * erf(2.0 * ua));
+    KTA3 = -8.0 * ra * exp(-9.0 * tb / a) + 4.0 * rb * exp(-9.0 * tb / b) +
+           4.0 * rc * exp(-9.0 * tb / c);
+    KTB3 = 12.0 * sqpt * (erf(3.0 * uc) + erf(3.0 * ub) - 2.0 * erf(3.0 * ua));
+  }
+  ker[(size_t)i * stride + mem] = KT0 + KTA1 + KTB1 + KTA2 + KTB2 + KTA3 + KTB3;
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers (the only symbols the host runtime uses)
+// ---------------------------------------------------------------------------
+extern "C++" {
+hipError_t hx_launch_spinup(int B, const HxBuffers &buf, const HxConst &kc,
+                            int nmem_launch, int *d_steps, hipStream_t st) {
+  HxBuffers b = buf;
+  const int blocks = (nmem_launch + 63) / 64;
+  if (nmem_launch < b.npad) { /* prototype launch: still index rows with npad */ }
+  switch (B) {
+    case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
+    case 2: hipLaunchKernelGGL(hx_spinup_kernel<2>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
+    case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
+    case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t hx_launch_run(int B, const HxBuffers &buf, const HxConst &kc, int iy_from,
+                         int iy_to, hipStream_t st) {
+  const int blocks = buf.npad / 64;
+  const size_t lds = (size_t)(buf.out[HXO_HEATFLUX] ? 3 : 2) * HX_DBLK * 64 * sizeof(double);
+  switch (B) {
+    case 1: hipLaunchKernelGGL(hx_run_kernel<1>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
+    case 2: hipLaunchKernelGGL(hx_run_kernel<2>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
+    case 3: hipLaunchKernelGGL(hx_run_kernel<3>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
+    case 4: hipLaunchKernelGGL(hx_run_kernel<4>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st) {
+  hipLaunchKernelGGL(hx_broadcast_rows_kernel, dim3((npad + 255) / 256), dim3(256), 0, st,
+                     table, nrows, npad);
+  return hipGetLastError();
+}
+hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st) {
+  hipLaunchKernelGGL(hx_broadcast_u32_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, v, npad);
+  return hipGetLastError();
+}
+hipError_t hx_launch_doeclim_kernel(const double *diff_row, double *ker, int ns, int count,
+                                    int stride, hipStream_t st) {
+  hipLaunchKernelGGL(hx_doeclim_table_kernel, dim3((count + 255) / 256, ns), dim3(256), 0, st,
+                     diff_row, ker, ns, count, stride);
+  return hipGetLastError();
+}
+hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
+                           double *stats, hipStream_t st) {
+  hipLaunchKernelGGL(hx_stats_kernel, dim3(nyears), dim3(256), 0, st, var, n, npad, iy0, stats);
+  return hipGetLastError();
+}
+}

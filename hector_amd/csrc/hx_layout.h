@@ -1,0 +1,106 @@
+// hx_layout.h -- HBM data layout shared by the host runtime and the HIP kernels.
+//
+// Everything per-member is structure-of-arrays: row r of a table lives at
+// base[r * npad + member], npad = members rounded up to 64, so lane i of a wave
+// reads member i of a row with one coalesced 512-byte transaction.
+#pragma once
+#include <stdint.h>
+
+#define HX_MAXB 4          // biomes supported by the kernels (template B = 1..4)
+#define HX_WAVE 64
+
+// ---- per-member parameter rows (read-only during a run) -------------------
+enum HxParamRow {
+  HXP_S = 0,        // ECS                     temperature_component.cpp:165
+  HXP_DIFF,         // ocean heat diffusivity
+  HXP_QCO2,
+  HXP_AERO,         // aero_scalar (alpha)     forcing_component.cpp:430-470
+  HXP_VOL,          // vol_scalar
+  HXP_C0,           // preindustrial CO2 ppmv
+  HXP_TT, HXP_TU, HXP_TWI, HXP_TID,           // ocean transports m3/s
+  HXP_PRE_SURF, HXP_PRE_ID,                   // preindustrial ocean C
+  HXP_NGLOBAL
+};
+enum HxBiomeParam {  // row = HXP_NGLOBAL + biome * HXPB_N + k
+  HXPB_BETA = 0, HXPB_Q10, HXPB_WF, HXPB_NPP0,
+  HXPB_VEG0, HXPB_DET0, HXPB_SOIL0, HXPB_PF0,
+  HXPB_F_NPPV, HXPB_F_NPPD, HXPB_F_LITTERD,
+  HXPB_RH_CH4_FRAC, HXPB_PF_MU, HXPB_PF_SIGMA, HXPB_FPF_STATIC,
+  HXPB_N
+};
+#define HX_NPARAM(B) (HXP_NGLOBAL + (B) * HXPB_N)
+
+// ---- per-member state rows (carried across years / run() calls) -----------
+enum HxStateRow {
+  HXS_C_HL = 0, HXS_C_LL, HXS_C_IO, HXS_C_DO,   // ocean box carbon, PgC
+  HXS_ATMOS, HXS_EARTH,
+  HXS_CUM_LUC_VA, HXS_CUM_PF_CH4, HXS_MASSTOT, HXS_EOS_VEGC,
+  HXS_MAX_TS, HXS_TS_TIMEOUT, HXS_LASTFLUX_ANN,  // ocean timestep controller
+  HXS_SOLVER_DT,
+  HXS_CH4, HXS_ALK_HL, HXS_ALK_LL, HXS_H_HL, HXS_H_LL,
+  HXS_TLAND, HXS_SST, HXS_F_PREV, HXS_BASE_TOT, HXS_BASE_CO2,
+  HXS_TL_M1, HXS_TL_M2, HXS_TWIN,                // Q10 window bookkeeping
+  HXS_NGLOBAL
+};
+enum HxBiomeState {  // row = HXS_NGLOBAL + biome * HXSB_N + k
+  HXSB_VEG = 0, HXSB_DET, HXSB_SOIL, HXSB_PF, HXSB_THAWED,
+  HXSB_TEMPFERTS, HXSB_F_FROZEN,
+  HXSB_N
+};
+#define HX_NSTATE(B) (HXS_NGLOBAL + (B) * HXSB_N)
+
+// ---- outputs: one [ns][npad] array per variable ---------------------------
+enum HxOutVar {
+  HXO_SST = 0,      // always on: it is DOECLIM's history
+  HXO_TLAND,        // always on: Q10 window history
+  HXO_CO2,          // CO2_concentration, ppmv
+  HXO_TGAV,         // global_tas
+  HXO_RF_TOT, HXO_RF_CO2, HXO_OCEAN_C, HXO_HL_PH, HXO_ATMOS_C,
+  HXO_PERMAFROST_C, HXO_HEATFLUX,
+  HXO_CH4, HXO_O3, HXO_VEG_C, HXO_DET_C, HXO_SOIL_C, HXO_THAWED_C, HXO_EARTH_C,
+  HXO_NBP, HXO_OCEAN_UPTAKE, HXO_NSTASH, HXO_NSTEPS, HXO_LL_PH,
+  HXO_NVAR
+};
+
+// ---- shared per-year scenario table: row iy = year - startDate ------------
+enum HxSharedCol {
+  HXSH_FFI = 0, HXSH_DACCS, HXSH_LUC_E, HXSH_LUC_U,  // of date year-1 (slowparameval t)
+  HXSH_OH_B, HXSH_OH_C, HXSH_OH_D,                   // OH lifetime terms of year
+  HXSH_CH4_EM, HXSH_CH4N,
+  HXSH_O3_NOX, HXSH_O3_CO, HXSH_O3_NMVOC,
+  HXSH_N2O, HXSH_SQRT_N2O,
+  HXSH_RF_OTHER,   // halocarbons + albedo + misc (member independent)
+  HXSH_RF_AERO,    // BC+OC+SO2+NH3+aci for aero_scalar = 1
+  HXSH_RF_VOL,     // SV
+  HXSH_NCOL,
+  HXSH_STRIDE = 24
+};
+
+// ---- status bits (per member) ---------------------------------------------
+#define HX_ERR_MASS 1u       // mass balance > 1e-3 PgC   simpleNbox-runtime.cpp:553-563
+#define HX_ERR_RETRIES 2u    // > 8 solver retries        carbon-cycle-solver.cpp:242-294
+#define HX_ERR_NEGPOOL 4u    // negative pool (fluxpool assert)
+#define HX_ERR_SPINUP 8u     // not spun up in max_spinup steps
+#define HX_ERR_SINGULAR 16u  // DOECLIM 2x2 singular
+#define HX_ERR_ROOT 32u      // carbonate root not found
+#define HX_ERR_STEPFAIL 64u  // > 500 rejected steps
+
+// scenario scalars every lane needs (kernel argument, lives in SGPRs)
+struct HxConst {
+  int start_year, ns, baseyear_idx, max_spinup, spinup_chem;
+  double eps_abs, eps_rel, dt0, eps_spinup;
+  double M0, lnM0, sqrtM0, Tsoil, Tstrat, UC_CH4, TOH0, CCH4;
+  double N0, sqrtN0;
+  double delta_co2, delta_ch4, delta_n2o;
+};
+
+// pointers handed to the kernels
+struct HxBuffers {
+  const double *params;  // [HX_NPARAM(B)][npad]
+  double *state;         // [HX_NSTATE(B)][npad]
+  unsigned *status;      // [npad]
+  const double *shared;  // [ns][HXSH_STRIDE]
+  const double *ker;     // [ns] DOECLIM kernel (shared diffusivity) or [ns][npad]
+  double *out[HXO_NVAR]; // each [ns][npad] or nullptr
+  int n, npad, ker_per_member;
+};

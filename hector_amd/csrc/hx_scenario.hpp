@@ -1,0 +1,45 @@
+// hx_scenario.hpp -- scenario inputs of one Hector configuration (what
+// INIToCoreReader + CSVTableReader push into Core::setData, reference
+// src/ini_to_core_reader.cpp:100-180, src/csv_table_reader.cpp:115-198),
+// held as plain scalars and dense per-year series on startDate..endDate.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+namespace hx {
+
+struct Halocarbon {
+  std::string name;  // e.g. "CF4" (section "<name>_halocarbon")
+  double tau = 0, rho = 0, delta = 0, H0 = 0, molarMass = 0;
+  std::vector<double> emissions;
+};
+
+class Scenario {
+ public:
+  // Load a dense scenario pack (.hxs, written by tools/import_scenario.py) or a
+  // Hector INI file (with its csv: tables).  Throws std::runtime_error.
+  static Scenario load(const std::string &path);
+
+  int start = 0, end = 0;
+  int ns() const { return end - start + 1; }
+
+  double scalar(const std::string &section, const std::string &key) const;
+  double scalar(const std::string &section, const std::string &key, double dflt) const;
+  bool has_scalar(const std::string &section, const std::string &key) const;
+  const std::vector<double> &series(const std::string &section,
+                                    const std::string &key) const;
+  bool has_series(const std::string &section, const std::string &key) const;
+
+  std::vector<Halocarbon> halocarbons;
+  std::string source;
+
+ private:
+  static Scenario load_pack(const std::string &path);
+  static Scenario load_ini(const std::string &path);
+  void finish();
+  std::map<std::string, std::string> scalars_;           // "section.key" -> text
+  std::map<std::string, std::vector<double>> series_;    // "section.key" -> [ns]
+};
+
+}  // namespace hx

@@ -1,0 +1,121 @@
+/*
+ * hector_amd.h -- C ABI of libhector_amd.so: an MI355X-native ensemble
+ * integrator for Hector's coupled carbon-cycle / climate year loop.
+ *
+ * Each entry point names the reference interface it replaces (file:line in
+ * JGCRI/hector v3.5.0).  The reference drives ONE member through
+ *   Core::mkcore/getcore/delcore   inst/include/core.hpp:105-109, src/core.cpp:813-857
+ *   Core::init + INIToCoreReader   src/rcpp_hector.cpp:31-86 (newcore_impl)
+ *   Core::sendMessage(SETDATA/GETDATA, capability, message_data)
+ *                                  src/core.cpp:716-778, src/rcpp_hector.cpp:282-356
+ *   Core::run / Core::reset / Core::shutDown
+ *                                  src/core.cpp:448-549, src/rcpp_hector.cpp:88-181
+ * This library keeps those verbs and the capability strings of
+ * inst/include/component_data.hpp, and adds a member axis: every parameter is a
+ * vector over members and every result is [year][member].
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a
+ * non-zero code on failure, with the message available from hx_last_error()
+ * (the reference throws h_exception; nothing is thrown across this ABI).
+ * Per-member MODEL errors (mass balance, >8 solver retries, negative pool...)
+ * do not fail a call: they set bits in the member's status word (hx_status).
+ * A core is bound to one GPU; there is no CPU execution path -- hx_newcore
+ * fails if no HIP device is present.  Not thread-safe per handle (like Core).
+ */
+#ifndef HECTOR_AMD_H
+#define HECTOR_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hx_core hx_core; /* opaque; replaces the int index of Core::mkcore */
+
+/* "hip" for the product library.  (A test-only host-emulation build reports
+ * "host-emulation"; the Python loader refuses it outside tests.) */
+const char *hx_backend(void);
+const char *hx_last_error(void);
+
+/* newcore(inifile, ...)  R/hector.R:81-87, src/rcpp_hector.cpp:31-86.
+ * `scenario` is a Hector INI file (csv: tables resolved like the reference) or
+ * a dense scenario pack (.hxs).  Creates an n_members ensemble on GPU `device`,
+ * all members at the INI's parameter values, one biome "global". */
+int hx_newcore(const char *scenario, int n_members, int device, hx_core **out);
+
+/* shutdown(core)  src/rcpp_hector.cpp:88-101 (Core::shutDown + delcore) */
+int hx_shutdown(hx_core *core);
+
+/* setvar(core, NA, var, values, unit)  R/messages.R:107-140 ->
+ * sendmessage(SETDATA)  src/rcpp_hector.cpp:282-356 -> Core::setData.
+ * capability: component_data.hpp string, optionally "<biome>.<capability>".
+ * nvalues is 1 (every member) or n_members.  units: NULL/"" = unchecked, else it
+ * must match the reference's unit string (e.g. "degC" for S).  Like the R
+ * wrapper this invalidates results from date 0 (the next run respins if needed). */
+int hx_setvar(hx_core *core, const char *capability, const double *values, int nvalues,
+              const char *units);
+/* fetchvars(core, NA, var) for parameters: GETDATA without a date. out[n_members] */
+int hx_getvar(hx_core *core, const char *capability, double *out);
+
+/* split_biome(core, "global", names, fveg_c, ...)  R/biome.R:61-130.
+ * names: n_biomes C strings.  Fraction arrays may be NULL (equal split / same as fveg). */
+int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const double *fveg,
+                   const double *fdet, const double *fsoil, const double *fpf,
+                   const double *fnpp);
+
+/* Select which per-year outputs are recorded (capability strings such as
+ * "CO2_concentration", "global_tas", "RF_tot"...).  sst and land_tas are always
+ * recorded.  The reference records everything always (tseries in every
+ * component); here it is opt-in because each variable costs 8 B/member-year. */
+int hx_set_outputs(hx_core *core, int nvars, const char *const *capabilities);
+int hx_output_capabilities(const char *const **names, int *count);
+
+/* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.
+ * date < startDate (e.g. 0): rerun the spinup on the next run; date == startDate:
+ * back to the post-spinup state.  Other dates: error (no per-year state history). */
+int hx_reset(hx_core *core, double date);
+
+/* run(core, runtodate)  src/rcpp_hector.cpp:153-181 -> Core::run src/core.cpp:448-509.
+ * runtodate < 0: run to endDate.  Callable repeatedly with increasing dates.
+ * hx_run returns after the GPU work is queued; hx_sync waits for it.
+ * Prepares the core first (parameter upload, spinup) if anything changed. */
+int hx_run(hx_core *core, double runtodate);
+int hx_sync(hx_core *core);
+
+/* fetchvars(core, dates, var)  R/messages.R:46-88: GETDATA per (variable, year).
+ * out[(year - year0) * n_members + member], host memory. */
+int hx_fetchvars(hx_core *core, const char *capability, int year0, int year1, double *out);
+/* Same data without leaving the GPU: device pointer to the variable's
+ * [n_years_total][npad] array (row = year - startDate, npad >= n_members). */
+int hx_device_var(hx_core *core, const char *capability, const double **d_ptr, int *npad);
+/* Per-year ensemble statistics {count, sum, sum of squares, min, max} of one
+ * variable into a caller-owned DEVICE buffer of (year1-year0+1)*5 doubles --
+ * the sufficient statistics that a multi-GPU job all-reduces over RCCL. */
+int hx_stats_device(hx_core *core, const char *capability, int year0, int year1,
+                    double *d_stats);
+
+/* per-member model-error bitmask (HX_ERR_* below), host array of n_members */
+int hx_status(hx_core *core, unsigned *out);
+int hx_spinup_steps(hx_core *core, int member, int *steps);
+
+/* core metadata: startDate, endDate, current date, members, biomes */
+int hx_dates(hx_core *core, int *start, int *end, int *current);
+int hx_sizes(hx_core *core, int *n_members, int *n_biomes);
+
+/* HIP-event time of the last run / spinup launch on the core's stream, ms */
+int hx_last_run_ms(hx_core *core, double *ms);
+int hx_last_spinup_ms(hx_core *core, double *ms);
+/* the core's hipStream_t, as void* */
+int hx_stream(hx_core *core, void **stream);
+
+#define HX_ERR_MASS 1u     /* mass not conserved        simpleNbox-runtime.cpp:553-563 */
+#define HX_ERR_RETRIES 2u  /* solver retries exhausted  carbon-cycle-solver.cpp:242-294 */
+#define HX_ERR_NEGPOOL 4u  /* negative pool             fluxpool.hpp:100-102 */
+#define HX_ERR_SPINUP 8u   /* did not spin up           core.cpp:394-420 */
+#define HX_ERR_SINGULAR 16u /* DOECLIM matrix singular  temperature_component.cpp:84-86 */
+#define HX_ERR_ROOT 32u    /* carbonate root not found  ocean_csys.cpp:134-156 */
+#define HX_ERR_STEPFAIL 64u /* >500 rejected ODE steps  (odeint failed_step_checker) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1544,21 +1544,18 @@ static void record_outputs(member_t *m, int iy, double *out) {
 #undef O
 }
 
-int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,
-                   double *out, int *spinup_steps) {
-  member_t M, *m = &M;
-  memset(m, 0, sizeof *m);
-  m->sc = s; m->pa = p; m->B = p->nbiome; m->ns = s->ns;
+/* prepareToRun of every component (core.cpp:372-376) */
+static void member_prepare(member_t *m, const hxo_scenario *s, const hxo_params *p,
+                           double *buf) {
   const int ns = s->ns;
-  memset(out, 0, sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
-  double *buf = (double *)calloc((size_t)ns * 8, sizeof(double));
+  memset(m, 0, sizeof *m);
+  m->sc = s; m->pa = p; m->B = p->nbiome; m->ns = ns;
+  memset(buf, 0, sizeof(double) * (size_t)ns * 8);
   m->Ker = buf; m->forcing = buf + ns; m->temp = buf + 2 * ns;
   m->temp_landair = buf + 3 * ns; m->temp_sst = buf + 4 * ns;
   m->heatflux_mixed = buf + 5 * ns; m->heatflux_interior = buf + 6 * ns;
   m->Tland_record = buf + 7 * ns;
   m->Tland_first = -1;
-
-  /* ---- prepareToRun of every component ---- */
   ocean_prepare(m);
   /* SimpleNbox: simpleNbox.cpp:45-79, runtime.cpp:66-190 */
   m->earth_c = 5500;
@@ -1582,18 +1579,19 @@ int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,
   for (int h = 0; h < s->nhalo; h++) m->halo_conc[h] = s->halo[h].H0;
   doeclim_prepare(m);
   m->tas_land = 0.0; m->sst_now = 0.0;
+}
 
-  /* ---- spinup: Core::run_spinup core.cpp:394-420 ---- */
+/* Core::run_spinup core.cpp:394-420; returns the number of steps */
+static int member_spinup(member_t *m) {
+  const hxo_scenario *s = m->sc;
   int step = 0, spunup = 0;
   if (s->do_spinup) {
     m->core_in_spinup = 1;
     int first = 1;
     double c_old[NC], c_new[NC];
     while (!spunup && ++step < s->max_spinup) {
-      /* ocean.run_spinup = run(step) */
-      ocean_run(m);
-      /* simpleNbox.run_spinup */
-      m->snbox_in_spinup = 1;
+      ocean_run(m);            /* ocean.run_spinup = run(step) */
+      m->snbox_in_spinup = 1;  /* simpleNbox.run_spinup */
       /* solver.run_spinup  carbon-cycle-solver.cpp:313-370 */
       if (first) {
         first = 0;
@@ -1616,14 +1614,18 @@ int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,
     if (!spunup) m->err |= HXO_ERR_SPINUP;
     m->core_in_spinup = 0;
   }
-  if (spinup_steps) *spinup_steps = step;
+  return step;
+}
+
+/* Core::run core.cpp:483-504, component order SURVEY 3c */
+static void member_main(member_t *m, int run_to, double *out) {
+  const hxo_scenario *s = m->sc;
+  const int ns = s->ns;
   m->nsteps_year = m->nrhs_year = 0;
   m->timesteps = 0;
   record_outputs(m, 0, out);
   out[HXO_HL_PH * ns] = m->chem[HL].pH;
   out[HXO_CH4 * ns] = s->M0; out[HXO_N2O * ns] = s->N0; out[HXO_O3 * ns] = s->PO3;
-
-  /* ---- main loop: Core::run core.cpp:483-504, order SURVEY 3c ---- */
   for (int year = s->start + 1; year <= run_to && year <= s->end; year++) {
     int iy = year - s->start;
     m->nsteps_year = m->nrhs_year = 0;
@@ -1655,24 +1657,55 @@ int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,
     out[HXO_N2O * ns + iy] = m->n2o;
     out[HXO_O3 * ns + iy] = m->o3;
   }
+}
+
+int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,
+                   double *out, int *spinup_steps) {
+  member_t M, *m = &M;
+  const int ns = s->ns;
+  memset(out, 0, sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
+  double *buf = (double *)malloc(sizeof(double) * (size_t)ns * 8);
+  member_prepare(m, s, p, buf);
+  int step = member_spinup(m);
+  if (spinup_steps) *spinup_steps = step;
+  member_main(m, run_to, out);
   free(buf);
   return m->err;
 }
 
+/* The ensemble of BASELINE configs 2-4: members differ only in S and q10_rh,
+ * which do not enter the spinup, so the spinup is done once and its
+ * end state is the starting point of every member -- the same sharing the GPU
+ * path uses; tests check it equals per-member hxo_run_member bit for bit. */
 int hxo_run_ensemble_ecs_q10(const hxo_scenario *s, const hxo_params *base,
                              int n, const double *S, const double *q10,
                              int run_to, double *co2, double *tgav) {
   int err = 0;
   const int ns = s->ns;
   double *out = (double *)malloc(sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
+  double *buf0 = (double *)malloc(sizeof(double) * (size_t)ns * 8);
+  double *buf = (double *)malloc(sizeof(double) * (size_t)ns * 8);
+  member_t M0;
+  member_prepare(&M0, s, base, buf0);
+  (void)member_spinup(&M0);
   for (int i = 0; i < n; i++) {
     hxo_params p = *base;
     p.S = S[i];
     for (int b = 0; b < p.nbiome; b++) p.q10_rh[b] = q10[i];
-    err |= hxo_run_member(s, &p, run_to, out, NULL);
+    member_t M = M0;
+    memcpy(buf, buf0, sizeof(double) * (size_t)ns * 8);
+    M.pa = &p;
+    M.Ker = buf; M.forcing = buf + ns; M.temp = buf + 2 * ns;
+    M.temp_landair = buf + 3 * ns; M.temp_sst = buf + 4 * ns;
+    M.heatflux_mixed = buf + 5 * ns; M.heatflux_interior = buf + 6 * ns;
+    M.Tland_record = buf + 7 * ns;
+    doeclim_prepare(&M); /* A, IB, time scales depend on S */
+    memset(out, 0, sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
+    member_main(&M, run_to, out);
+    err |= M.err;
     if (co2) memcpy(co2 + (size_t)i * ns, out + HXO_CO2 * ns, sizeof(double) * ns);
     if (tgav) memcpy(tgav + (size_t)i * ns, out + HXO_TGAV * ns, sizeof(double) * ns);
   }
-  free(out);
+  free(out); free(buf); free(buf0);
   return err;
 }

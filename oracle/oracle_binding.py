@@ -1,0 +1,105 @@
+"""ctypes binding of the CPU oracle (oracle/libhector_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing in the product path imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+ORACLE_DIR = os.path.dirname(os.path.abspath(__file__))
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libhector_oracle.so")
+MAXB = 8
+
+VARS = ["CO2_concentration", "global_tas", "RF_tot", "RF_CO2", "heatflux", "ocean_c", "HL_pH",
+        "atmos_co2", "sst", "permafrost_c", "land_tas", "CH4_concentration", "N2O_concentration",
+        "O3_concentration", "veg_c", "detritus_c", "soil_c", "thawedp_c", "earth_c", "timesteps",
+        "max_timestep", "solver_dt", "solver_steps", "rhs_evals", "LL_pH", "HL_PCO2", "LL_PCO2",
+        "ocean_uptake", "NBP", "RF_CH4", "RF_N2O"]
+
+
+class Params(ctypes.Structure):
+    _fields_ = ([("S", ctypes.c_double), ("diff", ctypes.c_double), ("qco2", ctypes.c_double),
+                 ("aero_scalar", ctypes.c_double), ("vol_scalar", ctypes.c_double),
+                 ("C0", ctypes.c_double), ("nbiome", ctypes.c_int)] +
+                [(n, ctypes.c_double * MAXB) for n in
+                 "beta q10_rh warmingfactor npp_flux0 veg_c detritus_c soil_c permafrost_c "
+                 "f_nppv f_nppd f_litterd rh_ch4_frac pf_mu pf_sigma fpf_static".split()] +
+                [(n, ctypes.c_double) for n in
+                 "tt tu twi tid preind_surface_c preind_interdeep_c".split()])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+class Oracle:
+    def __init__(self, scenario):
+        if not os.path.exists(ORACLE_LIB):
+            build()
+        lib = ctypes.CDLL(ORACLE_LIB)
+        lib.hxo_scenario_load.restype = ctypes.c_void_p
+        lib.hxo_scenario_load.argtypes = [ctypes.c_char_p]
+        lib.hxo_scenario_free.argtypes = [ctypes.c_void_p]
+        lib.hxo_scenario_start.argtypes = [ctypes.c_void_p]
+        lib.hxo_scenario_end.argtypes = [ctypes.c_void_p]
+        lib.hxo_params_default.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params)]
+        lib.hxo_params_split_equal.argtypes = [ctypes.POINTER(Params), ctypes.c_int]
+        lib.hxo_run_member.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        lib.hxo_run_ensemble_ecs_q10.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params),
+                                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.hxo_csys.argtypes = [ctypes.c_double] * 4 + [ctypes.c_void_p]
+        lib.hxo_doeclim_kernel.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+        self.lib = lib
+        self.sc = lib.hxo_scenario_load(scenario.encode())
+        if not self.sc:
+            raise RuntimeError("oracle: cannot load scenario " + scenario)
+        self.start = lib.hxo_scenario_start(self.sc)
+        self.end = lib.hxo_scenario_end(self.sc)
+        self.ns = self.end - self.start + 1
+
+    def default_params(self):
+        p = Params()
+        self.lib.hxo_params_default(self.sc, ctypes.byref(p))
+        return p
+
+    def split_equal(self, p, n):
+        self.lib.hxo_params_split_equal(ctypes.byref(p), n)
+        return p
+
+    def run(self, p=None, run_to=None):
+        """-> (dict var -> [ns], err, spinup_steps)"""
+        p = p or self.default_params()
+        out = np.zeros((len(VARS), self.ns))
+        steps = ctypes.c_int(0)
+        err = self.lib.hxo_run_member(self.sc, ctypes.byref(p), run_to or self.end,
+                                      out.ctypes.data, ctypes.byref(steps))
+        return {v: out[i] for i, v in enumerate(VARS)}, err, steps.value
+
+    def run_ecs_q10(self, S, q10, run_to=None, base=None):
+        """-> co2[n, ns], tgav[n, ns], err"""
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        q10 = np.ascontiguousarray(q10, dtype=np.float64)
+        n = S.size
+        co2 = np.zeros((n, self.ns))
+        tg = np.zeros((n, self.ns))
+        base = base or self.default_params()
+        err = self.lib.hxo_run_ensemble_ecs_q10(self.sc, ctypes.byref(base), n, S.ctypes.data,
+                                                q10.ctypes.data, run_to or self.end,
+                                                co2.ctypes.data, tg.ctypes.data)
+        return co2, tg, err
+
+    def csys(self, Tc, carbon, alk, volume):
+        out = np.zeros(6)
+        self.lib.hxo_csys(Tc, carbon, alk, volume, out.ctypes.data)
+        return out
+
+    def doeclim_kernel(self, diff, ns):
+        out = np.zeros(ns)
+        self.lib.hxo_doeclim_kernel(diff, ns, out.ctypes.data)
+        return out

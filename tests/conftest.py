@@ -1,0 +1,57 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+SCENARIO = os.path.join(ROOT, "hector_amd", "data", "ssp245.hxs")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "hector_comp_ssp245.txt")
+EMUL_LIB = os.path.join(ROOT, "tests", "emul", "libhector_amd_emul.so")
+HIP_LIB = os.path.join(ROOT, "hector_amd", "lib", "libhector_amd.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _make(path):
+    subprocess.check_call(["make", "-s", "-C", path])
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    _make(os.path.join(ROOT, "oracle"))
+    import oracle_binding
+    return oracle_binding.Oracle(SCENARIO)
+
+
+@pytest.fixture(scope="session")
+def emul_lib():
+    """Test-only host build of the product sources (tests/emul/README)."""
+    _make(os.path.join(ROOT, "tests", "emul"))
+    return EMUL_LIB
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    g = {}
+    with open(GOLDEN) as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            p = line.split()
+            g[p[0]] = np.array([float(x) for x in p[3:]])
+    return g
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library; GPU tests must load THIS, never the emulation."""
+    if not os.path.exists(HIP_LIB):
+        _make(os.path.join(ROOT, "hector_amd", "csrc"))
+    return HIP_LIB

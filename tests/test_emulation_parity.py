@@ -1,0 +1,166 @@
+"""The kernel SOURCE (hector_amd/csrc/hx_kernels.hip) and the host runtime,
+compiled for the host through tests/emul (one lane at a time), against the
+oracle and the reference golden trajectory.  CPU-only stand-in for the GPU
+parity tests in test_gpu_parity.py: same checks, same tolerances.
+
+Tolerances: the kernels reproduce the reference's decisions exactly (stash
+schedule, step counts) but not its arithmetic bit for bit (FMA contraction,
+warm-started Newton, grouped sums -- DESIGN.md "numerics"); the dominant term is
+the alkalinity tuner, whose result is only defined to 2^-25 relative
+(oceanbox.cpp:382-445) and maps to ~1e-10 relative in CO2.
+"""
+import numpy as np
+import pytest
+
+import hector_amd
+from hector_amd import ensemble
+from conftest import SCENARIO
+
+REL_CO2 = 2e-8   # relative, CO2 / atmos C / ocean C
+ABS_T = 2e-8     # K, temperatures; W/m2 forcings
+
+
+def mk(emul_lib, n):
+    return hector_amd.Core(SCENARIO, n, lib_path=emul_lib, allow_emulation=True)
+
+
+def test_default_member_vs_golden(emul_lib, golden):
+    c = mk(emul_lib, 1)
+    c.set_outputs(list(golden.keys()) + ["timesteps", "solver_steps"])
+    c.run(2300)
+    assert c.status()[0] == 0 and c.spinup_steps(0) == 498
+    for var, ref in golden.items():
+        got = c.fetchvars(var, (1745, 2300))[:, 0]
+        if var in ("CO2_concentration", "atmos_co2", "ocean_c", "permafrost_c", "HL_pH"):
+            m = ref != 0
+            assert (np.abs(got[m] - ref[m]) / np.abs(ref[m])).max() < REL_CO2, var
+        else:
+            assert np.abs(got - ref).max() < ABS_T, var
+    ts = c.fetchvars("timesteps", (1746, 2300))[:, 0].astype(int)
+    assert np.bincount(ts).tolist() == [0, 340, 71, 2, 142]
+    assert int(c.fetchvars("solver_steps", (1746, 2300)).sum()) == 1891
+
+
+def test_perturbed_ensemble_vs_oracle(emul_lib, oracle):
+    n = 24
+    S, q10 = ensemble.ecs_q10(n)
+    c = mk(emul_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+    c.run(2300)
+    assert (c.status() == 0).all()
+    co2 = c.fetchvars("CO2_concentration", (1745, 2300)).T
+    tg = c.fetchvars("global_tas", (1745, 2300)).T
+    oco2, otg, err = oracle.run_ecs_q10(S, q10)
+    assert err == 0
+    assert (np.abs(co2 - oco2) / oco2).max() < REL_CO2
+    assert np.abs(tg - otg).max() < ABS_T
+    # decisions: identical stash schedule member by member
+    ts = c.fetchvars("timesteps", (1746, 2300)).T
+    for i in range(0, n, 5):
+        p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        o, _, _ = oracle.run(p)
+        assert np.array_equal(ts[i], o["timesteps"][1:])
+
+
+def test_other_parameters_vs_oracle(emul_lib, oracle):
+    """beta, diffusivity (per-member DOECLIM kernel table), aerosol / volcanic scale, C0."""
+    n = 6
+    beta = np.linspace(0.3, 0.9, n); diff = np.linspace(0.8, 2.4, n)
+    aero = np.linspace(0.5, 1.5, n); vol = np.linspace(0.7, 1.3, n)
+    c = mk(emul_lib, n)
+    c.setvar("beta", beta, "(unitless)").setvar("diff", diff, "cm2/s")
+    c.setvar("aero_scalar", aero).setvar("vol_scalar", vol)
+    c.set_outputs(["CO2_concentration", "global_tas", "RF_tot", "heatflux"])
+    c.run(2150)
+    assert (c.status() == 0).all()
+    for i in range(n):
+        p = oracle.default_params()
+        p.beta[0] = beta[i]; p.diff = diff[i]; p.aero_scalar = aero[i]; p.vol_scalar = vol[i]
+        o, err, _ = oracle.run(p, run_to=2150)
+        assert err == 0
+        k = 2150 - 1745 + 1
+        got = c.fetchvars("CO2_concentration", (1745, 2150))[:, i]
+        assert (np.abs(got - o["CO2_concentration"][:k]) / o["CO2_concentration"][:k]).max() < REL_CO2
+        for v in ("global_tas", "RF_tot", "heatflux"):
+            assert np.abs(c.fetchvars(v, (1745, 2150))[:, i] - o[v][:k]).max() < ABS_T, v
+
+
+def test_four_biomes_vs_oracle(emul_lib, oracle):
+    n = 4
+    S, q10s, wfs = ensemble.biome4(n)
+    names = ["b1", "b2", "b3", "b4"]
+    c = mk(emul_lib, n)
+    c.split_biome(names)
+    c.setvar("S", S, "degC")
+    for b, nm in enumerate(names):
+        c.setvar(nm + ".q10_rh", q10s[b]).setvar(nm + ".warmingfactor", wfs[b])
+    c.set_outputs(["CO2_concentration", "global_tas", "permafrost_c", "veg_c"])
+    c.run(2300)
+    assert (c.status() == 0).all()
+    for i in range(n):
+        p = oracle.split_equal(oracle.default_params(), 4)
+        p.S = S[i]
+        for b in range(4):
+            p.q10_rh[b] = q10s[b][i]; p.warmingfactor[b] = wfs[b][i]
+        o, err, _ = oracle.run(p)
+        assert err == 0
+        for v in ("CO2_concentration", "permafrost_c", "veg_c"):
+            got = c.fetchvars(v, (1745, 2300))[:, i]
+            assert (np.abs(got - o[v]) / o[v]).max() < REL_CO2, v
+        assert np.abs(c.fetchvars("global_tas", (1745, 2300))[:, i] - o["global_tas"]).max() < ABS_T
+
+
+def test_identical_biome_split_equals_global(emul_lib):
+    """test_biome.R:193-256 on the kernel source."""
+    a = mk(emul_lib, 1).run(2100)
+    b = mk(emul_lib, 1); b.split_biome(["x", "y", "z", "w"]); b.run(2100)
+    for v in ("CO2_concentration", "global_tas"):
+        x, y = a.fetchvars(v), b.fetchvars(v)
+        assert np.abs(x - y).max() <= 1e-9 * np.abs(x).max(), v
+
+
+def test_run_in_segments_equals_one_run(emul_lib):
+    """Core::run is resumable (core.cpp:448-509): state carried through HBM."""
+    S, q10 = ensemble.ecs_q10(3)
+    a = mk(emul_lib, 3).setvar("S", S).setvar("q10_rh", q10).run(2100)
+    b = mk(emul_lib, 3).setvar("S", S).setvar("q10_rh", q10)
+    for y in (1750, 1751, 1800, 1983, 2100):
+        b.run(y)
+    for v in ("CO2_concentration", "global_tas", "sst", "land_tas"):
+        assert np.array_equal(a.fetchvars(v), b.fetchvars(v)), v
+
+
+def test_reset_and_rerun_reproduces(emul_lib):
+    c = mk(emul_lib, 2).setvar("S", [2.0, 4.5]).run(1900)
+    first = c.fetchvars("CO2_concentration")
+    c.reset(1745).run(1900)
+    assert np.array_equal(first, c.fetchvars("CO2_concentration"))
+    c.reset(0).run(1900)
+    assert np.array_equal(first, c.fetchvars("CO2_concentration"))
+    c.setvar("S", [3.0, 3.0]).run(1900)  # setvar invalidates from date 0
+    again = c.fetchvars("CO2_concentration")
+    assert np.array_equal(again[:, 0], again[:, 1]) and not np.array_equal(again, first)
+
+
+def test_error_behaviour_mirrors_reference(emul_lib):
+    c = mk(emul_lib, 2)
+    with pytest.raises(hector_amd.HectorAmdError, match="Unknown variable"):
+        c.setvar("no_such_var", 1.0)
+    with pytest.raises(hector_amd.HectorAmdError, match="[Uu]nits"):
+        c.setvar("S", 3.0, "W/m2")
+    with pytest.raises(hector_amd.HectorAmdError, match="Biome"):
+        c.setvar("boreal.q10_rh", 2.0)
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar("S", [1.0, 2.0, 3.0])
+    c.run(1760)
+    with pytest.raises(hector_amd.HectorAmdError, match="dates"):
+        c.fetchvars("CO2_concentration", (1745, 1800))
+    with pytest.raises(hector_amd.HectorAmdError, match="not enabled"):
+        c.fetchvars("RF_tot", (1745, 1760))
+    with pytest.raises(hector_amd.HectorAmdError, match="unknown variable"):
+        c.fetchvars("bogus", (1745, 1760))
+    with pytest.raises(hector_amd.HectorAmdError, match="end date"):
+        c.run(2400)
+    with pytest.raises(hector_amd.HectorAmdError, match="does not exist"):
+        hector_amd.Core("/nonexistent.ini", 1, lib_path=emul_lib, allow_emulation=True)
+    assert np.array_equal(c.getvar("S"), [3.0, 3.0])

@@ -1,0 +1,84 @@
+"""CPU tests of host-side logic: scenario pack, ensemble generator, sharding,
+ABI surface of the HIP library (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENARIO, HIP_LIB
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "hector_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(hx_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(hip_lib)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.hx_backend.restype = ctypes.c_char_p
+    assert lib.hx_backend() == b"hip"
+    from hector_amd import _lib
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+
+
+def test_product_fails_loudly_without_gpu(hip_lib):
+    """No CPU fallback: creating a core on a box without a HIP device is an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import hector_amd
+    with pytest.raises(hector_amd.HectorAmdError):
+        hector_amd.Core(n_members=4)
+
+
+def test_loader_refuses_emulation_as_product(emul_lib):
+    import hector_amd
+    from hector_amd import _lib
+    with pytest.raises(hector_amd.HectorAmdError):
+        _lib.load(emul_lib)
+    assert _lib.load(emul_lib, allow_emulation=True).hx_backend() == b"host-emulation"
+
+
+def test_ensemble_generator_is_counter_based():
+    from hector_amd import ensemble
+    S, q = ensemble.ecs_q10(1000)
+    S2, q2 = ensemble.ecs_q10(300, offset=500)
+    assert np.array_equal(S[500:800], S2) and np.array_equal(q[500:800], q2)
+    assert 1.5 <= S.min() and S.max() < 6.0 and 1.0 <= q.min() and q.max() < 3.0
+    assert abs(S.mean() - 3.75) < 0.15 and abs(q.mean() - 2.0) < 0.07
+
+
+def test_shard_ranges_partition_exactly():
+    from hector_amd.distributed import shard_range
+    for n, w in [(1048576, 8), (65536, 3), (10, 4), (7, 8)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+            assert o0 + c0 == o1
+
+
+def test_scenario_pack_matches_reference_inputs_when_available(tmp_path):
+    """The committed pack is regenerated from the reference INI/CSV and must be identical."""
+    ini = "/root/reference/inst/input/hector_ssp245.ini"
+    if not os.path.exists(ini):
+        pytest.skip("reference not present on this box")
+    import subprocess, sys
+    out = tmp_path / "x.hxs"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "import_scenario.py"),
+                           ini, str(out)])
+    assert open(out).read() == open(SCENARIO).read()
+
+
+def test_ini_reader_equals_pack(emul_lib):
+    """The C++ INI/CSV front end (hx_scenario.cpp) on the reference's own INI gives
+    the same core as the committed dense pack."""
+    ini = "/root/reference/inst/input/hector_ssp245.ini"
+    if not os.path.exists(ini):
+        pytest.skip("reference not present on this box")
+    import hector_amd
+    a = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True).run(1800)
+    b = hector_amd.Core(ini, 1, lib_path=emul_lib, allow_emulation=True).run(1800)
+    for v in ("CO2_concentration", "global_tas"):
+        assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
