@@ -38,29 +38,45 @@ HBM_PEAK = 8.0e12                               # MI355X_MICROARCH.md: 8 TB/s sp
 YEARS = 555
 
 
-def cpu_baseline(n_threads, members_per_thread, biomes):
-    """Oracle on host cores: ctypes releases the GIL, one thread per core."""
-    import numpy as np
+def effective_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(target_seconds=15.0):
+    """Oracle on the host cores (ctypes releases the GIL: one thread per usable core),
+    on a bounded sample of the same seeded ensemble, 555-year loop only."""
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_binding
     import hector_amd
     from hector_amd import ensemble
     orc = oracle_binding.Oracle(hector_amd.DEFAULT_SCENARIO)
-    n = n_threads * members_per_thread
+    cores = effective_cores()
+    S, q10 = ensemble.ecs_q10(8)
+    t0 = time.perf_counter()
+    orc.run_ecs_q10(S, q10)
+    per_member = (time.perf_counter() - t0) / 8
+    per_thread = int(min(4096, max(16, target_seconds / per_member)))
+    n = cores * per_thread
     S, q10 = ensemble.ecs_q10(n)
 
     def work(t):
-        sl = slice(t * members_per_thread, (t + 1) * members_per_thread)
-        _, _, err = orc.run_ecs_q10(S[sl], q10[sl])
-        return err
-    work(0) if members_per_thread <= 8 else orc.run_ecs_q10(S[:4], q10[:4])  # warm
+        sl = slice(t * per_thread, (t + 1) * per_thread)
+        return orc.run_ecs_q10(S[sl], q10[sl])[2]
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(n_threads) as ex:
-        errs = list(ex.map(work, range(n_threads)))
+    with ThreadPoolExecutor(cores) as ex:
+        errs = list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     assert not any(errs)
-    return n * YEARS / dt, dt, n
+    return n * YEARS / dt, dt, n, cores
 
 
 def main():
@@ -71,7 +87,8 @@ def main():
     ap.add_argument("--members", type=int, default=65536, help="members per GPU")
     ap.add_argument("--biomes", type=int, default=1, choices=[1, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-members-per-thread", type=int, default=256)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target wall time of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
     import numpy as np
@@ -185,8 +202,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            v, dt, ns = cpu_baseline(cores, args.cpu_members_per_thread, args.biomes)
+            v, dt, ns, cores = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": v, "unit": "member-years/s", "cores": cores, "kind": "port",
                 "sample": "%d members (first of the same seeded ECS/Q10 ensemble) x 555 years, "

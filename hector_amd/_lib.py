@@ -61,6 +61,7 @@ def _declare(lib):
         "hx_stats_device": [P, c.c_char_p, c.c_int, c.c_int, P],
         "hx_status": [P, c.POINTER(c.c_uint)],
         "hx_spinup_steps": [P, c.c_int, c.POINTER(c.c_int)],
+        "hx_state_row": [P, c.c_int, dp],
         "hx_dates": [P, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "hx_sizes": [P, c.POINTER(c.c_int), c.POINTER(c.c_int)],
         "hx_last_run_ms": [P, dp],
@@ -76,5 +77,5 @@ def _declare(lib):
 ABI_SYMBOLS = ["hx_backend", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_setvar",
                "hx_getvar", "hx_split_biome", "hx_set_outputs", "hx_output_capabilities",
                "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
-               "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_dates", "hx_sizes",
+               "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_state_row", "hx_dates", "hx_sizes",
                "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream"]

@@ -137,6 +137,12 @@ class Core:
         self._ck(self._lib.hx_status(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint))))
         return out
 
+    def state_row(self, row):
+        out = np.empty(self.n_members)
+        self._ck(self._lib.hx_state_row(self._h, int(row),
+                                        out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
+
     def spinup_steps(self, member=0):
         s = ctypes.c_int()
         self._ck(self._lib.hx_spinup_steps(self._h, int(member), ctypes.byref(s)))

@@ -7,10 +7,10 @@
 #include <stdexcept>
 
 // launchers defined in hx_kernels.hip
-hipError_t hx_launch_spinup(int B, const HxBuffers &buf, const HxConst &kc, int nmem_launch,
-                            int *d_steps, hipStream_t st);
-hipError_t hx_launch_run(int B, const HxBuffers &buf, const HxConst &kc, int iy_from, int iy_to,
-                         hipStream_t st);
+hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
+                            hipStream_t st);
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, int iy_from,
+                         int iy_to, hipStream_t st);
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
@@ -268,7 +268,9 @@ void EnsembleCore::build_shared() {
 void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
+  fr(d_args_);
   d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
+  d_args_ = nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) { fr(d_out_[v]); d_out_[v] = nullptr; }
 }
 
@@ -282,6 +284,7 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_ker_, sizeof(double) * ns * np), "hipMalloc ker");
   check(hipMalloc(&d_status_, sizeof(unsigned) * np * 2), "hipMalloc status");
   check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
+  check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
   for (int v = 0; v < HXO_NVAR; ++v)
     if (out_enabled_[v]) {
       check(hipMalloc(&d_out_[v], sizeof(double) * ns * np), "hipMalloc out");
@@ -434,6 +437,13 @@ void EnsembleCore::upload_params() {
   // DOECLIM convolution kernel: one shared table when every member has the same
   // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]
   ker_per_member_ = !row_uniform_[HXP_DIFF];
+  {
+    HxArgs a;
+    a.buf = buffers();
+    a.kc = kc_;
+    check(hipMemcpyAsync(d_args_, &a, sizeof a, hipMemcpyHostToDevice, stream_), "upload args");
+    check(hipStreamSynchronize(stream_), "sync args");
+  }
   check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
                                  ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,
                                  stream_), "doeclim kernel table");
@@ -456,9 +466,8 @@ void EnsembleCore::prepare() {
         if (!row_uniform_[HXP_NGLOBAL + b * HXPB_N + d.row]) uniform = false;
     } else if (!row_uniform_[d.row]) uniform = false;
   }
-  const HxBuffers b = buffers();
   check(hipEventRecord(ev0_, stream_), "event");
-  check(hx_launch_spinup(B_, b, kc_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
+  check(hx_launch_spinup(B_, d_args_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
   if (uniform) {
     check(hx_launch_broadcast(d_state_, HX_NSTATE(B_), npad_, stream_), "broadcast state");
     check(hx_launch_broadcast_u32(d_status_, npad_, stream_), "broadcast status");
@@ -509,9 +518,9 @@ void EnsembleCore::run(double runtodate) {
     throw std::runtime_error("Requested run-to date is after the configured end date.");
   const int target = (int)runtodate - scen_.start;
   if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
-  const HxBuffers b = buffers();
   check(hipEventRecord(ev0_, stream_), "event");
-  check(hx_launch_run(B_, b, kc_, last_iy_, target, stream_), "run kernel");
+  check(hx_launch_run(B_, d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, last_iy_, target,
+                      stream_), "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
   last_iy_ = target;
@@ -566,6 +575,14 @@ void EnsembleCore::status(unsigned *out_host) {
   sync();
   check(hipMemcpy(out_host, d_status_, sizeof(unsigned) * (size_t)n_, hipMemcpyDeviceToHost),
         "status");
+}
+
+void EnsembleCore::state_row(int row, double *out_host) {
+  prepare();
+  sync();
+  if (row < 0 || row >= HX_NSTATE(B_)) throw std::runtime_error("state_row: bad row");
+  check(hipMemcpy(out_host, d_state_ + (size_t)row * npad_, sizeof(double) * (size_t)n_,
+                  hipMemcpyDeviceToHost), "state row");
 }
 
 int EnsembleCore::spinup_steps(int member) {

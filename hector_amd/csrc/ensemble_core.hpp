@@ -65,6 +65,7 @@ class EnsembleCore {
   // of (year1-year0+1)*5 doubles (caller-owned, e.g. a torch tensor for RCCL)
   void stats_device(const std::string &capability, int year0, int year1, double *d_stats);
   void status(unsigned *out_host);
+  void state_row(int row, double *out_host);
   int spinup_steps(int member);
 
   double last_run_kernel_ms() const { return run_ms_; }
@@ -98,6 +99,7 @@ class EnsembleCore {
   double *d_out_[HXO_NVAR];
   unsigned *d_status_ = nullptr;
   int *d_spin_steps_ = nullptr;
+  HxArgs *d_args_ = nullptr;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool run_timed_ = false;

@@ -101,6 +101,10 @@ int hx_spinup_steps(hx_core *core, int member, int *steps) {
   if (!steps) return fail("null argument");
   HX_TRY(*steps = core->core->spinup_steps(member))
 }
+int hx_state_row(hx_core *core, int row, double *out) {
+  if (!out) return fail("null argument");
+  HX_TRY(core->core->state_row(row, out))
+}
 int hx_dates(hx_core *core, int *start, int *end, int *current) {
   HX_TRY(if (start) *start = core->core->start_date(); if (end) *end = core->core->end_date();
          if (current) *current = core->core->last_date())

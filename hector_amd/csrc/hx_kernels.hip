@@ -175,6 +175,7 @@ struct Member {
   double annualflux_sum, nbp;
   int nstash, nsteps;
   double ode_start;
+  bool chem_fresh;  // pco2H/L already computed for the current box carbon
 };
 
 // rhs constants that only change at a stash (pools frozen in between,
@@ -284,8 +285,14 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     aH = 1.000 * yf;
     aL = -1.000 * yf;
   } else {
-    m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
-    m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+    // compute_fluxes re-runs the chemistry with the PRE-update carbon; at the
+    // first stash of a year that is the carbon the year-start solve already used
+    // (same T, DIC, alk -> same result), so only later stashes need a new solve
+    if (!m.chem_fresh) {
+      m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
+      m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+    }
+    m.chem_fresh = false;
     aH = surf_flux(co2, m.pco2H, 1.0, m.kH.Tr, O_AsHL) * yf;
     aL = surf_flux(co2, m.pco2L, 1.0, m.kL.Tr, O_AsLL) * yf;
   }
@@ -368,13 +375,21 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
   m.ode_start = t;
 }
 
-// CarbonCycleSolver::run for one model year t0 -> tnew, all 64 lanes in
-// lock-step over "one try_step attempt or one stash" iterations.
+// exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
+// scales the next trial step, so ~1e-15 relative error is immaterial.
+__device__ __forceinline__ double powr(double x, double p) { return exp(p * log(x)); }
+
+// CarbonCycleSolver::run for one model year t0 -> tnew (carbon-cycle-solver.cpp:
+// 222-303).  The 64 lanes walk the reference's control flow in lock-step over
+// SEGMENTS (one stash interval each): inner loop = dopri5 attempts until every
+// lane has reached its own t_target (retries only move t_target), then ONE stash
+// block for all lanes.  Lanes in reduced-timestep mode take up to 4 segments a
+// year, the others idle through the extra ones; the expensive step and stash
+// blocks are never interleaved lane by lane.
 template <int B, bool SPIN>
 __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                                            double t0, double tnew) {
   // dopri5 tableau (odeint runge_kutta_dopri5)
-  constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
   constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
                    b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
                    b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
@@ -385,7 +400,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
                    dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
                    dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
-  (void)a2; (void)a3; (void)a4; (void)a5;
+  constexpr double EPS = 2.220446049250313e-16;
 
   Interval K;
   prep_interval<B, SPIN>(m, K);
@@ -396,26 +411,30 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 #pragma unroll
     for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                    p += m.pf[b]; th += m.thawed[b]; }
-    y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = K.totC;
+    y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;
     l4 = p; l5 = th; l7 = m.earth;
   };
   load_pools();
   m.ode_start = t0;
-  double t = t0;            // time reached by accepted steps
-  double t_start = t0, t_target = tnew;
-  double dtl = m.sdt;       // integrate_adaptive's by-value dt
-  double dxdt[5];
-  bool first_call = true;   // fresh controlled stepper per integrate_adaptive
-  int retry = 0, fails = 0;
-  bool active = true;
-  while (__any(active)) {
-    if (active) {
-      if ((t_target - t) > 2.220446049250313e-16) {  // less_with_sign(t, t1)
+  double t = t0;   // time reached by accepted steps
+  int retry = 0;
+  bool alive = true;
+  while (__any(alive && t < tnew)) {
+    const bool seg = alive && t < tnew;
+    // fresh integrate_adaptive call: by-value dt, fresh controlled stepper
+    const double t_start = t;
+    double t_target = tnew, dtl = m.sdt;
+    double dxdt[5];
+    bool first_call = true;
+    int fails = 0;
+    bool stepping = seg;
+    while (__any(stepping)) {
+      if (stepping) {
         if (first_call) { rhs<B, SPIN>(m, K, y, dxdt); first_call = false; }
-        if (((t + dtl) - t_target) > 2.220446049250313e-16) dtl = t_target - t;
-        // Every dopri5 stage time is <= t+dtl, and the model refuses any
-        // RHS evaluation beyond max_timestep (ocean_component.cpp:621-625),
-        // so the attempt throws CARBON_CYCLE_RETRY iff its last stage does.
+        if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
+        // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
+        // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
+        // attempt throws CARBON_CYCLE_RETRY iff its last stage does.
         if (((t + dtl) - m.ode_start) > m.max_ts) {
           ++retry;  // carbon-cycle-solver.cpp:266-276
           t_target = t_start + (t_target - t_start) / 2.0;
@@ -425,7 +444,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           load_pools();
           first_call = true;
           fails = 0;
-          if (retry >= 8) { m.status |= HX_ERR_RETRIES; active = false; }
+          if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
         } else {
           double k2[5], k3[5], k4[5], k5[5], k6[5], xt[5], xn[5], dn[5];
 #pragma unroll
@@ -465,37 +484,30 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             err = fmax(err, e);
           }
           if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
-            dtl *= fmax(0.9 * pow(err, -1.0 / 3.0), 0.2);
-            if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; active = false; }
+            dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
+            if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
           } else {          // accept
             // pools with a constant derivative over the interval advance exactly
             l4 += dtl * K.k4; l5 += dtl * K.k5; l7 += dtl * K.k7;
             t += dtl;
-            if (err < 0.5) {  // increase_step
-              err = fmax(0.00032, err);  // 5^-5
-              dtl *= 0.9 * pow(err, -1.0 / 5.0);
-            }
+            // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
+            const double grow = 0.9 * powr(fmax(0.00032, err), -1.0 / 5.0);
+            if (err < 0.5) dtl *= grow;
 #pragma unroll
             for (int i = 0; i < 5; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
             fails = 0;
             m.nsteps++;
+            if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
           }
         }
-      } else {
-        // integrate_adaptive returned: we are at t_target -> stash
-        retry = 0;
-        stash<B, SPIN>(m, t, y, l4, l5, l7);
-        if (t < tnew) {
-          // the solver keeps integrating its own c[] (no getCValues here,
-          // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
-          prep_interval<B, SPIN>(m, K);
-          t_start = t; t_target = tnew;
-          dtl = m.sdt;
-          first_call = true;
-        } else {
-          active = false;
-        }
       }
+    }
+    if (seg && alive) {
+      // the solver keeps integrating its own c[] afterwards (no getCValues,
+      // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
+      retry = 0;
+      stash<B, SPIN>(m, t, y, l4, l5, l7);
+      if (t < tnew) prep_interval<B, SPIN>(m, K);
     }
   }
 }
@@ -507,6 +519,12 @@ __device__ __forceinline__ double equilibrate_alk(const ChemK &k, double carbon,
                                                   double inv_vol, double As,
                                                   double co2, double f_target,
                                                   double &h, unsigned &status) {
+  // Brent's branch decisions hinge on differences of nearly equal numbers (it is
+  // minimising a V-shaped |flux - target|); its resolution here is only
+  // tol/4 = 7.5e-9 absolute = 3e-6 of the alkalinity, so a different path ends
+  // 1e-6..1e-5 away and moves CO2 by up to ~3e-6 relative.  Keep the arithmetic of
+  // the decision logic exactly the reference's: no FMA contraction in here.
+#pragma clang fp contract(off)
   auto fmin_ = [&](double alk) {
     const double p = chem_solve(k, carbon, inv_vol, alk, h, status);
     return fabs(surf_flux(co2, p, 1.0, k.Tr, As) - f_target);
@@ -675,8 +693,10 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf, int mem,
 // Initialises the whole state table from the parameter rows.
 // ===========================================================================
 template <int B>
-__global__ __launch_bounds__(64) void hx_spinup_kernel(HxBuffers buf, HxConst kc,
+__global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict__ args,
                                                        int *spinup_steps) {
+  const HxBuffers &buf = args->buf;
+  const HxConst &kc = args->kc;
   const int mem = blockIdx.x * 64 + threadIdx.x;
   if (mem >= buf.npad) return;
   Member<B> m;
@@ -710,6 +730,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(HxBuffers buf, HxConst kc
   m.npp_luc_adjust = 1.0;  // (eos - 0)/eos
   m.pco2H = m.pco2L = 0; m.annualflux_sum = 0; m.nbp = 0; m.nsteps = 0;
   m.kH.Tr = m.kL.Tr = 0;
+  m.chem_fresh = false;
 
   bool spun = (kc.max_spinup <= 1);
   int steps = 0;
@@ -773,9 +794,11 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(HxBuffers buf, HxConst kc
 // ===========================================================================
 // Main run: years (iy_from, iy_to] (indices relative to startDate).
 // ===========================================================================
-template <int B>
-__global__ __launch_bounds__(64) void hx_run_kernel(HxBuffers buf, HxConst kc,
+template <int B, bool HF>
+__global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
+  const HxBuffers &buf = args->buf;
+  const HxConst &kc = args->kc;
   // LDS (dynamic, sized by the launcher): per-lane partial sums of the current
   // DOECLIM block and the SSTs produced inside it
   extern __shared__ double s_lds[];
@@ -848,7 +871,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(HxBuffers buf, HxConst kc,
     dpscale = fso * sq;
     hfscale = cas * fso / sqrt(taudif);
   }
-  const bool want_hf = buf.out[HXO_HEATFLUX] != nullptr;
+  constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   const double *sst_hist = buf.out[HXO_SST];
   int blk0 = -1;  // first year index of the current DOECLIM block
 
@@ -887,6 +910,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(HxBuffers buf, HxConst kc,
     }
     m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
     m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+    m.chem_fresh = true;
     // ================= slowparameval (t = year-1) ============================
     m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
     m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
@@ -1154,30 +1178,36 @@ __global__ __launch_bounds__(256) void hx_doeclim_table_kernel(const double *dif
 // host-callable launchers (the only symbols the host runtime uses)
 // ---------------------------------------------------------------------------
 extern "C++" {
-hipError_t hx_launch_spinup(int B, const HxBuffers &buf, const HxConst &kc,
-                            int nmem_launch, int *d_steps, hipStream_t st) {
-  HxBuffers b = buf;
+hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
+                            hipStream_t st) {
   const int blocks = (nmem_launch + 63) / 64;
-  if (nmem_launch < b.npad) { /* prototype launch: still index rows with npad */ }
   switch (B) {
-    case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
-    case 2: hipLaunchKernelGGL(hx_spinup_kernel<2>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
-    case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
-    case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, b, kc, d_steps); break;
+    case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 2: hipLaunchKernelGGL(hx_spinup_kernel<2>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t hx_launch_run(int B, const HxBuffers &buf, const HxConst &kc, int iy_from,
+template <int B>
+static void launch_run_b(const HxArgs *d_args, int npad, bool hf, int iy_from, int iy_to,
+                         hipStream_t st) {
+  const int blocks = npad / 64;
+  const size_t lds = (size_t)(hf ? 3 : 2) * HX_DBLK * 64 * sizeof(double);
+  if (hf)
+    hipLaunchKernelGGL((hx_run_kernel<B, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else
+    hipLaunchKernelGGL((hx_run_kernel<B, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+}
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, int iy_from,
                          int iy_to, hipStream_t st) {
-  const int blocks = buf.npad / 64;
-  const size_t lds = (size_t)(buf.out[HXO_HEATFLUX] ? 3 : 2) * HX_DBLK * 64 * sizeof(double);
   switch (B) {
-    case 1: hipLaunchKernelGGL(hx_run_kernel<1>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
-    case 2: hipLaunchKernelGGL(hx_run_kernel<2>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
-    case 3: hipLaunchKernelGGL(hx_run_kernel<3>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
-    case 4: hipLaunchKernelGGL(hx_run_kernel<4>, dim3(blocks), dim3(64), lds, st, buf, kc, iy_from, iy_to); break;
+    case 1: launch_run_b<1>(d_args, npad, heatflux, iy_from, iy_to, st); break;
+    case 2: launch_run_b<2>(d_args, npad, heatflux, iy_from, iy_to, st); break;
+    case 3: launch_run_b<3>(d_args, npad, heatflux, iy_from, iy_to, st); break;
+    case 4: launch_run_b<4>(d_args, npad, heatflux, iy_from, iy_to, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -104,3 +104,10 @@ struct HxBuffers {
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
   int n, npad, ker_per_member;
 };
+
+// kernel arguments live in device memory (one copy per core) and are read through
+// wave-uniform scalar loads on demand -- passing them by value would pin ~110 SGPRs
+struct HxArgs {
+  HxBuffers buf;
+  HxConst kc;
+};

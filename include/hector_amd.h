@@ -97,6 +97,12 @@ int hx_stats_device(hx_core *core, const char *capability, int year0, int year1,
 int hx_status(hx_core *core, unsigned *out);
 int hx_spinup_steps(hx_core *core, int member, int *steps);
 
+/* Diagnostic: one row of the per-member state table (hx_layout.h HxStateRow /
+ * HxBiomeState numbering) at the current date, host array of n_members.  The
+ * reference exposes the same quantities as undated GETDATA (e.g. ocean box
+ * carbon, max timestep: src/ocean_component.cpp:422-512). */
+int hx_state_row(hx_core *core, int row, double *out);
+
 /* core metadata: startDate, endDate, current date, members, biomes */
 int hx_dates(hx_core *core, int *start, int *end, int *current);
 int hx_sizes(hx_core *core, int *n_members, int *n_biomes);
