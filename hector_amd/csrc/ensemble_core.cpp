@@ -9,12 +9,14 @@
 // launchers defined in hx_kernels.hip
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st);
-hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, int iy_from,
-                         int iy_to, hipStream_t st);
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm,
+                         int iy_from, int iy_to, hipStream_t st);
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
                            double *stats, hipStream_t st);
+hipError_t hx_launch_derive(const double *params, double *derived, const double *ker,
+                            int ker_per_member, int ns, int nbiome, int npad, hipStream_t st);
 hipError_t hx_launch_doeclim_kernel(const double *diff_row, double *ker, int ns, int count,
                                     int stride, hipStream_t st);
 
@@ -268,7 +270,8 @@ void EnsembleCore::build_shared() {
 void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
-  fr(d_args_);
+  fr(d_args_); fr(d_derived_);
+  d_derived_ = nullptr;
   d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
   d_args_ = nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) { fr(d_out_[v]); d_out_[v] = nullptr; }
@@ -281,10 +284,12 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
   check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
   check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
-  check(hipMalloc(&d_ker_, sizeof(double) * ns * np), "hipMalloc ker");
+  // DOECLIM kernel table, zero-padded by HX_KPAD (= 16) entries on both sides
+  check(hipMalloc(&d_ker_, sizeof(double) * (ns + 32) * np), "hipMalloc ker");
   check(hipMalloc(&d_status_, sizeof(unsigned) * np * 2), "hipMalloc status");
   check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
+  check(hipMalloc(&d_derived_, sizeof(double) * np * HX_NDERIVED(B_)), "hipMalloc derived");
   for (int v = 0; v < HXO_NVAR; ++v)
     if (out_enabled_[v]) {
       check(hipMalloc(&d_out_[v], sizeof(double) * ns * np), "hipMalloc out");
@@ -299,7 +304,7 @@ void EnsembleCore::alloc_device() {
 
 HxBuffers EnsembleCore::buffers() const {
   HxBuffers b;
-  b.params = d_params_; b.state = d_state_; b.status = d_status_; b.shared = d_shared_;
+  b.params = d_params_; b.derived = d_derived_; b.state = d_state_; b.status = d_status_; b.shared = d_shared_;
   b.ker = d_ker_;
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
@@ -437,6 +442,13 @@ void EnsembleCore::upload_params() {
   // DOECLIM convolution kernel: one shared table when every member has the same
   // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]
   ker_per_member_ = !row_uniform_[HXP_DIFF];
+  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 32) * np, stream_),
+        "zero ker");
+  check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
+                                 ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,
+                                 stream_), "doeclim kernel table");
+  check(hx_launch_derive(d_params_, d_derived_, d_ker_, ker_per_member_ ? 1 : 0, scen_.ns(), B_,
+                         npad_, stream_), "derive kernel");
   {
     HxArgs a;
     a.buf = buffers();
@@ -444,9 +456,6 @@ void EnsembleCore::upload_params() {
     check(hipMemcpyAsync(d_args_, &a, sizeof a, hipMemcpyHostToDevice, stream_), "upload args");
     check(hipStreamSynchronize(stream_), "sync args");
   }
-  check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
-                                 ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,
-                                 stream_), "doeclim kernel table");
   params_dirty_ = false;
 }
 
@@ -519,8 +528,8 @@ void EnsembleCore::run(double runtodate) {
   const int target = (int)runtodate - scen_.start;
   if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
   check(hipEventRecord(ev0_, stream_), "event");
-  check(hx_launch_run(B_, d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, last_iy_, target,
-                      stream_), "run kernel");
+  check(hx_launch_run(B_, d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_,
+                      last_iy_, target, stream_), "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
   last_iy_ = target;

@@ -1,0 +1,16 @@
+// hx_addrspace.h -- pointers fetched from the kernel-argument block are "generic"
+// to the compiler, which then emits flat_load/flat_store (slower, and they tie up
+// both wait counters).  Everything per-member lives in HBM: say so.
+#pragma once
+#define HX_GLOBAL __attribute__((address_space(1)))
+typedef const double HX_GLOBAL *hx_gcd;  // global const double*
+typedef double HX_GLOBAL *hx_gd;         // global double*
+typedef unsigned HX_GLOBAL *hx_gu;
+// wave-uniform read-only tables (scenario series, shared DOECLIM kernel): the constant
+// address space lets the compiler use scalar loads (s_load) and SGPR operands
+#define HX_CONSTANT __attribute__((address_space(4)))
+typedef const double HX_CONSTANT *hx_ccd;
+#define HX_CCD(p) ((hx_ccd)(p))
+#define HX_GCD(p) ((hx_gcd)(p))
+#define HX_GD(p) ((hx_gd)(p))
+#define HX_GU(p) ((hx_gu)(p))

@@ -32,9 +32,12 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <hx_addrspace.h>
+
 #include "hx_layout.h"
 
 #define HX_DBLK 16  // DOECLIM block length (years per SST-history pass)
+#define HX_KPAD HX_DBLK  // zero entries in front of / behind the Ker table
 
 namespace {
 
@@ -152,20 +155,24 @@ __device__ __forceinline__ double surf_flux(double co2, double pco2, double scal
 }
 
 // ---------------------------------------------------------------------------
+// A compiler-only fence: values cached from memory may not be carried across it.
+// The year loop is split into phases by these so that per-member constants that a
+// phase needs are (re)loaded from HBM / L2 inside the phase instead of being kept
+// in registers across the whole solver -- register pressure, not bandwidth, is what
+// limits this kernel (DESIGN.md "registers").
+#define HX_FENCE() asm volatile("" ::: "memory")
+
+// What stays in registers through the carbon-cycle solver of one year.
 template <int B>
 struct Member {
-  // parameters
-  double C0, aero, vol;
-  double beta[B], q10[B], wf[B], npp0[B], f_nppv[B], f_nppd[B], f_litterd[B],
-      rh_ch4_frac[B], pf_mu[B], pf_sigma[B], fpf_static[B];
-  double kLH, kLI, kHD, kIL, kIH, kID, kDI;  // ocean exchange, 1/yr
+  double C0;
   // state
   double cHL, cLL, cIO, cDO, atmos, earth;
-  double veg[B], det[B], soil[B], pf[B], thawed[B], tempferts[B], f_frozen[B];
-  double cum_luc_va, cum_pf_ch4, masstot, eos_vegc;
+  double veg[B], det[B], soil[B], pf[B], thawed[B], tempferts[B];
+  double cum_luc_va, cum_pf_ch4, masstot;
   double max_ts, lastflux_ann, sdt;
   int ts_timeout;
-  double ch4, alkH, alkL, hH, hL;
+  double alkH, alkL, hH, hL;
   unsigned status;
   // per-year
   double co2fert[B], tempfertd[B], f_new_thaw[B];
@@ -176,7 +183,31 @@ struct Member {
   int nstash, nsteps;
   double ode_start;
   bool chem_fresh;  // pco2H/L already computed for the current box carbon
+  // where this lane's constants live
+  hx_gcd par;  // params + mem   (row stride npad)
+  hx_gcd der;  // derived + mem
+  int npad;
 };
+
+// biome constants of the land model, fetched where they are used
+template <int B>
+struct LandK {
+  double npp0[B], f_nppv[B], f_nppd[B], f_litterd[B], rh_ch4_frac[B], fpf_static[B];
+};
+template <int B>
+__device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
+  HX_FENCE();
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
+    k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
+    k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
+    k.f_nppd[b] = r[(size_t)HXPB_F_NPPD * m.npad];
+    k.f_litterd[b] = r[(size_t)HXPB_F_LITTERD * m.npad];
+    k.rh_ch4_frac[b] = r[(size_t)HXPB_RH_CH4_FRAC * m.npad];
+    k.fpf_static[b] = r[(size_t)HXPB_FPF_STATIC * m.npad];
+  }
+}
 
 // rhs constants that only change at a stash (pools frozen in between,
 // src/simpleNbox-runtime.cpp:809-840)
@@ -185,8 +216,8 @@ struct Interval {
   double totC, surf, inv_surf;
 };
 
-template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, int b) {
-  return (m.npp0[b] * m.co2fert[b]) * m.npp_luc_adjust;  // :622-635
+template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, const LandK<B> &k, int b) {
+  return (k.npp0[b] * m.co2fert[b]) * m.npp_luc_adjust;  // :622-635
 }
 template <int B> __device__ __forceinline__ double m_rh_fda(const Member<B> &m, int b) {
   return (m.det[b] * 0.25) * m.tempfertd[b];  // :653-665
@@ -194,34 +225,35 @@ template <int B> __device__ __forceinline__ double m_rh_fda(const Member<B> &m, 
 template <int B> __device__ __forceinline__ double m_rh_fsa(const Member<B> &m, int b) {
   return (m.soil[b] * 0.02) * m.tempferts[b];  // :671-683
 }
-template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &m, int b) {
-  return ((m.thawed[b] * (1 - m.fpf_static[b])) * 0.02) * m.tempferts[b] *
-         (1.0 - m.rh_ch4_frac[b]);  // :689-701
+template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &m, const LandK<B> &k, int b) {
+  return ((m.thawed[b] * (1 - k.fpf_static[b])) * 0.02) * m.tempferts[b] *
+         (1.0 - k.rh_ch4_frac[b]);  // :689-701
 }
-template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, int b) {
-  return m_rh_tp_co2(m, b) / (1.0 - m.rh_ch4_frac[b]) * m.rh_ch4_frac[b];  // :707-711
+template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, const LandK<B> &k, int b) {
+  return m_rh_tp_co2(m, k, b) / (1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
 }
 
 template <int B, bool SPIN>
-__device__ __forceinline__ void prep_interval(const Member<B> &m, Interval &K) {
+__device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
+                                              Interval &K) {
   double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
   double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
 #pragma unroll
   for (int b = 0; b < B; ++b) {
-    const double n = m_npp(m, b);
+    const double n = m_npp(m, lk, b);
     npp_c += n;
-    fav += n * m.f_nppv[b];
-    fad += n * m.f_nppd[b];
-    fas += n * (1 - m.f_nppv[b] - m.f_nppd[b]);
+    fav += n * lk.f_nppv[b];
+    fad += n * lk.f_nppd[b];
+    fas += n * (1 - lk.f_nppv[b] - lk.f_nppd[b]);
     fda += m_rh_fda(m, b);
     fsa += m_rh_fsa(m, b);
-    const double co2 = m_rh_tp_co2(m, b), ch4 = m_rh_tp_ch4(m, b);
+    const double co2 = m_rh_tp_co2(m, lk, b), ch4 = m_rh_tp_ch4(m, lk, b);
     tpc += co2;
     tpm += ch4;
     const double v = m.veg[b] * 0.035;
     litter += v;
-    lfvd += v * m.f_litterd[b];
-    lfvs += v * (1 - m.f_litterd[b]);
+    lfvd += v * lk.f_litterd[b];
+    lfvs += v * (1 - lk.f_litterd[b]);
     detsoil += m.det[b] * 0.6;
     if (!SPIN) {  // compute_pf_thaw_refreeze :744-772
       double c_thaw = m.pf[b] * m.f_new_thaw[b];
@@ -275,7 +307,14 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K,
 // OceanComponent::stashCValues + SimpleNbox::stashCValues for one lane
 template <int B, bool SPIN>
 __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
-                                      double c4, double c5, double c7) {
+                                      double c4, double c5, double c7, Interval &K,
+                                      bool more) {
+  LandK<B> lk;
+  load_landk<B>(m, lk);
+  const double kHD = m.der[(size_t)HXD_KHD * m.npad], kLH = m.der[(size_t)HXD_KLH * m.npad],
+               kLI = m.der[(size_t)HXD_KLI * m.npad], kIL = m.der[(size_t)HXD_KIL * m.npad],
+               kIH = m.der[(size_t)HXD_KIH * m.npad], kID = m.der[(size_t)HXD_KID * m.npad],
+               kDI = m.der[(size_t)HXD_KDI * m.npad];
   const double yf = t - m.ode_start;
   m.nstash++;
   const bool in_partial_year = (t != floor(t));
@@ -297,11 +336,11 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     aL = surf_flux(co2, m.pco2L, 1.0, m.kL.Tr, O_AsLL) * yf;
   }
   // box-to-box transports, oceanbox.cpp:244-257 (order: HL, LL, IO, DO)
-  const double lHD = m.cHL * m.kHD * yf;
-  const double lLH = m.cLL * m.kLH * yf, lLI = m.cLL * m.kLI * yf;
-  const double lIL = m.cIO * m.kIL * yf, lIH = m.cIO * m.kIH * yf,
-               lID = m.cIO * m.kID * yf;
-  const double lDI = m.cDO * m.kDI * yf;
+  const double lHD = m.cHL * kHD * yf;
+  const double lLH = m.cLL * kLH * yf, lLI = m.cLL * kLI * yf;
+  const double lIL = m.cIO * kIL * yf, lIH = m.cIO * kIH * yf,
+               lID = m.cIO * kID * yf;
+  const double lDI = m.cDO * kDI * yf;
   const double currentflux = aH + aL;
   const double totC = m.cDO + m.cIO + m.cLL + m.cHL;
   const double solver_flux = y[4] - totC;
@@ -332,10 +371,10 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
   // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
   double npp_t = 0, rh_t = 0, pf_t = 0;
 #pragma unroll
-  for (int b = 0; b < B; ++b) npp_t += m_npp(m, b);
+  for (int b = 0; b < B; ++b) npp_t += m_npp(m, lk, b);
 #pragma unroll
   for (int b = 0; b < B; ++b)
-    rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, b);
+    rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
 #pragma unroll
   for (int b = 0; b < B; ++b) pf_t += m.pf[b];
   m.nbp = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
@@ -351,9 +390,9 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const double wt = (B == 1) ? 1.0
-        : (m_npp(m, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, b))) * inv_nr;
+        : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
     const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
-    m.cum_pf_ch4 += m_rh_tp_ch4(m, b) * yf;  // :481
+    m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
     m.veg[b] = y[1] * wt;
     m.det[b] = y[2] * wt;
     m.soil[b] = y[3] * wt;
@@ -373,6 +412,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     m.atmos = m.atmos - residual;
   }
   m.ode_start = t;
+  if (more) prep_interval<B, SPIN>(m, lk, K);  // frozen-pool constants of the next segment
 }
 
 // exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
@@ -403,7 +443,11 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   constexpr double EPS = 2.220446049250313e-16;
 
   Interval K;
-  prep_interval<B, SPIN>(m, K);
+  {
+    LandK<B> lk;
+    load_landk<B>(m, lk);
+    prep_interval<B, SPIN>(m, lk, K);
+  }
   // getCValues  simpleNbox-runtime.cpp:247-258
   double y[5], l4, l5, l7;
   auto load_pools = [&]() {
@@ -506,8 +550,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       // the solver keeps integrating its own c[] afterwards (no getCValues,
       // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
       retry = 0;
-      stash<B, SPIN>(m, t, y, l4, l5, l7);
-      if (t < tnew) prep_interval<B, SPIN>(m, K);
+      stash<B, SPIN>(m, t, y, l4, l5, l7, K, t < tnew);
     }
   }
 }
@@ -581,51 +624,27 @@ __device__ __forceinline__ double equilibrate_alk(const ChemK &k, double carbon,
 
 // ---- SoA helpers ------------------------------------------------------------
 __device__ __forceinline__ double ldp(const HxBuffers &b, int row, int mem) {
-  return b.params[(size_t)row * b.npad + mem];
+  return HX_GCD(b.params)[(size_t)row * b.npad + mem];
 }
 __device__ __forceinline__ double lds_(const HxBuffers &b, int row, int mem) {
-  return b.state[(size_t)row * b.npad + mem];
+  return HX_GCD(b.state)[(size_t)row * b.npad + mem];
 }
 __device__ __forceinline__ void sts_(const HxBuffers &b, int row, int mem, double v) {
-  b.state[(size_t)row * b.npad + mem] = v;
+  HX_GD(b.state)[(size_t)row * b.npad + mem] = v;
+}
+__device__ __forceinline__ void sto_(const HxBuffers &b, int var, size_t off, double v) {
+  HX_GD(b.out[var])[off] = v;
 }
 
 template <int B>
-__device__ __forceinline__ void load_member(const HxBuffers &buf, int mem, Member<B> &m) {
+__device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Member<B> &m) {
+  m.par = HX_GCD(buf.params) + mem;
+  m.der = HX_GCD(buf.derived) + mem;
+  m.npad = buf.npad;
   m.C0 = ldp(buf, HXP_C0, mem);
-  m.aero = ldp(buf, HXP_AERO, mem);
-  m.vol = ldp(buf, HXP_VOL, mem);
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const int r = HXP_NGLOBAL + b * HXPB_N;
-    m.beta[b] = ldp(buf, r + HXPB_BETA, mem);
-    m.q10[b] = ldp(buf, r + HXPB_Q10, mem);
-    m.wf[b] = ldp(buf, r + HXPB_WF, mem);
-    m.npp0[b] = ldp(buf, r + HXPB_NPP0, mem);
-    m.f_nppv[b] = ldp(buf, r + HXPB_F_NPPV, mem);
-    m.f_nppd[b] = ldp(buf, r + HXPB_F_NPPD, mem);
-    m.f_litterd[b] = ldp(buf, r + HXPB_F_LITTERD, mem);
-    m.rh_ch4_frac[b] = ldp(buf, r + HXPB_RH_CH4_FRAC, mem);
-    m.pf_mu[b] = ldp(buf, r + HXPB_PF_MU, mem);
-    m.pf_sigma[b] = ldp(buf, r + HXPB_PF_SIGMA, mem);
-    m.fpf_static[b] = ldp(buf, r + HXPB_FPF_STATIC, mem);
-  }
-  // exchange coefficients  src/ocean_component.cpp:265-284
-  const double tt = ldp(buf, HXP_TT, mem), tu = ldp(buf, HXP_TU, mem),
-               twi = ldp(buf, HXP_TWI, mem), tid = ldp(buf, HXP_TID, mem);
-  m.kLH = (tt * O_spy) / O_vLL;
-  m.kHD = ((tt + tu) * O_spy) / O_vHL;
-  const double DO_IO = ((tt + tu) * O_spy) / O_vD;
-  m.kIH = (tu * O_spy) / O_vI;
-  const double IO_LL = (tt * O_spy) / O_vI;
-  const double IO_LLex = (twi * O_spy) / O_vI;
-  m.kLI = (twi * O_spy) / O_vLL;
-  const double DO_IOex = (tid * O_spy) / O_vD;
-  m.kID = (tid * O_spy) / O_vI;
-  m.kIL = IO_LL + IO_LLex;
-  m.kDI = DO_IO + DO_IOex;
 }
 
+// solver-resident state <-> HBM state table
 template <int B>
 __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member<B> &m) {
   m.cHL = lds_(buf, HXS_C_HL, mem); m.cLL = lds_(buf, HXS_C_LL, mem);
@@ -634,12 +653,10 @@ __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member
   m.cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem);
   m.cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem);
   m.masstot = lds_(buf, HXS_MASSTOT, mem);
-  m.eos_vegc = lds_(buf, HXS_EOS_VEGC, mem);
   m.max_ts = lds_(buf, HXS_MAX_TS, mem);
   m.ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
   m.lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
   m.sdt = lds_(buf, HXS_SOLVER_DT, mem);
-  m.ch4 = lds_(buf, HXS_CH4, mem);
   m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem);
   m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
 #pragma unroll
@@ -649,9 +666,8 @@ __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member
     m.soil[b] = lds_(buf, r + HXSB_SOIL, mem); m.pf[b] = lds_(buf, r + HXSB_PF, mem);
     m.thawed[b] = lds_(buf, r + HXSB_THAWED, mem);
     m.tempferts[b] = lds_(buf, r + HXSB_TEMPFERTS, mem);
-    m.f_frozen[b] = lds_(buf, r + HXSB_F_FROZEN, mem);
   }
-  m.status = buf.status[mem];
+  m.status = HX_GU(buf.status)[mem];
 }
 
 template <int B>
@@ -663,12 +679,10 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf, int mem,
   sts_(buf, HXS_CUM_LUC_VA, mem, m.cum_luc_va);
   sts_(buf, HXS_CUM_PF_CH4, mem, m.cum_pf_ch4);
   sts_(buf, HXS_MASSTOT, mem, m.masstot);
-  sts_(buf, HXS_EOS_VEGC, mem, m.eos_vegc);
   sts_(buf, HXS_MAX_TS, mem, m.max_ts);
   sts_(buf, HXS_TS_TIMEOUT, mem, (double)m.ts_timeout);
   sts_(buf, HXS_LASTFLUX_ANN, mem, m.lastflux_ann);
   sts_(buf, HXS_SOLVER_DT, mem, m.sdt);
-  sts_(buf, HXS_CH4, mem, m.ch4);
   sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
   sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
 #pragma unroll
@@ -678,12 +692,144 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf, int mem,
     sts_(buf, r + HXSB_SOIL, mem, m.soil[b]); sts_(buf, r + HXSB_PF, mem, m.pf[b]);
     sts_(buf, r + HXSB_THAWED, mem, m.thawed[b]);
     sts_(buf, r + HXSB_TEMPFERTS, mem, m.tempferts[b]);
-    sts_(buf, r + HXSB_F_FROZEN, mem, m.f_frozen[b]);
   }
-  buf.status[mem] = m.status;
+  HX_GU(buf.status)[mem] = m.status;
 }
 
 }  // namespace
+
+// ===========================================================================
+// Per-member derived constants, once per parameter upload: DOECLIM matrices and
+// time scales (temperature_component.cpp:251-412), ocean exchange coefficients
+// (ocean_component.cpp:265-284), ln(q10).  ker: DOECLIM kernel table.
+// ===========================================================================
+__global__ __launch_bounds__(256) void hx_derive_kernel(const double *params, double *derived,
+                                                        const double *ker, int ker_per_member,
+                                                        int ns, int nbiome, int npad) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mem >= npad) return;
+  auto P = [&](int row) { return params[(size_t)row * npad + mem]; };
+  auto D = [&](int row, double v) { derived[(size_t)row * npad + mem] = v; };
+  const double S = P(HXP_S), qco2 = P(HXP_QCO2), diff = P(HXP_DIFF);
+  const double flnd = D_flnd, bsi = D_bsi, rlam = D_rlam, ak = D_ak, bk = D_bk,
+               cal = D_cal, cas = D_cas, fso = D_fso;
+  const double cnum = rlam * flnd + bsi * (1.0 - flnd);
+  const double cden = rlam * flnd - ak * (rlam - bsi);
+  const double cfl = flnd * cnum / cden * qco2 / S - bk * (rlam - bsi) / cden;
+  const double cfs = (rlam * flnd - ak / (1.0 - flnd) * (rlam - bsi)) * cnum / cden *
+                         qco2 / S +
+                     rlam * flnd / (1.0 - flnd) * bk * (rlam - bsi) / cden;
+  const double kls = bk * rlam * flnd / cden - ak * flnd * cnum / cden * qco2 / S;
+  const double keff = (D_secs / 10000) * diff;
+  const double taucfs = cas / cfs, taucfl = cal / cfl;
+  const double taudif = (cas * cas) / (D_csw * D_csw) * M_PI / keff;
+  const double tauksl = (1.0 - flnd) * cas / kls, taukls = flnd * cal / kls;
+  double C0_ = 1.0 / (taucfl * taucfl) + 1.0 / (taukls * taukls) +
+               2.0 / taucfl / taukls + bsi / taukls / tauksl;
+  double C1_ = -1 * bsi / (taukls * taukls) - bsi / taucfl / taukls -
+               bsi / taucfs / taukls - (bsi * bsi) / taukls / tauksl;
+  double C2_ = -1 * bsi / (tauksl * tauksl) - 1.0 / taucfs / tauksl -
+               1.0 / taucfl / tauksl - 1.0 / taukls / tauksl;
+  double C3_ = 1.0 / (taucfs * taucfs) + (bsi * bsi) / (tauksl * tauksl) +
+               2.0 * bsi / taucfs / tauksl + bsi / taukls / tauksl;
+  C0_ *= 1.0 / 12.0; C1_ *= 1.0 / 12.0; C2_ *= 1.0 / 12.0; C3_ *= 1.0 / 12.0;
+  const double sq = sqrt(1.0 / taudif);
+  const double ker_last = ker_per_member ? ker[(size_t)(ns - 1 + HX_KPAD) * npad + mem]
+                                         : ker[ns - 1 + HX_KPAD];
+  const double B0 = 1.0 + 1.0 / (2.0 * taucfl) + 1.0 / (2.0 * taukls) + C0_;
+  const double B1 = -1.0 / (2.0 * taukls) * bsi + C1_;
+  const double B2 = -1.0 / (2.0 * tauksl) + C2_;
+  const double B3 = 1.0 + 1.0 / (2.0 * taucfs) + 1.0 / (2.0 * tauksl) * bsi +
+                    2.0 * fso * sq + C3_;
+  D(HXD_A0, 1.0 - 1.0 / (2.0 * taucfl) - 1.0 / (2.0 * taukls) + C0_);
+  D(HXD_A1, 1.0 / (2.0 * taukls) * bsi + C1_);
+  D(HXD_A2, 1.0 / (2.0 * tauksl) + C2_);
+  D(HXD_A3, 1.0 - 1.0 / (2.0 * taucfs) - 1.0 / (2.0 * tauksl) * bsi + ker_last * fso * sq + C3_);
+  const double det = B0 * B3 - B1 * B2;
+  const double idet = 1 / det;
+  D(HXD_IB0, idet * B3); D(HXD_IB1, idet * -1 * B1); D(HXD_IB2, idet * -1 * B2);
+  D(HXD_IB3, idet * B0);
+  // QC1/QC2 with DelQL == DelQO (temperature_component.cpp:462-477)
+  D(HXD_QC1, ((1.0 / cal) * (1.0 / taucfl + 1.0 / taukls) - bsi / cas / taukls) / 12.0);
+  D(HXD_QC2, ((1.0 / cas) * (1.0 / taucfs + bsi / tauksl) - 1.0 / cal / tauksl) / 12.0);
+  D(HXD_DQ1, 0.5 / cal); D(HXD_DQ2, 0.5 / cas);
+  D(HXD_DPSCALE, fso * sq);
+  D(HXD_HFSCALE, cas * fso / sqrt(taudif));
+  D(HXD_FLAG, det == 0 ? (double)HX_ERR_SINGULAR : 0.0);
+  // exchange coefficients  src/ocean_component.cpp:265-284
+  const double tt = P(HXP_TT), tu = P(HXP_TU), twi = P(HXP_TWI), tid = P(HXP_TID);
+  D(HXD_KLH, (tt * O_spy) / O_vLL);
+  D(HXD_KHD, ((tt + tu) * O_spy) / O_vHL);
+  const double DO_IO = ((tt + tu) * O_spy) / O_vD;
+  D(HXD_KIH, (tu * O_spy) / O_vI);
+  const double IO_LL = (tt * O_spy) / O_vI;
+  const double IO_LLex = (twi * O_spy) / O_vI;
+  D(HXD_KLI, (twi * O_spy) / O_vLL);
+  const double DO_IOex = (tid * O_spy) / O_vD;
+  D(HXD_KID, (tid * O_spy) / O_vI);
+  D(HXD_KIL, IO_LL + IO_LLex);
+  D(HXD_KDI, DO_IO + DO_IOex);
+  for (int b = 0; b < nbiome; ++b)
+    D(HXD_NGLOBAL + b, log(P(HXP_NGLOBAL + b * HXPB_N + HXPB_Q10)));
+}
+
+namespace {
+__device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
+  return HX_GCD(b.derived)[(size_t)row * b.npad + mem];
+}
+}  // namespace
+
+// DOECLIM's history term  sum_{i<t} Tsst[i] * Ker[ns - t + i - 1]  (temperature_
+// component.cpp:488-491; :534-537 for the heat-flux diagnostic, Ker index + 1) is a
+// causal convolution: evaluated per year it re-reads the whole SST history every
+// year (83 % of the algorithmic HBM bytes).  Here the history BEFORE a
+// block of HX_DBLK years is read ONCE per block and contributes to all HX_DBLK
+// partial sums at once -- same ascending summation order per year as the reference
+// -- in chunks of 16 history years: 16 coalesced SST loads and one 31-entry window
+// of Ker (wave-uniform -> scalar loads when the diffusivity is shared) feed 256
+// FMAs.  Ker is stored zero-padded by HX_KPAD entries on both sides, so block years
+// beyond the end of the run and the ragged last chunk need no bounds branches.
+template <bool KERPM, bool HF>
+__device__ __forceinline__ void doeclim_block_pass(const HxBuffers &buf, int mem, int lane,
+                                                   int ns, int blk0, double (*s_part)[64],
+                                                   double (*s_part2)[64]) {
+  double acc[HX_DBLK], acc2[HX_DBLK];
+#pragma unroll
+  for (int j = 0; j < HX_DBLK; ++j) { acc[j] = 0; acc2[j] = 0; }
+  hx_gcd hist = HX_GCD(buf.out[HXO_SST]) + mem;
+  const size_t np = (size_t)buf.npad;
+  // window entry w of chunk i0 = Ker[(ns - blk0 - 1) + i0 - (HX_DBLK - 1) + w]
+  const int k0 = ns - blk0 - 1 - (HX_DBLK - 1) + HX_KPAD;
+  auto ldk = [&](int idx) -> double {
+    if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * np + mem];
+    else return HX_CCD(buf.ker)[idx];
+  };
+  for (int i0 = 0; i0 < blk0; i0 += 16) {
+    double T[16], kw[HX_DBLK + 16];
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {
+      const int i = i0 + ii;
+      // rows >= blk0 may hold stale values of an earlier run: mask them
+      const double v = hist[(size_t)(i < ns ? i : ns - 1) * np];
+      T[ii] = (i < blk0) ? v : 0.0;
+    }
+#pragma unroll
+    for (int w = 0; w < HX_DBLK + 16; ++w) kw[w] = ldk(k0 + i0 + w);
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {
+#pragma unroll
+      for (int j = 0; j < HX_DBLK; ++j) {
+        acc[j] += T[ii] * kw[HX_DBLK - 1 + ii - j];
+        if (HF) acc2[j] += T[ii] * kw[HX_DBLK + ii - j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < HX_DBLK; ++j) {
+    s_part[j][lane] = acc[j];
+    if (HF) s_part2[j][lane] = acc2[j];
+  }
+}
 
 // ===========================================================================
 // Spinup: Core::run_spinup (src/core.cpp:394-420) + CarbonCycleSolver::
@@ -700,7 +846,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   const int mem = blockIdx.x * 64 + threadIdx.x;
   if (mem >= buf.npad) return;
   Member<B> m;
-  load_member<B>(buf, mem, m);
+  bind_member<B>(buf, mem, m);
   // initial conditions: ocean_component.cpp:234-260, simpleNbox.cpp:45-79,
   // simpleNbox-runtime.cpp:146-172
   {
@@ -713,19 +859,16 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   m.atmos = m.C0 * (1.0 / PGC2PPM);
   m.cum_luc_va = 0; m.cum_pf_ch4 = 0; m.masstot = 0;
   m.max_ts = 1.0; m.ts_timeout = 0; m.lastflux_ann = 0; m.sdt = kc.dt0;
-  m.ch4 = kc.M0; m.alkH = 0; m.alkL = 0; m.hH = 1e-8; m.hL = 1e-8;
-  m.status = 0;
-  double v0 = 0;
+  m.alkH = 0; m.alkL = 0; m.hH = 1e-8; m.hL = 1e-8;
+  m.status = (unsigned)ldd(buf, HXD_FLAG, mem);
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const int r = HXP_NGLOBAL + b * HXPB_N;
     m.veg[b] = ldp(buf, r + HXPB_VEG0, mem); m.det[b] = ldp(buf, r + HXPB_DET0, mem);
     m.soil[b] = ldp(buf, r + HXPB_SOIL0, mem); m.pf[b] = ldp(buf, r + HXPB_PF0, mem);
-    m.thawed[b] = 0; m.tempferts[b] = 1; m.f_frozen[b] = 1;
+    m.thawed[b] = 0; m.tempferts[b] = 1;
     m.co2fert[b] = 1; m.tempfertd[b] = 1; m.f_new_thaw[b] = 0;
-    v0 += m.veg[b];
   }
-  m.eos_vegc = v0;
   m.luc_e = m.luc_u = m.ffi = m.daccs = 0;
   m.npp_luc_adjust = 1.0;  // (eos - 0)/eos
   m.pco2H = m.pco2L = 0; m.annualflux_sum = 0; m.nbp = 0; m.nsteps = 0;
@@ -758,12 +901,16 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
     }
   }
   if (!spun) m.status |= HX_ERR_SPINUP;
+  store_state<B>(buf, mem, m);
   // SimpleNbox::run, first call: end_of_spinup_vegc  runtime.cpp:209-213
   double v1 = 0;
 #pragma unroll
-  for (int b = 0; b < B; ++b) v1 += m.veg[b];
-  m.eos_vegc = v1;
-  store_state<B>(buf, mem, m);
+  for (int b = 0; b < B; ++b) {
+    v1 += m.veg[b];
+    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, 1.0);
+  }
+  sts_(buf, HXS_EOS_VEGC, mem, v1);
+  sts_(buf, HXS_CH4, mem, kc.M0);
   sts_(buf, HXS_TLAND, mem, 0.0); sts_(buf, HXS_SST, mem, 0.0);
   sts_(buf, HXS_F_PREV, mem, 0.0); sts_(buf, HXS_BASE_TOT, mem, 0.0);
   sts_(buf, HXS_BASE_CO2, mem, 0.0);
@@ -771,7 +918,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   sts_(buf, HXS_TWIN, mem, 0.0);
   // year-0 (startDate) outputs = state recorded at the end of spinup
   const size_t o = (size_t)mem;
-  auto put = [&](int var, double v) { if (buf.out[var]) buf.out[var][o] = v; };
+  auto put = [&](int var, double v) { if (buf.out[var]) sto_(buf, var, o, v); };
   put(HXO_SST, 0.0); put(HXO_TLAND, 0.0);
   put(HXO_CO2, m.atmos * PGC2PPM); put(HXO_TGAV, 0.0);
   put(HXO_RF_TOT, 0.0); put(HXO_RF_CO2, 0.0);
@@ -792,13 +939,17 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 }
 
 // ===========================================================================
-// Main run: years (iy_from, iy_to] (indices relative to startDate).
+// Main run: years (iy_from, iy_to] (indices relative to startDate).  Each year
+// is three phases separated by compiler fences:
+//   A  gases, ocean year start, slow parameters   (year-level constants from HBM)
+//   B  carbon-cycle solver                        (registers only)
+//   C  forcing, DOECLIM, outputs                  (year-level constants from HBM)
+// Year-level state (Tland, SST, forcing[t-1], CH4, Q10 window...) lives in the HBM
+// state table between phases; the solver's pools stay in registers for the launch.
 // ===========================================================================
-template <int B, bool HF>
+template <int B, bool HF, bool KERPM>
 __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
-  const HxBuffers &buf = args->buf;
-  const HxConst &kc = args->kc;
   // LDS (dynamic, sized by the launcher): per-lane partial sums of the current
   // DOECLIM block and the SSTs produced inside it
   extern __shared__ double s_lds[];
@@ -807,283 +958,226 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   double (*s_part2)[64] = reinterpret_cast<double (*)[64]>(s_lds + 2 * HX_DBLK * 64);  // heat-flux partials (only if requested)
   const int lane = threadIdx.x;
   const int mem = blockIdx.x * 64 + lane;
-  if (mem >= buf.npad) return;
-  const int ns = kc.ns;
+  if (mem >= args->buf.npad) return;
   Member<B> m;
-  load_member<B>(buf, mem, m);
-  load_state<B>(buf, mem, m);
-  double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem);
-  double f_prev = lds_(buf, HXS_F_PREV, mem), base_tot = lds_(buf, HXS_BASE_TOT, mem),
-         base_co2 = lds_(buf, HXS_BASE_CO2, mem);
-  double tl_m1 = lds_(buf, HXS_TL_M1, mem), tl_m2 = lds_(buf, HXS_TL_M2, mem),
-         twin = lds_(buf, HXS_TWIN, mem);
-  double lnq10[B];
-#pragma unroll
-  for (int b = 0; b < B; ++b) lnq10[b] = log(m.q10[b]);
-
-  // ---- DOECLIM member constants  temperature_component.cpp:251-412 ---------
-  double A0, A1, A2, A3, IB0, IB1, IB2, IB3, qc1, qc2, dq1, dq2, dpscale, hfscale;
-  {
-    const double S = ldp(buf, HXP_S, mem), qco2 = ldp(buf, HXP_QCO2, mem),
-                 diff = ldp(buf, HXP_DIFF, mem);
-    const double flnd = D_flnd, bsi = D_bsi, rlam = D_rlam, ak = D_ak, bk = D_bk,
-                 cal = D_cal, cas = D_cas, fso = D_fso;
-    const double cnum = rlam * flnd + bsi * (1.0 - flnd);
-    const double cden = rlam * flnd - ak * (rlam - bsi);
-    const double cfl = flnd * cnum / cden * qco2 / S - bk * (rlam - bsi) / cden;
-    const double cfs = (rlam * flnd - ak / (1.0 - flnd) * (rlam - bsi)) * cnum / cden *
-                           qco2 / S +
-                       rlam * flnd / (1.0 - flnd) * bk * (rlam - bsi) / cden;
-    const double kls = bk * rlam * flnd / cden - ak * flnd * cnum / cden * qco2 / S;
-    const double keff = (D_secs / 10000) * diff;
-    const double taucfs = cas / cfs, taucfl = cal / cfl;
-    const double taudif = (cas * cas) / (D_csw * D_csw) * M_PI / keff;
-    const double tauksl = (1.0 - flnd) * cas / kls, taukls = flnd * cal / kls;
-    double C0_ = 1.0 / (taucfl * taucfl) + 1.0 / (taukls * taukls) +
-                 2.0 / taucfl / taukls + bsi / taukls / tauksl;
-    double C1_ = -1 * bsi / (taukls * taukls) - bsi / taucfl / taukls -
-                 bsi / taucfs / taukls - (bsi * bsi) / taukls / tauksl;
-    double C2_ = -1 * bsi / (tauksl * tauksl) - 1.0 / taucfs / tauksl -
-                 1.0 / taucfl / tauksl - 1.0 / taukls / tauksl;
-    double C3_ = 1.0 / (taucfs * taucfs) + (bsi * bsi) / (tauksl * tauksl) +
-                 2.0 * bsi / taucfs / tauksl + bsi / taukls / tauksl;
-    C0_ *= 1.0 / 12.0; C1_ *= 1.0 / 12.0; C2_ *= 1.0 / 12.0; C3_ *= 1.0 / 12.0;
-    const double sq = sqrt(1.0 / taudif);
-    const double ker_last = buf.ker_per_member ? buf.ker[(size_t)(ns - 1) * buf.npad + mem]
-                                               : buf.ker[ns - 1];
-    const double B0 = 1.0 + 1.0 / (2.0 * taucfl) + 1.0 / (2.0 * taukls) + C0_;
-    const double B1 = -1.0 / (2.0 * taukls) * bsi + C1_;
-    const double B2 = -1.0 / (2.0 * tauksl) + C2_;
-    const double B3 = 1.0 + 1.0 / (2.0 * taucfs) + 1.0 / (2.0 * tauksl) * bsi +
-                      2.0 * fso * sq + C3_;
-    A0 = 1.0 - 1.0 / (2.0 * taucfl) - 1.0 / (2.0 * taukls) + C0_;
-    A1 = 1.0 / (2.0 * taukls) * bsi + C1_;
-    A2 = 1.0 / (2.0 * tauksl) + C2_;
-    A3 = 1.0 - 1.0 / (2.0 * taucfs) - 1.0 / (2.0 * tauksl) * bsi + ker_last * fso * sq + C3_;
-    const double det = B0 * B3 - B1 * B2;
-    if (det == 0) m.status |= HX_ERR_SINGULAR;
-    const double idet = 1 / det;
-    IB0 = idet * B3; IB1 = idet * -1 * B1; IB2 = idet * -1 * B2; IB3 = idet * B0;
-    // QC1/QC2 with DelQL == DelQO (temperature_component.cpp:462-477)
-    qc1 = ((1.0 / cal) * (1.0 / taucfl + 1.0 / taukls) - bsi / cas / taukls) / 12.0;
-    qc2 = ((1.0 / cas) * (1.0 / taucfs + bsi / tauksl) - 1.0 / cal / tauksl) / 12.0;
-    dq1 = 0.5 / cal; dq2 = 0.5 / cas;
-    dpscale = fso * sq;
-    hfscale = cas * fso / sqrt(taudif);
-  }
+  bind_member<B>(args->buf, mem, m);
+  load_state<B>(args->buf, mem, m);
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
-  const double *sst_hist = buf.out[HXO_SST];
   int blk0 = -1;  // first year index of the current DOECLIM block
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
-    const double *sh = buf.shared + (size_t)iy * HXSH_STRIDE;
-    const double year = (double)(kc.start_year + iy);
-    // ================= OH, CH4, O3 =========================================
-    const double prev_ch4 = m.ch4;
-    double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
-    if (iy > 1) {
+    HX_FENCE();
+    double ch4, o3;
+    // ======================= phase A ========================================
+    {
+      const HxBuffers &buf = args->buf;
+      const HxConst &kc = args->kc;
+      hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      // ---- OH, CH4, O3 ----
+      const double prev_ch4 = lds_(buf, HXS_CH4, mem);
+      double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
+      if (iy > 1) {
+        LandK<B> lk;
+        load_landk<B>(m, lk);
 #pragma unroll
-      for (int b = 0; b < B; ++b) rh_ch4 += m_rh_tp_ch4(m, b);
-    }
-    double toh = 0.0;
-    if (prev_ch4 != kc.M0)
-      toh = ((kc.CCH4 * (log(prev_ch4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
-            sh[HXSH_OH_D];
-    const double tau_oh = kc.TOH0 * exp(-toh);
-    {
-      const double emisTocon =
-          ((sh[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
-      const double dCH4 = ((emisTocon - prev_ch4 / kc.Tsoil) - prev_ch4 / kc.Tstrat) -
-                          prev_ch4 / tau_oh;
-      m.ch4 = prev_ch4 + dCH4;
-    }
-    const double o3 = ((5 * log(m.ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) +
-                      sh[HXSH_O3_NMVOC];
-    // ================= ocean: new year ======================================
-    chem_constants(sst + 18 + (-16.4), m.kH);
-    chem_constants(sst + 18 + 2.9, m.kL);
-    m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
-    if (m.alkH == 0.0) {  // first year after spinup: turn the chemistry on
-      const double co2 = m.atmos * PGC2PPM;
-      m.alkH = equilibrate_alk(m.kH, m.cHL, 1.0 / O_vHL, O_AsHL, co2, 1.000, m.hH, m.status);
-      m.alkL = equilibrate_alk(m.kL, m.cLL, 1.0 / O_vLL, O_AsLL, co2, -1.000, m.hL, m.status);
-    }
-    m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
-    m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
-    m.chem_fresh = true;
-    // ================= slowparameval (t = year-1) ============================
-    m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
-    m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
-    m.npp_luc_adjust = (m.eos_vegc - m.cum_luc_va) / m.eos_vegc;
-    {
+        for (int b = 0; b < B; ++b) rh_ch4 += m_rh_tp_ch4(m, lk, b);
+      }
+      double toh = 0.0;
+      if (prev_ch4 != kc.M0)
+        toh = ((kc.CCH4 * (log(prev_ch4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
+              sh[HXSH_OH_D];
+      const double tau_oh = kc.TOH0 * exp(-toh);
+      {
+        const double emisTocon =
+            ((sh[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
+        const double dCH4 = ((emisTocon - prev_ch4 / kc.Tsoil) - prev_ch4 / kc.Tstrat) -
+                            prev_ch4 / tau_oh;
+        ch4 = prev_ch4 + dCH4;
+      }
+      sts_(buf, HXS_CH4, mem, ch4);
+      o3 = ((5 * log(ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
+      // ---- ocean: new year ----
+      const double sst = lds_(buf, HXS_SST, mem);
+      chem_constants(sst + 18 + (-16.4), m.kH);
+      chem_constants(sst + 18 + 2.9, m.kL);
+      m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
+      if (m.alkH == 0.0) {  // first year after spinup: turn the chemistry on
+        const double co2 = m.atmos * PGC2PPM;
+        m.alkH = equilibrate_alk(m.kH, m.cHL, 1.0 / O_vHL, O_AsHL, co2, 1.000, m.hH, m.status);
+        m.alkL = equilibrate_alk(m.kL, m.cLL, 1.0 / O_vLL, O_AsLL, co2, -1.000, m.hL, m.status);
+      }
+      m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
+      m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+      m.chem_fresh = true;
+      // ---- slowparameval (t = year-1) ----
+      m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
+      m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
+      const double eos = lds_(buf, HXS_EOS_VEGC, mem);
+      m.npp_luc_adjust = (eos - m.cum_luc_va) / eos;
+      const double tland = lds_(buf, HXS_TLAND, mem);
       const double lnc = log((m.atmos * PGC2PPM) / m.C0);
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
       // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
+      double twin = lds_(buf, HXS_TWIN, mem);
       if (iy >= 3) {
-        twin += tl_m2;  // Tland of year iy-3 enters
+        twin += lds_(buf, HXS_TL_M2, mem);  // Tland of year iy-3 enters
         const int iold = iy - 203;
-        if (iold >= 1) twin -= buf.out[HXO_TLAND][(size_t)iold * buf.npad + mem];
+        if (iold >= 1) twin -= HX_GCD(buf.out[HXO_TLAND])[(size_t)iold * buf.npad + mem];
+        sts_(buf, HXS_TWIN, mem, twin);
       }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        m.co2fert[b] = 1 + m.beta[b] * lnc;
-        const double Tb = tland * m.wf[b];
-        m.tempfertd[b] = exp(lnq10[b] * (Tb / 10.0));
+        const int pr = HXP_NGLOBAL + b * HXPB_N;
+        const int fr = HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN;
+        const double beta = ldp(buf, pr + HXPB_BETA, mem), wf = ldp(buf, pr + HXPB_WF, mem);
+        const double lnq10 = ldd(buf, HXD_NGLOBAL + b, mem);
+        m.co2fert[b] = 1 + beta * lnc;
+        const double Tb = tland * wf;
+        m.tempfertd[b] = exp(lnq10 * (Tb / 10.0));
         m.f_new_thaw[b] = 0.0;
         if (m.pf[b] != 0.0) {
           double ff = 1.0;
           if (Tb > 0) {
-            const double d = (log(Tb) - m.pf_mu[b]) /
-                             (m.pf_sigma[b] * 1.4142135623730951);
+            const double d = (log(Tb) - ldp(buf, pr + HXPB_PF_MU, mem)) /
+                             (ldp(buf, pr + HXPB_PF_SIGMA, mem) * 1.4142135623730951);
             ff = 1 - erfc(-d) / 2;
           }
-          m.f_new_thaw[b] = m.f_frozen[b] - ff;
-          m.f_frozen[b] = ff;
+          m.f_new_thaw[b] = lds_(buf, fr, mem) - ff;
+          sts_(buf, fr, mem, ff);
         }
-        const double Trm = (iy > 1) ? (twin * m.wf[b]) / 200 : 0.0;
-        double tfs = exp(lnq10[b] * (Trm / 10.0));
+        const double Trm = (iy > 1) ? (twin * wf) / 200 : 0.0;
+        const double tfs = exp(lnq10 * (Trm / 10.0));
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
         m.tempferts[b] = fmax(tfs, last);  // sticky :1054-1059
       }
     }
-    // ================= carbon-cycle solver ==================================
-    solve_year<B, false>(m, kc, year - 1.0, year);
-    // ================= forcing ==============================================
-    const double co2c = m.atmos * PGC2PPM;
-    double rf_tot = 0, rf_co2 = 0;
-    if (iy >= kc.baseyear_idx) {
-      const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
-      const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
-      const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
-      const double sqN = sh[HXSH_SQRT_N2O], sqM = sqrt(m.ch4), sqC = sqrt(co2c);
-      const double C_alpha_max = m.C0 - (b1 / (2 * a1));
-      double alpha_prime;
-      if (co2c > C_alpha_max) alpha_prime = d1 - ((b1 * b1) / (4 * a1));
-      else if (m.C0 < co2c && co2c < C_alpha_max)
-        alpha_prime = d1 + a1 * ((co2c - m.C0) * (co2c - m.C0)) + b1 * (co2c - m.C0);
-      else alpha_prime = d1;
-      const double sarf_co2 = (alpha_prime + c1 * sqN) * log(co2c / m.C0);
-      const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
-      const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - kc.sqrtN0);
-      const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
-      const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
-      const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
-      const double fh2o = 0.0485 * ((m.ch4 - kc.M0) / (1831 - kc.M0));
-      const double fo3 = 0.042 * o3;
-      const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
-                           m.aero * sh[HXSH_RF_AERO]) + m.vol * sh[HXSH_RF_VOL];
-      if (iy == kc.baseyear_idx) { base_tot = ftot; base_co2 = fco2; }
-      rf_tot = ftot - base_tot;
-      rf_co2 = fco2 - base_co2;
-    }
-    // ================= DOECLIM ==============================================
-    if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
-      // block-causal pass: partial sums over the history BEFORE this block for
-      // each year of the block, same ascending order as the reference loop
-      // (temperature_component.cpp:488-491, 534-537)
-      blk0 = iy;
-      double acc[HX_DBLK], acc2[HX_DBLK];
-#pragma unroll
-      for (int j = 0; j < HX_DBLK; ++j) { acc[j] = 0; acc2[j] = 0; }
-      for (int i = 0; i < blk0; ++i) {
-        const double T = sst_hist[(size_t)i * buf.npad + mem];
-#pragma unroll
-        for (int j = 0; j < HX_DBLK; ++j) {
-          const int kidx = ns - (blk0 + j) + i - 1;
-          if (kidx >= 0) {
-            const double kk = buf.ker_per_member ? buf.ker[(size_t)kidx * buf.npad + mem]
-                                                 : buf.ker[kidx];
-            acc[j] += T * kk;
-            if (want_hf) {
-              const double k2 = buf.ker_per_member
-                                    ? buf.ker[(size_t)(kidx + 1) * buf.npad + mem]
-                                    : buf.ker[kidx + 1];
-              acc2[j] += T * k2;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < HX_DBLK; ++j) {
-        s_part[j][lane] = acc[j];
-        if (want_hf) s_part2[j][lane] = acc2[j];
-      }
-    }
-    double tl_new, sst_new, heatflux = 0;
+    HX_FENCE();
+    // ======================= phase B: carbon-cycle solver ====================
     {
-      const int j = iy - blk0;
-      double dpast = s_part[j][lane];
-      double hint = want_hf ? s_part2[j][lane] : 0.0;
-      for (int i = blk0; i < iy; ++i) {
-        const double T = s_tblk[i - blk0][lane];
-        const int kidx = ns - iy + i - 1;
-        const double kk = buf.ker_per_member ? buf.ker[(size_t)kidx * buf.npad + mem]
-                                             : buf.ker[kidx];
-        dpast += T * kk;
-        if (want_hf) {
-          const double k2 = buf.ker_per_member ? buf.ker[(size_t)(kidx + 1) * buf.npad + mem]
-                                               : buf.ker[kidx + 1];
-          hint += T * k2;
+      const double year = (double)(args->kc.start_year + iy);
+      solve_year<B, false>(m, args->kc, year - 1.0, year);
+    }
+    HX_FENCE();
+    // ======================= phase C ========================================
+    {
+      const HxBuffers &buf = args->buf;
+      const HxConst &kc = args->kc;
+      const int ns = kc.ns;
+      hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      const double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem);
+      const double f_prev = lds_(buf, HXS_F_PREV, mem);
+      // ---- forcing ----
+      const double co2c = m.atmos * PGC2PPM;
+      double rf_tot = 0, rf_co2 = 0;
+      if (iy >= kc.baseyear_idx) {
+        const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
+        const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
+        const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
+        const double sqN = sh[HXSH_SQRT_N2O], sqM = sqrt(ch4), sqC = sqrt(co2c);
+        const double C_alpha_max = m.C0 - (b1 / (2 * a1));
+        double alpha_prime;
+        if (co2c > C_alpha_max) alpha_prime = d1 - ((b1 * b1) / (4 * a1));
+        else if (m.C0 < co2c && co2c < C_alpha_max)
+          alpha_prime = d1 + a1 * ((co2c - m.C0) * (co2c - m.C0)) + b1 * (co2c - m.C0);
+        else alpha_prime = d1;
+        const double sarf_co2 = (alpha_prime + c1 * sqN) * log(co2c / m.C0);
+        const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
+        const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - kc.sqrtN0);
+        const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
+        const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
+        const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
+        const double fh2o = 0.0485 * ((ch4 - kc.M0) / (1831 - kc.M0));
+        const double fo3 = 0.042 * o3;
+        const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
+                             ldp(buf, HXP_AERO, mem) * sh[HXSH_RF_AERO]) +
+                            ldp(buf, HXP_VOL, mem) * sh[HXSH_RF_VOL];
+        if (iy == kc.baseyear_idx) {
+          sts_(buf, HXS_BASE_TOT, mem, ftot);
+          sts_(buf, HXS_BASE_CO2, mem, fco2);
+          rf_tot = 0; rf_co2 = 0;  // x - x
+        } else {
+          rf_tot = ftot - lds_(buf, HXS_BASE_TOT, mem);
+          rf_co2 = fco2 - lds_(buf, HXS_BASE_CO2, mem);
         }
       }
-      dpast *= dpscale;
-      const double DelQ = rf_tot - f_prev;
-      const double DQ1 = dq1 * (rf_tot + f_prev) + DelQ * qc1;
-      const double DQ2 = dq2 * (rf_tot + f_prev) + DelQ * qc2;
-      const double X1 = DQ1 + (A0 * tland + A1 * sst);
-      const double X2 = (DQ2 + dpast) + (A2 * tland + A3 * sst);
-      tl_new = IB0 * X1 + IB1 * X2;
-      sst_new = IB2 * X1 + IB3 * X2;
-      if (want_hf) {
-        const double hmix = D_cas * (sst_new - sst);
-        const double hi = hfscale * (2.0 * sst_new - hint);
-        heatflux = hmix + D_fso * hi;
+      // ---- DOECLIM ----
+      if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
+        blk0 = iy;
+        doeclim_block_pass<KERPM, HF>(buf, mem, lane, ns, blk0, s_part, s_part2);
       }
-      s_tblk[j][lane] = sst_new;
-    }
-    const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
-    f_prev = rf_tot;
-    tl_m2 = tl_m1; tl_m1 = tland;  // Tland of years iy-2, iy-1 for the next year
-    tland = tl_new; sst = sst_new;
-    // ================= outputs ==============================================
-    const size_t o = (size_t)iy * buf.npad + mem;
-    buf.out[HXO_SST][o] = sst_new;
-    buf.out[HXO_TLAND][o] = tl_new;
-    if (buf.out[HXO_CO2]) buf.out[HXO_CO2][o] = co2c;
-    if (buf.out[HXO_TGAV]) buf.out[HXO_TGAV][o] = tgav;
-    if (buf.out[HXO_RF_TOT]) buf.out[HXO_RF_TOT][o] = rf_tot;
-    if (buf.out[HXO_RF_CO2]) buf.out[HXO_RF_CO2][o] = rf_co2;
-    if (buf.out[HXO_OCEAN_C]) buf.out[HXO_OCEAN_C][o] = m.cDO + m.cIO + m.cLL + m.cHL;
-    if (buf.out[HXO_HL_PH]) buf.out[HXO_HL_PH][o] = -log10(m.hH);
-    if (buf.out[HXO_LL_PH]) buf.out[HXO_LL_PH][o] = -log10(m.hL);
-    if (buf.out[HXO_ATMOS_C]) buf.out[HXO_ATMOS_C][o] = m.atmos;
-    if (buf.out[HXO_HEATFLUX]) buf.out[HXO_HEATFLUX][o] = heatflux;
-    if (buf.out[HXO_CH4]) buf.out[HXO_CH4][o] = m.ch4;
-    if (buf.out[HXO_O3]) buf.out[HXO_O3][o] = o3;
-    if (buf.out[HXO_EARTH_C]) buf.out[HXO_EARTH_C][o] = m.earth;
-    if (buf.out[HXO_NBP]) buf.out[HXO_NBP][o] = m.nbp;
-    if (buf.out[HXO_OCEAN_UPTAKE]) buf.out[HXO_OCEAN_UPTAKE][o] = m.annualflux_sum;
-    if (buf.out[HXO_NSTASH]) buf.out[HXO_NSTASH][o] = (double)m.nstash;
-    if (buf.out[HXO_NSTEPS]) buf.out[HXO_NSTEPS][o] = (double)m.nsteps;
-    if (buf.out[HXO_PERMAFROST_C] || buf.out[HXO_VEG_C] || buf.out[HXO_DET_C] ||
-        buf.out[HXO_SOIL_C] || buf.out[HXO_THAWED_C]) {
-      double v = 0, d = 0, s = 0, p = 0, th = 0;
+      double tl_new, sst_new, heatflux = 0;
+      {
+        const int j = iy - blk0;
+        double dpast = s_part[j][lane];
+        double hint = want_hf ? s_part2[j][lane] : 0.0;
+        // Ker is stored with HX_KPAD zeros in front: entry k lives at k + HX_KPAD
+        const int kq = ns - iy - 1 + HX_KPAD;
+        auto ldk = [&](int idx) -> double {
+          if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * buf.npad + mem];
+          else return HX_CCD(buf.ker)[idx];
+        };
+        for (int i = blk0; i < iy; ++i) {
+          const double T = s_tblk[i - blk0][lane];
+          dpast += T * ldk(kq + i);
+          if (want_hf) hint += T * ldk(kq + i + 1);
+        }
+        dpast *= ldd(buf, HXD_DPSCALE, mem);
+        const double DelQ = rf_tot - f_prev;
+        const double DQ1 = ldd(buf, HXD_DQ1, mem) * (rf_tot + f_prev) + DelQ * ldd(buf, HXD_QC1, mem);
+        const double DQ2 = ldd(buf, HXD_DQ2, mem) * (rf_tot + f_prev) + DelQ * ldd(buf, HXD_QC2, mem);
+        const double X1 = DQ1 + (ldd(buf, HXD_A0, mem) * tland + ldd(buf, HXD_A1, mem) * sst);
+        const double X2 = (DQ2 + dpast) + (ldd(buf, HXD_A2, mem) * tland + ldd(buf, HXD_A3, mem) * sst);
+        tl_new = ldd(buf, HXD_IB0, mem) * X1 + ldd(buf, HXD_IB1, mem) * X2;
+        sst_new = ldd(buf, HXD_IB2, mem) * X1 + ldd(buf, HXD_IB3, mem) * X2;
+        if (want_hf) {
+          const double hmix = D_cas * (sst_new - sst);
+          const double hi = ldd(buf, HXD_HFSCALE, mem) * (2.0 * sst_new - hint);
+          heatflux = hmix + D_fso * hi;
+        }
+        s_tblk[j][lane] = sst_new;
+      }
+      const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+      sts_(buf, HXS_F_PREV, mem, rf_tot);
+      sts_(buf, HXS_TL_M2, mem, lds_(buf, HXS_TL_M1, mem));  // Tland of years iy-2, iy-1
+      sts_(buf, HXS_TL_M1, mem, tland);                      // for the next year
+      sts_(buf, HXS_TLAND, mem, tl_new);
+      sts_(buf, HXS_SST, mem, sst_new);
+      // ---- outputs ----
+      const size_t o = (size_t)iy * buf.npad + mem;
+      sto_(buf, HXO_SST, o, sst_new);
+      sto_(buf, HXO_TLAND, o, tl_new);
+      if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
+      if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
+      if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);
+      if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);
+      if (buf.out[HXO_OCEAN_C]) sto_(buf, HXO_OCEAN_C, o, m.cDO + m.cIO + m.cLL + m.cHL);
+      if (buf.out[HXO_HL_PH]) sto_(buf, HXO_HL_PH, o, -log10(m.hH));
+      if (buf.out[HXO_LL_PH]) sto_(buf, HXO_LL_PH, o, -log10(m.hL));
+      if (buf.out[HXO_ATMOS_C]) sto_(buf, HXO_ATMOS_C, o, m.atmos);
+      if (buf.out[HXO_HEATFLUX]) sto_(buf, HXO_HEATFLUX, o, heatflux);
+      if (buf.out[HXO_CH4]) sto_(buf, HXO_CH4, o, ch4);
+      if (buf.out[HXO_O3]) sto_(buf, HXO_O3, o, o3);
+      if (buf.out[HXO_EARTH_C]) sto_(buf, HXO_EARTH_C, o, m.earth);
+      if (buf.out[HXO_NBP]) sto_(buf, HXO_NBP, o, m.nbp);
+      if (buf.out[HXO_OCEAN_UPTAKE]) sto_(buf, HXO_OCEAN_UPTAKE, o, m.annualflux_sum);
+      if (buf.out[HXO_NSTASH]) sto_(buf, HXO_NSTASH, o, (double)m.nstash);
+      if (buf.out[HXO_NSTEPS]) sto_(buf, HXO_NSTEPS, o, (double)m.nsteps);
+      if (buf.out[HXO_PERMAFROST_C] || buf.out[HXO_VEG_C] || buf.out[HXO_DET_C] ||
+          buf.out[HXO_SOIL_C] || buf.out[HXO_THAWED_C]) {
+        double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll
-      for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
-                                     p += m.pf[b]; th += m.thawed[b]; }
-      if (buf.out[HXO_PERMAFROST_C]) buf.out[HXO_PERMAFROST_C][o] = p;
-      if (buf.out[HXO_VEG_C]) buf.out[HXO_VEG_C][o] = v;
-      if (buf.out[HXO_DET_C]) buf.out[HXO_DET_C][o] = d;
-      if (buf.out[HXO_SOIL_C]) buf.out[HXO_SOIL_C][o] = s;
-      if (buf.out[HXO_THAWED_C]) buf.out[HXO_THAWED_C][o] = th;
+        for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+                                       p += m.pf[b]; th += m.thawed[b]; }
+        if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, p);
+        if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, v);
+        if (buf.out[HXO_DET_C]) sto_(buf, HXO_DET_C, o, d);
+        if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, s);
+        if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, th);
+      }
     }
   }
-  store_state<B>(buf, mem, m);
-  sts_(buf, HXS_TLAND, mem, tland); sts_(buf, HXS_SST, mem, sst);
-  sts_(buf, HXS_F_PREV, mem, f_prev); sts_(buf, HXS_BASE_TOT, mem, base_tot);
-  sts_(buf, HXS_BASE_CO2, mem, base_co2);
-  sts_(buf, HXS_TL_M1, mem, tl_m1); sts_(buf, HXS_TL_M2, mem, tl_m2);
-  sts_(buf, HXS_TWIN, mem, twin);
+  HX_FENCE();
+  store_state<B>(args->buf, mem, m);
 }
 
 // ===========================================================================
@@ -1171,7 +1265,7 @@ __global__ __launch_bounds__(256) void hx_doeclim_table_kernel(const double *dif
            4.0 * rc * exp(-9.0 * tb / c);
     KTB3 = 12.0 * sqpt * (erf(3.0 * uc) + erf(3.0 * ub) - 2.0 * erf(3.0 * ua));
   }
-  ker[(size_t)i * stride + mem] = KT0 + KTA1 + KTB1 + KTA2 + KTB2 + KTA3 + KTB3;
+  ker[(size_t)(i + HX_KPAD) * stride + mem] = KT0 + KTA1 + KTB1 + KTA2 + KTB2 + KTA3 + KTB3;
 }
 
 // ---------------------------------------------------------------------------
@@ -1192,22 +1286,26 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
 }
 
 template <int B>
-static void launch_run_b(const HxArgs *d_args, int npad, bool hf, int iy_from, int iy_to,
-                         hipStream_t st) {
+static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int iy_from,
+                         int iy_to, hipStream_t st) {
   const int blocks = npad / 64;
   const size_t lds = (size_t)(hf ? 3 : 2) * HX_DBLK * 64 * sizeof(double);
-  if (hf)
-    hipLaunchKernelGGL((hx_run_kernel<B, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  if (hf && kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (hf)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, false, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else
-    hipLaunchKernelGGL((hx_run_kernel<B, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, false, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
 }
-hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, int iy_from,
-                         int iy_to, hipStream_t st) {
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm,
+                         int iy_from, int iy_to, hipStream_t st) {
   switch (B) {
-    case 1: launch_run_b<1>(d_args, npad, heatflux, iy_from, iy_to, st); break;
-    case 2: launch_run_b<2>(d_args, npad, heatflux, iy_from, iy_to, st); break;
-    case 3: launch_run_b<3>(d_args, npad, heatflux, iy_from, iy_to, st); break;
-    case 4: launch_run_b<4>(d_args, npad, heatflux, iy_from, iy_to, st); break;
+    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
+    case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
+    case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
+    case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -1226,6 +1324,12 @@ hipError_t hx_launch_doeclim_kernel(const double *diff_row, double *ker, int ns,
                                     int stride, hipStream_t st) {
   hipLaunchKernelGGL(hx_doeclim_table_kernel, dim3((count + 255) / 256, ns), dim3(256), 0, st,
                      diff_row, ker, ns, count, stride);
+  return hipGetLastError();
+}
+hipError_t hx_launch_derive(const double *params, double *derived, const double *ker,
+                            int ker_per_member, int ns, int nbiome, int npad, hipStream_t st) {
+  hipLaunchKernelGGL(hx_derive_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, params,
+                     derived, ker, ker_per_member, ns, nbiome, npad);
   return hipGetLastError();
 }
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,

@@ -49,6 +49,17 @@ enum HxBiomeState {  // row = HXS_NGLOBAL + biome * HXSB_N + k
 };
 #define HX_NSTATE(B) (HXS_NGLOBAL + (B) * HXSB_N)
 
+// ---- per-member derived constants (computed once per parameter upload) -----
+enum HxDerivedRow {
+  HXD_A0 = 0, HXD_A1, HXD_A2, HXD_A3,          // DOECLIM predecessor matrix
+  HXD_IB0, HXD_IB1, HXD_IB2, HXD_IB3,          // inverse successor matrix
+  HXD_QC1, HXD_QC2, HXD_DQ1, HXD_DQ2, HXD_DPSCALE, HXD_HFSCALE,
+  HXD_KLH, HXD_KLI, HXD_KHD, HXD_KIL, HXD_KIH, HXD_KID, HXD_KDI,  // ocean exchange, 1/yr
+  HXD_FLAG,                                     // status bits found while deriving
+  HXD_NGLOBAL                                   // then ln(q10_rh) per biome
+};
+#define HX_NDERIVED(B) (HXD_NGLOBAL + (B))
+
 // ---- outputs: one [ns][npad] array per variable ---------------------------
 enum HxOutVar {
   HXO_SST = 0,      // always on: it is DOECLIM's history
@@ -99,6 +110,7 @@ struct HxBuffers {
   const double *params;  // [HX_NPARAM(B)][npad]
   double *state;         // [HX_NSTATE(B)][npad]
   unsigned *status;      // [npad]
+  const double *derived; // [HX_NDERIVED(B)][npad]
   const double *shared;  // [ns][HXSH_STRIDE]
   const double *ker;     // [ns] DOECLIM kernel (shared diffusivity) or [ns][npad]
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
