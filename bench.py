@@ -38,6 +38,17 @@ HBM_PEAK = 8.0e12                               # MI355X_MICROARCH.md: 8 TB/s sp
 YEARS = 555
 
 
+def pmc_traffic(members, biomes):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE +
+    WRITE_SIZE, calibrated; profiles/r01_pmc_traffic.json) for this exact workload, or None:
+    counters cannot be read from inside the timed run."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return d["traffic_bytes_per_launch"].get("%dx%d" % (members, biomes))
+    except Exception:
+        return None
+
+
 def effective_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -195,7 +206,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(n, args.biomes),
                 "kernel": "hx_run_kernel<%d>" % args.biomes, "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_member_year": bpmy,
                 "algorithmic_bytes_per_launch": alg_bytes,
