@@ -11,6 +11,10 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
                             hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm,
                          int iy_from, int iy_to, hipStream_t st);
+hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, double *part,
+                                  double *part2, int ns, int npad, int blk0, int nyears,
+                                  bool heatflux, bool kpm, hipStream_t st);
+int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
@@ -270,8 +274,8 @@ void EnsembleCore::build_shared() {
 void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
-  fr(d_args_); fr(d_derived_);
-  d_derived_ = nullptr;
+  fr(d_args_); fr(d_derived_); fr(d_dpart_);
+  d_derived_ = nullptr; d_dpart_ = nullptr;
   d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
   d_args_ = nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) { fr(d_out_[v]); d_out_[v] = nullptr; }
@@ -284,12 +288,14 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
   check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
   check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
-  // DOECLIM kernel table, zero-padded by HX_KPAD (= 16) entries on both sides
-  check(hipMalloc(&d_ker_, sizeof(double) * (ns + 32) * np), "hipMalloc ker");
+  // DOECLIM kernel table, zero-padded by HX_KPAD (= 32) entries on both sides
+  check(hipMalloc(&d_ker_, sizeof(double) * (ns + 64) * np), "hipMalloc ker");
   check(hipMalloc(&d_status_, sizeof(unsigned) * np * 2), "hipMalloc status");
   check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
   check(hipMalloc(&d_derived_, sizeof(double) * np * HX_NDERIVED(B_)), "hipMalloc derived");
+  check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
+        "hipMalloc doeclim partial sums");
   for (int v = 0; v < HXO_NVAR; ++v)
     if (out_enabled_[v]) {
       check(hipMalloc(&d_out_[v], sizeof(double) * ns * np), "hipMalloc out");
@@ -306,6 +312,8 @@ HxBuffers EnsembleCore::buffers() const {
   HxBuffers b;
   b.params = d_params_; b.derived = d_derived_; b.state = d_state_; b.status = d_status_; b.shared = d_shared_;
   b.ker = d_ker_;
+  b.dpart = d_dpart_;
+  b.dpart2 = d_dpart_ ? d_dpart_ + (size_t)npad_ * hx_doeclim_block_years() : nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   return b;
@@ -442,7 +450,7 @@ void EnsembleCore::upload_params() {
   // DOECLIM convolution kernel: one shared table when every member has the same
   // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]
   ker_per_member_ = !row_uniform_[HXP_DIFF];
-  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 32) * np, stream_),
+  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 64) * np, stream_),
         "zero ker");
   check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
                                  ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,
@@ -528,8 +536,17 @@ void EnsembleCore::run(double runtodate) {
   const int target = (int)runtodate - scen_.start;
   if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
   check(hipEventRecord(ev0_, stream_), "event");
-  check(hx_launch_run(B_, d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_,
-                      last_iy_, target, stream_), "run kernel");
+  // one DOECLIM history pass + one run-kernel launch per block of years
+  const int L = hx_doeclim_block_years();
+  const bool hf = d_out_[HXO_HEATFLUX] != nullptr;
+  for (int from = last_iy_; from < target; from += L) {
+    const int to = std::min(from + L, target);
+    check(hx_launch_doeclim_pass(d_out_[HXO_SST], d_ker_, d_dpart_,
+                                 d_dpart_ + (size_t)npad_ * L, scen_.ns(), npad_, from + 1,
+                                 to - from, hf, ker_per_member_, stream_), "doeclim pass");
+    check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, from, to, stream_),
+          "run kernel");
+  }
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
   last_iy_ = target;

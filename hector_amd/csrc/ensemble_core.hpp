@@ -100,7 +100,7 @@ class EnsembleCore {
   unsigned *d_status_ = nullptr;
   int *d_spin_steps_ = nullptr;
   HxArgs *d_args_ = nullptr;
-  double *d_derived_ = nullptr;
+  double *d_derived_ = nullptr, *d_dpart_ = nullptr;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool run_timed_ = false;

@@ -36,8 +36,9 @@
 
 #include "hx_layout.h"
 
-#define HX_DBLK 16  // DOECLIM block length (years per SST-history pass)
-#define HX_KPAD HX_DBLK  // zero entries in front of / behind the Ker table
+#define HX_DBLK 32  // DOECLIM block length = years per run-kernel launch
+#define HX_DJT 8    // block years per thread in the history-pass kernel
+#define HX_KPAD 32  // zero entries in front of / behind the Ker table
 
 namespace {
 
@@ -779,33 +780,41 @@ __device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
 }
 }  // namespace
 
-// DOECLIM's history term  sum_{i<t} Tsst[i] * Ker[ns - t + i - 1]  (temperature_
-// component.cpp:488-491; :534-537 for the heat-flux diagnostic, Ker index + 1) is a
-// causal convolution: evaluated per year it re-reads the whole SST history every
-// year (83 % of the algorithmic HBM bytes).  Here the history BEFORE a
-// block of HX_DBLK years is read ONCE per block and contributes to all HX_DBLK
-// partial sums at once -- same ascending summation order per year as the reference
-// -- in chunks of 16 history years: 16 coalesced SST loads and one 31-entry window
-// of Ker (wave-uniform -> scalar loads when the diffusivity is shared) feed 256
-// FMAs.  Ker is stored zero-padded by HX_KPAD entries on both sides, so block years
-// beyond the end of the run and the ragged last chunk need no bounds branches.
+// ===========================================================================
+// DOECLIM history pass.  sum_{i<t} Tsst[i] * Ker[ns - t + i - 1]
+// (temperature_component.cpp:488-491; :534-537 for the heat-flux diagnostic, Ker
+// index + 1) is a causal convolution: evaluated per year it re-reads the whole SST
+// history every year (83 % of the algorithmic HBM bytes).  The run
+// kernel is launched per block of <= HX_DBLK years; before each launch this kernel
+// reads the history BEFORE the block once and leaves, for every year of the block,
+// the partial sum over that history in part[j][member] -- same ascending summation
+// order per year as the reference; the run kernel appends the in-block terms.
+// Thread = (member, HX_DJT block years); history in chunks of 16 years: 16 coalesced
+// loads in flight + a 23-entry window of Ker (scalar loads when the diffusivity is
+// shared) per 128 FMAs.  Ker is zero-padded by HX_KPAD entries on both sides, so
+// block years beyond the end of the run and the ragged last chunk need no branches.
+// ===========================================================================
 template <bool KERPM, bool HF>
-__device__ __forceinline__ void doeclim_block_pass(const HxBuffers &buf, int mem, int lane,
-                                                   int ns, int blk0, double (*s_part)[64],
-                                                   double (*s_part2)[64]) {
-  double acc[HX_DBLK], acc2[HX_DBLK];
+__global__ __launch_bounds__(64) void hx_doeclim_pass_kernel(const double *sst_hist,
+                                                             const double *ker, double *part,
+                                                             double *part2, int ns, int npad,
+                                                             int blk0) {
+  const int mem = blockIdx.x * 64 + threadIdx.x;
+  const int j0 = blockIdx.y * HX_DJT;
+  if (mem >= npad) return;
+  double acc[HX_DJT], acc2[HX_DJT];
 #pragma unroll
-  for (int j = 0; j < HX_DBLK; ++j) { acc[j] = 0; acc2[j] = 0; }
-  hx_gcd hist = HX_GCD(buf.out[HXO_SST]) + mem;
-  const size_t np = (size_t)buf.npad;
-  // window entry w of chunk i0 = Ker[(ns - blk0 - 1) + i0 - (HX_DBLK - 1) + w]
-  const int k0 = ns - blk0 - 1 - (HX_DBLK - 1) + HX_KPAD;
+  for (int j = 0; j < HX_DJT; ++j) { acc[j] = 0; acc2[j] = 0; }
+  hx_gcd hist = HX_GCD(sst_hist) + mem;
+  const size_t np = (size_t)npad;
+  // window entry w of chunk i0 = Ker[(ns - (blk0 + j0) - 1) + i0 - (HX_DJT - 1) + w]
+  const int k0 = ns - (blk0 + j0) - 1 - (HX_DJT - 1) + HX_KPAD;
   auto ldk = [&](int idx) -> double {
-    if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * np + mem];
-    else return HX_CCD(buf.ker)[idx];
+    if constexpr (KERPM) return HX_GCD(ker)[(size_t)idx * np + mem];
+    else return HX_CCD(ker)[idx];
   };
   for (int i0 = 0; i0 < blk0; i0 += 16) {
-    double T[16], kw[HX_DBLK + 16];
+    double T[16], kw[HX_DJT + 16];
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) {
       const int i = i0 + ii;
@@ -814,20 +823,20 @@ __device__ __forceinline__ void doeclim_block_pass(const HxBuffers &buf, int mem
       T[ii] = (i < blk0) ? v : 0.0;
     }
 #pragma unroll
-    for (int w = 0; w < HX_DBLK + 16; ++w) kw[w] = ldk(k0 + i0 + w);
+    for (int w = 0; w < HX_DJT + 16; ++w) kw[w] = ldk(k0 + i0 + w);
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) {
 #pragma unroll
-      for (int j = 0; j < HX_DBLK; ++j) {
-        acc[j] += T[ii] * kw[HX_DBLK - 1 + ii - j];
-        if (HF) acc2[j] += T[ii] * kw[HX_DBLK + ii - j];
+      for (int j = 0; j < HX_DJT; ++j) {
+        acc[j] += T[ii] * kw[HX_DJT - 1 + ii - j];
+        if (HF) acc2[j] += T[ii] * kw[HX_DJT + ii - j];
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < HX_DBLK; ++j) {
-    s_part[j][lane] = acc[j];
-    if (HF) s_part2[j][lane] = acc2[j];
+  for (int j = 0; j < HX_DJT; ++j) {
+    HX_GD(part)[(size_t)(j0 + j) * np + mem] = acc[j];
+    if (HF) HX_GD(part2)[(size_t)(j0 + j) * np + mem] = acc2[j];
   }
 }
 
@@ -950,12 +959,8 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 template <int B, bool HF, bool KERPM>
 __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
-  // LDS (dynamic, sized by the launcher): per-lane partial sums of the current
-  // DOECLIM block and the SSTs produced inside it
-  extern __shared__ double s_lds[];
-  double (*s_part)[64] = reinterpret_cast<double (*)[64]>(s_lds);                  // DPAST2 partials
-  double (*s_tblk)[64] = reinterpret_cast<double (*)[64]>(s_lds + HX_DBLK * 64);   // in-block SSTs
-  double (*s_part2)[64] = reinterpret_cast<double (*)[64]>(s_lds + 2 * HX_DBLK * 64);  // heat-flux partials (only if requested)
+  // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
+  __shared__ double s_tblk[HX_DBLK][64];
   const int lane = threadIdx.x;
   const int mem = blockIdx.x * 64 + lane;
   if (mem >= args->buf.npad) return;
@@ -963,7 +968,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   bind_member<B>(args->buf, mem, m);
   load_state<B>(args->buf, mem, m);
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
-  int blk0 = -1;  // first year index of the current DOECLIM block
+  const int blk0 = iy_from + 1;  // first year of this launch = first year of the DOECLIM block
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
@@ -973,12 +978,34 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       const HxBuffers &buf = args->buf;
       const HxConst &kc = args->kc;
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
-      // ---- OH, CH4, O3 ----
+      // every HBM value this phase needs, issued back to back (one exposed latency:
+      // with one wavefront per SIMD nothing else hides it)
       const double prev_ch4 = lds_(buf, HXS_CH4, mem);
+      const double sst = lds_(buf, HXS_SST, mem);
+      const double eos = lds_(buf, HXS_EOS_VEGC, mem);
+      const double tland = lds_(buf, HXS_TLAND, mem);
+      double twin = lds_(buf, HXS_TWIN, mem);
+      const double tl_m2 = lds_(buf, HXS_TL_M2, mem);
+      const int iold = iy - 203;
+      const double tl_old =
+          HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * buf.npad + mem];
+      double p_beta[B], p_wf[B], p_lnq10[B], p_mu[B], p_sigma[B], s_ffrozen[B];
+      LandK<B> lk;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int pr = HXP_NGLOBAL + b * HXPB_N;
+        p_beta[b] = ldp(buf, pr + HXPB_BETA, mem);
+        p_wf[b] = ldp(buf, pr + HXPB_WF, mem);
+        p_mu[b] = ldp(buf, pr + HXPB_PF_MU, mem);
+        p_sigma[b] = ldp(buf, pr + HXPB_PF_SIGMA, mem);
+        p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
+        s_ffrozen[b] = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
+        lk.fpf_static[b] = ldp(buf, pr + HXPB_FPF_STATIC, mem);
+        lk.rh_ch4_frac[b] = ldp(buf, pr + HXPB_RH_CH4_FRAC, mem);
+      }
+      // ---- OH, CH4, O3 ----
       double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
       if (iy > 1) {
-        LandK<B> lk;
-        load_landk<B>(m, lk);
 #pragma unroll
         for (int b = 0; b < B; ++b) rh_ch4 += m_rh_tp_ch4(m, lk, b);
       }
@@ -997,7 +1024,6 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       sts_(buf, HXS_CH4, mem, ch4);
       o3 = ((5 * log(ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
       // ---- ocean: new year ----
-      const double sst = lds_(buf, HXS_SST, mem);
       chem_constants(sst + 18 + (-16.4), m.kH);
       chem_constants(sst + 18 + 2.9, m.kL);
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
@@ -1012,41 +1038,33 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       // ---- slowparameval (t = year-1) ----
       m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
       m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
-      const double eos = lds_(buf, HXS_EOS_VEGC, mem);
       m.npp_luc_adjust = (eos - m.cum_luc_va) / eos;
-      const double tland = lds_(buf, HXS_TLAND, mem);
       const double lnc = log((m.atmos * PGC2PPM) / m.C0);
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
       // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
-      double twin = lds_(buf, HXS_TWIN, mem);
       if (iy >= 3) {
-        twin += lds_(buf, HXS_TL_M2, mem);  // Tland of year iy-3 enters
-        const int iold = iy - 203;
-        if (iold >= 1) twin -= HX_GCD(buf.out[HXO_TLAND])[(size_t)iold * buf.npad + mem];
+        twin += tl_m2;  // Tland of year iy-3 enters
+        if (iold >= 1) twin -= tl_old;
         sts_(buf, HXS_TWIN, mem, twin);
       }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        const int pr = HXP_NGLOBAL + b * HXPB_N;
         const int fr = HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN;
-        const double beta = ldp(buf, pr + HXPB_BETA, mem), wf = ldp(buf, pr + HXPB_WF, mem);
-        const double lnq10 = ldd(buf, HXD_NGLOBAL + b, mem);
-        m.co2fert[b] = 1 + beta * lnc;
-        const double Tb = tland * wf;
-        m.tempfertd[b] = exp(lnq10 * (Tb / 10.0));
+        m.co2fert[b] = 1 + p_beta[b] * lnc;
+        const double Tb = tland * p_wf[b];
+        m.tempfertd[b] = exp(p_lnq10[b] * (Tb / 10.0));
         m.f_new_thaw[b] = 0.0;
         if (m.pf[b] != 0.0) {
           double ff = 1.0;
           if (Tb > 0) {
-            const double d = (log(Tb) - ldp(buf, pr + HXPB_PF_MU, mem)) /
-                             (ldp(buf, pr + HXPB_PF_SIGMA, mem) * 1.4142135623730951);
+            const double d = (log(Tb) - p_mu[b]) / (p_sigma[b] * 1.4142135623730951);
             ff = 1 - erfc(-d) / 2;
           }
-          m.f_new_thaw[b] = lds_(buf, fr, mem) - ff;
+          m.f_new_thaw[b] = s_ffrozen[b] - ff;
           sts_(buf, fr, mem, ff);
         }
-        const double Trm = (iy > 1) ? (twin * wf) / 200 : 0.0;
-        const double tfs = exp(lnq10 * (Trm / 10.0));
+        const double Trm = (iy > 1) ? (twin * p_wf[b]) / 200 : 0.0;
+        const double tfs = exp(p_lnq10[b] * (Trm / 10.0));
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
         m.tempferts[b] = fmax(tfs, last);  // sticky :1054-1059
       }
@@ -1064,8 +1082,23 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       const HxConst &kc = args->kc;
       const int ns = kc.ns;
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      // every HBM value this phase needs, issued back to back
       const double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem);
       const double f_prev = lds_(buf, HXS_F_PREV, mem);
+      const double base_tot = lds_(buf, HXS_BASE_TOT, mem), base_co2 = lds_(buf, HXS_BASE_CO2, mem);
+      const double tl_m1 = lds_(buf, HXS_TL_M1, mem);
+      const double p_aero = ldp(buf, HXP_AERO, mem), p_vol = ldp(buf, HXP_VOL, mem);
+      const double dA0 = ldd(buf, HXD_A0, mem), dA1 = ldd(buf, HXD_A1, mem),
+                   dA2 = ldd(buf, HXD_A2, mem), dA3 = ldd(buf, HXD_A3, mem),
+                   dIB0 = ldd(buf, HXD_IB0, mem), dIB1 = ldd(buf, HXD_IB1, mem),
+                   dIB2 = ldd(buf, HXD_IB2, mem), dIB3 = ldd(buf, HXD_IB3, mem),
+                   dQC1 = ldd(buf, HXD_QC1, mem), dQC2 = ldd(buf, HXD_QC2, mem),
+                   dDQ1 = ldd(buf, HXD_DQ1, mem), dDQ2 = ldd(buf, HXD_DQ2, mem),
+                   dDPS = ldd(buf, HXD_DPSCALE, mem),
+                   dHFS = want_hf ? ldd(buf, HXD_HFSCALE, mem) : 0.0;
+      const int jb = iy - blk0;
+      double dpast = HX_GCD(buf.dpart)[(size_t)jb * buf.npad + mem];
+      double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
       // ---- forcing ----
       const double co2c = m.atmos * PGC2PPM;
       double rf_tot = 0, rf_co2 = 0;
@@ -1089,27 +1122,21 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double fh2o = 0.0485 * ((ch4 - kc.M0) / (1831 - kc.M0));
         const double fo3 = 0.042 * o3;
         const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
-                             ldp(buf, HXP_AERO, mem) * sh[HXSH_RF_AERO]) +
-                            ldp(buf, HXP_VOL, mem) * sh[HXSH_RF_VOL];
+                             p_aero * sh[HXSH_RF_AERO]) +
+                            p_vol * sh[HXSH_RF_VOL];
         if (iy == kc.baseyear_idx) {
           sts_(buf, HXS_BASE_TOT, mem, ftot);
           sts_(buf, HXS_BASE_CO2, mem, fco2);
           rf_tot = 0; rf_co2 = 0;  // x - x
         } else {
-          rf_tot = ftot - lds_(buf, HXS_BASE_TOT, mem);
-          rf_co2 = fco2 - lds_(buf, HXS_BASE_CO2, mem);
+          rf_tot = ftot - base_tot;
+          rf_co2 = fco2 - base_co2;
         }
       }
-      // ---- DOECLIM ----
-      if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
-        blk0 = iy;
-        doeclim_block_pass<KERPM, HF>(buf, mem, lane, ns, blk0, s_part, s_part2);
-      }
+      // ---- DOECLIM: history before the block (hx_doeclim_pass_kernel) + in-block terms ----
       double tl_new, sst_new, heatflux = 0;
       {
-        const int j = iy - blk0;
-        double dpast = s_part[j][lane];
-        double hint = want_hf ? s_part2[j][lane] : 0.0;
+        const int j = jb;
         // Ker is stored with HX_KPAD zeros in front: entry k lives at k + HX_KPAD
         const int kq = ns - iy - 1 + HX_KPAD;
         auto ldk = [&](int idx) -> double {
@@ -1121,24 +1148,24 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           dpast += T * ldk(kq + i);
           if (want_hf) hint += T * ldk(kq + i + 1);
         }
-        dpast *= ldd(buf, HXD_DPSCALE, mem);
+        dpast *= dDPS;
         const double DelQ = rf_tot - f_prev;
-        const double DQ1 = ldd(buf, HXD_DQ1, mem) * (rf_tot + f_prev) + DelQ * ldd(buf, HXD_QC1, mem);
-        const double DQ2 = ldd(buf, HXD_DQ2, mem) * (rf_tot + f_prev) + DelQ * ldd(buf, HXD_QC2, mem);
-        const double X1 = DQ1 + (ldd(buf, HXD_A0, mem) * tland + ldd(buf, HXD_A1, mem) * sst);
-        const double X2 = (DQ2 + dpast) + (ldd(buf, HXD_A2, mem) * tland + ldd(buf, HXD_A3, mem) * sst);
-        tl_new = ldd(buf, HXD_IB0, mem) * X1 + ldd(buf, HXD_IB1, mem) * X2;
-        sst_new = ldd(buf, HXD_IB2, mem) * X1 + ldd(buf, HXD_IB3, mem) * X2;
+        const double DQ1 = dDQ1 * (rf_tot + f_prev) + DelQ * dQC1;
+        const double DQ2 = dDQ2 * (rf_tot + f_prev) + DelQ * dQC2;
+        const double X1 = DQ1 + (dA0 * tland + dA1 * sst);
+        const double X2 = (DQ2 + dpast) + (dA2 * tland + dA3 * sst);
+        tl_new = dIB0 * X1 + dIB1 * X2;
+        sst_new = dIB2 * X1 + dIB3 * X2;
         if (want_hf) {
           const double hmix = D_cas * (sst_new - sst);
-          const double hi = ldd(buf, HXD_HFSCALE, mem) * (2.0 * sst_new - hint);
+          const double hi = dHFS * (2.0 * sst_new - hint);
           heatflux = hmix + D_fso * hi;
         }
         s_tblk[j][lane] = sst_new;
       }
       const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
       sts_(buf, HXS_F_PREV, mem, rf_tot);
-      sts_(buf, HXS_TL_M2, mem, lds_(buf, HXS_TL_M1, mem));  // Tland of years iy-2, iy-1
+      sts_(buf, HXS_TL_M2, mem, tl_m1);  // Tland of years iy-2, iy-1
       sts_(buf, HXS_TL_M1, mem, tland);                      // for the next year
       sts_(buf, HXS_TLAND, mem, tl_new);
       sts_(buf, HXS_SST, mem, sst_new);
@@ -1289,7 +1316,7 @@ template <int B>
 static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int iy_from,
                          int iy_to, hipStream_t st) {
   const int blocks = npad / 64;
-  const size_t lds = (size_t)(hf ? 3 : 2) * HX_DBLK * 64 * sizeof(double);
+  const size_t lds = 0;
   if (hf && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (hf)
@@ -1311,6 +1338,21 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
   return hipGetLastError();
 }
 
+hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, double *part,
+                                  double *part2, int ns, int npad, int blk0, int nyears,
+                                  bool heatflux, bool kpm, hipStream_t st) {
+  const dim3 grid(npad / 64, (nyears + HX_DJT - 1) / HX_DJT), block(64);
+  if (heatflux && kpm)
+    hipLaunchKernelGGL((hx_doeclim_pass_kernel<true, true>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
+  else if (heatflux)
+    hipLaunchKernelGGL((hx_doeclim_pass_kernel<false, true>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
+  else if (kpm)
+    hipLaunchKernelGGL((hx_doeclim_pass_kernel<true, false>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
+  else
+    hipLaunchKernelGGL((hx_doeclim_pass_kernel<false, false>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
+  return hipGetLastError();
+}
+int hx_doeclim_block_years() { return HX_DBLK; }
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st) {
   hipLaunchKernelGGL(hx_broadcast_rows_kernel, dim3((npad + 255) / 256), dim3(256), 0, st,
                      table, nrows, npad);

@@ -112,7 +112,9 @@ struct HxBuffers {
   unsigned *status;      // [npad]
   const double *derived; // [HX_NDERIVED(B)][npad]
   const double *shared;  // [ns][HXSH_STRIDE]
-  const double *ker;     // [ns] DOECLIM kernel (shared diffusivity) or [ns][npad]
+  const double *ker;     // zero-padded DOECLIM kernel: [ns+64] (shared diffusivity) or [ns+64][npad]
+  const double *dpart;   // [HX_DBLK][npad] history partial sums of the current block
+  const double *dpart2;  // same for the heat-flux diagnostic
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
   int n, npad, ker_per_member;
 };
