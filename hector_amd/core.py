@@ -101,6 +101,15 @@ class Core:
         self._ck(self._lib.hx_set_outputs(self._h, n, arr))
         return self
 
+    def set_member_sorting(self, on=True):
+        self._ck(self._lib.hx_set_member_sorting(self._h, 1 if on else 0))
+        return self
+
+    def lane_of_member(self):
+        out = np.zeros(self.n_members, dtype=np.int32)
+        self._ck(self._lib.hx_lane_of_member(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out
+
     def reset(self, date=0):
         self._ck(self._lib.hx_reset(self._h, float(date)))
         return self

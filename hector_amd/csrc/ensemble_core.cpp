@@ -17,6 +17,8 @@ hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, dou
 int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
+hipError_t hx_launch_gather(const double *src, const int *lane_of_member, double *dst, int n,
+                            int npad, int nyears, hipStream_t st);
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
                            double *stats, hipStream_t st);
 hipError_t hx_launch_derive(const double *params, double *derived, const double *ker,
@@ -274,8 +276,9 @@ void EnsembleCore::build_shared() {
 void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
-  fr(d_args_); fr(d_derived_); fr(d_dpart_);
-  d_derived_ = nullptr; d_dpart_ = nullptr;
+  fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_);
+  d_derived_ = nullptr; d_dpart_ = nullptr; d_gather_ = nullptr; d_lane_of_member_ = nullptr;
+  gather_cap_ = 0;
   d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
   d_args_ = nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) { fr(d_out_[v]); d_out_[v] = nullptr; }
@@ -294,6 +297,7 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
   check(hipMalloc(&d_derived_, sizeof(double) * np * HX_NDERIVED(B_)), "hipMalloc derived");
+  check(hipMalloc(&d_lane_of_member_, sizeof(int) * np), "hipMalloc lane map");
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
   for (int v = 0; v < HXO_NVAR; ++v)
@@ -439,11 +443,58 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
   last_iy_ = 0;
 }
 
+void EnsembleCore::lane_of_member(int *out) {
+  prepare();
+  std::memcpy(out, lane_of_member_.data(), sizeof(int) * (size_t)n_);
+}
+
+void EnsembleCore::set_member_sorting(bool on) {
+  if (on == sort_members_) return;
+  sort_members_ = on;
+  params_dirty_ = true;
+  need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+// Lanes of a wavefront execute the solver in lock-step, so a wavefront costs the
+// maximum over its members of steps / stashes per year.  Members with similar
+// perturbed parameters follow similar schedules: tile the members by the first two
+// varying parameters (quantile bins of the first, sorted by the second inside a
+// bin).  On the ECS/Q10 ensemble this brings the wave-max stash count from 2.69 to
+// 2.06 per year (member mean 2.00) and steps from 4.63 to 3.62 (mean 3.52).
+void EnsembleCore::assign_lanes() {
+  member_of_lane_.resize((size_t)npad_);
+  lane_of_member_.resize((size_t)n_);
+  std::vector<int> order((size_t)n_);
+  for (int i = 0; i < n_; ++i) order[(size_t)i] = i;
+  std::vector<int> varying;
+  for (int r = 0; r < HX_NPARAM(B_); ++r)
+    if (!row_uniform_[r]) varying.push_back(r);
+  if (sort_members_ && n_ > HX_WAVE && !varying.empty()) {
+    const std::vector<double> &p = params_[varying[0]];
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p[a] < p[b]; });
+    if (varying.size() > 1) {
+      const std::vector<double> &q = params_[varying[1]];
+      int nbins = (int)std::lround(std::sqrt((double)n_ / HX_WAVE));
+      nbins = std::max(1, nbins);
+      const int per = (n_ + nbins - 1) / nbins;
+      for (int b0 = 0; b0 < n_; b0 += per)
+        std::stable_sort(order.begin() + b0, order.begin() + std::min(n_, b0 + per),
+                         [&](int a, int b) { return q[a] < q[b]; });
+    }
+  }
+  for (int l = 0; l < npad_; ++l) member_of_lane_[(size_t)l] = order[(size_t)std::min(l, n_ - 1)];
+  for (int l = 0; l < n_; ++l) lane_of_member_[(size_t)order[(size_t)l]] = l;
+}
+
 void EnsembleCore::upload_params() {
   const size_t np = (size_t)npad_;
+  assign_lanes();
   std::vector<double> flat(np * HX_NPARAM(B_));
   for (int r = 0; r < HX_NPARAM(B_); ++r)
-    std::memcpy(&flat[(size_t)r * np], params_[r].data(), sizeof(double) * np);
+    for (size_t l = 0; l < np; ++l) flat[(size_t)r * np + l] = params_[r][(size_t)member_of_lane_[l]];
+  check(hipMemcpyAsync(d_lane_of_member_, lane_of_member_.data(), sizeof(int) * (size_t)n_,
+                       hipMemcpyHostToDevice, stream_), "upload lane map");
   check(hipMemcpyAsync(d_params_, flat.data(), sizeof(double) * flat.size(),
                        hipMemcpyHostToDevice, stream_), "upload params");
   check(hipStreamSynchronize(stream_), "sync params");
@@ -571,9 +622,18 @@ void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1
     throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
   sync();
   const int iy0 = year0 - scen_.start, ny = year1 - year0 + 1;
-  check(hipMemcpy2D(out_host, sizeof(double) * (size_t)n_, d_out_[v] + (size_t)iy0 * npad_,
-                    sizeof(double) * (size_t)npad_, sizeof(double) * (size_t)n_, (size_t)ny,
-                    hipMemcpyDeviceToHost), "fetch");
+  const size_t need = (size_t)ny * (size_t)n_;
+  if (need > gather_cap_) {
+    if (d_gather_) (void)hipFree(d_gather_);
+    d_gather_ = nullptr;
+    check(hipMalloc(&d_gather_, sizeof(double) * need), "hipMalloc gather");
+    gather_cap_ = need;
+  }
+  check(hx_launch_gather(d_out_[v] + (size_t)iy0 * npad_, d_lane_of_member_, d_gather_, n_, npad_,
+                         ny, stream_), "gather");
+  check(hipMemcpyAsync(out_host, d_gather_, sizeof(double) * need, hipMemcpyDeviceToHost, stream_),
+        "fetch");
+  check(hipStreamSynchronize(stream_), "fetch sync");
 }
 
 const double *EnsembleCore::device_var(const std::string &capability, int *npad) const {
@@ -599,23 +659,29 @@ void EnsembleCore::stats_device(const std::string &capability, int year0, int ye
 void EnsembleCore::status(unsigned *out_host) {
   prepare();
   sync();
-  check(hipMemcpy(out_host, d_status_, sizeof(unsigned) * (size_t)n_, hipMemcpyDeviceToHost),
+  std::vector<unsigned> tmp((size_t)npad_);
+  check(hipMemcpy(tmp.data(), d_status_, sizeof(unsigned) * (size_t)npad_, hipMemcpyDeviceToHost),
         "status");
+  for (int i = 0; i < n_; ++i) out_host[i] = tmp[(size_t)lane_of_member_[(size_t)i]];
 }
 
 void EnsembleCore::state_row(int row, double *out_host) {
   prepare();
   sync();
   if (row < 0 || row >= HX_NSTATE(B_)) throw std::runtime_error("state_row: bad row");
-  check(hipMemcpy(out_host, d_state_ + (size_t)row * npad_, sizeof(double) * (size_t)n_,
+  std::vector<double> tmp((size_t)npad_);
+  check(hipMemcpy(tmp.data(), d_state_ + (size_t)row * npad_, sizeof(double) * (size_t)npad_,
                   hipMemcpyDeviceToHost), "state row");
+  for (int i = 0; i < n_; ++i) out_host[i] = tmp[(size_t)lane_of_member_[(size_t)i]];
 }
 
 int EnsembleCore::spinup_steps(int member) {
   prepare();
   sync();
   int v = 0;
-  check(hipMemcpy(&v, d_spin_steps_ + member, sizeof(int), hipMemcpyDeviceToHost), "steps");
+  if (member < 0 || member >= n_) throw std::runtime_error("spinup_steps: bad member index");
+  check(hipMemcpy(&v, d_spin_steps_ + lane_of_member_[(size_t)member], sizeof(int),
+                  hipMemcpyDeviceToHost), "steps");
   return v;
 }
 

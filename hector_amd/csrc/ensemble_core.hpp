@@ -52,6 +52,10 @@ class EnsembleCore {
   // which output variables are recorded per year (capability strings);
   // sst and land_tas are always recorded (the model needs their history).
   void set_outputs(const std::vector<std::string> &capabilities);
+  // lane assignment: sort members by their perturbed parameters so that the lanes of a
+  // wavefront follow similar solver schedules (default on; results do not depend on it)
+  void set_member_sorting(bool on);
+  void lane_of_member(int *out);
   static const char *const *output_capabilities(int *count);
 
   void reset(double date);      // Core::reset: date < startDate => redo spinup
@@ -89,6 +93,9 @@ class EnsembleCore {
   std::vector<std::string> biome_names_;
   std::vector<std::vector<double>> params_;  // [row][npad]
   std::vector<bool> row_uniform_;
+  std::vector<int> member_of_lane_, lane_of_member_;  // lane <-> member (size npad / n)
+  bool sort_members_ = true;
+  void assign_lanes();
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
   int last_iy_ = 0;
   HxConst kc_{};
@@ -100,7 +107,9 @@ class EnsembleCore {
   unsigned *d_status_ = nullptr;
   int *d_spin_steps_ = nullptr;
   HxArgs *d_args_ = nullptr;
-  double *d_derived_ = nullptr, *d_dpart_ = nullptr;
+  double *d_derived_ = nullptr, *d_dpart_ = nullptr, *d_gather_ = nullptr;
+  int *d_lane_of_member_ = nullptr;
+  size_t gather_cap_ = 0;
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool run_timed_ = false;

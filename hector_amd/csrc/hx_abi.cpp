@@ -77,6 +77,11 @@ int hx_output_capabilities(const char *const **names, int *count) {
   *names = hx::EnsembleCore::output_capabilities(count);
   return 0;
 }
+int hx_set_member_sorting(hx_core *core, int on) { HX_TRY(core->core->set_member_sorting(on != 0)) }
+int hx_lane_of_member(hx_core *core, int *out) {
+  if (!out) return fail("null argument");
+  HX_TRY(core->core->lane_of_member(out))
+}
 int hx_reset(hx_core *core, double date) { HX_TRY(core->core->reset(date)) }
 int hx_run(hx_core *core, double runtodate) { HX_TRY(core->core->run(runtodate)) }
 int hx_sync(hx_core *core) { HX_TRY(core->core->sync()) }

@@ -1222,6 +1222,19 @@ __global__ void hx_broadcast_u32_kernel(unsigned *v, int npad) {
 }
 
 // ===========================================================================
+// Output gather: members are assigned to lanes in a behaviour-sorted order (see
+// EnsembleCore::upload_params); results go back to the caller in member order.
+// dst[y][member] = src[y][lane_of_member[member]]
+// ===========================================================================
+__global__ __launch_bounds__(256) void hx_gather_kernel(const double *src, const int *lane_of_member,
+                                                        double *dst, int n, int npad, int nyears) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (mem >= n || y >= nyears) return;
+  dst[(size_t)y * n + mem] = src[(size_t)y * npad + lane_of_member[mem]];
+}
+
+// ===========================================================================
 // Per-year ensemble statistics of one output variable over members [0, n):
 // count, sum, sum of squares, min, max -> stats[year][5].  One workgroup per
 // year; wave-level DPP/shuffle reduction, then one LDS hop across the waves.
@@ -1372,6 +1385,12 @@ hipError_t hx_launch_derive(const double *params, double *derived, const double 
                             int ker_per_member, int ns, int nbiome, int npad, hipStream_t st) {
   hipLaunchKernelGGL(hx_derive_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, params,
                      derived, ker, ker_per_member, ns, nbiome, npad);
+  return hipGetLastError();
+}
+hipError_t hx_launch_gather(const double *src, const int *lane_of_member, double *dst, int n,
+                            int npad, int nyears, hipStream_t st) {
+  hipLaunchKernelGGL(hx_gather_kernel, dim3((n + 255) / 256, nyears), dim3(256), 0, st, src,
+                     lane_of_member, dst, n, npad, nyears);
   return hipGetLastError();
 }
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,

@@ -69,6 +69,13 @@ int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const 
 int hx_set_outputs(hx_core *core, int nvars, const char *const *capabilities);
 int hx_output_capabilities(const char *const **names, int *count);
 
+/* Internal lane assignment: by default members are mapped to GPU lanes sorted by their
+ * perturbed parameters (wavefronts then follow similar solver schedules); every result is
+ * returned in the caller's member order either way and does not depend on this switch.
+ * hx_device_var exposes the raw lane-ordered arrays; hx_lane_of_member maps them. */
+int hx_set_member_sorting(hx_core *core, int on);
+int hx_lane_of_member(hx_core *core, int *out /* n_members */);
+
 /* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.
  * date < startDate (e.g. 0): rerun the spinup on the next run; date == startDate:
  * back to the post-spinup state.  Other dates: error (no per-year state history). */
@@ -85,7 +92,8 @@ int hx_sync(hx_core *core);
  * out[(year - year0) * n_members + member], host memory. */
 int hx_fetchvars(hx_core *core, const char *capability, int year0, int year1, double *out);
 /* Same data without leaving the GPU: device pointer to the variable's
- * [n_years_total][npad] array (row = year - startDate, npad >= n_members). */
+ * [n_years_total][npad] array (row = year - startDate, npad >= n_members), columns in
+ * LANE order (see hx_lane_of_member). */
 int hx_device_var(hx_core *core, const char *capability, const double **d_ptr, int *npad);
 /* Per-year ensemble statistics {count, sum, sum of squares, min, max} of one
  * variable into a caller-owned DEVICE buffer of (year1-year0+1)*5 doubles --

@@ -164,3 +164,17 @@ def test_error_behaviour_mirrors_reference(emul_lib):
     with pytest.raises(hector_amd.HectorAmdError, match="does not exist"):
         hector_amd.Core("/nonexistent.ini", 1, lib_path=emul_lib, allow_emulation=True)
     assert np.array_equal(c.getvar("S"), [3.0, 3.0])
+
+
+def test_member_sorting_is_transparent(emul_lib):
+    """Lane assignment by parameter tiling must not change any member's result."""
+    n = 200
+    S, q10 = ensemble.ecs_q10(n)
+    a = mk(emul_lib, n).setvar("S", S).setvar("q10_rh", q10).run(1900)
+    b = mk(emul_lib, n).set_member_sorting(False).setvar("S", S).setvar("q10_rh", q10).run(1900)
+    assert not np.array_equal(a.lane_of_member(), np.arange(n))
+    assert np.array_equal(b.lane_of_member(), np.arange(n))
+    for v in ("CO2_concentration", "global_tas"):
+        assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
+    assert np.array_equal(a.status(), b.status())
+    assert np.array_equal(a.getvar("S"), S)

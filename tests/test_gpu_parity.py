@@ -195,3 +195,14 @@ def test_error_behaviour_on_gpu(hip_lib):
         c.fetchvars("CO2_concentration", (1745, 1800))
     with pytest.raises(hector_amd.HectorAmdError, match="invalid device"):
         hector_amd.Core(SCENARIO, 4, device=99, lib_path=hip_lib)
+
+
+def test_member_sorting_is_transparent_on_gpu(hip_lib):
+    n = 4096
+    S, q10 = ensemble.ecs_q10(n)
+    a = mk(hip_lib, n).setvar("S", S).setvar("q10_rh", q10).run(2300)
+    b = mk(hip_lib, n).set_member_sorting(False).setvar("S", S).setvar("q10_rh", q10).run(2300)
+    assert not np.array_equal(a.lane_of_member(), np.arange(n))
+    for v in ("CO2_concentration", "global_tas"):
+        assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
+    assert np.array_equal(a.status(), b.status())
