@@ -64,6 +64,7 @@ constexpr double O_S = 34.5, O_U = 6.7;
 
 struct ChemK {  // T-dependent equilibrium constants of one surface box
   double K1, K2, Kb, Kw, Kh, Tr;
+  double g;  // Tr * As * 12 / 1e15: annual flux per uatm of air-sea pCO2 difference
 };
 
 // oceancsys::ocean_csys_run, the part that depends only on T (S = 34.5, U = 6.7)
@@ -147,6 +148,114 @@ __device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
   h_io = h;
   const double co2st = dic / (1.0 + K1 / h + K1 * K2 / h / h);
   return co2st * 1e6 / k.Kh;  // PCO2o, uatm
+}
+
+// Both surface boxes at once.  Same formulas as chem_constants / chem_solve; the two
+// boxes are independent, so writing them side by side gives the single resident
+// wavefront two dependency chains to interleave, and the seven divisions by Tk
+// share one reciprocal.
+__device__ __forceinline__ void chem_constants2(double TcH, double TcL, ChemK &kH, ChemK &kL) {
+  const double S = O_S;
+  const double sqrtS = 5.873670062235365;      // sqrt(34.5)
+  const double S15 = 202.64161714712009;       // 34.5^1.5
+  const double Tc[2] = {TcH, TcL};
+  const double As[2] = {O_AsHL, O_AsLL};
+  ChemK *k[2] = {&kH, &kL};
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const double Tk = Tc[b] + 273.15;
+    const double rTk = 1.0 / Tk;
+    const double T100 = Tk * 0.01;
+    const double lnTk = log(Tk);
+    const double lnTk100 = lnTk - 4.605170185988092;  // ln(Tk/100)
+    double tmp1 = -58.0931 + 9050.69 * rTk + 22.2940 * lnTk100;
+    double tmp2 = S * (0.027766 - 0.025888 * T100 + 0.0050578 * (T100 * T100));
+    const double K0 = exp(tmp1 + tmp2);
+    const double Sc = 2073.1 - (125.62 * Tc[b]) + (3.6276 * Tc[b] * Tc[b]) -
+                      (0.043219 * Tc[b] * Tc[b] * Tc[b]);
+    tmp1 = -13847.26 * rTk + 148.96502 - 23.6521 * lnTk;
+    tmp2 = +(118.67 * rTk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S;
+    k[b]->Kw = exp(tmp1 + tmp2);
+    double tmp = 9345.17 * rTk - 60.2409 + 23.3585 * lnTk100;
+    k[b]->Kh = exp(tmp + S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk));
+    const double pK1 = 3633.86 * rTk - 61.2172 + 9.6777 * lnTk - 0.011555 * S +
+                       0.0001152 * S * S;
+    k[b]->K1 = exp10(-pK1);
+    const double pK2 = 471.78 * rTk + 25.9290 - 3.16967 * lnTk - 0.01781 * S +
+                       0.0001122 * S * S;
+    k[b]->K2 = exp10(-pK2);
+    tmp1 = (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 - 0.0996 * S * S) * rTk;
+    tmp2 = +148.0248 + 137.1942 * sqrtS + 1.62142 * S;
+    double tmp3 = +(-24.4344 - 25.085 * sqrtS - 0.2474 * S) * lnTk + 0.053105 * sqrtS * Tk;
+    k[b]->Kb = exp(tmp1 + tmp2 + tmp3);
+    k[b]->Tr = (0.585 * K0 * rsqrt(Sc) * O_U * O_U);
+    k[b]->g = k[b]->Tr * As[b] * (12.0 / 1e15);
+  }
+}
+
+__device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, double cH,
+                                            double cL, double alkH, double alkL, double &hH,
+                                            double &hL, double &pco2H, double &pco2L,
+                                            unsigned &status) {
+  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
+  const ChemK *k[2] = {&kH, &kL};
+  const double carbon[2] = {cH, cL}, alk[2] = {alkH, alkL};
+  const double inv_vol[2] = {1.0 / O_vHL, 1.0 / O_vLL};
+  double dic[2], p4[2], p3[2], p2[2], p1[2], p0[2], h[2] = {hH, hL};
+  double lo[2] = {0.0, 0.0}, hi[2] = {1.0, 1.0};
+  bool done[2] = {false, false};
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const double K1 = k[b]->K1, K2 = k[b]->K2, Kb = k[b]->Kb, Kw = k[b]->Kw;
+    dic[b] = ((carbon[b] * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol[b]);
+    p4[b] = -alk[b] - Kb - K1;
+    p3[b] = dic[b] * K1 - alk[b] * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
+    double tmp = dic[b] * (Kb * K1 + 2.0 * K1 * K2) - alk[b] * (Kb * K1 + K1 * K2) +
+                 Kb * bor * K1;
+    p2[b] = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
+    tmp = 2.0 * dic[b] * Kb * K1 * K2 - alk[b] * Kb * K1 * K2 + Kb * bor * K1 * K2;
+    p1[b] = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
+    p0[b] = Kw * Kb * K1 * K2;
+  }
+  const double factor = 0x1p-30;
+  for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const double x = h[b];
+      double f = -1.0;
+      f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
+      f = f * x + p0[b];
+      double fp = -5.0;
+      fp = fp * x + 4.0 * p4[b]; fp = fp * x + 3.0 * p3[b]; fp = fp * x + 2.0 * p2[b];
+      fp = fp * x + p1[b];
+      if (!done[b]) {
+        if (f == 0.0) {
+          done[b] = true;
+        } else {
+          if (f > 0) lo[b] = x; else hi[b] = x;
+          double delta = f / fp;
+          double hn = x - delta;
+          if (!(hn > lo[b] && hn < hi[b])) {  // left the bracket (or fp == 0): bisect
+            hn = 0.5 * (lo[b] + hi[b]);
+            delta = x - hn;
+          }
+          done[b] = !(fabs(hn * factor) < fabs(delta));
+          h[b] = hn;
+        }
+      }
+    }
+  }
+  if (!(done[0] && done[1])) status |= HX_ERR_ROOT;
+  hH = h[0]; hL = h[1];
+  double pc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
+    const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
+    const double co2st = (dic[b] * (x * x)) / ((x * x + K1 * x) + K1 * K2);
+    pc[b] = co2st * 1e6 / k[b]->Kh;
+  }
+  pco2H = pc[0]; pco2L = pc[1];
 }
 
 // calc_annual_surface_flux  src/ocean_csys.cpp:375-396
@@ -295,8 +404,7 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K,
   } else {
     const double scale = (K.surf + (y[4] - K.totC)) * K.inv_surf;
     const double co2 = y[0] * PGC2PPM;
-    ao = surf_flux(co2, m.pco2H, scale, m.kH.Tr, O_AsHL) +
-         surf_flux(co2, m.pco2L, scale, m.kL.Tr, O_AsLL);
+    ao = (co2 - m.pco2H * scale) * m.kH.g + (co2 - m.pco2L * scale) * m.kL.g;
   }
   d[0] = ((K.P - ao) - K.npp) + K.rh;
   d[1] = (K.v1 - r * y[1]) + m.luc_u;
@@ -328,13 +436,12 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     // compute_fluxes re-runs the chemistry with the PRE-update carbon; at the
     // first stash of a year that is the carbon the year-start solve already used
     // (same T, DIC, alk -> same result), so only later stashes need a new solve
-    if (!m.chem_fresh) {
-      m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
-      m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
-    }
+    if (!m.chem_fresh)
+      chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
+                  m.status);
     m.chem_fresh = false;
-    aH = surf_flux(co2, m.pco2H, 1.0, m.kH.Tr, O_AsHL) * yf;
-    aL = surf_flux(co2, m.pco2L, 1.0, m.kL.Tr, O_AsLL) * yf;
+    aH = ((co2 - m.pco2H) * m.kH.g) * yf;
+    aL = ((co2 - m.pco2L) * m.kL.g) * yf;
   }
   // box-to-box transports, oceanbox.cpp:244-257 (order: HL, LL, IO, DO)
   const double lHD = m.cHL * kHD * yf;
@@ -881,7 +988,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   m.luc_e = m.luc_u = m.ffi = m.daccs = 0;
   m.npp_luc_adjust = 1.0;  // (eos - 0)/eos
   m.pco2H = m.pco2L = 0; m.annualflux_sum = 0; m.nbp = 0; m.nsteps = 0;
-  m.kH.Tr = m.kL.Tr = 0;
+  m.kH.Tr = m.kL.Tr = 0; m.kH.g = m.kL.g = 0;
   m.chem_fresh = false;
 
   bool spun = (kc.max_spinup <= 1);
@@ -1024,16 +1131,15 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       sts_(buf, HXS_CH4, mem, ch4);
       o3 = ((5 * log(ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
       // ---- ocean: new year ----
-      chem_constants(sst + 18 + (-16.4), m.kH);
-      chem_constants(sst + 18 + 2.9, m.kL);
+      chem_constants2(sst + 18 + (-16.4), sst + 18 + 2.9, m.kH, m.kL);
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
       if (m.alkH == 0.0) {  // first year after spinup: turn the chemistry on
         const double co2 = m.atmos * PGC2PPM;
         m.alkH = equilibrate_alk(m.kH, m.cHL, 1.0 / O_vHL, O_AsHL, co2, 1.000, m.hH, m.status);
         m.alkL = equilibrate_alk(m.kL, m.cLL, 1.0 / O_vLL, O_AsLL, co2, -1.000, m.hL, m.status);
       }
-      m.pco2H = chem_solve(m.kH, m.cHL, 1.0 / O_vHL, m.alkH, m.hH, m.status);
-      m.pco2L = chem_solve(m.kL, m.cLL, 1.0 / O_vLL, m.alkL, m.hL, m.status);
+      chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
+                  m.status);
       m.chem_fresh = true;
       // ---- slowparameval (t = year-1) ----
       m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
