@@ -587,17 +587,11 @@ void EnsembleCore::run(double runtodate) {
   const int target = (int)runtodate - scen_.start;
   if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
   check(hipEventRecord(ev0_, stream_), "event");
-  // one DOECLIM history pass + one run-kernel launch per block of years
-  const int L = hx_doeclim_block_years();
+  // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
+  // history pass every HX_DBLK years), so there is no global barrier to wait at
   const bool hf = d_out_[HXO_HEATFLUX] != nullptr;
-  for (int from = last_iy_; from < target; from += L) {
-    const int to = std::min(from + L, target);
-    check(hx_launch_doeclim_pass(d_out_[HXO_SST], d_ker_, d_dpart_,
-                                 d_dpart_ + (size_t)npad_ * L, scen_.ns(), npad_, from + 1,
-                                 to - from, hf, ker_per_member_, stream_), "doeclim pass");
-    check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, from, to, stream_),
-          "run kernel");
-  }
+  check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, last_iy_, target, stream_),
+        "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
   last_iy_ = target;

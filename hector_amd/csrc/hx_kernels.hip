@@ -887,6 +887,58 @@ __device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
 }
 }  // namespace
 
+// In-kernel form of the DOECLIM history pass (see hx_doeclim_pass_kernel below for
+// the algorithm): one lane = one member, all HX_DBLK block years, two sweeps of 16
+// accumulators.  Deliberately NOT inlined: as a real call it gets its own register
+// allocation (16 loads in flight need landing registers the year loop does not have),
+// and the caller's live registers are saved around it once per HX_DBLK years.
+template <bool KERPM, bool HF>
+__device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_hist,
+                                                           const double *ker, double *part,
+                                                           double *part2, int ns, int npad,
+                                                           int blk0, int mem) {
+  hx_gcd hist = HX_GCD(sst_hist) + mem;
+  const size_t np = (size_t)npad;
+  auto ldk = [&](int idx) -> double {
+    if constexpr (KERPM) return HX_GCD(ker)[(size_t)idx * np + mem];
+    else return HX_CCD(ker)[idx];
+  };
+  for (int j0 = 0; j0 < HX_DBLK; j0 += 16) {
+    double acc[16], acc2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[j] = 0; acc2[j] = 0; }
+    // window entry w of chunk i0 = Ker[(ns - (blk0 + j0) - 1) + i0 - 15 + w]
+    const int k0 = ns - (blk0 + j0) - 1 - 15 + HX_KPAD;
+    if (blk0 + j0 < ns) {
+      for (int i0 = 0; i0 < blk0; i0 += 16) {
+        double T[16], kw[32];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+          const int i = i0 + ii;
+          // rows >= blk0 may hold stale values of an earlier run: mask them
+          const double v = hist[(size_t)(i < ns ? i : ns - 1) * np];
+          T[ii] = (i < blk0) ? v : 0.0;
+        }
+#pragma unroll
+        for (int w = 0; w < 32; ++w) kw[w] = ldk(k0 + i0 + w);
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            acc[j] += T[ii] * kw[15 + ii - j];
+            if (HF) acc2[j] += T[ii] * kw[16 + ii - j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      HX_GD(part)[(size_t)(j0 + j) * np + mem] = acc[j];
+      if (HF) HX_GD(part2)[(size_t)(j0 + j) * np + mem] = acc2[j];
+    }
+  }
+}
+
 // ===========================================================================
 // DOECLIM history pass.  sum_{i<t} Tsst[i] * Ker[ns - t + i - 1]
 // (temperature_component.cpp:488-491; :534-537 for the heat-flux diagnostic, Ker
@@ -1075,7 +1127,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   bind_member<B>(args->buf, mem, m);
   load_state<B>(args->buf, mem, m);
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
-  const int blk0 = iy_from + 1;  // first year of this launch = first year of the DOECLIM block
+  int blk0 = -1;  // first year index of the current DOECLIM block
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
@@ -1188,6 +1240,13 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       const HxConst &kc = args->kc;
       const int ns = kc.ns;
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
+        // new DOECLIM block: this lane's partial sums over its SST history
+        blk0 = iy;
+        doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+                                    const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
+        HX_FENCE();
+      }
       // every HBM value this phase needs, issued back to back
       const double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem);
       const double f_prev = lds_(buf, HXS_F_PREV, mem);
