@@ -272,6 +272,24 @@ __device__ __forceinline__ double surf_flux(double co2, double pco2, double scal
 // limits this kernel (DESIGN.md "registers").
 #define HX_FENCE() asm volatile("" ::: "memory")
 
+// Per-lane LDS scratchpad ("park"): year-level state and the constants that the
+// phases and the stash block need a few times per year.  One wavefront per SIMD
+// means every HBM/L2 access is an exposed ~1-2k-cycle stall; LDS answers in ~64.
+// Filled from the HBM tables at kernel entry, state slots written back at exit.
+enum HxPark {
+  PK_CH4 = 0, PK_SST, PK_EOS, PK_TLAND, PK_TWIN, PK_TL_M1, PK_TL_M2, PK_F_PREV,
+  PK_BASE_TOT, PK_BASE_CO2,            // <- year-level state (HBM state rows)
+  PK_AERO, PK_VOL,
+  PK_D0,                               // 14 DOECLIM constants HXD_A0..HXD_HFSCALE
+  PK_K0 = PK_D0 + 14,                  // 7 ocean exchange coefficients HXD_KLH..HXD_KDI
+  PK_FFROZEN0 = PK_K0 + 7,             // f_frozen per biome
+};
+// single-biome kernels also park the biome constants (11 more slots)
+enum HxParkB1 { PKB_NPP0 = 0, PKB_F_NPPV, PKB_F_NPPD, PKB_F_LITTERD, PKB_RH_CH4_FRAC,
+                PKB_FPF_STATIC, PKB_BETA, PKB_WF, PKB_LNQ10, PKB_MU, PKB_SIGMA, PKB_N };
+template <int B> constexpr int hx_npark() { return PK_FFROZEN0 + B + (B == 1 ? PKB_N : 0); }
+template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + B; }
+
 // What stays in registers through the carbon-cycle solver of one year.
 template <int B>
 struct Member {
@@ -297,7 +315,10 @@ struct Member {
   hx_gcd par;  // params + mem   (row stride npad)
   hx_gcd der;  // derived + mem
   int npad;
+  double (*pk)[64];  // LDS park
+  int lane;
 };
+#define PKM(m, slot) ((m).pk[(slot)][(m).lane])
 
 // biome constants of the land model, fetched where they are used
 template <int B>
@@ -307,6 +328,13 @@ struct LandK {
 template <int B>
 __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
   HX_FENCE();
+  if constexpr (B == 1) {
+    constexpr int o = hx_pkb1<B>();
+    k.npp0[0] = PKM(m, o + PKB_NPP0); k.f_nppv[0] = PKM(m, o + PKB_F_NPPV);
+    k.f_nppd[0] = PKM(m, o + PKB_F_NPPD); k.f_litterd[0] = PKM(m, o + PKB_F_LITTERD);
+    k.rh_ch4_frac[0] = PKM(m, o + PKB_RH_CH4_FRAC); k.fpf_static[0] = PKM(m, o + PKB_FPF_STATIC);
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
@@ -420,10 +448,10 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
                                       bool more) {
   LandK<B> lk;
   load_landk<B>(m, lk);
-  const double kHD = m.der[(size_t)HXD_KHD * m.npad], kLH = m.der[(size_t)HXD_KLH * m.npad],
-               kLI = m.der[(size_t)HXD_KLI * m.npad], kIL = m.der[(size_t)HXD_KIL * m.npad],
-               kIH = m.der[(size_t)HXD_KIH * m.npad], kID = m.der[(size_t)HXD_KID * m.npad],
-               kDI = m.der[(size_t)HXD_KDI * m.npad];
+  const double kHD = PKM(m, PK_K0 + (HXD_KHD - HXD_KLH)), kLH = PKM(m, PK_K0 + 0),
+               kLI = PKM(m, PK_K0 + (HXD_KLI - HXD_KLH)), kIL = PKM(m, PK_K0 + (HXD_KIL - HXD_KLH)),
+               kIH = PKM(m, PK_K0 + (HXD_KIH - HXD_KLH)), kID = PKM(m, PK_K0 + (HXD_KID - HXD_KLH)),
+               kDI = PKM(m, PK_K0 + (HXD_KDI - HXD_KLH));
   const double yf = t - m.ode_start;
   m.nstash++;
   const bool in_partial_year = (t != floor(t));
@@ -734,6 +762,9 @@ __device__ __forceinline__ double equilibrate_alk(const ChemK &k, double carbon,
 __device__ __forceinline__ double ldp(const HxBuffers &b, int row, int mem) {
   return HX_GCD(b.params)[(size_t)row * b.npad + mem];
 }
+__device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
+  return HX_GCD(b.derived)[(size_t)row * b.npad + mem];
+}
 __device__ __forceinline__ double lds_(const HxBuffers &b, int row, int mem) {
   return HX_GCD(b.state)[(size_t)row * b.npad + mem];
 }
@@ -745,11 +776,36 @@ __device__ __forceinline__ void sto_(const HxBuffers &b, int var, size_t off, do
 }
 
 template <int B>
-__device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Member<B> &m) {
+__device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Member<B> &m,
+                                            double (*park)[64], int lane) {
   m.par = HX_GCD(buf.params) + mem;
   m.der = HX_GCD(buf.derived) + mem;
   m.npad = buf.npad;
+  m.pk = park;
+  m.lane = lane;
   m.C0 = ldp(buf, HXP_C0, mem);
+  // constants -> park
+  PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
+  PKM(m, PK_VOL) = ldp(buf, HXP_VOL, mem);
+#pragma unroll
+  for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) PKM(m, PK_K0 + k) = ldd(buf, HXD_KLH + k, mem);
+  if constexpr (B == 1) {
+    constexpr int o = hx_pkb1<B>();
+    const int r = HXP_NGLOBAL;
+    PKM(m, o + PKB_NPP0) = ldp(buf, r + HXPB_NPP0, mem);
+    PKM(m, o + PKB_F_NPPV) = ldp(buf, r + HXPB_F_NPPV, mem);
+    PKM(m, o + PKB_F_NPPD) = ldp(buf, r + HXPB_F_NPPD, mem);
+    PKM(m, o + PKB_F_LITTERD) = ldp(buf, r + HXPB_F_LITTERD, mem);
+    PKM(m, o + PKB_RH_CH4_FRAC) = ldp(buf, r + HXPB_RH_CH4_FRAC, mem);
+    PKM(m, o + PKB_FPF_STATIC) = ldp(buf, r + HXPB_FPF_STATIC, mem);
+    PKM(m, o + PKB_BETA) = ldp(buf, r + HXPB_BETA, mem);
+    PKM(m, o + PKB_WF) = ldp(buf, r + HXPB_WF, mem);
+    PKM(m, o + PKB_LNQ10) = ldd(buf, HXD_NGLOBAL, mem);
+    PKM(m, o + PKB_MU) = ldp(buf, r + HXPB_PF_MU, mem);
+    PKM(m, o + PKB_SIGMA) = ldp(buf, r + HXPB_PF_SIGMA, mem);
+  }
 }
 
 // solver-resident state <-> HBM state table
@@ -881,11 +937,6 @@ __global__ __launch_bounds__(256) void hx_derive_kernel(const double *params, do
     D(HXD_NGLOBAL + b, log(P(HXP_NGLOBAL + b * HXPB_N + HXPB_Q10)));
 }
 
-namespace {
-__device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
-  return HX_GCD(b.derived)[(size_t)row * b.npad + mem];
-}
-}  // namespace
 
 // In-kernel form of the DOECLIM history pass (see hx_doeclim_pass_kernel below for
 // the algorithm): one lane = one member, all HX_DBLK block years, two sweeps of 16
@@ -1013,8 +1064,9 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   const HxConst &kc = args->kc;
   const int mem = blockIdx.x * 64 + threadIdx.x;
   if (mem >= buf.npad) return;
+  __shared__ double s_park[hx_npark<B>()][64];
   Member<B> m;
-  bind_member<B>(buf, mem, m);
+  bind_member<B>(buf, mem, m, s_park, (int)threadIdx.x);
   // initial conditions: ocean_component.cpp:234-260, simpleNbox.cpp:45-79,
   // simpleNbox-runtime.cpp:146-172
   {
@@ -1123,9 +1175,22 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   const int lane = threadIdx.x;
   const int mem = blockIdx.x * 64 + lane;
   if (mem >= args->buf.npad) return;
+  __shared__ double s_park[hx_npark<B>()][64];
   Member<B> m;
-  bind_member<B>(args->buf, mem, m);
+  bind_member<B>(args->buf, mem, m, s_park, lane);
   load_state<B>(args->buf, mem, m);
+  {  // year-level state -> park
+    const HxBuffers &buf = args->buf;
+    PKM(m, PK_CH4) = lds_(buf, HXS_CH4, mem); PKM(m, PK_SST) = lds_(buf, HXS_SST, mem);
+    PKM(m, PK_EOS) = lds_(buf, HXS_EOS_VEGC, mem); PKM(m, PK_TLAND) = lds_(buf, HXS_TLAND, mem);
+    PKM(m, PK_TWIN) = lds_(buf, HXS_TWIN, mem); PKM(m, PK_TL_M1) = lds_(buf, HXS_TL_M1, mem);
+    PKM(m, PK_TL_M2) = lds_(buf, HXS_TL_M2, mem); PKM(m, PK_F_PREV) = lds_(buf, HXS_F_PREV, mem);
+    PKM(m, PK_BASE_TOT) = lds_(buf, HXS_BASE_TOT, mem);
+    PKM(m, PK_BASE_CO2) = lds_(buf, HXS_BASE_CO2, mem);
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      PKM(m, PK_FFROZEN0 + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
+  }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
 
@@ -1139,12 +1204,12 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
       // every HBM value this phase needs, issued back to back (one exposed latency:
       // with one wavefront per SIMD nothing else hides it)
-      const double prev_ch4 = lds_(buf, HXS_CH4, mem);
-      const double sst = lds_(buf, HXS_SST, mem);
-      const double eos = lds_(buf, HXS_EOS_VEGC, mem);
-      const double tland = lds_(buf, HXS_TLAND, mem);
-      double twin = lds_(buf, HXS_TWIN, mem);
-      const double tl_m2 = lds_(buf, HXS_TL_M2, mem);
+      const double prev_ch4 = PKM(m, PK_CH4);
+      const double sst = PKM(m, PK_SST);
+      const double eos = PKM(m, PK_EOS);
+      const double tland = PKM(m, PK_TLAND);
+      double twin = PKM(m, PK_TWIN);
+      const double tl_m2 = PKM(m, PK_TL_M2);
       const int iold = iy - 203;
       const double tl_old =
           HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * buf.npad + mem];
@@ -1152,15 +1217,24 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       LandK<B> lk;
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        const int pr = HXP_NGLOBAL + b * HXPB_N;
-        p_beta[b] = ldp(buf, pr + HXPB_BETA, mem);
-        p_wf[b] = ldp(buf, pr + HXPB_WF, mem);
-        p_mu[b] = ldp(buf, pr + HXPB_PF_MU, mem);
-        p_sigma[b] = ldp(buf, pr + HXPB_PF_SIGMA, mem);
-        p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
-        s_ffrozen[b] = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
-        lk.fpf_static[b] = ldp(buf, pr + HXPB_FPF_STATIC, mem);
-        lk.rh_ch4_frac[b] = ldp(buf, pr + HXPB_RH_CH4_FRAC, mem);
+        s_ffrozen[b] = PKM(m, PK_FFROZEN0 + b);
+        if constexpr (B == 1) {
+          constexpr int o = hx_pkb1<B>();
+          p_beta[b] = PKM(m, o + PKB_BETA); p_wf[b] = PKM(m, o + PKB_WF);
+          p_mu[b] = PKM(m, o + PKB_MU); p_sigma[b] = PKM(m, o + PKB_SIGMA);
+          p_lnq10[b] = PKM(m, o + PKB_LNQ10);
+          lk.fpf_static[b] = PKM(m, o + PKB_FPF_STATIC);
+          lk.rh_ch4_frac[b] = PKM(m, o + PKB_RH_CH4_FRAC);
+        } else {
+          const int pr = HXP_NGLOBAL + b * HXPB_N;
+          p_beta[b] = ldp(buf, pr + HXPB_BETA, mem);
+          p_wf[b] = ldp(buf, pr + HXPB_WF, mem);
+          p_mu[b] = ldp(buf, pr + HXPB_PF_MU, mem);
+          p_sigma[b] = ldp(buf, pr + HXPB_PF_SIGMA, mem);
+          p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
+          lk.fpf_static[b] = ldp(buf, pr + HXPB_FPF_STATIC, mem);
+          lk.rh_ch4_frac[b] = ldp(buf, pr + HXPB_RH_CH4_FRAC, mem);
+        }
       }
       // ---- OH, CH4, O3 ----
       double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
@@ -1180,7 +1254,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
                             prev_ch4 / tau_oh;
         ch4 = prev_ch4 + dCH4;
       }
-      sts_(buf, HXS_CH4, mem, ch4);
+      PKM(m, PK_CH4) = ch4;
       o3 = ((5 * log(ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
       // ---- ocean: new year ----
       chem_constants2(sst + 18 + (-16.4), sst + 18 + 2.9, m.kH, m.kL);
@@ -1203,11 +1277,10 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if (iy >= 3) {
         twin += tl_m2;  // Tland of year iy-3 enters
         if (iold >= 1) twin -= tl_old;
-        sts_(buf, HXS_TWIN, mem, twin);
+        PKM(m, PK_TWIN) = twin;
       }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        const int fr = HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN;
         m.co2fert[b] = 1 + p_beta[b] * lnc;
         const double Tb = tland * p_wf[b];
         m.tempfertd[b] = exp(p_lnq10[b] * (Tb / 10.0));
@@ -1219,7 +1292,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
             ff = 1 - erfc(-d) / 2;
           }
           m.f_new_thaw[b] = s_ffrozen[b] - ff;
-          sts_(buf, fr, mem, ff);
+          PKM(m, PK_FFROZEN0 + b) = ff;
         }
         const double Trm = (iy > 1) ? (twin * p_wf[b]) / 200 : 0.0;
         const double tfs = exp(p_lnq10[b] * (Trm / 10.0));
@@ -1248,19 +1321,18 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         HX_FENCE();
       }
       // every HBM value this phase needs, issued back to back
-      const double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem);
-      const double f_prev = lds_(buf, HXS_F_PREV, mem);
-      const double base_tot = lds_(buf, HXS_BASE_TOT, mem), base_co2 = lds_(buf, HXS_BASE_CO2, mem);
-      const double tl_m1 = lds_(buf, HXS_TL_M1, mem);
-      const double p_aero = ldp(buf, HXP_AERO, mem), p_vol = ldp(buf, HXP_VOL, mem);
-      const double dA0 = ldd(buf, HXD_A0, mem), dA1 = ldd(buf, HXD_A1, mem),
-                   dA2 = ldd(buf, HXD_A2, mem), dA3 = ldd(buf, HXD_A3, mem),
-                   dIB0 = ldd(buf, HXD_IB0, mem), dIB1 = ldd(buf, HXD_IB1, mem),
-                   dIB2 = ldd(buf, HXD_IB2, mem), dIB3 = ldd(buf, HXD_IB3, mem),
-                   dQC1 = ldd(buf, HXD_QC1, mem), dQC2 = ldd(buf, HXD_QC2, mem),
-                   dDQ1 = ldd(buf, HXD_DQ1, mem), dDQ2 = ldd(buf, HXD_DQ2, mem),
-                   dDPS = ldd(buf, HXD_DPSCALE, mem),
-                   dHFS = want_hf ? ldd(buf, HXD_HFSCALE, mem) : 0.0;
+      const double tland = PKM(m, PK_TLAND), sst = PKM(m, PK_SST);
+      const double f_prev = PKM(m, PK_F_PREV);
+      const double base_tot = PKM(m, PK_BASE_TOT), base_co2 = PKM(m, PK_BASE_CO2);
+      const double tl_m1 = PKM(m, PK_TL_M1);
+      const double p_aero = PKM(m, PK_AERO), p_vol = PKM(m, PK_VOL);
+#define HXDK(row) PKM(m, PK_D0 + ((row) - HXD_A0))
+      const double dA0 = HXDK(HXD_A0), dA1 = HXDK(HXD_A1), dA2 = HXDK(HXD_A2), dA3 = HXDK(HXD_A3),
+                   dIB0 = HXDK(HXD_IB0), dIB1 = HXDK(HXD_IB1), dIB2 = HXDK(HXD_IB2),
+                   dIB3 = HXDK(HXD_IB3), dQC1 = HXDK(HXD_QC1), dQC2 = HXDK(HXD_QC2),
+                   dDQ1 = HXDK(HXD_DQ1), dDQ2 = HXDK(HXD_DQ2), dDPS = HXDK(HXD_DPSCALE),
+                   dHFS = want_hf ? HXDK(HXD_HFSCALE) : 0.0;
+#undef HXDK
       const int jb = iy - blk0;
       double dpast = HX_GCD(buf.dpart)[(size_t)jb * buf.npad + mem];
       double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
@@ -1290,8 +1362,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
                              p_aero * sh[HXSH_RF_AERO]) +
                             p_vol * sh[HXSH_RF_VOL];
         if (iy == kc.baseyear_idx) {
-          sts_(buf, HXS_BASE_TOT, mem, ftot);
-          sts_(buf, HXS_BASE_CO2, mem, fco2);
+          PKM(m, PK_BASE_TOT) = ftot;
+          PKM(m, PK_BASE_CO2) = fco2;
           rf_tot = 0; rf_co2 = 0;  // x - x
         } else {
           rf_tot = ftot - base_tot;
@@ -1329,11 +1401,11 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         s_tblk[j][lane] = sst_new;
       }
       const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
-      sts_(buf, HXS_F_PREV, mem, rf_tot);
-      sts_(buf, HXS_TL_M2, mem, tl_m1);  // Tland of years iy-2, iy-1
-      sts_(buf, HXS_TL_M1, mem, tland);                      // for the next year
-      sts_(buf, HXS_TLAND, mem, tl_new);
-      sts_(buf, HXS_SST, mem, sst_new);
+      PKM(m, PK_F_PREV) = rf_tot;
+      PKM(m, PK_TL_M2) = tl_m1;  // Tland of years iy-2, iy-1
+      PKM(m, PK_TL_M1) = tland;  // for the next year
+      PKM(m, PK_TLAND) = tl_new;
+      PKM(m, PK_SST) = sst_new;
       // ---- outputs ----
       const size_t o = (size_t)iy * buf.npad + mem;
       sto_(buf, HXO_SST, o, sst_new);
@@ -1370,6 +1442,18 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   }
   HX_FENCE();
   store_state<B>(args->buf, mem, m);
+  {  // park -> year-level state rows
+    const HxBuffers &buf = args->buf;
+    sts_(buf, HXS_CH4, mem, PKM(m, PK_CH4)); sts_(buf, HXS_SST, mem, PKM(m, PK_SST));
+    sts_(buf, HXS_TLAND, mem, PKM(m, PK_TLAND)); sts_(buf, HXS_TWIN, mem, PKM(m, PK_TWIN));
+    sts_(buf, HXS_TL_M1, mem, PKM(m, PK_TL_M1)); sts_(buf, HXS_TL_M2, mem, PKM(m, PK_TL_M2));
+    sts_(buf, HXS_F_PREV, mem, PKM(m, PK_F_PREV));
+    sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
+    sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
+  }
 }
 
 // ===========================================================================
