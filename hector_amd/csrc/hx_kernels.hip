@@ -555,6 +555,21 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
 // scales the next trial step, so ~1e-15 relative error is immaterial.
 __device__ __forceinline__ double powr(double x, double p) { return exp(p * log(x)); }
 
+// x^(-1/5) for the step-growth rule: single-precision seed, two Newton steps on
+// y^-5 = x in fp64 (relative error e -> 3e^2: 1e-6 -> 3e-12 -> ~1e-16).  The
+// fp64 log/exp pair it replaces is a ~75-instruction dependent chain, the longest
+// in the step block, and a single resident wavefront cannot hide it.
+__device__ __forceinline__ double pow_m15(double x) {
+  double y = (double)exp2f(-0.2f * log2f((float)x));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double y2 = y * y;
+    const double y5 = y2 * y2 * y;
+    y = y + y * ((1.0 - x * y5) * 0.2);
+  }
+  return y;
+}
+
 // CarbonCycleSolver::run for one model year t0 -> tnew (carbon-cycle-solver.cpp:
 // 222-303).  The 64 lanes walk the reference's control flow in lock-step over
 // SEGMENTS (one stash interval each): inner loop = dopri5 attempts until every
@@ -671,7 +686,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             l4 += dtl * K.k4; l5 += dtl * K.k5; l7 += dtl * K.k7;
             t += dtl;
             // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
-            const double grow = 0.9 * powr(fmax(0.00032, err), -1.0 / 5.0);
+            const double grow = 0.9 * pow_m15(fmax(0.00032, err));
             if (err < 0.5) dtl *= grow;
 #pragma unroll
             for (int i = 0; i < 5; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
