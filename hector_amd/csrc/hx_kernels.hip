@@ -668,16 +668,20 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
                     dtl * c5 * k5[i] + dtl * c6 * k6[i];
           rhs<B, SPIN>(m, K, xn, dn);
-          double err = 0.0;  // default_error_checker, max norm
+          // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
+          // The maximum of the five quotients is found by cross-multiplication
+          // (all denominators > 0) and divided once.
+          double en = 0.0, ed = 1.0;
 #pragma unroll
           for (int i = 0; i < 5; ++i) {
             const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
                               dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
                               dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
-            const double e = fabs(xe) / (kc.eps_abs +
-                             kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i])));
-            err = fmax(err, e);
+            const double n = fabs(xe);
+            const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
+            if (n * ed > en * d) { en = n; ed = d; }
           }
+          double err = en / ed;
           if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
             dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
             if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
