@@ -980,8 +980,9 @@ __device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_his
     // window entry w of chunk i0 = Ker[(ns - (blk0 + j0) - 1) + i0 - 15 + w]
     const int k0 = ns - (blk0 + j0) - 1 - 15 + HX_KPAD;
     if (blk0 + j0 < ns) {
-      for (int i0 = 0; i0 < blk0; i0 += 16) {
-        double T[16], kw[32];
+      // software pipeline: the 16 loads of the next chunk are in flight while the
+      // 256 FMAs of the current one execute
+      auto load_chunk = [&](double *T, int i0) {
 #pragma unroll
         for (int ii = 0; ii < 16; ++ii) {
           const int i = i0 + ii;
@@ -989,6 +990,9 @@ __device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_his
           const double v = hist[(size_t)(i < ns ? i : ns - 1) * np];
           T[ii] = (i < blk0) ? v : 0.0;
         }
+      };
+      auto compute_chunk = [&](const double *T, int i0) {
+        double kw[32];
 #pragma unroll
         for (int w = 0; w < 32; ++w) kw[w] = ldk(k0 + i0 + w);
 #pragma unroll
@@ -998,6 +1002,16 @@ __device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_his
             acc[j] += T[ii] * kw[15 + ii - j];
             if (HF) acc2[j] += T[ii] * kw[16 + ii - j];
           }
+        }
+      };
+      double Ta[16], Tb[16];
+      load_chunk(Ta, 0);
+      for (int i0 = 0; i0 < blk0; i0 += 32) {
+        load_chunk(Tb, i0 + 16);
+        compute_chunk(Ta, i0);
+        if (i0 + 16 < blk0) {
+          load_chunk(Ta, i0 + 32);
+          compute_chunk(Tb, i0 + 16);
         }
       }
     }
