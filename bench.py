@@ -61,32 +61,40 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(target_seconds=15.0):
+def cpu_baseline(target_seconds=15.0, chunk=32):
     """Oracle on the host cores (ctypes releases the GIL: one thread per usable core),
-    on a bounded sample of the same seeded ensemble, 555-year loop only."""
-    from concurrent.futures import ThreadPoolExecutor
+    on a time-bounded sample of the same seeded ensemble, 555-year loop only: every
+    thread keeps taking chunks of members until the deadline."""
+    import itertools
+    import threading
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_binding
     import hector_amd
     from hector_amd import ensemble
     orc = oracle_binding.Oracle(hector_amd.DEFAULT_SCENARIO)
     cores = effective_cores()
-    S, q10 = ensemble.ecs_q10(8)
+    S, q10 = ensemble.ecs_q10(4)
+    orc.run_ecs_q10(S, q10)  # warm (page in libm etc.)
+    counter = itertools.count()
+    done = [0] * cores
+    errs = [0] * cores
     t0 = time.perf_counter()
-    orc.run_ecs_q10(S, q10)
-    per_member = (time.perf_counter() - t0) / 8
-    per_thread = int(min(4096, max(16, target_seconds / per_member)))
-    n = cores * per_thread
-    S, q10 = ensemble.ecs_q10(n)
+    deadline = t0 + target_seconds
 
     def work(t):
-        sl = slice(t * per_thread, (t + 1) * per_thread)
-        return orc.run_ecs_q10(S[sl], q10[sl])[2]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        errs = list(ex.map(work, range(cores)))
+        while time.perf_counter() < deadline:
+            k = next(counter)
+            S, q10 = ensemble.ecs_q10(chunk, offset=k * chunk)
+            errs[t] |= orc.run_ecs_q10(S, q10)[2]
+            done[t] += chunk
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
     dt = time.perf_counter() - t0
     assert not any(errs)
+    n = sum(done)
     return n * YEARS / dt, dt, n, cores
 
 
@@ -216,7 +224,7 @@ def main():
             v, dt, ns, cores = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": v, "unit": "member-years/s", "cores": cores, "kind": "port",
-                "sample": "%d members (first of the same seeded ECS/Q10 ensemble) x 555 years, "
+                "sample": "%d members (the first ones of the same seeded ECS/Q10 ensemble) x 555 years, "
                           "oracle/hector_oracle.c (scalar C restatement of the reference loop, "
                           "spinup shared and excluded), %d threads, %.1f s wall" % (ns, cores, dt),
             }
