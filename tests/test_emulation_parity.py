@@ -178,3 +178,69 @@ def test_member_sorting_is_transparent(emul_lib):
         assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
     assert np.array_equal(a.status(), b.status())
     assert np.array_equal(a.getvar("S"), S)
+
+
+def test_spinup_relevant_parameters_per_member(emul_lib, oracle):
+    """Parameters that enter the spinup (C0, npp_flux0, ocean transports, initial pools,
+    NPP partitioning) vary per member -> every lane spins up on its own (no broadcast)."""
+    n = 5
+    C0 = np.array([270.0, 277.15, 285.0, 277.15, 280.0])
+    npp = np.array([50.0, 56.2, 60.0, 56.2, 58.0])
+    tt = np.array([7.2e7, 7.2e7, 6.5e7, 8.0e7, 7.2e7])
+    fv = np.array([0.35, 0.30, 0.35, 0.40, 0.35])
+    veg = np.array([550.0, 500.0, 600.0, 550.0, 520.0])
+    c = mk(emul_lib, n)
+    c.setvar("C0", C0, "ppmv CO2").setvar("npp_flux0", npp, "Pg C/yr").setvar("tt", tt, "m3/s")
+    c.setvar("f_nppv", fv).setvar("veg_c", veg, "Pg C")
+    c.set_outputs(["CO2_concentration", "global_tas", "ocean_c", "veg_c"])
+    c.run(2100)
+    assert (c.status() == 0).all()
+    for i in range(n):
+        p = oracle.default_params()
+        p.C0 = C0[i]; p.npp_flux0[0] = npp[i]; p.tt = tt[i]; p.f_nppv[0] = fv[i]; p.veg_c[0] = veg[i]
+        o, err, steps = oracle.run(p, run_to=2100)
+        assert err == 0 and c.spinup_steps(i) == steps
+        k = 2100 - 1745 + 1
+        for v in ("CO2_concentration", "ocean_c", "veg_c"):
+            got = c.fetchvars(v, (1745, 2100))[:, i]
+            assert (np.abs(got - o[v][:k]) / o[v][:k]).max() < REL_CO2, (v, i)
+        assert np.abs(c.fetchvars("global_tas", (1745, 2100))[:, i] - o["global_tas"][:k]).max() < ABS_T
+
+
+def test_unequal_biome_split_vs_oracle(emul_lib, oracle):
+    """split_biome with explicit fractions (R/biome.R:61-130)."""
+    fveg = [0.5, 0.3, 0.2]; fdet = [0.2, 0.3, 0.5]; fsoil = [0.4, 0.4, 0.2]
+    fpf = [0.0, 0.3, 0.7]; fnpp = [0.6, 0.25, 0.15]
+    c = mk(emul_lib, 1)
+    c.split_biome(["trop", "temp", "bor"], fveg, fdet, fsoil, fpf, fnpp)
+    c.setvar("bor.warmingfactor", 2.0).setvar("trop.q10_rh", 1.6).setvar("temp.beta", 0.4)
+    c.set_outputs(["CO2_concentration", "global_tas", "permafrost_c", "soil_c"])
+    c.run(2300)
+    assert c.status()[0] == 0
+    p = oracle.default_params()
+    base = dict(v=p.veg_c[0], d=p.detritus_c[0], s=p.soil_c[0], pf=p.permafrost_c[0], n=p.npp_flux0[0])
+    oracle.split_equal(p, 3)
+    for b in range(3):
+        p.veg_c[b] = base["v"] * fveg[b]; p.detritus_c[b] = base["d"] * fdet[b]
+        p.soil_c[b] = base["s"] * fsoil[b]; p.permafrost_c[b] = base["pf"] * fpf[b]
+        p.npp_flux0[b] = base["n"] * fnpp[b]
+    p.warmingfactor[2] = 2.0; p.q10_rh[0] = 1.6; p.beta[1] = 0.4
+    o, err, _ = oracle.run(p)
+    assert err == 0
+    for v in ("CO2_concentration", "permafrost_c", "soil_c"):
+        got = c.fetchvars(v, (1745, 2300))[:, 0]
+        assert (np.abs(got - o[v]) / o[v]).max() < REL_CO2, v
+    assert np.abs(c.fetchvars("global_tas", (1745, 2300))[:, 0] - o["global_tas"]).max() < ABS_T
+
+
+def test_model_errors_are_flags_not_crashes(emul_lib):
+    """A member the reference would abort on (fluxpool / mass-balance / retry asserts)
+    sets status bits; its neighbours are unaffected."""
+    S = np.array([3.0, 3.0, 3.0]); npp = np.array([56.2, 1e5, 56.2])
+    c = mk(emul_lib, 3).setvar("S", S).setvar("npp_flux0", npp).run(1800)
+    st = c.status()
+    assert st[0] == 0 and st[2] == 0 and st[1] != 0
+    a = c.fetchvars("CO2_concentration")
+    assert np.array_equal(a[:, 0], a[:, 2]) and np.isfinite(a[:, 0]).all()
+    with pytest.raises(hector_amd.HectorAmdError):
+        mk(emul_lib, 0)

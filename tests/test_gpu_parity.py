@@ -206,3 +206,54 @@ def test_member_sorting_is_transparent_on_gpu(hip_lib):
     for v in ("CO2_concentration", "global_tas"):
         assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
     assert np.array_equal(a.status(), b.status())
+
+
+def test_spinup_relevant_parameters_per_member_on_gpu(hip_lib, oracle):
+    """Every lane spins up on its own when C0 / npp_flux0 / transports / pools vary."""
+    n = 96
+    r = np.random.default_rng(7)
+    C0 = 270 + 15 * r.random(n); npp = 50 + 12 * r.random(n); tt = 6.5e7 + 1.5e7 * r.random(n)
+    fv = 0.3 + 0.1 * r.random(n); veg = 500 + 100 * r.random(n)
+    c = mk(hip_lib, n)
+    c.setvar("C0", C0, "ppmv CO2").setvar("npp_flux0", npp, "Pg C/yr").setvar("tt", tt, "m3/s")
+    c.setvar("f_nppv", fv).setvar("veg_c", veg, "Pg C")
+    c.set_outputs(["CO2_concentration", "global_tas", "ocean_c"])
+    c.run(2300)
+    assert (c.status() == 0).all()
+    co2 = c.fetchvars("CO2_concentration"); tg = c.fetchvars("global_tas"); oc = c.fetchvars("ocean_c")
+    for i in range(0, n, 5):
+        p = oracle.default_params()
+        p.C0 = C0[i]; p.npp_flux0[0] = npp[i]; p.tt = tt[i]; p.f_nppv[0] = fv[i]; p.veg_c[0] = veg[i]
+        o, err, steps = oracle.run(p)
+        assert err == 0 and c.spinup_steps(i) == steps
+        assert (np.abs(co2[:, i] - o["CO2_concentration"]) / o["CO2_concentration"]).max() < REL_CO2
+        assert (np.abs(oc[:, i] - o["ocean_c"]) / o["ocean_c"]).max() < REL_CO2
+        assert np.abs(tg[:, i] - o["global_tas"]).max() < ABS_T
+
+
+def test_million_member_ensemble_properties(hip_lib, oracle):
+    """BASELINE config 3's member count (1 048 576) on one GPU: clean status words,
+    replicated parameters reproduce bit for bit anywhere in the grid, sampled members
+    match the oracle."""
+    n = 1 << 20
+    S, q10 = ensemble.ecs_q10(n)
+    S[n // 2:n // 2 + 64] = S[:64]; q10[n // 2:n // 2 + 64] = q10[:64]
+    c = mk(hip_lib, n).setvar("S", S).setvar("q10_rh", q10).run(2300)
+    assert (c.status() == 0).all()
+    co2 = c.fetchvars("CO2_concentration", (2290, 2300)); tg = c.fetchvars("global_tas", (2290, 2300))
+    assert np.array_equal(co2[:, :64], co2[:, n // 2:n // 2 + 64])
+    assert np.isfinite(co2).all() and np.isfinite(tg).all()
+    idx = np.array([0, 65535, 65536, 500000, n - 1])
+    oco2, otg, err = oracle.run_ecs_q10(S[idx], q10[idx])
+    assert err == 0
+    assert (np.abs(co2[:, idx].T - oco2[:, -11:]) / oco2[:, -11:]).max() < REL_CO2
+    assert np.abs(tg[:, idx].T - otg[:, -11:]).max() < ABS_T
+
+
+def test_model_errors_are_flags_on_gpu(hip_lib):
+    S = np.full(130, 3.0); npp = np.full(130, 56.2); npp[77] = 1e5
+    c = mk(hip_lib, 130).setvar("S", S).setvar("npp_flux0", npp).run(1800)
+    st = c.status()
+    assert st[77] != 0 and (np.delete(st, 77) == 0).all()
+    a = c.fetchvars("CO2_concentration")
+    assert np.array_equal(a[:, 0], a[:, 129]) and np.isfinite(a[:, 0]).all()
