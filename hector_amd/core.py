@@ -101,6 +101,19 @@ class Core:
         self._ck(self._lib.hx_set_outputs(self._h, n, arr))
         return self
 
+    def enable_history(self, on=True):
+        self._ck(self._lib.hx_enable_history(self._h, 1 if on else 0))
+        return self
+
+    def setvar_dated(self, var, years, values, unit=None):
+        y = np.ascontiguousarray(np.atleast_1d(np.asarray(years, dtype=np.int32)))
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), y.shape))
+        self._ck(self._lib.hx_setvar_dated(self._h, var.encode(),
+                                           y.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                           v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), y.size,
+                                           unit.encode() if unit else None))
+        return self
+
     def set_member_sorting(self, on=True):
         self._ck(self._lib.hx_set_member_sorting(self._h, 1 if on else 0))
         return self
@@ -198,7 +211,7 @@ def shutdown(core):
 
 def setvar(core, dates, var, values, unit=None):
     if dates is not None and not (isinstance(dates, float) and np.isnan(dates)):
-        raise HectorAmdError("setvar: dated inputs are not supported by the ensemble path")
+        return core.setvar_dated(var, dates, values, unit)
     return core.setvar(var, values, unit)
 
 

@@ -276,7 +276,8 @@ void EnsembleCore::build_shared() {
 void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
-  fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_);
+  fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
+  d_hist_ = nullptr;
   d_derived_ = nullptr; d_dpart_ = nullptr; d_gather_ = nullptr; d_lane_of_member_ = nullptr;
   gather_cap_ = 0;
   d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
@@ -298,6 +299,9 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
   check(hipMalloc(&d_derived_, sizeof(double) * np * HX_NDERIVED(B_)), "hipMalloc derived");
   check(hipMalloc(&d_lane_of_member_, sizeof(int) * np), "hipMalloc lane map");
+  if (history_)
+    check(hipMalloc(&d_hist_, sizeof(double) * ns * np * HX_NSTATE(B_)), "hipMalloc state history");
+  hist_valid_to_ = 0;
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
   for (int v = 0; v < HXO_NVAR; ++v)
@@ -319,6 +323,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.dpart = d_dpart_;
   b.dpart2 = d_dpart_ ? d_dpart_ + (size_t)npad_ * hx_doeclim_block_years() : nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
+  b.hist = d_hist_;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   return b;
 }
@@ -443,6 +448,75 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
   last_iy_ = 0;
 }
 
+void EnsembleCore::enable_history(bool on) {
+  if (on == history_) return;
+  history_ = on;
+  layout_dirty_ = true;
+  need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+namespace {
+struct DatedDef { const char *name; const char *sections[2]; const char *units; };
+// inputs with dates: capability -> INI section(s) holding the series (component_data.hpp;
+// NOX/CO/NMVOC are read by both the OH and the ozone component)
+const DatedDef kDated[] = {
+    {"ffi_emissions", {"simpleNbox", nullptr}, "Pg C/yr"},
+    {"luc_emissions", {"simpleNbox", nullptr}, "Pg C/yr"},
+    {"daccs_uptake", {"simpleNbox", nullptr}, "Pg C/yr"},
+    {"luc_uptake", {"simpleNbox", nullptr}, "Pg C/yr"},
+    {"RF_albedo", {"simpleNbox", nullptr}, "W/m2"},
+    {"SO2_emissions", {"so2", nullptr}, "Gg S"},
+    {"SV", {"so2", nullptr}, "W/m2"},
+    {"CH4_emissions", {"CH4", nullptr}, "Tg CH4"},
+    {"CH4N", {"CH4", nullptr}, "Tg CH4"},
+    {"NOX_emissions", {"OH", "ozone"}, "Tg N"},
+    {"CO_emissions", {"OH", "ozone"}, "Tg CO"},
+    {"NMVOC_emissions", {"OH", "ozone"}, "Tg NMVOC"},
+    {"N2O_emissions", {"N2O", nullptr}, "Tg N"},
+    {"N2O_natural_emissions", {"N2O", nullptr}, "Tg N"},
+    {"RF_misc", {"forcing", nullptr}, "W/m2"},
+    {"BC_emissions", {"bc", nullptr}, "Tg"},
+    {"OC_emissions", {"oc", nullptr}, "Tg"},
+    {"NH3_emissions", {"nh3", nullptr}, "Tg"},
+};
+}  // namespace
+
+void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
+                                const double *values, int n, const char *units) {
+  std::string sections[2];
+  std::string expect;
+  for (const DatedDef &d : kDated)
+    if (capability == d.name) {
+      sections[0] = d.sections[0];
+      if (d.sections[1]) sections[1] = d.sections[1];
+      expect = d.units;
+    }
+  const std::string suf = "_emissions";
+  if (sections[0].empty() && capability.size() > suf.size() &&
+      capability.compare(capability.size() - suf.size(), suf.size(), suf) == 0) {
+    const std::string gas = capability.substr(0, capability.size() - suf.size());
+    for (auto &h : scen_.halocarbons)
+      if (h.name == gas) { sections[0] = gas + "_halocarbon"; expect = "Gg"; }
+  }
+  if (sections[0].empty())
+    throw std::runtime_error("Unknown variable name while parsing: " + capability +
+                             " (dated inputs)");
+  if (units && units[0] && expect != units)
+    throw std::runtime_error("Units: " + std::string(units) + " do not match expected: " + expect +
+                             " for " + capability);
+  int miny = scen_.end;
+  for (int i = 0; i < n; ++i) {
+    for (auto &sec : sections)
+      if (!sec.empty()) scen_.set_series_value(sec, capability, years[i], values[i]);
+    miny = std::min(miny, years[i]);
+  }
+  shared_dirty_ = true;
+  // R/messages.R:125-133: reset_date = min(date) - 1
+  const int target = std::max(0, miny - 1 - scen_.start);
+  if (target < last_iy_) dirty_from_iy_ = (dirty_from_iy_ < 0) ? target : std::min(dirty_from_iy_, target);
+}
+
 void EnsembleCore::lane_of_member(int *out) {
   prepare();
   std::memcpy(out, lane_of_member_.data(), sizeof(int) * (size_t)n_);
@@ -521,6 +595,13 @@ void EnsembleCore::upload_params() {
 void EnsembleCore::prepare() {
   check(hipSetDevice(device_), "hipSetDevice");
   if (layout_dirty_) alloc_device();
+  if (shared_dirty_) {  // dated inputs changed: rebuild the per-year table
+    build_shared();
+    check(hipMemcpyAsync(d_shared_, shared_.data(), sizeof(double) * shared_.size(),
+                         hipMemcpyHostToDevice, stream_), "upload shared");
+    check(hipStreamSynchronize(stream_), "sync shared");
+    shared_dirty_ = false;
+  }
   if (params_dirty_) upload_params();
   if (!need_spinup_) return;
   // Spinup is independent of every parameter that is not in the spinup set
@@ -557,26 +638,41 @@ void EnsembleCore::prepare() {
   spin_ms_ = ms;
   need_spinup_ = false;
   last_iy_ = 0;
+  hist_valid_to_ = 0;
+  dirty_from_iy_ = -1;
 }
 
 void EnsembleCore::reset(double date) {
   if (date < scen_.start) {  // core.cpp:511-549: rerun spinup
     need_spinup_ = true;
     last_iy_ = 0;
+    dirty_from_iy_ = -1;
     return;
   }
   const int iy = (int)date - scen_.start;
-  if (iy == last_iy_ && !need_spinup_) return;
-  if (iy != 0)
-    throw std::runtime_error("reset: only reset(0), reset(startDate) and reset(current date) are "
-                             "supported (no per-year state history is kept)");
-  if (need_spinup_ || layout_dirty_ || params_dirty_) { prepare(); return; }
-  const size_t np = (size_t)npad_;
-  check(hipMemcpyAsync(d_state_, d_state_ + np * HX_NSTATE(B_), sizeof(double) * np * HX_NSTATE(B_),
-                       hipMemcpyDeviceToDevice, stream_), "restore state");
-  check(hipMemcpyAsync(d_status_, d_status_ + np, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
-                       stream_), "restore status");
-  last_iy_ = 0;
+  if (need_spinup_ || layout_dirty_ || params_dirty_) {
+    if (iy != 0) throw std::runtime_error("reset: the core has pending changes from date 0");
+    prepare();
+    return;
+  }
+  if (iy == last_iy_) return;
+  if (iy > last_iy_) throw std::runtime_error("reset: date is after the current date");
+  const size_t np = (size_t)npad_, rows = (size_t)HX_NSTATE(B_);
+  sync();
+  if (iy == 0) {  // the post-spinup snapshot
+    check(hipMemcpyAsync(d_state_, d_state_ + np * rows, sizeof(double) * np * rows,
+                         hipMemcpyDeviceToDevice, stream_), "restore state");
+    check(hipMemcpyAsync(d_status_, d_status_ + np, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
+                         stream_), "restore status");
+  } else {
+    if (!d_hist_ || iy > hist_valid_to_)
+      throw std::runtime_error("reset: no state history for that date (enable_history() before "
+                               "running; only reset(0) and reset(startDate) work without it)");
+    check(hipMemcpyAsync(d_state_, d_hist_ + (size_t)iy * rows * np, sizeof(double) * np * rows,
+                         hipMemcpyDeviceToDevice, stream_), "restore state from history");
+  }
+  last_iy_ = iy;
+  if (dirty_from_iy_ >= iy) dirty_from_iy_ = -1;
 }
 
 void EnsembleCore::run(double runtodate) {
@@ -585,6 +681,13 @@ void EnsembleCore::run(double runtodate) {
   if (runtodate > scen_.end)
     throw std::runtime_error("Requested run-to date is after the configured end date.");
   const int target = (int)runtodate - scen_.start;
+  if (dirty_from_iy_ >= 0 && dirty_from_iy_ < last_iy_) {
+    // rcpp_hector.cpp:160-166: a core that is not clean is reset before it runs
+    const int back = (d_hist_ && dirty_from_iy_ <= hist_valid_to_) ? dirty_from_iy_ : 0;
+    dirty_from_iy_ = -1;
+    reset((double)(scen_.start + back));
+  }
+  dirty_from_iy_ = -1;
   if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
   check(hipEventRecord(ev0_, stream_), "event");
   // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
@@ -594,6 +697,7 @@ void EnsembleCore::run(double runtodate) {
         "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
+  if (d_hist_) hist_valid_to_ = target;  // slabs last_iy_+1..target were just (re)written
   last_iy_ = target;
 }
 

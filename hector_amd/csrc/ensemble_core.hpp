@@ -55,6 +55,14 @@ class EnsembleCore {
   // lane assignment: sort members by their perturbed parameters so that the lanes of a
   // wavefront follow similar solver schedules (default on; results do not depend on it)
   void set_member_sorting(bool on);
+  // keep every year's component state in HBM (272 B per member-year for one biome) so that
+  // reset(date) can go back to any computed year, like the reference's tseries records
+  void enable_history(bool on);
+  // SETDATA with dates for a scenario input series (emissions, SV, RF_albedo...): the same
+  // new values for every member.  Like R/messages.R:107-140 the core becomes dirty from
+  // min(year) - 1; the next run() resets there (needs the history) or to startDate.
+  void setvar_dated(const std::string &capability, const int *years, const double *values,
+                    int n, const char *units);
   void lane_of_member(int *out);
   static const char *const *output_capabilities(int *count);
 
@@ -107,7 +115,10 @@ class EnsembleCore {
   unsigned *d_status_ = nullptr;
   int *d_spin_steps_ = nullptr;
   HxArgs *d_args_ = nullptr;
-  double *d_derived_ = nullptr, *d_dpart_ = nullptr, *d_gather_ = nullptr;
+  double *d_derived_ = nullptr, *d_dpart_ = nullptr, *d_gather_ = nullptr, *d_hist_ = nullptr;
+  bool history_ = false, shared_dirty_ = false;
+  int hist_valid_to_ = 0;   // history slabs 1..hist_valid_to_ are valid
+  int dirty_from_iy_ = -1;  // pending auto-reset target (R wrapper's reset_date)
   int *d_lane_of_member_ = nullptr;
   size_t gather_cap_ = 0;
   hipStream_t stream_ = nullptr;

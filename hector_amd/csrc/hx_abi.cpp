@@ -78,6 +78,12 @@ int hx_output_capabilities(const char *const **names, int *count) {
   return 0;
 }
 int hx_set_member_sorting(hx_core *core, int on) { HX_TRY(core->core->set_member_sorting(on != 0)) }
+int hx_enable_history(hx_core *core, int on) { HX_TRY(core->core->enable_history(on != 0)) }
+int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
+                    int n, const char *units) {
+  if (!capability || !years || !values || n < 1) return fail("hx_setvar_dated: bad arguments");
+  HX_TRY(core->core->setvar_dated(capability, years, values, n, units))
+}
 int hx_lane_of_member(hx_core *core, int *out) {
   if (!out) return fail("null argument");
   HX_TRY(core->core->lane_of_member(out))

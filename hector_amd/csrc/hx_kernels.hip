@@ -854,8 +854,11 @@ __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member
 }
 
 template <int B>
-__device__ __forceinline__ void store_state(const HxBuffers &buf, int mem,
-                                            const Member<B> &m) {
+__device__ __forceinline__ void store_state(const HxBuffers &buf_, int mem,
+                                            const Member<B> &m, double *base = nullptr) {
+  // base == nullptr: the live state table; otherwise a per-year history slab
+  HxBuffers buf = buf_;
+  if (base) buf.state = base;
   sts_(buf, HXS_C_HL, mem, m.cHL); sts_(buf, HXS_C_LL, mem, m.cLL);
   sts_(buf, HXS_C_IO, mem, m.cIO); sts_(buf, HXS_C_DO, mem, m.cDO);
   sts_(buf, HXS_ATMOS, mem, m.atmos); sts_(buf, HXS_EARTH, mem, m.earth);
@@ -876,7 +879,25 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf, int mem,
     sts_(buf, r + HXSB_THAWED, mem, m.thawed[b]);
     sts_(buf, r + HXSB_TEMPFERTS, mem, m.tempferts[b]);
   }
-  HX_GU(buf.status)[mem] = m.status;
+  if (!base) HX_GU(buf.status)[mem] = m.status;
+}
+
+// year-level state: park -> state rows of `base` (live table or history slab)
+template <int B>
+__device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
+                                                 const Member<B> &m, double *base = nullptr) {
+  HxBuffers buf = buf_;
+  if (base) buf.state = base;
+  sts_(buf, HXS_CH4, mem, PKM(m, PK_CH4)); sts_(buf, HXS_SST, mem, PKM(m, PK_SST));
+  sts_(buf, HXS_TLAND, mem, PKM(m, PK_TLAND)); sts_(buf, HXS_TWIN, mem, PKM(m, PK_TWIN));
+  sts_(buf, HXS_TL_M1, mem, PKM(m, PK_TL_M1)); sts_(buf, HXS_TL_M2, mem, PKM(m, PK_TL_M2));
+  sts_(buf, HXS_F_PREV, mem, PKM(m, PK_F_PREV));
+  sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
+  sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
+  if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
 }
 
 }  // namespace
@@ -1471,22 +1492,16 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, s);
         if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, th);
       }
+      if (buf.hist) {  // Core::reset(date) needs every component's state of every year
+        double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(B) * buf.npad;
+        store_state<B>(buf, mem, m, slab);
+        store_park_state<B>(buf, mem, m, slab);
+      }
     }
   }
   HX_FENCE();
   store_state<B>(args->buf, mem, m);
-  {  // park -> year-level state rows
-    const HxBuffers &buf = args->buf;
-    sts_(buf, HXS_CH4, mem, PKM(m, PK_CH4)); sts_(buf, HXS_SST, mem, PKM(m, PK_SST));
-    sts_(buf, HXS_TLAND, mem, PKM(m, PK_TLAND)); sts_(buf, HXS_TWIN, mem, PKM(m, PK_TWIN));
-    sts_(buf, HXS_TL_M1, mem, PKM(m, PK_TL_M1)); sts_(buf, HXS_TL_M2, mem, PKM(m, PK_TL_M2));
-    sts_(buf, HXS_F_PREV, mem, PKM(m, PK_F_PREV));
-    sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
-    sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
-#pragma unroll
-    for (int b = 0; b < B; ++b)
-      sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
-  }
+  store_park_state<B>(args->buf, mem, m);
 }
 
 // ===========================================================================

@@ -116,6 +116,7 @@ struct HxBuffers {
   const double *dpart;   // [HX_DBLK][npad] history partial sums of the current block
   const double *dpart2;  // same for the heat-flux diagnostic
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
+  double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   int n, npad, ker_per_member;
 };
 

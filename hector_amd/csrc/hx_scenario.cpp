@@ -125,6 +125,20 @@ bool Scenario::has_series(const std::string &section, const std::string &key) co
   return series_.count(section + "." + key) != 0;
 }
 
+void Scenario::set_series_value(const std::string &section, const std::string &key, int year,
+                                double v) {
+  auto it = series_.find(section + "." + key);
+  if (it == series_.end()) {
+    series_[section + "." + key] = std::vector<double>((size_t)ns(), 0.0);
+    it = series_.find(section + "." + key);
+  }
+  if (year < start || year > end) throw std::runtime_error("date outside startDate..endDate");
+  it->second[(size_t)(year - start)] = v;
+  for (auto &h : halocarbons)
+    if (section == h.name + "_halocarbon" && key == h.name + "_emissions")
+      h.emissions[(size_t)(year - start)] = v;
+}
+
 void Scenario::finish() {
   start = (int)scalar("core", "startDate");
   end = (int)scalar("core", "endDate");

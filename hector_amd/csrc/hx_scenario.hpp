@@ -30,6 +30,7 @@ class Scenario {
   const std::vector<double> &series(const std::string &section,
                                     const std::string &key) const;
   bool has_series(const std::string &section, const std::string &key) const;
+  void set_series_value(const std::string &section, const std::string &key, int year, double v);
 
   std::vector<Halocarbon> halocarbons;
   std::string source;

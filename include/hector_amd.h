@@ -53,6 +53,17 @@ int hx_shutdown(hx_core *core);
  * wrapper this invalidates results from date 0 (the next run respins if needed). */
 int hx_setvar(hx_core *core, const char *capability, const double *values, int nvalues,
               const char *units);
+/* setvar(core, dates, var, values, unit) for a scenario INPUT series (emissions, SV,
+ * RF_albedo, RF_misc ...; R/messages.R:107-140 with dates): the same new values for every
+ * member.  Marks the core dirty from min(year)-1: the next hx_run first resets there (if the
+ * state history is enabled, else to startDate), like run() does for a core that is not clean
+ * (src/rcpp_hector.cpp:160-166). */
+int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
+                    int n, const char *units);
+/* Keep every year's component state in HBM so hx_reset can return to any computed date --
+ * what the reference's per-component tseries records provide (src/simpleNbox.cpp:708-840,
+ * src/ocean_component.cpp:767-846).  272 B per member-year (one biome); default off. */
+int hx_enable_history(hx_core *core, int on);
 /* fetchvars(core, NA, var) for parameters: GETDATA without a date. out[n_members] */
 int hx_getvar(hx_core *core, const char *capability, double *out);
 
@@ -78,7 +89,7 @@ int hx_lane_of_member(hx_core *core, int *out /* n_members */);
 
 /* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.
  * date < startDate (e.g. 0): rerun the spinup on the next run; date == startDate:
- * back to the post-spinup state.  Other dates: error (no per-year state history). */
+ * back to the post-spinup state; any earlier computed date if hx_enable_history is on. */
 int hx_reset(hx_core *core, double date);
 
 /* run(core, runtodate)  src/rcpp_hector.cpp:153-181 -> Core::run src/core.cpp:448-509.

@@ -55,3 +55,22 @@ def hip_lib():
     if not os.path.exists(HIP_LIB):
         _make(os.path.join(ROOT, "hector_amd", "csrc"))
     return HIP_LIB
+
+
+def edited_pack(path, section, key, years, values):
+    """Write a copy of the packaged scenario with `section.key` changed at `years` -- what a
+    reference user gets from setvar(core, dates, var, values) -- for the oracle to read."""
+    out = []
+    with open(SCENARIO) as f:
+        for line in f:
+            p = line.split()
+            if len(p) > 5 and p[0] == "series" and p[1] == section and p[2] == key:
+                y0, n = int(p[3]), int(p[4])
+                v = p[5:5 + n]
+                for y, x in zip(years, values):
+                    v[int(y) - y0] = repr(float(x))
+                line = " ".join(p[:5] + v) + "\n"
+            out.append(line)
+    with open(path, "w") as f:
+        f.writelines(out)
+    return str(path)

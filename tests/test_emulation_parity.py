@@ -244,3 +244,71 @@ def test_model_errors_are_flags_not_crashes(emul_lib):
     assert np.array_equal(a[:, 0], a[:, 2]) and np.isfinite(a[:, 0]).all()
     with pytest.raises(hector_amd.HectorAmdError):
         mk(emul_lib, 0)
+
+
+def test_state_history_and_reset_to_any_date(emul_lib):
+    """Core::reset(date) for startDate < date < current date (core.cpp:511-549): every
+    component goes back to its recorded state of that year; rerunning reproduces the
+    first run bit for bit, and the history does not change any result."""
+    n = 5
+    S, q10 = ensemble.ecs_q10(n)
+    outs = ["CO2_concentration", "global_tas", "ocean_c", "CH4_concentration", "timesteps"]
+    a = mk(emul_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    a.set_outputs(outs); a.run(2100)
+    ref = {v: a.fetchvars(v, (1745, 2100)) for v in outs}
+    b = mk(emul_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    b.enable_history(True); b.set_outputs(outs); b.run(2100)
+    for v in outs:
+        assert np.array_equal(b.fetchvars(v, (1745, 2100)), ref[v]), v
+    for date in (2050, 1790, 1746, 2099):     # mid-block, early, first year, last year
+        b.reset(date)
+        assert b.current_date == date
+        b.run(2100)
+        for v in outs:
+            assert np.array_equal(b.fetchvars(v, (1745, 2100)), ref[v]), (v, date)
+    with pytest.raises(hector_amd.HectorAmdError):
+        a.reset(2000)           # no history on this core
+    with pytest.raises(hector_amd.HectorAmdError):
+        b.reset(2200)           # not computed yet
+
+
+def test_dated_setvar_emissions_vs_oracle(emul_lib, oracle, tmp_path):
+    """setvar(core, dates, FFI_EMISSIONS(), values) after a run (R/messages.R:107-140): the core
+    goes back to min(date)-1 and the changed years are recomputed -- compared with the oracle
+    reading a scenario whose table holds the new values."""
+    import oracle_binding
+    from conftest import edited_pack
+    years = np.arange(2030, 2061)
+    vals = np.linspace(12.0, 2.0, years.size)
+    c = mk(emul_lib, 2).setvar("S", np.array([2.5, 4.0]), "degC")
+    c.enable_history(True)
+    c.set_outputs(["CO2_concentration", "global_tas"])
+    c.run(2100)
+    before = c.fetchvars("CO2_concentration", (1745, 2100)).copy()
+    c.setvar_dated("ffi_emissions", years, vals, "Pg C/yr")
+    c.run(2100)
+    co2 = c.fetchvars("CO2_concentration", (1745, 2100))
+    tg = c.fetchvars("global_tas", (1745, 2100))
+    assert np.array_equal(co2[:2030 - 1745], before[:2030 - 1745])
+    assert np.abs(co2[2060 - 1745] - before[2060 - 1745]).min() > 1.0
+    o = oracle_binding.Oracle(edited_pack(tmp_path / "ffi.hxs", "simpleNbox", "ffi_emissions",
+                                          years, vals))
+    for i, s in enumerate((2.5, 4.0)):
+        p = o.default_params(); p.S = s
+        r, err, _ = o.run(p, run_to=2100)
+        assert err == 0
+        oc, ot = r["CO2_concentration"][:co2.shape[0]], r["global_tas"][:co2.shape[0]]
+        assert (np.abs(co2[:, i] - oc) / oc).max() < REL_CO2
+        assert np.abs(tg[:, i] - ot).max() < ABS_T
+    # the same edit on a core without history (falls back to startDate) and on a fresh core
+    d = mk(emul_lib, 2).setvar("S", np.array([2.5, 4.0]), "degC")
+    d.set_outputs(["CO2_concentration"]); d.run(2100)
+    d.setvar_dated("ffi_emissions", years, vals); d.run(2100)
+    e = mk(emul_lib, 2).setvar("S", np.array([2.5, 4.0]), "degC")
+    e.set_outputs(["CO2_concentration"]); e.setvar_dated("ffi_emissions", years, vals); e.run(2100)
+    assert np.array_equal(d.fetchvars("CO2_concentration", (1745, 2100)), co2)
+    assert np.array_equal(e.fetchvars("CO2_concentration", (1745, 2100)), co2)
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar_dated("ffi_emissions", years, vals, "Tg C/yr")     # unit check
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar_dated("no_such_series", years, vals)

@@ -257,3 +257,60 @@ def test_model_errors_are_flags_on_gpu(hip_lib):
     assert st[77] != 0 and (np.delete(st, 77) == 0).all()
     a = c.fetchvars("CO2_concentration")
     assert np.array_equal(a[:, 0], a[:, 129]) and np.isfinite(a[:, 0]).all()
+
+
+def test_state_history_and_reset_to_any_date_on_gpu(hip_lib):
+    """Core::reset(date), core.cpp:511-549: back to any computed year from the per-year state
+    history in HBM; the rerun is bit-identical and the history changes no result."""
+    n = 1000
+    S, q10 = ensemble.ecs_q10(n)
+    outs = ["CO2_concentration", "global_tas", "ocean_c", "CH4_concentration", "timesteps"]
+    a = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    a.set_outputs(outs); a.run(2300)
+    ref = {v: a.fetchvars(v, (1745, 2300)) for v in outs}
+    b = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    b.enable_history(True); b.set_outputs(outs); b.run(2300)
+    for v in outs:
+        assert np.array_equal(b.fetchvars(v, (1745, 2300)), ref[v]), v
+    for date in (2050, 1790, 1746, 2299):
+        b.reset(date)
+        assert b.current_date == date
+        b.run(2300)
+        for v in outs:
+            assert np.array_equal(b.fetchvars(v, (1745, 2300)), ref[v]), (v, date)
+    with pytest.raises(hector_amd.HectorAmdError):
+        a.reset(2000)
+
+
+def test_dated_setvar_emissions_vs_oracle_on_gpu(hip_lib, oracle, tmp_path):
+    """setvar(core, dates, FFI_EMISSIONS(), values) after a run, R/messages.R:107-140."""
+    import oracle_binding
+    from conftest import edited_pack
+    years = np.arange(2030, 2061)
+    vals = np.linspace(12.0, 2.0, years.size)
+    n = 64
+    S = np.linspace(2.0, 5.0, n)
+    c = mk(hip_lib, n).setvar("S", S, "degC")
+    c.enable_history(True)
+    c.set_outputs(["CO2_concentration", "global_tas"])
+    c.run(2100)
+    before = c.fetchvars("CO2_concentration", (1745, 2100)).copy()
+    c.setvar_dated("ffi_emissions", years, vals, "Pg C/yr")
+    c.run(2100)
+    assert (c.status() == 0).all()
+    co2 = c.fetchvars("CO2_concentration", (1745, 2100))
+    tg = c.fetchvars("global_tas", (1745, 2100))
+    assert np.array_equal(co2[:2030 - 1745], before[:2030 - 1745])
+    assert np.abs(co2[2060 - 1745] - before[2060 - 1745]).min() > 1.0
+    o = oracle_binding.Oracle(edited_pack(tmp_path / "ffi.hxs", "simpleNbox", "ffi_emissions",
+                                          years, vals))
+    for i in range(0, n, 7):
+        p = o.default_params(); p.S = S[i]
+        r, err, _ = o.run(p, run_to=2100)
+        assert err == 0
+        oc, ot = r["CO2_concentration"][:co2.shape[0]], r["global_tas"][:co2.shape[0]]
+        assert (np.abs(co2[:, i] - oc) / oc).max() < REL_CO2
+        assert np.abs(tg[:, i] - ot).max() < ABS_T
+    d = mk(hip_lib, n).setvar("S", S, "degC")
+    d.set_outputs(["CO2_concentration"]); d.setvar_dated("ffi_emissions", years, vals); d.run(2100)
+    assert np.array_equal(d.fetchvars("CO2_concentration", (1745, 2100)), co2)
