@@ -713,6 +713,18 @@ void EnsembleCore::sync() {
 
 void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
                              double *out_host) {
+  // scenario INPUT series (emissions, SV, RF_albedo ...): the same for every member; the
+  // reference answers GETDATA for them from the component's tseries
+  for (const DatedDef &d : kDated)
+    if (capability == d.name && scen_.has_series(d.sections[0], capability)) {
+      if (year0 < scen_.start || year1 > scen_.end || year1 < year0)
+        throw std::runtime_error("fetchvars: dates must lie between startDate and endDate");
+      const std::vector<double> &ser = scen_.series(d.sections[0], capability);
+      for (int y = year0; y <= year1; ++y)
+        std::fill(out_host + (size_t)(y - year0) * n_, out_host + (size_t)(y - year0 + 1) * n_,
+                  ser[(size_t)(y - scen_.start)]);
+      return;
+    }
   const int v = out_index(capability);
   if (!d_out_[v])
     throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");

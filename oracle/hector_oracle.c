@@ -143,6 +143,8 @@ hxo_scenario *hxo_scenario_load(const char *path) {
   s->eps_abs = s->eps_rel = 1e-6;
   s->dt = 0.3; /* carbon-cycle-solver.cpp:35 */
   s->aero_scalar = s->vol_scalar = 1.0;
+  s->preind_surface_c = 900.0;    /* ocean_component.cpp:90-91 defaults */
+  s->preind_interdeep_c = 37100.0;
   size_t cap = 1 << 20;
   char *line = (char *)malloc(cap);
   int ok = 0;

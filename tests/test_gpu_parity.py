@@ -314,3 +314,24 @@ def test_dated_setvar_emissions_vs_oracle_on_gpu(hip_lib, oracle, tmp_path):
     d = mk(hip_lib, n).setvar("S", S, "degC")
     d.set_outputs(["CO2_concentration"]); d.setvar_dated("ffi_emissions", years, vals); d.run(2100)
     assert np.array_equal(d.fetchvars("CO2_concentration", (1745, 2100)), co2)
+
+
+@pytest.mark.parametrize("name", ["picontrol", "ssp119", "ssp126", "ssp370", "ssp434", "ssp460",
+                                  "ssp534-over", "ssp585"])
+def test_shipped_scenarios_vs_oracle_on_gpu(hip_lib, oracle, name):
+    """Every scenario the reference ships (inst/input/hector_*.ini), 16 members each."""
+    from test_scenarios import check_scenario_vs_oracle, pack
+    S, q10 = ensemble.ecs_q10(16, offset=1000)
+    check_scenario_vs_oracle(hip_lib, pack(name), S, q10, device=0)
+
+
+def test_luc_pulse_on_gpu(hip_lib, oracle):
+    """tests/testthat/test_pulse.R on the GPU path."""
+    import os
+    from conftest import ROOT
+    from test_scenarios import check_scenario_vs_oracle
+    c = check_scenario_vs_oracle(hip_lib, os.path.join(ROOT, "tests", "golden", "luc_pulse.hxs"),
+                                 np.array([3.0, 4.5]), np.array([1.0, 1.0]), device=0)
+    c.set_outputs(["veg_c"]); c.run(1850)
+    v = c.fetchvars("veg_c", (1745, 1850))
+    assert (np.diff(v[5:55], axis=0) < 1e-6).all() and (np.diff(v[56:], axis=0) < 1e-6).all()
