@@ -9,7 +9,7 @@
 // launchers defined in hx_kernels.hip
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st);
-hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm,
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, bool con,
                          int iy_from, int iy_to, hipStream_t st);
 hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, double *part,
                                   double *part2, int ns, int npad, int blk0, int nyears,
@@ -46,6 +46,7 @@ const ParamDef kParams[] = {
     {"tid", HXP_TID, false, "m3/s", true},
     {"preind_surface_c", HXP_PRE_SURF, false, "Pg C", true},
     {"preind_interdeep_c", HXP_PRE_ID, false, "Pg C", true},
+    {"lo_warming_ratio", HXP_LO_RATIO, false, "(unitless)", false},
     {"beta", HXPB_BETA, true, "(unitless)", false},
     {"q10_rh", HXPB_Q10, true, "(unitless)", false},
     {"warmingfactor", HXPB_WF, true, "(unitless)", false},
@@ -73,6 +74,7 @@ const OutDef kOutputs[] = {
     {"detritus_c", HXO_DET_C}, {"soil_c", HXO_SOIL_C}, {"thawedp_c", HXO_THAWED_C},
     {"earth_c", HXO_EARTH_C}, {"NBP", HXO_NBP}, {"ocean_uptake", HXO_OCEAN_UPTAKE},
     {"timesteps", HXO_NSTASH}, {"solver_steps", HXO_NSTEPS}, {"LL_pH", HXO_LL_PH},
+    {"sst_reported", HXO_SST_LO},  // internal: see out_index()
 };
 const char *kOutputNames[HXO_NVAR];
 
@@ -124,6 +126,8 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   setrow(HXP_TID, s.scalar("ocean", "tid"));
   setrow(HXP_PRE_SURF, s.scalar("ocean", "preind_surface_c", 900));
   setrow(HXP_PRE_ID, s.scalar("ocean", "preind_interdeep_c", 37100));
+  setrow(HXP_LO_RATIO, s.scalar("temperature", "lo_warming_ratio", 0.0));
+  out_enabled_[HXO_SST_LO] = s.scalar("temperature", "lo_warming_ratio", 0.0) != 0.0;
   const int r = HXP_NGLOBAL;
   setrow(r + HXPB_BETA, s.scalar("simpleNbox", "beta"));
   setrow(r + HXPB_Q10, s.scalar("simpleNbox", "q10_rh"));
@@ -207,9 +211,38 @@ void EnsembleCore::build_shared() {
   std::sort(horder.begin(), horder.end(), [&](size_t a, size_t b) {
     return s.halocarbons[a].name < s.halocarbons[b].name;
   });
-  double n2o = N0;
+  // constraints: dense series, NaN where the reference's tseries has no value
+  const std::vector<double> none;
+  auto con = [&](const std::string &sec, const std::string &key) -> const std::vector<double> & {
+    return s.has_series(sec, key) ? s.series(sec, key) : none;
+  };
+  auto has = [](const std::vector<double> &c, int iy) { return !c.empty() && !std::isnan(c[(size_t)iy]); };
+  auto any = [](const std::vector<double> &c) {
+    for (double v : c) if (!std::isnan(v)) return true;
+    return false;
+  };
+  const auto &co2_con = con("simpleNbox", "CO2_constrain");
+  const auto &nbp_con = con("simpleNbox", "NBP_constrain");
+  const auto &tas_con = con("temperature", "tas_constrain");
+  const auto &ftot_con = con("forcing", "RF_tot_constrain");
+  const auto &ch4_con = con("CH4", "CH4_constrain");
+  const auto &n2o_con = con("N2O", "N2O_constrain");
+  std::vector<const std::vector<double> *> hcon(hconc.size());
+  for (size_t h = 0; h < hconc.size(); ++h)
+    hcon[h] = &con(s.halocarbons[h].name + "_halocarbon", s.halocarbons[h].name + "_constrain");
+  // a constraint at startDate replaces the preindustrial value (n2o_component.cpp:137-145,
+  // ch4_component.cpp:137-147); the OH component read M0 before that (its prepareToRun runs
+  // first: CH4 depends on the OH lifetime)
+  const double N0f = has(n2o_con, 0) ? n2o_con[0] : N0;
+  double n2o = N0f;
+  halo_conc_.assign(hconc.size(), std::vector<double>((size_t)ns, 0.0));
   for (int iy = 0; iy < ns; ++iy) {
     double *row = &shared_[(size_t)iy * HXSH_STRIDE];
+    row[HXSH_CO2_CON] = has(co2_con, iy) ? co2_con[(size_t)iy] : std::nan("");
+    row[HXSH_NBP_CON] = has(nbp_con, iy) ? nbp_con[(size_t)iy] : std::nan("");
+    row[HXSH_TAS_CON] = has(tas_con, iy) ? tas_con[(size_t)iy] : std::nan("");
+    row[HXSH_FTOT_CON] = has(ftot_con, iy) ? ftot_con[(size_t)iy] : std::nan("");
+    row[HXSH_CH4_CON] = has(ch4_con, iy) ? ch4_con[(size_t)iy] : std::nan("");
     if (iy >= 1) {  // slowparameval(t = year-1): emissions of date t (runtime.cpp:951-955)
       row[HXSH_FFI] = ffi[iy - 1]; row[HXSH_DACCS] = daccs[iy - 1];
       row[HXSH_LUC_E] = luce[iy - 1]; row[HXSH_LUC_U] = lucu[iy - 1];
@@ -227,9 +260,10 @@ void EnsembleCore::build_shared() {
     double rf_h = 0.0;
     if (iy >= 1) {
       // n2o_component.cpp:152-191
-      const double tau = TN2O0 * std::pow(n2o / N0, -0.05);
+      const double tau = TN2O0 * std::pow(n2o / N0f, -0.05);
       const double em = n2o_em[iy] + n2o_nat[iy];
       n2o = n2o + (em / UC_N2O - n2o / tau);
+      if (has(n2o_con, iy)) n2o = n2o_con[(size_t)iy];  // n2o_component.cpp:157-158
       // halocarbon_component.cpp:181-229
       for (size_t h = 0; h < hconc.size(); ++h) {
         const Halocarbon &H = s.halocarbons[h];
@@ -238,6 +272,7 @@ void EnsembleCore::build_shared() {
         const double dconc = emissMol / (0.1 * 1.8);
         const double expfac = std::exp(-alpha);
         hconc[h] = hconc[h] * expfac + dconc * H.tau * (1.0 - expfac);
+        if (has(*hcon[h], iy)) hconc[h] = (*hcon[h])[(size_t)iy];  // halocarbon_component.cpp:189
       }
       for (size_t k = 0; k < horder.size(); ++k) {
         const Halocarbon &H = s.halocarbons[horder[k]];
@@ -245,6 +280,7 @@ void EnsembleCore::build_shared() {
         rf_h = rf_h + (rf_un + H.delta * rf_un);
       }
     }
+    for (size_t h = 0; h < hconc.size(); ++h) halo_conc_[h][(size_t)iy] = hconc[h];
     row[HXSH_N2O] = n2o;
     row[HXSH_SQRT_N2O] = std::sqrt(n2o);
     row[HXSH_RF_OTHER] = (rf_h + albedo[iy]) + misc[iy];
@@ -264,11 +300,18 @@ void EnsembleCore::build_shared() {
   k.eps_rel = s.scalar("carbon-cycle-solver", "eps_rel", 1e-6);
   k.dt0 = s.scalar("carbon-cycle-solver", "dt", 0.3);
   k.eps_spinup = s.scalar("carbon-cycle-solver", "eps_spinup");
-  k.M0 = s.scalar("CH4", "M0"); k.lnM0 = std::log(k.M0); k.sqrtM0 = std::sqrt(k.M0);
+  k.M0 = s.scalar("CH4", "M0"); k.lnM0 = std::log(k.M0);
+  const double M0f_old = k.M0f;
+  k.M0f = has(ch4_con, 0) ? ch4_con[0] : k.M0;
+  k.sqrtM0 = std::sqrt(k.M0f);
+  if (k.M0f != M0f_old) need_spinup_ = true;  // the post-spinup state holds CH4(startDate)
+  k.con_mask = (any(co2_con) ? HXC_CO2 : 0) | (any(nbp_con) ? HXC_NBP : 0) |
+               (any(tas_con) ? HXC_TAS : 0) | (any(ftot_con) ? HXC_FTOT : 0) |
+               (any(ch4_con) ? HXC_CH4 : 0);
   k.Tsoil = s.scalar("CH4", "Tsoil"); k.Tstrat = s.scalar("CH4", "Tstrat");
   k.UC_CH4 = s.scalar("CH4", "UC_CH4");
   k.TOH0 = s.scalar("OH", "TOH0"); k.CCH4 = s.scalar("OH", "CCH4");
-  k.N0 = N0; k.sqrtN0 = std::sqrt(N0);
+  k.N0 = N0f; k.sqrtN0 = std::sqrt(N0f);
   k.delta_co2 = s.scalar("forcing", "delta_co2"); k.delta_ch4 = s.scalar("forcing", "delta_ch4");
   k.delta_n2o = s.scalar("forcing", "delta_n2o");
 }
@@ -378,6 +421,11 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
   // R/messages.R:107-140: a parameter change invalidates the run from date 0
   last_iy_ = 0;
   need_spinup_ = true;
+  if (row == HXP_LO_RATIO) {  // the reported SST needs its own output array
+    bool any = false;
+    for (double v : r) if (v != 0.0) any = true;
+    if (any != out_enabled_[HXO_SST_LO]) { out_enabled_[HXO_SST_LO] = any; layout_dirty_ = true; }
+  }
   (void)d;
 }
 
@@ -430,6 +478,9 @@ void EnsembleCore::split_biome(const std::vector<std::string> &names, const doub
 }
 
 int EnsembleCore::out_index(const std::string &capability) const {
+  // with a land-ocean warming ratio D_SST is not DOECLIM's own SST (temperature_component.cpp:
+  // 614-625); the kernel records the reported one separately
+  if (capability == "sst" && out_enabled_[HXO_SST_LO]) return HXO_SST_LO;
   for (auto &o : kOutputs) if (capability == o.name) return o.idx;
   throw std::runtime_error("Caller is requesting unknown variable: " + capability);
 }
@@ -438,6 +489,7 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
   bool want[HXO_NVAR];
   for (int v = 0; v < HXO_NVAR; ++v) want[v] = false;
   want[HXO_SST] = want[HXO_TLAND] = true;
+  want[HXO_SST_LO] = out_enabled_[HXO_SST_LO];
   for (auto &c : caps) want[out_index(c)] = true;
   bool changed = false;
   for (int v = 0; v < HXO_NVAR; ++v) if (want[v] != out_enabled_[v]) changed = true;
@@ -479,6 +531,13 @@ const DatedDef kDated[] = {
     {"BC_emissions", {"bc", nullptr}, "Tg"},
     {"OC_emissions", {"oc", nullptr}, "Tg"},
     {"NH3_emissions", {"nh3", nullptr}, "Tg"},
+    // constraints (component_data.hpp:46,263,273,379-381)
+    {"CO2_constrain", {"simpleNbox", nullptr}, "ppmv CO2"},
+    {"NBP_constrain", {"simpleNbox", nullptr}, "Pg C/yr"},
+    {"tas_constrain", {"temperature", nullptr}, "degC"},
+    {"RF_tot_constrain", {"forcing", nullptr}, "W/m2"},
+    {"CH4_constrain", {"CH4", nullptr}, "ppbv CH4"},
+    {"N2O_constrain", {"N2O", nullptr}, "ppbv N2O"},
 };
 }  // namespace
 
@@ -498,6 +557,11 @@ void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
     const std::string gas = capability.substr(0, capability.size() - suf.size());
     for (auto &h : scen_.halocarbons)
       if (h.name == gas) { sections[0] = gas + "_halocarbon"; expect = "Gg"; }
+  }
+  if (sections[0].empty() && Scenario::is_constraint(capability)) {
+    const std::string gas = capability.substr(0, capability.size() - 10);
+    for (auto &h : scen_.halocarbons)
+      if (h.name == gas) { sections[0] = gas + "_halocarbon"; expect = "pptv"; }
   }
   if (sections[0].empty())
     throw std::runtime_error("Unknown variable name while parsing: " + capability +
@@ -583,6 +647,9 @@ void EnsembleCore::upload_params() {
   check(hx_launch_derive(d_params_, d_derived_, d_ker_, ker_per_member_ ? 1 : 0, scen_.ns(), B_,
                          npad_, stream_), "derive kernel");
   {
+    bool lo_any = false;
+    for (double v : params_[HXP_LO_RATIO]) if (v != 0.0) lo_any = true;
+    kc_.con_mask = (kc_.con_mask & ~HXC_LO) | (lo_any ? HXC_LO : 0);
     HxArgs a;
     a.buf = buffers();
     a.kc = kc_;
@@ -601,6 +668,7 @@ void EnsembleCore::prepare() {
                          hipMemcpyHostToDevice, stream_), "upload shared");
     check(hipStreamSynchronize(stream_), "sync shared");
     shared_dirty_ = false;
+    params_dirty_ = true;  // HxConst (constraint mask, preindustrial values) is re-uploaded
   }
   if (params_dirty_) upload_params();
   if (!need_spinup_) return;
@@ -693,7 +761,8 @@ void EnsembleCore::run(double runtodate) {
   // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
   // history pass every HX_DBLK years), so there is no global barrier to wait at
   const bool hf = d_out_[HXO_HEATFLUX] != nullptr;
-  check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, last_iy_, target, stream_),
+  check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, kc_.con_mask != 0, last_iy_, target,
+                      stream_),
         "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
@@ -725,6 +794,33 @@ void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1
                   ser[(size_t)(y - scen_.start)]);
       return;
     }
+  // member-independent results of the shared gas cycles (N2O and halocarbon components run
+  // on the host while the per-year table is built)
+  {
+    const std::vector<double> *src = nullptr;
+    std::vector<double> tmp;
+    if (capability == "N2O_concentration") {
+      tmp.resize((size_t)scen_.ns());
+      for (int iy = 0; iy < scen_.ns(); ++iy) tmp[(size_t)iy] = shared_[(size_t)iy * HXSH_STRIDE + HXSH_N2O];
+      src = &tmp;
+    }
+    const std::string csuf = "_concentration";
+    if (!src && capability.size() > csuf.size() &&
+        capability.compare(capability.size() - csuf.size(), csuf.size(), csuf) == 0) {
+      const std::string gas = capability.substr(0, capability.size() - csuf.size());
+      for (size_t h = 0; h < scen_.halocarbons.size(); ++h)
+        if (scen_.halocarbons[h].name == gas) src = &halo_conc_[h];
+    }
+    if (src) {
+      if (shared_dirty_) throw std::runtime_error("fetchvars: run the core after changing inputs");
+      if (year0 < scen_.start || year1 > last_date() || year1 < year0)
+        throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
+      for (int y = year0; y <= year1; ++y)
+        std::fill(out_host + (size_t)(y - year0) * n_, out_host + (size_t)(y - year0 + 1) * n_,
+                  (*src)[(size_t)(y - scen_.start)]);
+      return;
+    }
+  }
   const int v = out_index(capability);
   if (!d_out_[v])
     throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");

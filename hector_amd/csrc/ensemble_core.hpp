@@ -107,6 +107,7 @@ class EnsembleCore {
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
   int last_iy_ = 0;
   HxConst kc_{};
+  std::vector<std::vector<double>> halo_conc_;  // [gas][ns] halocarbon concentrations, pptv
   std::vector<double> shared_, ker_;
   bool out_enabled_[HXO_NVAR];
   // device

@@ -371,9 +371,59 @@ template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &
   return m_rh_tp_co2(m, k, b) / (1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
 }
 
+// constraints of one model year, as the solver and the stash see them (CON kernels only)
+struct YearCon {
+  int mask;          // HXC_* bits
+  double co2;        // CO2 constraint of the year that ends at tnew (NaN = none)
+  double nbp_lo;     // NBP constraint of date tnew - 1  (round(t) for t < tnew - 0.5)
+  double nbp_hi;     // NBP constraint of date tnew
+  double t_half;     // tnew - 0.5: round(t) switches from tnew - 1 to tnew here
+};
+
+// the land flows of an interval with frozen pools
+struct Flows {
+  double npp, rh, fav, fad, fas, fda, fsa, tpc, tpm, litter, lfvd, lfvs, detsoil, thaw, refr;
+};
+
+template <int B>
+__device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F, Interval &K) {
+  K.npp = F.npp;
+  K.rh = F.rh;
+  K.P = ((m.ffi - m.daccs) + m.luc_e) - m.luc_u;
+  K.v1 = F.fav - F.litter;
+  K.d2 = ((F.fad + F.lfvd) - F.detsoil) - F.fda;
+  K.s3 = ((F.fas + F.lfvs) + F.detsoil) - F.fsa;
+  K.k4 = -F.thaw + F.refr;
+  K.k5 = ((F.thaw - F.refr) - F.tpm) - F.tpc;
+  K.k7 = -m.ffi + m.daccs;
+  K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
+  K.surf = m.cLL + m.cHL;
+  K.inv_surf = 1.0 / K.surf;
+}
+
+// NBP constraint inside calcderivs: NPP and RH moved by +-diff/2, their parts scaled
+// (simpleNbox-runtime.cpp:871-898)
+template <int B>
+__device__ __forceinline__ void make_interval_nbp(const Member<B> &m, Flows F, double target,
+                                                  Interval &K) {
+  if (!isnan(target)) {
+    const double nbp = ((F.npp - F.rh) - m.luc_e) + m.luc_u;
+    const double diff = target - nbp;
+    const double npp_old = F.npp;
+    F.npp = F.npp + diff / 2.0;
+    const double npp_ratio = F.npp / npp_old;
+    F.fav = F.fav * npp_ratio; F.fad = F.fad * npp_ratio; F.fas = F.fas * npp_ratio;
+    const double rh_old = F.rh;
+    F.rh = F.rh - diff / 2.0;
+    const double rh_ratio = F.rh / rh_old;
+    F.fda = F.fda * rh_ratio; F.fsa = F.fsa * rh_ratio; F.tpc = F.tpc * rh_ratio;
+  }
+  make_interval<B>(m, F, K);
+}
+
 template <int B, bool SPIN>
-__device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
-                                              Interval &K) {
+__device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B> &lk,
+                                              Flows &F) {
   double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
   double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
 #pragma unroll
@@ -405,25 +455,41 @@ __device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B>
       refr += r_tp;
     }
   }
-  K.npp = npp_c;
-  K.rh = fda + fsa + tpc;
-  K.P = ((m.ffi - m.daccs) + m.luc_e) - m.luc_u;
-  K.v1 = fav - litter;
-  K.d2 = ((fad + lfvd) - detsoil) - fda;
-  K.s3 = ((fas + lfvs) + detsoil) - fsa;
-  K.k4 = -thaw + refr;
-  K.k5 = ((thaw - refr) - tpm) - tpc;
-  K.k7 = -m.ffi + m.daccs;
-  K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
-  K.surf = m.cLL + m.cHL;
-  K.inv_surf = 1.0 / K.surf;
+  F.npp = npp_c; F.rh = fda + fsa + tpc;
+  F.fav = fav; F.fad = fad; F.fas = fas; F.fda = fda; F.fsa = fsa; F.tpc = tpc; F.tpm = tpm;
+  F.litter = litter; F.lfvd = lfvd; F.lfvs = lfvs; F.detsoil = detsoil;
+  F.thaw = thaw; F.refr = refr;
+}
+
+// K: the interval's constants; K2 (CON kernels): the same for the second half of the year,
+// where round(t) picks the next date's NBP constraint
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
+                                              Interval &K, Interval &K2, const YearCon &yc) {
+  Flows F;
+  compute_flows<B, SPIN>(m, lk, F);
+  if constexpr (CON && !SPIN) {
+    if (yc.mask & HXC_NBP) {
+      make_interval_nbp<B>(m, F, yc.nbp_lo, K);
+      make_interval_nbp<B>(m, F, yc.nbp_hi, K2);
+      return;
+    }
+    make_interval<B>(m, F, K);
+    K2 = K;
+    return;
+  }
+  make_interval<B>(m, F, K);
 }
 
 // SimpleNbox::calcderivs + OceanComponent::calcderivs restricted to the five
 // pools whose derivative depends on c[] (atmos, veg, det, soil, ocean)
-template <int B, bool SPIN>
-__device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K,
-                                    const double y[5], double d[5]) {
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, const Interval &K2,
+                                    const YearCon &yc, double t, const double *y, double *d) {
+  // CON kernels carry the thawed-permafrost pool as a sixth solver variable: with an NBP
+  // constraint its derivative changes where round(t) does, so it is no longer constant
+  const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
+  if constexpr (CON) d[5] = K.k5;
   const double total = y[1] + y[2] + y[3];
   const double r = m.luc_e / total;
   double ao;
@@ -442,10 +508,10 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K,
 }
 
 // OceanComponent::stashCValues + SimpleNbox::stashCValues for one lane
-template <int B, bool SPIN>
-__device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
                                       double c4, double c5, double c7, Interval &K,
-                                      bool more) {
+                                      Interval &K2, const YearCon &yc, bool more) {
   LandK<B> lk;
   load_landk<B>(m, lk);
   const double kHD = PKM(m, PK_K0 + (HXD_KHD - HXD_KLH)), kLH = PKM(m, PK_K0 + 0),
@@ -513,12 +579,34 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
 #pragma unroll
   for (int b = 0; b < B; ++b) pf_t += m.pf[b];
-  m.nbp = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
+  double alf = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
   const double npp_rh = npp_t + rh_t;
   double tpf = c5;
   if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
   if (y[0] < 0 || y[1] < 0 || y[2] < 0 || y[3] < 0 || c4 < 0 || tpf < 0)
     m.status |= HX_ERR_NEGPOOL;
+  double nveg = y[1], ndet = y[2], nsoil = y[3];
+  double rh_adj = 1.0;
+  if constexpr (CON && !SPIN) {
+    // NBP constraint in stashCValues :343-383: fluxes moved by +-diff/2, the pools by
+    // diff * yf shared by size, the same amount taken out of the deep ocean
+    const double target = (t >= yc.t_half) ? yc.nbp_hi : yc.nbp_lo;
+    if ((yc.mask & HXC_NBP) && !isnan(target)) {
+      const double diff = target - alf;
+      const double npp2 = npp_t + diff / 2.0;
+      rh_adj = (rh_t - diff / 2.0) / rh_t;
+      const double rh2 = rh_t - diff / 2.0;
+      const double pool_diff = diff * yf;
+      const double total_land = ((y[2] + y[1]) + y[3]) + c5;
+      ndet = ndet + pool_diff * y[2] / total_land;
+      nveg = nveg + pool_diff * y[1] / total_land;
+      nsoil = nsoil + pool_diff * y[3] / total_land;
+      tpf = tpf + pool_diff * c5 / total_land;
+      m.cDO = (-pool_diff) + m.cDO;
+      alf = ((npp2 - rh2) - m.luc_e) + m.luc_u;
+    }
+  }
+  m.nbp = alf;
   const double total = y[1] + y[2] + y[3];
   m.cum_luc_va += ((m.luc_e - m.luc_u) * y[1]) / total;  // no yf: :388-393
   const double inv_nr = 1.0 / npp_rh;
@@ -528,10 +616,11 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     const double wt = (B == 1) ? 1.0
         : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
     const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
-    m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
-    m.veg[b] = y[1] * wt;
-    m.det[b] = y[2] * wt;
-    m.soil[b] = y[3] * wt;
+    if constexpr (CON) m.cum_pf_ch4 += (m_rh_tp_ch4(m, lk, b) * rh_adj) * yf;
+    else m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
+    m.veg[b] = nveg * wt;
+    m.det[b] = ndet * wt;
+    m.soil[b] = nsoil * wt;
     m.pf[b] = c4 * wt_pf;
     m.thawed[b] = tpf * wt_pf;
   }
@@ -546,9 +635,17 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double y[5],
     const double residual = m.atmos - match;
     m.cDO = residual + m.cDO;
     m.atmos = m.atmos - residual;
+  } else if constexpr (CON) {
+    // user-supplied [CO2] at this date: same transfer (:567-603); only whole dates exist
+    if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {
+      const double match = yc.co2 / PGC2PPM;
+      const double residual = m.atmos - match;
+      m.cDO = residual + m.cDO;
+      m.atmos = m.atmos - residual;
+    }
   }
   m.ode_start = t;
-  if (more) prep_interval<B, SPIN>(m, lk, K);  // frozen-pool constants of the next segment
+  if (more) prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);  // constants of the next segment
 }
 
 // exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
@@ -577,9 +674,10 @@ __device__ __forceinline__ double pow_m15(double x) {
 // block for all lanes.  Lanes in reduced-timestep mode take up to 4 segments a
 // year, the others idle through the extra ones; the expensive step and stash
 // blocks are never interleaved lane by lane.
-template <int B, bool SPIN>
+template <int B, bool SPIN, bool CON = false>
 __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
-                                           double t0, double tnew) {
+                                           double t0, double tnew, const YearCon &yc) {
+  constexpr int NP = CON ? 6 : 5;  // solver variables (see rhs)
   // dopri5 tableau (odeint runge_kutta_dopri5)
   constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
                    b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
@@ -593,14 +691,15 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                    dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
   constexpr double EPS = 2.220446049250313e-16;
 
-  Interval K;
+  Interval K, K2s;
+  Interval &K2 = CON ? K2s : K;
   {
     LandK<B> lk;
     load_landk<B>(m, lk);
-    prep_interval<B, SPIN>(m, lk, K);
+    prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);
   }
   // getCValues  simpleNbox-runtime.cpp:247-258
-  double y[5], l4, l5, l7;
+  double y[NP], l4, l5, l7;
   auto load_pools = [&]() {
     double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll
@@ -608,6 +707,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                                    p += m.pf[b]; th += m.thawed[b]; }
     y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;
     l4 = p; l5 = th; l7 = m.earth;
+    if constexpr (CON) y[5] = th;
   };
   load_pools();
   m.ode_start = t0;
@@ -619,13 +719,13 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     // fresh integrate_adaptive call: by-value dt, fresh controlled stepper
     const double t_start = t;
     double t_target = tnew, dtl = m.sdt;
-    double dxdt[5];
+    double dxdt[NP];
     bool first_call = true;
     int fails = 0;
     bool stepping = seg;
     while (__any(stepping)) {
       if (stepping) {
-        if (first_call) { rhs<B, SPIN>(m, K, y, dxdt); first_call = false; }
+        if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
         if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
         // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
         // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
@@ -641,39 +741,39 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           fails = 0;
           if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
         } else {
-          double k2[5], k3[5], k4[5], k5[5], k6[5], xt[5], xn[5], dn[5];
+          double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
 #pragma unroll
-          for (int i = 0; i < 5; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
-          rhs<B, SPIN>(m, K, xt, k2);
+          for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (1.0 / 5), xt, k2);
 #pragma unroll
-          for (int i = 0; i < 5; ++i)
+          for (int i = 0; i < NP; ++i)
             xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
-          rhs<B, SPIN>(m, K, xt, k3);
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (3.0 / 10), xt, k3);
 #pragma unroll
-          for (int i = 0; i < 5; ++i)
+          for (int i = 0; i < NP; ++i)
             xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
-          rhs<B, SPIN>(m, K, xt, k4);
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (4.0 / 5), xt, k4);
 #pragma unroll
-          for (int i = 0; i < 5; ++i)
+          for (int i = 0; i < NP; ++i)
             xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] +
                     dtl * b53 * k3[i] + dtl * b54 * k4[i];
-          rhs<B, SPIN>(m, K, xt, k5);
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (8.0 / 9), xt, k5);
 #pragma unroll
-          for (int i = 0; i < 5; ++i)
+          for (int i = 0; i < NP; ++i)
             xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] +
                     dtl * b63 * k3[i] + dtl * b64 * k4[i] + dtl * b65 * k5[i];
-          rhs<B, SPIN>(m, K, xt, k6);
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xt, k6);
 #pragma unroll
-          for (int i = 0; i < 5; ++i)
+          for (int i = 0; i < NP; ++i)
             xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
                     dtl * c5 * k5[i] + dtl * c6 * k6[i];
-          rhs<B, SPIN>(m, K, xn, dn);
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xn, dn);
           // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
           // The maximum of the five quotients is found by cross-multiplication
           // (all denominators > 0) and divided once.
           double en = 0.0, ed = 1.0;
 #pragma unroll
-          for (int i = 0; i < 5; ++i) {
+          for (int i = 0; i < NP; ++i) {
             const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
                               dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
                               dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
@@ -687,13 +787,14 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
           } else {          // accept
             // pools with a constant derivative over the interval advance exactly
-            l4 += dtl * K.k4; l5 += dtl * K.k5; l7 += dtl * K.k7;
+            l4 += dtl * K.k4; l7 += dtl * K.k7;
+            if constexpr (!CON) l5 += dtl * K.k5;
             t += dtl;
             // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
             const double grow = 0.9 * pow_m15(fmax(0.00032, err));
             if (err < 0.5) dtl *= grow;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
+            for (int i = 0; i < NP; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
             fails = 0;
             m.nsteps++;
             if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
@@ -705,7 +806,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       // the solver keeps integrating its own c[] afterwards (no getCValues,
       // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
       retry = 0;
-      stash<B, SPIN>(m, t, y, l4, l5, l7, K, t < tnew);
+      stash<B, SPIN, CON>(m, t, y, l4, CON ? y[NP - 1] : l5, l7, K, K2, yc, t < tnew);
     }
   }
 }
@@ -1159,7 +1260,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
       for (int b = 0; b < B; ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
                                      op += m.pf[b]; ot += m.thawed[b]; }
       m.nstash = 0;
-      solve_year<B, true>(m, kc, (double)(step - 1), (double)step);
+      solve_year<B, true>(m, kc, (double)(step - 1), (double)step, YearCon{});
       double nv = 0, nd = 0, nso = 0, np = 0, nt = 0;
 #pragma unroll
       for (int b = 0; b < B; ++b) { nv += m.veg[b]; nd += m.det[b]; nso += m.soil[b];
@@ -1184,7 +1285,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
     sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, 1.0);
   }
   sts_(buf, HXS_EOS_VEGC, mem, v1);
-  sts_(buf, HXS_CH4, mem, kc.M0);
+  sts_(buf, HXS_CH4, mem, kc.M0f);  // CH4(startDate): M0 or the constraint of that date
   sts_(buf, HXS_TLAND, mem, 0.0); sts_(buf, HXS_SST, mem, 0.0);
   sts_(buf, HXS_F_PREV, mem, 0.0); sts_(buf, HXS_BASE_TOT, mem, 0.0);
   sts_(buf, HXS_BASE_CO2, mem, 0.0);
@@ -1206,7 +1307,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
     put(HXO_PERMAFROST_C, p); put(HXO_VEG_C, v); put(HXO_DET_C, d);
     put(HXO_SOIL_C, s); put(HXO_THAWED_C, th);
   }
-  put(HXO_HEATFLUX, 0.0); put(HXO_CH4, kc.M0); put(HXO_O3, 0.0);
+  put(HXO_HEATFLUX, 0.0); put(HXO_CH4, kc.M0f); put(HXO_O3, 0.0);
   put(HXO_EARTH_C, m.earth); put(HXO_NBP, 0.0); put(HXO_OCEAN_UPTAKE, 0.0);
   put(HXO_NSTASH, 0.0); put(HXO_NSTEPS, 0.0);
   if (spinup_steps) spinup_steps[mem] = steps;
@@ -1221,7 +1322,9 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // Year-level state (Tland, SST, forcing[t-1], CH4, Q10 window...) lives in the HBM
 // state table between phases; the solver's pools stay in registers for the launch.
 // ===========================================================================
-template <int B, bool HF, bool KERPM>
+// CON: the scenario holds constraints (HxConst::con_mask) or a member a land-ocean warming
+// ratio -- a separate instantiation so that unconstrained runs carry none of it.
+template <int B, bool HF, bool KERPM, bool CON>
 __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
@@ -1259,9 +1362,20 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       // every HBM value this phase needs, issued back to back (one exposed latency:
       // with one wavefront per SIMD nothing else hides it)
       const double prev_ch4 = PKM(m, PK_CH4);
-      const double sst = PKM(m, PK_SST);
+      double sst = PKM(m, PK_SST);
       const double eos = PKM(m, PK_EOS);
-      const double tland = PKM(m, PK_TLAND);
+      double tland = PKM(m, PK_TLAND);
+      if constexpr (CON) {
+        // land-ocean warming ratio: the carbon cycle and the ocean see temperatures derived
+        // from global tas, DOECLIM keeps its own (temperature_component.cpp:586-625,722-739)
+        const double lo = ldp(buf, HXP_LO_RATIO, mem);
+        if (lo != 0 && iy > 1) {
+          const double tg = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
+          const double toa = tg / ((lo * D_flnd) + (1 - D_flnd));
+          tland = toa * lo;
+          sst = toa / D_bsi;
+        }
+      }
       double twin = PKM(m, PK_TWIN);
       const double tl_m2 = PKM(m, PK_TL_M2);
       const int iold = iy - 203;
@@ -1307,6 +1421,12 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double dCH4 = ((emisTocon - prev_ch4 / kc.Tsoil) - prev_ch4 / kc.Tstrat) -
                             prev_ch4 / tau_oh;
         ch4 = prev_ch4 + dCH4;
+      }
+      if constexpr (CON) {  // ch4_component.cpp:156-157
+        if (kc.con_mask & HXC_CH4) {
+          const double c = sh[HXSH_CH4_CON];
+          if (!isnan(c)) ch4 = c;
+        }
       }
       PKM(m, PK_CH4) = ch4;
       o3 = ((5 * log(ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
@@ -1358,7 +1478,16 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     // ======================= phase B: carbon-cycle solver ====================
     {
       const double year = (double)(args->kc.start_year + iy);
-      solve_year<B, false>(m, args->kc, year - 1.0, year);
+      YearCon yc{};
+      if constexpr (CON) {
+        hx_ccd sh = HX_CCD(args->buf.shared) + (size_t)iy * HXSH_STRIDE;
+        yc.mask = args->kc.con_mask;
+        yc.co2 = sh[HXSH_CO2_CON];
+        yc.nbp_hi = sh[HXSH_NBP_CON];
+        yc.nbp_lo = (sh - HXSH_STRIDE)[HXSH_NBP_CON];
+        yc.t_half = year - 0.5;
+      }
+      solve_year<B, false, CON>(m, args->kc, year - 1.0, year, yc);
     }
     HX_FENCE();
     // ======================= phase C ========================================
@@ -1410,11 +1539,17 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
         const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
         const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
-        const double fh2o = 0.0485 * ((ch4 - kc.M0) / (1831 - kc.M0));
+        const double fh2o = 0.0485 * ((ch4 - kc.M0f) / (1831 - kc.M0f));
         const double fo3 = 0.042 * o3;
-        const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
-                             p_aero * sh[HXSH_RF_AERO]) +
-                            p_vol * sh[HXSH_RF_VOL];
+        double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
+                       p_aero * sh[HXSH_RF_AERO]) +
+                      p_vol * sh[HXSH_RF_VOL];
+        if constexpr (CON) {  // forcing_component.cpp:498-505
+          if (kc.con_mask & HXC_FTOT) {
+            const double c = sh[HXSH_FTOT_CON];
+            if (!isnan(c)) ftot = c;
+          }
+        }
         if (iy == kc.baseyear_idx) {
           PKM(m, PK_BASE_TOT) = ftot;
           PKM(m, PK_BASE_CO2) = fco2;
@@ -1425,7 +1560,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         }
       }
       // ---- DOECLIM: history before the block (hx_doeclim_pass_kernel) + in-block terms ----
-      double tl_new, sst_new, heatflux = 0;
+      double tl_new, sst_new, heatflux = 0, tgav;
       {
         const int j = jb;
         // Ker is stored with HX_KPAD zeros in front: entry k lives at k + HX_KPAD
@@ -1447,6 +1582,17 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double X2 = (DQ2 + dpast) + (dA2 * tland + dA3 * sst);
         tl_new = dIB0 * X1 + dIB1 * X2;
         sst_new = dIB2 * X1 + dIB3 * X2;
+        tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+        if constexpr (CON) {  // user-supplied temperature :510-525
+          if (kc.con_mask & HXC_TAS) {
+            const double c = sh[HXSH_TAS_CON];
+            if (!isnan(c)) {
+              tgav = c;
+              tl_new = (tgav - (1.0 - D_flnd) * D_bsi * sst_new) / D_flnd;
+              sst_new = (tgav - D_flnd * tl_new) / ((1.0 - D_flnd) * D_bsi);
+            }
+          }
+        }
         if (want_hf) {
           const double hmix = D_cas * (sst_new - sst);
           const double hi = dHFS * (2.0 * sst_new - hint);
@@ -1454,16 +1600,29 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         }
         s_tblk[j][lane] = sst_new;
       }
-      const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+      double tl_seen = tland, tl_rep = tl_new, sst_rep = sst_new;  // what D_LAND_TAS / D_SST return
+      if constexpr (CON) {
+        const double lo = ldp(buf, HXP_LO_RATIO, mem);
+        if (lo != 0) {
+          if (iy > 1) {
+            const double tg0 = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
+            tl_seen = (tg0 / ((lo * D_flnd) + (1 - D_flnd))) * lo;
+          }
+          const double toa = tgav / ((lo * D_flnd) + (1 - D_flnd));
+          tl_rep = toa * lo;
+          sst_rep = toa / D_bsi;
+        }
+      }
       PKM(m, PK_F_PREV) = rf_tot;
       PKM(m, PK_TL_M2) = tl_m1;  // Tland of years iy-2, iy-1
-      PKM(m, PK_TL_M1) = tland;  // for the next year
+      PKM(m, PK_TL_M1) = tl_seen;  // for the next year
       PKM(m, PK_TLAND) = tl_new;
       PKM(m, PK_SST) = sst_new;
       // ---- outputs ----
       const size_t o = (size_t)iy * buf.npad + mem;
       sto_(buf, HXO_SST, o, sst_new);
-      sto_(buf, HXO_TLAND, o, tl_new);
+      sto_(buf, HXO_TLAND, o, tl_rep);
+      if constexpr (CON) { if (buf.out[HXO_SST_LO]) sto_(buf, HXO_SST_LO, o, sst_rep); }
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
       if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);
@@ -1623,26 +1782,30 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
 }
 
 template <int B>
-static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int iy_from,
-                         int iy_to, hipStream_t st) {
+static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, bool con,
+                         int iy_from, int iy_to, hipStream_t st) {
   const int blocks = npad / 64;
   const size_t lds = 0;
-  if (hf && kpm)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  if (con && kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (con)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (hf && kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (hf)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (kpm)
-    hipLaunchKernelGGL((hx_run_kernel<B, false, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, false, true, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else
-    hipLaunchKernelGGL((hx_run_kernel<B, false, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, false, false, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
 }
-hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm,
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, bool con,
                          int iy_from, int iy_to, hipStream_t st) {
   switch (B) {
-    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
-    case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
-    case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
-    case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, iy_from, iy_to, st); break;
+    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+    case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+    case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+    case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

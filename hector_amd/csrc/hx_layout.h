@@ -19,6 +19,7 @@ enum HxParamRow {
   HXP_C0,           // preindustrial CO2 ppmv
   HXP_TT, HXP_TU, HXP_TWI, HXP_TID,           // ocean transports m3/s
   HXP_PRE_SURF, HXP_PRE_ID,                   // preindustrial ocean C
+  HXP_LO_RATIO,     // land-ocean warming ratio, 0 = off  temperature_component.cpp:722-739
   HXP_NGLOBAL
 };
 enum HxBiomeParam {  // row = HXP_NGLOBAL + biome * HXPB_N + k
@@ -70,6 +71,8 @@ enum HxOutVar {
   HXO_PERMAFROST_C, HXO_HEATFLUX,
   HXO_CH4, HXO_O3, HXO_VEG_C, HXO_DET_C, HXO_SOIL_C, HXO_THAWED_C, HXO_EARTH_C,
   HXO_NBP, HXO_OCEAN_UPTAKE, HXO_NSTASH, HXO_NSTEPS, HXO_LL_PH,
+  HXO_SST_LO,       // D_SST as reported when a land-ocean warming ratio is set (HXO_SST stays
+                    // DOECLIM's own history); allocated only then
   HXO_NVAR
 };
 
@@ -83,6 +86,8 @@ enum HxSharedCol {
   HXSH_RF_OTHER,   // halocarbons + albedo + misc (member independent)
   HXSH_RF_AERO,    // BC+OC+SO2+NH3+aci for aero_scalar = 1
   HXSH_RF_VOL,     // SV
+  // constraints of the year, NaN = none (runs use them only if HxConst::con_mask says so)
+  HXSH_CO2_CON, HXSH_NBP_CON, HXSH_TAS_CON, HXSH_FTOT_CON, HXSH_CH4_CON,
   HXSH_NCOL,
   HXSH_STRIDE = 24
 };
@@ -96,11 +101,21 @@ enum HxSharedCol {
 #define HX_ERR_ROOT 32u      // carbonate root not found
 #define HX_ERR_STEPFAIL 64u  // > 500 rejected steps
 
+// constraint kinds present in the scenario (HxConst::con_mask)
+#define HXC_CO2 1
+#define HXC_NBP 2
+#define HXC_TAS 4
+#define HXC_FTOT 8
+#define HXC_CH4 16
+#define HXC_LO 32   // some member has a land-ocean warming ratio
+
 // scenario scalars every lane needs (kernel argument, lives in SGPRs)
 struct HxConst {
   int start_year, ns, baseyear_idx, max_spinup, spinup_chem;
   double eps_abs, eps_rel, dt0, eps_spinup;
-  double M0, lnM0, sqrtM0, Tsoil, Tstrat, UC_CH4, TOH0, CCH4;
+  double M0, lnM0, Tsoil, Tstrat, UC_CH4, TOH0, CCH4;  // M0: the INI value (OH component)
+  double M0f, sqrtM0;  // preindustrial CH4 as the forcing sees it (CH4 constraint at startDate)
+  int con_mask;        // HXC_* bits: which constraint columns hold values
   double N0, sqrtN0;
   double delta_co2, delta_ch4, delta_n2o;
 };

@@ -12,6 +12,7 @@
 //                             inst/include/tseries.hpp:302-334, src/h_interpolator.cpp:103-122
 #include "hx_scenario.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -125,8 +126,47 @@ bool Scenario::has_series(const std::string &section, const std::string &key) co
   return series_.count(section + "." + key) != 0;
 }
 
+bool Scenario::is_constraint(const std::string &key) {
+  const std::string suf = "_constrain";
+  return key.size() > suf.size() && key.compare(key.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+void Scenario::densify_constraint(const std::string &name) {
+  const std::map<int, double> &pts = con_points_[name];
+  std::vector<double> v((size_t)ns(), std::nan(""));
+  const std::string key = name.substr(name.find('.') + 1);
+  const bool interp = (key == "tas_constrain" || key == "RF_tot_constrain");
+  if (!pts.empty()) {
+    for (int y = start; y <= end; ++y) {
+      auto hit = pts.find(y);
+      if (hit != pts.end()) { v[(size_t)(y - start)] = hit->second; continue; }
+      if (!interp) continue;
+      if (y > pts.rbegin()->first) continue;
+      if (y < pts.begin()->first) {
+        if (key == "RF_tot_constrain") v[(size_t)(y - start)] = pts.begin()->second;
+        continue;
+      }
+      auto hi = pts.upper_bound(y);
+      auto lo = std::prev(hi);
+      v[(size_t)(y - start)] = lo->second + ((double)y - lo->first) * (hi->second - lo->second) /
+                                               (double)(hi->first - lo->first);
+    }
+  }
+  series_[name] = std::move(v);
+}
+
+void Scenario::set_constraint_point(const std::string &section, const std::string &key, int year,
+                                    double v) {
+  if (year < start || year > end) throw std::runtime_error("date outside startDate..endDate");
+  const std::string name = section + "." + key;
+  if (std::isnan(v)) con_points_[name].erase(year);
+  else con_points_[name][year] = v;
+  densify_constraint(name);
+}
+
 void Scenario::set_series_value(const std::string &section, const std::string &key, int year,
                                 double v) {
+  if (is_constraint(key)) { set_constraint_point(section, key, year, v); return; }
   auto it = series_.find(section + "." + key);
   if (it == series_.end()) {
     series_[section + "." + key] = std::vector<double>((size_t)ns(), 0.0);
@@ -174,6 +214,14 @@ void Scenario::finish() {
     if (key != gas + "_emissions") continue;
     if (!hc.count(gas)) { hc[gas].name = gas; order.push_back(gas); }
     hc[gas].emissions = kv.second;
+  }
+  // dense constraint series (packs): the given dates are the non-NaN entries
+  for (auto &kv : series_) {
+    const std::string key = kv.first.substr(kv.first.find('.') + 1);
+    if (!is_constraint(key) || con_points_.count(kv.first)) continue;
+    std::map<int, double> &pts = con_points_[kv.first];
+    for (size_t i = 0; i < kv.second.size(); ++i)
+      if (!std::isnan(kv.second[i])) pts[start + (int)i] = kv.second[i];
   }
   halocarbons.clear();
   for (auto &g : order) {
@@ -257,7 +305,16 @@ Scenario Scenario::load_ini(const std::string &path) {
     }
   }
   const int y0 = (int)s.scalar("core", "startDate"), y1 = (int)s.scalar("core", "endDate");
+  s.start = y0; s.end = y1;
   for (auto &kv : pts) {
+    const std::string key = kv.first.substr(kv.first.find('.') + 1);
+    if (is_constraint(key)) {
+      for (auto &pt : kv.second)
+        if (pt.first >= y0 && pt.first <= y1 && pt.first == std::floor(pt.first))
+          s.con_points_[kv.first][(int)pt.first] = pt.second;
+      s.densify_constraint(kv.first);
+      continue;
+    }
     std::vector<double> v;
     for (int y = y0; y <= y1; ++y) v.push_back(tseries_get(kv.second, (double)y));
     s.series_[kv.first] = std::move(v);

@@ -31,6 +31,14 @@ class Scenario {
                                     const std::string &key) const;
   bool has_series(const std::string &section, const std::string &key) const;
   void set_series_value(const std::string &section, const std::string &key, int year, double v);
+  // Constraint series ("*_constrain") are dense like the others but hold NaN where the
+  // reference's tseries would not return a value: CO2/NBP/CH4/N2O/halocarbon constraints exist
+  // only at the dates given (tseries::exists); tas_constrain interpolates between its first
+  // and last date (temperature_component.cpp:510-511); RF_tot_constrain also applies, flat,
+  // before its first date (forcing_component.cpp:498).
+  static bool is_constraint(const std::string &key);
+  void set_constraint_point(const std::string &section, const std::string &key, int year,
+                            double v);
 
   std::vector<Halocarbon> halocarbons;
   std::string source;
@@ -39,6 +47,8 @@ class Scenario {
   static Scenario load_pack(const std::string &path);
   static Scenario load_ini(const std::string &path);
   void finish();
+  void densify_constraint(const std::string &name);
+  std::map<std::string, std::map<int, double>> con_points_;  // "section.key" -> given dates
   std::map<std::string, std::string> scalars_;           // "section.key" -> text
   std::map<std::string, std::vector<double>> series_;    // "section.key" -> [ns]
 };

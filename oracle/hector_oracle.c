@@ -19,7 +19,8 @@
 typedef struct {
   char name[24];
   double tau, rho, delta, H0, molarMass;
-  double *em; /* [ns] */
+  double *em;  /* [ns] */
+  double *con; /* [ns] concentration constraint, NaN = none that year; NULL = none */
 } hxo_halo;
 
 struct hxo_scenario {
@@ -41,6 +42,10 @@ struct hxo_scenario {
   double *ffi, *daccs, *luc_e, *luc_u, *albedo, *so2, *sv, *ch4n, *ch4_em;
   double *nox_oh, *co_oh, *nmvoc_oh, *nox_o3, *co_o3, *nmvoc_o3;
   double *n2o_nat, *n2o_em, *rf_misc, *bc, *oc, *nh3;
+  /* constraints [ns]: NaN where the reference's tseries has no value for that date
+   * (the pack writer applies each series' exists / interpolation rule); NULL = unset */
+  double *co2_con, *nbp_con, *tas_con, *ftot_con, *ch4_con, *n2o_con;
+  double lo_warming_ratio;
   int nhalo;
   hxo_halo halo[HXO_NHALO];
 };
@@ -100,6 +105,7 @@ static void set_scalar(hxo_scenario *s, const char *sec, const char *key,
   SC("forcing", "rho_so2", rho_so2) SC("forcing", "rho_nh3", rho_nh3)
   SC("temperature", "S", S) SC("temperature", "diff", diff)
   SC("temperature", "qco2", qco2)
+  SC("temperature", "lo_warming_ratio", lo_warming_ratio)
 #undef SC
   hxo_halo *h = find_halo(s, sec, 1);
   if (h) {
@@ -128,9 +134,13 @@ static void set_series(hxo_scenario *s, const char *sec, const char *key,
   SE("forcing", "RF_misc", rf_misc)
   SE("bc", "BC_emissions", bc) SE("oc", "OC_emissions", oc)
   SE("nh3", "NH3_emissions", nh3)
+  SE("simpleNbox", "CO2_constrain", co2_con) SE("simpleNbox", "NBP_constrain", nbp_con)
+  SE("temperature", "tas_constrain", tas_con) SE("forcing", "RF_tot_constrain", ftot_con)
+  SE("CH4", "CH4_constrain", ch4_con) SE("N2O", "N2O_constrain", n2o_con)
 #undef SE
   hxo_halo *h = find_halo(s, sec, 1);
   if (h && strstr(key, "_emissions")) { h->em = vals; return; }
+  if (h && strstr(key, "_constrain")) { h->con = vals; return; }
   free(vals);
 }
 
@@ -183,7 +193,9 @@ void hxo_scenario_free(hxo_scenario *s) {
                     &s->nmvoc_o3, &s->n2o_nat, &s->n2o_em, &s->rf_misc,
                     &s->bc, &s->oc, &s->nh3};
   for (size_t i = 0; i < sizeof ser / sizeof ser[0]; i++) free(*ser[i]);
-  for (int i = 0; i < s->nhalo; i++) free(s->halo[i].em);
+  for (int i = 0; i < s->nhalo; i++) { free(s->halo[i].em); free(s->halo[i].con); }
+  free(s->co2_con); free(s->nbp_con); free(s->tas_con); free(s->ftot_con);
+  free(s->ch4_con); free(s->n2o_con);
   free(s);
 }
 int hxo_scenario_start(const hxo_scenario *s) { return s->start; }
@@ -207,6 +219,7 @@ void hxo_params_default(const hxo_scenario *s, hxo_params *p) {
   p->tt = s->tt; p->tu = s->tu; p->twi = s->twi; p->tid = s->tid;
   p->preind_surface_c = s->preind_surface_c;
   p->preind_interdeep_c = s->preind_interdeep_c;
+  p->lo_warming_ratio = s->lo_warming_ratio;
 }
 
 void hxo_params_split_equal(hxo_params *p, int n) {
@@ -499,6 +512,7 @@ typedef struct {
   long nsteps_year, nrhs_year;
   /* ---- gases ---- */
   double ch4_prev, n2o_prev, tau_oh, o3, ch4, n2o;
+  double M0_eff, N0_eff; /* preindustrial values after prepareToRun's constraint override */
   double halo_conc[HXO_NHALO], halo_rf[HXO_NHALO];
   /* ---- forcing ---- */
   int have_base;
@@ -510,7 +524,11 @@ typedef struct {
       *heatflux_interior;
   double A[4], IB[4], taucfl, taukls, taucfs, tauksl, taudif, powtoheat;
   double tas_land, sst_now; /* undated D_LAND_TAS, D_SST */
+  double Ca_residual;
 } member_t;
+
+/* tseries::exists for a constraint held as a NaN-filled dense series */
+static int con_has(const double *c, int iy) { return c && !isnan(c[iy]); }
 
 /* DOECLIM hard-coded parameters  inst/include/temperature_component.hpp:77-98 */
 static const double d_dt = 1, d_ak = 0.31, d_bk = 1.59, d_csw = 0.13,
@@ -693,6 +711,14 @@ static void doeclim_run(member_t *m, int tstep, double rf_total) {
   }
   m->temp[tstep] = flnd * m->temp_landair[tstep] +
                    (1.0 - flnd) * bsi * m->temp_sst[tstep];
+  /* user-supplied temperature  temperature_component.cpp:510-525 */
+  if (con_has(m->sc->tas_con, tstep)) {
+    m->temp[tstep] = m->sc->tas_con[tstep];
+    m->temp_landair[tstep] =
+        (m->temp[tstep] - (1.0 - flnd) * bsi * m->temp_sst[tstep]) / flnd;
+    m->temp_sst[tstep] =
+        (m->temp[tstep] - flnd * m->temp_landair[tstep]) / ((1.0 - flnd) * bsi);
+  }
   if (tstep > 0) {
     m->heatflux_mixed[tstep] = cas * (m->temp_sst[tstep] - m->temp_sst[tstep - 1]);
     for (int i = 0; i < tstep; i++)
@@ -708,6 +734,15 @@ static void doeclim_run(member_t *m, int tstep, double rf_total) {
   /* setoutputs  src/temperature_component.cpp:706-746 */
   m->tas_land = m->temp_landair[tstep];
   m->sst_now = m->temp_sst[tstep];
+  /* land-ocean warming ratio override :722-739; what D_LAND_TAS / D_SST return :586-625 */
+  const double lo = m->pa->lo_warming_ratio;
+  if (lo != 0) {
+    double temp_oceanair_constrain = m->temp[tstep] / ((lo * flnd) + (1 - flnd));
+    double temp_landair_constrain = temp_oceanair_constrain * lo;
+    double temp_sst_constrain = temp_oceanair_constrain / bsi;
+    m->tas_land = temp_landair_constrain;
+    m->sst_now = temp_sst_constrain;
+  }
 }
 
 /* ------------------------------------------------------------------ */
@@ -1096,6 +1131,26 @@ static int snb_calcderivs(member_t *m, double t, const double c[],
       pf_refreeze_soil = pf_refreeze_soil + z;
     }
   }
+  /* NBP constraint: NPP and RH adjusted equally  runtime.cpp:871-898 */
+  {
+    const int it = (int)round(t) - m->sc->start;
+    if (!m->snbox_in_spinup && it >= 0 && it < m->ns && con_has(m->sc->nbp_con, it)) {
+      const double nbp = npp_current - rh_current - m->cur_luc_e + m->cur_luc_u;
+      const double diff = m->sc->nbp_con[it] - nbp;
+      const double npp_current_old = npp_current;
+      npp_current = npp_current + diff / 2.0;
+      const double npp_ratio = npp_current / npp_current_old;
+      npp_fav = npp_fav * npp_ratio;
+      npp_fad = npp_fad * npp_ratio;
+      npp_fas = npp_fas * npp_ratio;
+      const double rh_current_old = rh_current;
+      rh_current = rh_current - diff / 2.0;
+      const double rh_ratio = rh_current / rh_current_old;
+      rh_fda_current = rh_fda_current * rh_ratio;
+      rh_fsa_current = rh_fsa_current * rh_ratio;
+      rh_ftpa_co2_current = rh_ftpa_co2_current * rh_ratio;
+    }
+  }
   dcdt[SNBOX_ATMOS] = m->cur_ffi - m->cur_daccs + m->cur_luc_e - m->cur_luc_u +
                       ch4ox_current - ocean_uptake + ocean_release -
                       npp_current + rh_current;
@@ -1197,6 +1252,26 @@ static void snb_stash(member_t *m, double t, const double c[]) {
   if (c[0] < 0 || newveg < 0 || newdet < 0 || newsoil < 0 ||
       newpermafrost < 0 || solver_tpf < 0)
     m->err |= HXO_ERR_NEGPOOL;
+  /* NBP constraint  runtime.cpp:343-383 */
+  double rh_nbp_constraint_adjust = 1.0;
+  {
+    const int it = (int)round(t) - m->sc->start;
+    if (!m->core_in_spinup && it >= 0 && it < m->ns && con_has(m->sc->nbp_con, it)) {
+      const double diff = m->sc->nbp_con[it] - alf;
+      npp_total = npp_total + diff / 2.0;
+      rh_nbp_constraint_adjust = (rh_total - diff / 2.0) / rh_total;
+      rh_total = rh_total - diff / 2.0;
+      const double pool_diff = diff * yf;
+      const double total_land =
+          c[SNBOX_DET] + c[SNBOX_VEG] + c[SNBOX_SOIL] + c[SNBOX_THAWEDP];
+      newdet = newdet + pool_diff * c[SNBOX_DET] / total_land;
+      newveg = newveg + pool_diff * c[SNBOX_VEG] / total_land;
+      newsoil = newsoil + pool_diff * c[SNBOX_SOIL] / total_land;
+      solver_tpf = solver_tpf + pool_diff * c[SNBOX_THAWEDP] / total_land;
+      m->carbon[DO] = (-pool_diff) + m->carbon[DO]; /* M_DUMP_TO_DEEP_OCEAN */
+      alf = npp_total - rh_total - m->cur_luc_e + m->cur_luc_u;
+    }
+  }
   m->nbp = alf;
   const double total = c[SNBOX_VEG] + c[SNBOX_DET] + c[SNBOX_SOIL];
   m->cum_luc_va = m->cum_luc_va +
@@ -1205,7 +1280,7 @@ static void snb_stash(member_t *m, double t, const double c[]) {
     const double wt = (snb_npp(m, b) + snb_rh(m, b)) / npp_rh_total;
     const double wt_pf =
         permafrost_total > 0 ? m->permafrost_c[b] / permafrost_total : 0;
-    double rh_ftpa_ch4_adj = snb_rh_ftpa_ch4(m, b) * 1.0;
+    double rh_ftpa_ch4_adj = snb_rh_ftpa_ch4(m, b) * rh_nbp_constraint_adjust;
     double rh_fpa_ch4_flux = rh_ftpa_ch4_adj * yf;
     m->cumulative_pf_ch4 += rh_fpa_ch4_flux;
     m->veg_c[b] = newveg * wt;
@@ -1222,12 +1297,17 @@ static void snb_stash(member_t *m, double t, const double c[]) {
   const double diff = fabs(sum - m->masstot);
   if (m->masstot > 0.0 && diff > MB_EPSILON) m->err |= HXO_ERR_MASS;
   m->masstot = sum;
-  if (m->core_in_spinup) {
-    double match = p->C0 / PGC_TO_PPMVCO2;
+  const int it = (int)t - m->sc->start;
+  if (m->core_in_spinup ||
+      (t == floor(t) && it >= 0 && it < m->ns && con_has(m->sc->co2_con, it))) {
+    double match = (m->core_in_spinup ? p->C0 : m->sc->co2_con[it]) / PGC_TO_PPMVCO2;
     double residual = m->atmos_c - match;
     /* deepOceanCarbonDump  ocean_component.cpp:146-154 */
     m->carbon[DO] = residual + m->carbon[DO];
     m->atmos_c = m->atmos_c - residual;
+    m->Ca_residual = residual;
+  } else {
+    m->Ca_residual = 0.0;
   }
   m->ODEstartdate = t;
 }
@@ -1420,6 +1500,7 @@ static void year_gases(member_t *m, int iy) {
     const double oh_sink = previous_ch4 / current_toh;
     const double dCH4 = emisTocon - soil_sink - strat_sink - oh_sink;
     m->ch4 = previous_ch4 + dCH4;
+    if (con_has(s->ch4_con, iy)) m->ch4 = s->ch4_con[iy]; /* :156-157 */
   }
   /* OzoneComponent::run  src/o3_component.cpp:126-146 */
   m->o3 = (5 * log(m->ch4)) + (0.125 * s->nox_o3[iy]) +
@@ -1427,10 +1508,11 @@ static void year_gases(member_t *m, int iy) {
   /* N2OComponent::run  src/n2o_component.cpp:152-191 */
   {
     double previous_n2o = m->n2o_prev;
-    double tau = s->TN2O0 * (pow(previous_n2o / s->N0, -0.05));
+    double tau = s->TN2O0 * (pow(previous_n2o / m->N0_eff, -0.05));
     const double current_n2oem = s->n2o_em[iy] + s->n2o_nat[iy];
     const double dN2O = current_n2oem / s->UC_N2O - previous_n2o / tau;
     m->n2o = previous_n2o + dN2O;
+    if (con_has(s->n2o_con, iy)) m->n2o = s->n2o_con[iy]; /* n2o_component.cpp:157-158 */
   }
   /* HalocarbonComponent::run  src/halocarbon_component.cpp:181-229 */
   for (int h = 0; h < s->nhalo; h++) {
@@ -1442,6 +1524,7 @@ static void year_gases(member_t *m, int iy) {
     double concDeltaEmiss = emissMol / (0.1 * 1.8);
     double expfac = exp(-alpha);
     Ha = Ha * expfac + concDeltaEmiss * H->tau * (1.0 - expfac);
+    if (con_has(H->con, iy)) Ha = H->con[iy]; /* halocarbon_component.cpp:189-191 */
     m->halo_conc[h] = Ha;
     double rf_unadjusted = H->rho * Ha;
     m->halo_rf[h] = rf_unadjusted + H->delta * rf_unadjusted;
@@ -1464,7 +1547,7 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
   static char names[HXO_NHALO][32];
   rf_item f[48];
   int nf = 0;
-  double C0 = p->C0, M0 = s->M0, N0 = s->N0, Ma = m->ch4, Na = m->n2o;
+  double C0 = p->C0, M0 = m->M0_eff, N0 = m->N0_eff, Ma = m->ch4, Na = m->n2o;
   double C_alpha_max = C0 - (b1 / (2 * a1));
   double n2o_alpha = c1 * sqrt(Na);
   double alpha_prime;
@@ -1507,6 +1590,7 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
   qsort(f, (size_t)nf, sizeof f[0], rf_cmp);
   double Ftot = 0.0;
   for (int i = 0; i < nf; i++) Ftot = Ftot + f[i].v;
+  if (con_has(s->ftot_con, iy)) Ftot = s->ftot_con[iy]; /* :498-505 */
   if (year == s->baseyear) {
     m->have_base = 1; m->base_tot = Ftot; m->base_co2 = fco2;
     m->base_ch4 = fch4; m->base_n2o = fn2o;
@@ -1576,8 +1660,12 @@ static void member_prepare(member_t *m, const hxo_scenario *s, const hxo_params 
   /* solver: carbon-cycle-solver.cpp:118-133 */
   m->t = s->start; m->dt = s->dt;
   /* gases: prepareToRun of CH4/OH/N2O/halocarbons */
-  m->ch4_prev = s->M0; m->n2o_prev = s->N0; m->tau_oh = s->TOH0;
-  m->ch4 = s->M0; m->n2o = s->N0; m->o3 = s->PO3;
+  /* ch4_component.cpp:137-147, n2o_component.cpp:137-145: a constraint at startDate replaces
+   * the preindustrial value (OH keeps the INI M0: its prepareToRun runs first) */
+  m->M0_eff = con_has(s->ch4_con, 0) ? s->ch4_con[0] : s->M0;
+  m->N0_eff = con_has(s->n2o_con, 0) ? s->n2o_con[0] : s->N0;
+  m->ch4_prev = m->M0_eff; m->n2o_prev = m->N0_eff; m->tau_oh = s->TOH0;
+  m->ch4 = m->M0_eff; m->n2o = m->N0_eff; m->o3 = s->PO3;
   for (int h = 0; h < s->nhalo; h++) m->halo_conc[h] = s->halo[h].H0;
   doeclim_prepare(m);
   m->tas_land = 0.0; m->sst_now = 0.0;
@@ -1627,7 +1715,7 @@ static void member_main(member_t *m, int run_to, double *out) {
   m->timesteps = 0;
   record_outputs(m, 0, out);
   out[HXO_HL_PH * ns] = m->chem[HL].pH;
-  out[HXO_CH4 * ns] = s->M0; out[HXO_N2O * ns] = s->N0; out[HXO_O3 * ns] = s->PO3;
+  out[HXO_CH4 * ns] = m->M0_eff; out[HXO_N2O * ns] = m->N0_eff; out[HXO_O3 * ns] = s->PO3;
   for (int year = s->start + 1; year <= run_to && year <= s->end; year++) {
     int iy = year - s->start;
     m->nsteps_year = m->nrhs_year = 0;
@@ -1647,8 +1735,8 @@ static void member_main(member_t *m, int run_to, double *out) {
     doeclim_run(m, iy, m->rf_tot);
     record_outputs(m, iy, out);
     out[HXO_TGAV * ns + iy] = m->temp[iy];
-    out[HXO_SST * ns + iy] = m->temp_sst[iy];
-    out[HXO_TLAND * ns + iy] = m->temp_landair[iy];
+    out[HXO_SST * ns + iy] = m->sst_now;     /* lo_sst / lo_temp_landair when the */
+    out[HXO_TLAND * ns + iy] = m->tas_land;  /* warming ratio is set, :586-625     */
     out[HXO_HEATFLUX * ns + iy] =
         m->heatflux_mixed[iy] + d_fso * m->heatflux_interior[iy];
     out[HXO_RF_TOT * ns + iy] = m->rf_tot;

@@ -88,6 +88,8 @@ typedef struct {
       fpf_static[HXO_MAXB];
   /* ocean */
   double tt, tu, twi, tid, preind_surface_c, preind_interdeep_c;
+  /* temperature: land-ocean warming ratio override, 0 = off */
+  double lo_warming_ratio;
 } hxo_params;
 
 /* Load a scenario pack (.hxs, see tools/import_scenario.py). NULL on error. */

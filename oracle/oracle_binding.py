@@ -29,7 +29,7 @@ class Params(ctypes.Structure):
                  "beta q10_rh warmingfactor npp_flux0 veg_c detritus_c soil_c permafrost_c "
                  "f_nppv f_nppd f_litterd rh_ch4_frac pf_mu pf_sigma fpf_static".split()] +
                 [(n, ctypes.c_double) for n in
-                 "tt tu twi tid preind_surface_c preind_interdeep_c".split()])
+                 "tt tu twi tid preind_surface_c preind_interdeep_c lo_warming_ratio".split()])
 
 
 def build():

@@ -57,20 +57,33 @@ def hip_lib():
     return HIP_LIB
 
 
-def edited_pack(path, section, key, years, values):
-    """Write a copy of the packaged scenario with `section.key` changed at `years` -- what a
-    reference user gets from setvar(core, dates, var, values) -- for the oracle to read."""
-    out = []
-    with open(SCENARIO) as f:
+def edited_pack(path, section, key, years, values, base=None, scalars=None):
+    """Write a copy of a scenario pack with `section.key` changed at `years` -- what a
+    reference user gets from setvar(core, dates, var, values) -- for the oracle to read.
+    A series the pack does not hold yet (a constraint) is added, NaN where it has no value.
+    `scalars`: {(section, key): value} to add or replace."""
+    out, found, y0, n = [], False, None, None
+    with open(base or SCENARIO) as f:
         for line in f:
             p = line.split()
-            if len(p) > 5 and p[0] == "series" and p[1] == section and p[2] == key:
+            if len(p) > 5 and p[0] == "series":
                 y0, n = int(p[3]), int(p[4])
-                v = p[5:5 + n]
-                for y, x in zip(years, values):
-                    v[int(y) - y0] = repr(float(x))
-                line = " ".join(p[:5] + v) + "\n"
+                if p[1] == section and p[2] == key:
+                    found = True
+                    v = p[5:5 + n]
+                    for y, x in zip(years, values):
+                        v[int(y) - y0] = repr(float(x))
+                    line = " ".join(p[:5] + v) + "\n"
+            if len(p) > 3 and p[0] == "scalar" and scalars and (p[1], p[2]) in scalars:
+                continue
             out.append(line)
+    if not found and section:
+        v = ["nan"] * n
+        for y, x in zip(years, values):
+            v[int(y) - y0] = repr(float(x))
+        out.append(" ".join(["series", section, key, str(y0), str(n)] + v) + "\n")
+    for (sec, k), val in (scalars or {}).items():
+        out.append("scalar %s %s %r\n" % (sec, k, float(val)))
     with open(path, "w") as f:
         f.writelines(out)
     return str(path)

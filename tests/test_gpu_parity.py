@@ -335,3 +335,53 @@ def test_luc_pulse_on_gpu(hip_lib, oracle):
     c.set_outputs(["veg_c"]); c.run(1850)
     v = c.fetchvars("veg_c", (1745, 1850))
     assert (np.diff(v[5:55], axis=0) < 1e-6).all() and (np.diff(v[56:], axis=0) < 1e-6).all()
+
+
+def test_constraints_on_gpu(hip_lib, oracle, tmp_path):
+    """Constraint branches (CO2, NBP, tas, RF_tot, CH4/N2O/halocarbon concentrations, land-ocean
+    warming ratio): the restated reference tests and the oracle parity of test_constraints.py,
+    through the HIP library."""
+    import test_constraints as tc
+    assert mk(hip_lib, 1).backend == "hip"
+    tc.test_co2_constraint_like_reference_test(hip_lib, tmp_path)
+    tc.test_discontinuous_co2_constraint(hip_lib, tmp_path)
+    tc.test_tas_constraint_like_reference_test(hip_lib, tmp_path)
+    tc.test_tas_constraint_interpolates_between_its_dates(hip_lib, tmp_path)
+    tc.test_nbp_constraint_like_reference_test(hip_lib, tmp_path)
+    tc.test_nbp_constraint_many_years_vs_oracle(hip_lib, tmp_path)
+    tc.test_concentration_forced_gases_like_reference_tests(hip_lib, tmp_path, "CH4", "CH4",
+                                                            "CH4_concentration", "ppbv CH4")
+    tc.test_concentration_forced_gases_like_reference_tests(hip_lib, tmp_path, "N2O", "N2O",
+                                                            "N2O_concentration", "ppbv N2O")
+    tc.test_concentration_forced_gases_like_reference_tests(
+        hip_lib, tmp_path, "HFC23", "HFC23_halocarbon", "HFC23_concentration", "pptv")
+    tc.test_ftot_constraint_vs_oracle(hip_lib, tmp_path)
+    tc.test_land_ocean_warming_ratio_per_member(hip_lib, oracle)
+
+
+def test_constrained_ensemble_vs_oracle_on_gpu(hip_lib, tmp_path):
+    """A 192-member ECS x Q10 ensemble under a CO2 + tas constraint (concentration-driven runs
+    are how the reference is used for emulation): every 7th member against the oracle."""
+    import oracle_binding
+    from conftest import edited_pack
+    n = 192
+    S, q10 = ensemble.ecs_q10(n, offset=5000)
+    yc = np.arange(1850, 2015)
+    c = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    c.set_outputs(["CO2_concentration", "global_tas", "RF_tot"])
+    c.run(2300)
+    co2 = c.fetchvars("CO2_concentration", (1850, 2014))[:, 0] * 1.1
+    c.setvar_dated("CO2_constrain", yc, co2).setvar_dated("tas_constrain", [1900, 1950], [0.1, 0.4])
+    c.run(2300)
+    assert (c.status() == 0).all()
+    p1 = edited_pack(tmp_path / "a.hxs", "simpleNbox", "CO2_constrain", yc, co2)
+    p2 = edited_pack(tmp_path / "b.hxs", "temperature", "tas_constrain", np.arange(1900, 1951),
+                     np.linspace(0.1, 0.4, 51), base=p1)
+    o = oracle_binding.Oracle(p2)
+    g = c.fetchvars("CO2_concentration", (1745, 2300)); t = c.fetchvars("global_tas", (1745, 2300))
+    for i in range(0, n, 7):
+        p = o.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        r, err, _ = o.run(p)
+        assert err == 0
+        assert (np.abs(g[:, i] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < REL_CO2
+        assert np.abs(t[:, i] - r["global_tas"]).max() < ABS_T

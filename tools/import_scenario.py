@@ -109,6 +109,23 @@ def tseries_get(points, t):
     return y0 + (t - lo) * (y1 - y0) / (hi - lo)
 
 
+def constraint_get(key, points, y):
+    """Constraint series keep the reference's per-series rule: CO2/NBP/CH4/N2O/halocarbon
+    constraints exist only at the dates given (tseries::exists); tas_constrain interpolates
+    between its first and last date (temperature_component.cpp:510-511); RF_tot_constrain is
+    also used, flat, before its first date (forcing_component.cpp:498).  NaN = no value."""
+    if y in points:
+        return points[y]
+    if key not in ("tas_constrain", "RF_tot_constrain"):
+        return float("nan")
+    xs = sorted(points)
+    if y > xs[-1]:
+        return float("nan")
+    if y < xs[0]:
+        return points[xs[0]] if key == "RF_tot_constrain" else float("nan")
+    return tseries_get(points, y)
+
+
 def main(ini_path, out_path):
     items = parse_ini(ini_path)
     inidir = os.path.dirname(os.path.abspath(ini_path))
@@ -147,7 +164,10 @@ def main(ini_path, out_path):
             f.write("scalar %s %s %s\n" % (s, k, v))
         for (s, k) in order:
             pts = series[(s, k)]
-            vals = [tseries_get(pts, float(y)) for y in range(start, end + 1)]
+            if k.endswith("_constrain"):
+                vals = [constraint_get(k, pts, float(y)) for y in range(start, end + 1)]
+            else:
+                vals = [tseries_get(pts, float(y)) for y in range(start, end + 1)]
             f.write("series %s %s %d %d %s\n" %
                     (s, k, start, n, " ".join(repr(float(x)) for x in vals)))
     print("wrote %s: %d scalars, %d series x %d years" %
