@@ -101,6 +101,12 @@ class Core:
         self._ck(self._lib.hx_set_outputs(self._h, n, arr))
         return self
 
+    def halocarbons(self):
+        names = ctypes.POINTER(ctypes.c_char_p)()
+        n = ctypes.c_int()
+        self._ck(self._lib.hx_halocarbons(self._h, ctypes.byref(names), ctypes.byref(n)))
+        return [names[i].decode() for i in range(n.value)]
+
     def enable_history(self, on=True):
         self._ck(self._lib.hx_enable_history(self._h, 1 if on else 0))
         return self

@@ -17,6 +17,9 @@ hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, dou
 int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
+hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st);
+hipError_t hx_launch_slr(const double *tgav, int npad, int start_year, int iy_to, double *out,
+                         size_t var_stride, hipStream_t st);
 hipError_t hx_launch_gather(const double *src, const int *lane_of_member, double *dst, int n,
                             int npad, int nyears, hipStream_t st);
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,
@@ -75,8 +78,43 @@ const OutDef kOutputs[] = {
     {"earth_c", HXO_EARTH_C}, {"NBP", HXO_NBP}, {"ocean_uptake", HXO_OCEAN_UPTAKE},
     {"timesteps", HXO_NSTASH}, {"solver_steps", HXO_NSTEPS}, {"LL_pH", HXO_LL_PH},
     {"sst_reported", HXO_SST_LO},  // internal: see out_index()
+    {"NPP", HXO_NPP}, {"RH", HXO_RH}, {"rh_det", HXO_RH_DET}, {"rh_soil", HXO_RH_SOIL},
+    {"HL_ocean_uptake", HXO_HL_UPTAKE}, {"LL_ocean_uptake", HXO_LL_UPTAKE},
+    {"HL_downwelling", HXO_HL_DO}, {"atmos_c_residual", HXO_CA_RESIDUAL},
+    {"rh_ch4", HXO_RH_CH4}, {"f_frozen", HXO_F_FROZEN}, {"gmst", HXO_GMST},
+    {"heatflux_mixed", HXO_FLUX_MIXED}, {"heatflux_interior", HXO_FLUX_INTERIOR},
+    {"HL_ocean_c", HXO_C_HL}, {"LL_ocean_c", HXO_C_LL}, {"IO_ocean_c", HXO_C_IO},
+    {"DO_ocean_c", HXO_C_DO}, {"HL_PCO2", HXO_PCO2_HL}, {"LL_PCO2", HXO_PCO2_LL},
+    {"TAU_OH", HXO_TAU_OH},
 };
 const char *kOutputNames[HXO_NVAR];
+
+// diagnostics computed on request from recorded outputs (hx_diag_kernel / hx_slr_kernel)
+struct DerivedDef { const char *name; int kind; int box; const char *deps[4]; };
+enum { DK_SLR = 100, DK_SL_RC, DK_SLR_NI, DK_SL_RC_NI };
+const DerivedDef kDerived[] = {
+    {"HL_sst", HXG_TEMP, 0, {"sst"}}, {"LL_sst", HXG_TEMP, 1, {"sst"}},
+    {"HL_DIC", HXG_DIC, 0, {"HL_ocean_c"}}, {"LL_DIC", HXG_DIC, 1, {"LL_ocean_c"}},
+    {"HL_CO3", HXG_CO3, 0, {"sst", "HL_pH", "HL_PCO2"}},
+    {"LL_CO3", HXG_CO3, 1, {"sst", "LL_pH", "LL_PCO2"}},
+    {"HL_OmegaAr", HXG_OMEGA_AR, 0, {"sst", "HL_pH", "HL_PCO2"}},
+    {"LL_OmegaAr", HXG_OMEGA_AR, 1, {"sst", "LL_pH", "LL_PCO2"}},
+    {"HL_OmegaCa", HXG_OMEGA_CA, 0, {"sst", "HL_pH", "HL_PCO2"}},
+    {"LL_OmegaCa", HXG_OMEGA_CA, 1, {"sst", "LL_pH", "LL_PCO2"}},
+    {"HL_Revelle", HXG_REVELLE, 0, {"sst", "HL_pH", "HL_PCO2", "HL_ocean_c"}},
+    {"LL_Revelle", HXG_REVELLE, 1, {"sst", "LL_pH", "LL_PCO2", "LL_ocean_c"}},
+    {"ocean_tas", HXG_OCEAN_TAS, -1, {"global_tas"}},
+    {"RF_N2O", HXG_RF_N2O, -1, {"CO2_concentration", "CH4_concentration"}},
+    {"RF_CH4", HXG_RF_CH4, -1, {"CH4_concentration"}},
+    {"RF_H2O_strat", HXG_RF_H2O, -1, {"CH4_concentration"}},
+    {"RF_O3_trop", HXG_RF_O3, -1, {"O3_concentration"}},
+    {"slr", DK_SLR, -1, {"global_tas"}}, {"sl_rc", DK_SL_RC, -1, {"global_tas"}},
+    {"slr_no_ice", DK_SLR_NI, -1, {"global_tas"}}, {"sl_rc_no_ice", DK_SL_RC_NI, -1, {"global_tas"}},
+};
+const DerivedDef *derived_of(const std::string &name) {
+  for (const DerivedDef &d : kDerived) if (name == d.name) return &d;
+  return nullptr;
+}
 
 }  // namespace
 
@@ -236,6 +274,8 @@ void EnsembleCore::build_shared() {
   const double N0f = has(n2o_con, 0) ? n2o_con[0] : N0;
   double n2o = N0f;
   halo_conc_.assign(hconc.size(), std::vector<double>((size_t)ns, 0.0));
+  halo_names_.clear();
+  for (auto &H : s.halocarbons) halo_names_.push_back(H.name);
   for (int iy = 0; iy < ns; ++iy) {
     double *row = &shared_[(size_t)iy * HXSH_STRIDE];
     row[HXSH_CO2_CON] = has(co2_con, iy) ? co2_con[(size_t)iy] : std::nan("");
@@ -321,6 +361,7 @@ void EnsembleCore::free_device() {
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   d_hist_ = nullptr;
+  fr(d_diag_); fr(d_slr_); d_diag_ = d_slr_ = nullptr; diag_cap_ = 0; slr_valid_to_ = -1;
   d_derived_ = nullptr; d_dpart_ = nullptr; d_gather_ = nullptr; d_lane_of_member_ = nullptr;
   gather_cap_ = 0;
   d_params_ = d_state_ = d_shared_ = d_ker_ = nullptr; d_status_ = nullptr; d_spin_steps_ = nullptr;
@@ -367,6 +408,8 @@ HxBuffers EnsembleCore::buffers() const {
   b.dpart2 = d_dpart_ ? d_dpart_ + (size_t)npad_ * hx_doeclim_block_years() : nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
   b.hist = d_hist_;
+  b.stash_diag = 0;
+  for (int v = HXO_NPP; v <= HXO_CA_RESIDUAL; ++v) if (d_out_[v]) b.stash_diag = 1;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   return b;
 }
@@ -481,6 +524,7 @@ int EnsembleCore::out_index(const std::string &capability) const {
   // with a land-ocean warming ratio D_SST is not DOECLIM's own SST (temperature_component.cpp:
   // 614-625); the kernel records the reported one separately
   if (capability == "sst" && out_enabled_[HXO_SST_LO]) return HXO_SST_LO;
+  if (capability == "ocean_timesteps") return HXO_NSTASH;  // D_TIMESTEPS, component_data.hpp:337
   for (auto &o : kOutputs) if (capability == o.name) return o.idx;
   throw std::runtime_error("Caller is requesting unknown variable: " + capability);
 }
@@ -490,7 +534,14 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
   for (int v = 0; v < HXO_NVAR; ++v) want[v] = false;
   want[HXO_SST] = want[HXO_TLAND] = true;
   want[HXO_SST_LO] = out_enabled_[HXO_SST_LO];
-  for (auto &c : caps) want[out_index(c)] = true;
+  for (auto &c : caps) {
+    if (const DerivedDef *d = derived_of(c)) {  // record what the diagnostic is derived from
+      for (const char *dep : d->deps) if (dep) want[out_index(dep)] = true;
+      continue;
+    }
+    if (host_output(c)) continue;  // answered from the scenario / the shared gas cycles
+    want[out_index(c)] = true;
+  }
   bool changed = false;
   for (int v = 0; v < HXO_NVAR; ++v) if (want[v] != out_enabled_[v]) changed = true;
   if (!changed) return;
@@ -760,12 +811,15 @@ void EnsembleCore::run(double runtodate) {
   check(hipEventRecord(ev0_, stream_), "event");
   // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
   // history pass every HX_DBLK years), so there is no global barrier to wait at
-  const bool hf = d_out_[HXO_HEATFLUX] != nullptr;
-  check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, kc_.con_mask != 0, last_iy_, target,
+  const bool hf = d_out_[HXO_HEATFLUX] || d_out_[HXO_FLUX_MIXED] || d_out_[HXO_FLUX_INTERIOR];
+  bool ext = kc_.con_mask != 0;  // extended kernel: constraints or the extra diagnostics
+  for (int v = HXO_NPP; v < HXO_NVAR; ++v) if (d_out_[v]) ext = true;
+  check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, ext, last_iy_, target,
                       stream_),
         "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;
+  slr_valid_to_ = -1;
   if (d_hist_) hist_valid_to_ = target;  // slabs last_iy_+1..target were just (re)written
   last_iy_ = target;
 }
@@ -780,49 +834,160 @@ void EnsembleCore::sync() {
   }
 }
 
-void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
-                             double *out_host) {
-  // scenario INPUT series (emissions, SV, RF_albedo ...): the same for every member; the
-  // reference answers GETDATA for them from the component's tseries
+// Variables answered on the host: scenario INPUT series, the member-independent gas cycles
+// (N2O, halocarbons: run while the per-year table is built) and the forcings that are a
+// member's scalar times a shared series.  Returns false if `capability` is not one of them;
+// with out_host == nullptr only answers the question.
+bool EnsembleCore::fetch_host(const std::string &capability, int year0, int year1,
+                              double *out_host) {
+  const int ns = scen_.ns();
+  std::vector<double> ser;          // member-independent series [ns]
+  const std::vector<double> *scale = nullptr;  // per-member factor (parameter row)
+  bool relative = false, computed = false;     // relative to the forcing base year / needs a run
+  auto input = [&](const std::string &sec, const std::string &key, double dflt) {
+    return scen_.has_series(sec, key) ? scen_.series(sec, key) : std::vector<double>((size_t)ns, dflt);
+  };
   for (const DatedDef &d : kDated)
-    if (capability == d.name && scen_.has_series(d.sections[0], capability)) {
-      if (year0 < scen_.start || year1 > scen_.end || year1 < year0)
-        throw std::runtime_error("fetchvars: dates must lie between startDate and endDate");
-      const std::vector<double> &ser = scen_.series(d.sections[0], capability);
-      for (int y = year0; y <= year1; ++y)
-        std::fill(out_host + (size_t)(y - year0) * n_, out_host + (size_t)(y - year0 + 1) * n_,
-                  ser[(size_t)(y - scen_.start)]);
-      return;
-    }
-  // member-independent results of the shared gas cycles (N2O and halocarbon components run
-  // on the host while the per-year table is built)
-  {
-    const std::vector<double> *src = nullptr;
-    std::vector<double> tmp;
-    if (capability == "N2O_concentration") {
-      tmp.resize((size_t)scen_.ns());
-      for (int iy = 0; iy < scen_.ns(); ++iy) tmp[(size_t)iy] = shared_[(size_t)iy * HXSH_STRIDE + HXSH_N2O];
-      src = &tmp;
-    }
-    const std::string csuf = "_concentration";
-    if (!src && capability.size() > csuf.size() &&
-        capability.compare(capability.size() - csuf.size(), csuf.size(), csuf) == 0) {
-      const std::string gas = capability.substr(0, capability.size() - csuf.size());
-      for (size_t h = 0; h < scen_.halocarbons.size(); ++h)
-        if (scen_.halocarbons[h].name == gas) src = &halo_conc_[h];
-    }
-    if (src) {
-      if (shared_dirty_) throw std::runtime_error("fetchvars: run the core after changing inputs");
-      if (year0 < scen_.start || year1 > last_date() || year1 < year0)
-        throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
-      for (int y = year0; y <= year1; ++y)
-        std::fill(out_host + (size_t)(y - year0) * n_, out_host + (size_t)(y - year0 + 1) * n_,
-                  (*src)[(size_t)(y - scen_.start)]);
-      return;
+    if (capability == d.name && scen_.has_series(d.sections[0], capability))
+      ser = scen_.series(d.sections[0], capability);
+  const std::string csuf = "_concentration", esuf = "_emissions";
+  auto ends = [&](const std::string &suf) {
+    return capability.size() > suf.size() &&
+           capability.compare(capability.size() - suf.size(), suf.size(), suf) == 0;
+  };
+  if (ser.empty() && capability == "N2O_concentration") {
+    ser.resize((size_t)ns);
+    for (int iy = 0; iy < ns; ++iy) ser[(size_t)iy] = shared_[(size_t)iy * HXSH_STRIDE + HXSH_N2O];
+    computed = true;
+  }
+  if (ser.empty() && (ends(csuf) || ends(esuf) || capability.compare(0, 3, "RF_") == 0)) {
+    for (size_t h = 0; h < scen_.halocarbons.size(); ++h) {
+      const Halocarbon &H = scen_.halocarbons[h];
+      if (capability == H.name + csuf) { ser = halo_conc_[h]; computed = true; }
+      else if (capability == H.name + esuf) ser = H.emissions;
+      else if (capability == "RF_" + H.name) {  // halocarbon_component.cpp:205-229
+        ser.resize((size_t)ns);
+        for (int iy = 0; iy < ns; ++iy) {
+          const double rf_un = H.rho * halo_conc_[h][(size_t)iy];
+          ser[(size_t)iy] = rf_un + H.delta * rf_un;
+        }
+        ser[0] = 0.0;  // the component has not run at startDate
+        relative = computed = true;
+      }
     }
   }
-  const int v = out_index(capability);
-  if (!d_out_[v])
+  if (ser.empty() && capability.compare(0, 3, "RF_") == 0) {
+    // forcing_component.cpp:430-487; alpha = aero_scalar, volscl = vol_scalar
+    const auto bc = input("bc", "BC_emissions", 0), oc = input("oc", "OC_emissions", 0),
+               so2 = input("so2", "SO2_emissions", 0), nh3 = input("nh3", "NH3_emissions", 0);
+    const double aci_beta = 2.279759, s_BCOC = 111.05064063;
+    const double s_SO2 = (260.34644166 * 1000) * (32.065 / 64.066);
+    auto scaled = [&](const std::vector<double> &e, const char *rho_key) {
+      const double rho = scen_.scalar("forcing", rho_key);
+      ser.resize((size_t)ns);
+      for (int iy = 0; iy < ns; ++iy) ser[(size_t)iy] = rho * e[(size_t)iy];
+      scale = &params_[HXP_AERO];
+    };
+    if (capability == "RF_BC") scaled(bc, "rho_bc");
+    else if (capability == "RF_OC") scaled(oc, "rho_oc");
+    else if (capability == "RF_SO2") scaled(so2, "rho_so2");
+    else if (capability == "RF_NH3") scaled(nh3, "rho_nh3");
+    else if (capability == "RF_aci") {
+      ser.resize((size_t)ns);
+      for (int iy = 0; iy < ns; ++iy)
+        ser[(size_t)iy] = -1 * aci_beta * std::log(1 + (so2[(size_t)iy] / s_SO2) +
+                                                   ((bc[(size_t)iy] + oc[(size_t)iy]) / s_BCOC));
+      scale = &params_[HXP_AERO];
+    } else if (capability == "RF_vol") {
+      ser = input("so2", "SV", 0);
+      scale = &params_[HXP_VOL];
+    } else if (capability == "RF_albedo") ser = input("simpleNbox", "RF_albedo", -0.2);
+    else if (capability == "RF_misc") ser = input("forcing", "RF_misc", 0);
+    if (!ser.empty()) relative = computed = true;
+  }
+  if (ser.empty()) return false;
+  if (!out_host) return true;
+  const int last = computed ? last_date() : scen_.end;
+  if (computed && (shared_dirty_ || need_spinup_))
+    throw std::runtime_error("fetchvars: run the core after changing inputs");
+  if (year0 < scen_.start || year1 > last || year1 < year0)
+    throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
+  const int base = kc_.baseyear_idx;
+  for (int y = year0; y <= year1; ++y) {
+    const int iy = y - scen_.start;
+    double *row = out_host + (size_t)(y - year0) * n_;
+    for (int i = 0; i < n_; ++i) {
+      const double f = scale ? (*scale)[(size_t)i] : 1.0;
+      double v = f * ser[(size_t)iy];
+      if (relative) v = (iy >= base) ? v - f * ser[(size_t)base] : 0.0;  // :507-527
+      row[i] = v;
+    }
+  }
+  return true;
+}
+
+bool EnsembleCore::host_output(const std::string &capability) {
+  return fetch_host(capability, 0, 0, nullptr);
+}
+
+// Diagnostics derived on the device from recorded outputs; the result is a lane-ordered
+// [ny][npad] block in d_diag_.
+void EnsembleCore::compute_derived(const std::string &capability, int iy0, int ny) {
+  const DerivedDef *d = derived_of(capability);
+  auto need = [&](const char *name) -> const double * {
+    const int v = out_index(name);
+    if (!d_out_[v])
+      throw std::runtime_error("variable " + capability + " needs " + name +
+                               ": enable it (or " + capability + ") with set_outputs()");
+    return d_out_[v];
+  };
+  const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
+  if (d->kind >= DK_SLR) {
+    if (!d_slr_) check(hipMalloc(&d_slr_, sizeof(double) * 4 * ns * np), "hipMalloc slr");
+    if (slr_valid_to_ != last_iy_) {
+      check(hipMemsetAsync(d_slr_, 0, sizeof(double) * 4 * ns * np, stream_), "zero slr");
+      check(hx_launch_slr(need("global_tas"), npad_, scen_.start, last_iy_, d_slr_, ns * np, stream_),
+            "slr kernel");
+      slr_valid_to_ = last_iy_;
+    }
+    check(hipMemcpyAsync(d_diag_, d_slr_ + (size_t)(d->kind - DK_SLR) * ns * np + (size_t)iy0 * np,
+                         sizeof(double) * (size_t)ny * np, hipMemcpyDeviceToDevice, stream_), "slr rows");
+    return;
+  }
+  HxDiagArgs a{};
+  a.npad = npad_; a.iy0 = iy0; a.ny = ny; a.base_idx = kc_.baseyear_idx;
+  a.shared = d_shared_;
+  a.lo_ratio = d_params_ + (size_t)HXP_LO_RATIO * np;
+  a.sqrtN0 = kc_.sqrtN0; a.sqrtM0 = kc_.sqrtM0; a.M0f = kc_.M0f;
+  a.delta_n2o = kc_.delta_n2o; a.delta_ch4 = kc_.delta_ch4;
+  const bool hl = d->box == 0;
+  // oceanbox.cpp:97-99 (deltaT), ocean_component.cpp:233-238 (box volumes)
+  a.deltaT = hl ? -16.4 : 2.9;
+  const double area = 3.6e14;
+  a.inv_vol = 1.0 / (area * (hl ? 0.15 : 1 - 0.15) * 100.0);
+  switch (d->kind) {
+    case HXG_TEMP: a.sst = need("sst"); break;
+    case HXG_DIC: a.sst = need("sst"); a.carbon = need(hl ? "HL_ocean_c" : "LL_ocean_c"); break;
+    case HXG_REVELLE: a.carbon = need(hl ? "HL_ocean_c" : "LL_ocean_c");  // fall through
+    case HXG_CO3: case HXG_OMEGA_AR: case HXG_OMEGA_CA:
+      a.sst = need("sst"); a.ph = need(hl ? "HL_pH" : "LL_pH");
+      a.pco2 = need(hl ? "HL_PCO2" : "LL_PCO2");
+      break;
+    case HXG_OCEAN_TAS: a.sst = d_out_[HXO_SST]; a.tgav = need("global_tas"); break;
+    case HXG_RF_N2O: a.co2 = need("CO2_concentration"); a.ch4 = need("CH4_concentration"); break;
+    case HXG_RF_CH4: case HXG_RF_H2O: a.ch4 = need("CH4_concentration"); break;
+    case HXG_RF_O3: a.o3 = need("O3_concentration"); break;
+    default: throw std::runtime_error("unknown diagnostic");
+  }
+  check(hx_launch_diag(d->kind, a, d_diag_, stream_), "diag kernel");
+}
+
+void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
+                             double *out_host) {
+  if (fetch_host(capability, year0, year1, out_host)) return;
+  const DerivedDef *dd = derived_of(capability);
+  const int v = dd ? -1 : out_index(capability);
+  if (!dd && !d_out_[v])
     throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");
   if (year0 < scen_.start || year1 > last_date() || year1 < year0)
     throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
@@ -835,8 +1000,21 @@ void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1
     check(hipMalloc(&d_gather_, sizeof(double) * need), "hipMalloc gather");
     gather_cap_ = need;
   }
-  check(hx_launch_gather(d_out_[v] + (size_t)iy0 * npad_, d_lane_of_member_, d_gather_, n_, npad_,
-                         ny, stream_), "gather");
+  const double *src = nullptr;
+  if (dd) {
+    const size_t dneed = (size_t)ny * (size_t)npad_;
+    if (dneed > diag_cap_) {
+      if (d_diag_) (void)hipFree(d_diag_);
+      d_diag_ = nullptr;
+      check(hipMalloc(&d_diag_, sizeof(double) * dneed), "hipMalloc diag");
+      diag_cap_ = dneed;
+    }
+    compute_derived(capability, iy0, ny);
+    src = d_diag_;
+  } else {
+    src = d_out_[v] + (size_t)iy0 * npad_;
+  }
+  check(hx_launch_gather(src, d_lane_of_member_, d_gather_, n_, npad_, ny, stream_), "gather");
   check(hipMemcpyAsync(out_host, d_gather_, sizeof(double) * need, hipMemcpyDeviceToHost, stream_),
         "fetch");
   check(hipStreamSynchronize(stream_), "fetch sync");

@@ -71,6 +71,8 @@ class EnsembleCore {
   void sync();                  // wait for the stream
   // GETDATA with dates: out[(year - year0) * n + member]
   void fetchvars(const std::string &capability, int year0, int year1, double *out_host);
+  bool host_output(const std::string &capability);
+  const std::vector<std::string> &halocarbon_names() const { return halo_names_; }
   // device pointer to the [ns][npad] array of an output variable
   const double *device_var(const std::string &capability, int *npad) const;
   // per-year ensemble statistics {count,sum,sumsq,min,max} into a DEVICE buffer
@@ -107,6 +109,7 @@ class EnsembleCore {
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
   int last_iy_ = 0;
   HxConst kc_{};
+  std::vector<std::string> halo_names_;
   std::vector<std::vector<double>> halo_conc_;  // [gas][ns] halocarbon concentrations, pptv
   std::vector<double> shared_, ker_;
   bool out_enabled_[HXO_NVAR];
@@ -121,7 +124,11 @@ class EnsembleCore {
   int hist_valid_to_ = 0;   // history slabs 1..hist_valid_to_ are valid
   int dirty_from_iy_ = -1;  // pending auto-reset target (R wrapper's reset_date)
   int *d_lane_of_member_ = nullptr;
-  size_t gather_cap_ = 0;
+  size_t gather_cap_ = 0, diag_cap_ = 0;
+  double *d_diag_ = nullptr, *d_slr_ = nullptr;
+  int slr_valid_to_ = -1;
+  bool fetch_host(const std::string &capability, int year0, int year1, double *out_host);
+  void compute_derived(const std::string &capability, int iy0, int ny);
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool run_timed_ = false;

@@ -78,6 +78,16 @@ int hx_output_capabilities(const char *const **names, int *count) {
   return 0;
 }
 int hx_set_member_sorting(hx_core *core, int on) { HX_TRY(core->core->set_member_sorting(on != 0)) }
+int hx_halocarbons(hx_core *core, const char *const **names, int *count) {
+  static thread_local std::vector<const char *> ptrs;
+  HX_TRY({
+    const auto &h = core->core->halocarbon_names();
+    ptrs.clear();
+    for (auto &n : h) ptrs.push_back(n.c_str());
+    if (names) *names = ptrs.data();
+    if (count) *count = (int)ptrs.size();
+  })
+}
 int hx_enable_history(hx_core *core, int on) { HX_TRY(core->core->enable_history(on != 0)) }
 int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
                     int n, const char *units) {

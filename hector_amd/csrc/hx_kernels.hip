@@ -317,6 +317,8 @@ struct Member {
   int npad;
   double (*pk)[64];  // LDS park
   int lane;
+  const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
+  int iy;                 // year index being integrated
 };
 #define PKM(m, slot) ((m).pk[(slot)][(m).lane])
 
@@ -561,6 +563,18 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       if (m.max_ts < 1.0) m.ts_timeout = 20;
     }
   }
+  bool diag = false;
+  size_t dgo = 0;
+  if constexpr (CON && !SPIN) {
+    diag = m.bufp->stash_diag != 0;
+    if (diag) {  // annualflux_sumHL/LL, annual_box_fluxes[HL->DO]: sums over the year's stashes
+      const HxBuffers &buf = *m.bufp;
+      dgo = (size_t)m.iy * buf.npad + (blockIdx.x * 64 + m.lane);
+      if (buf.out[HXO_HL_UPTAKE]) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
+      if (buf.out[HXO_LL_UPTAKE]) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
+      if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
+    }
+  }
   const double lastflux = aL + aH;
   m.annualflux_sum += lastflux;
   m.lastflux_ann = lastflux / yf;
@@ -587,6 +601,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     m.status |= HX_ERR_NEGPOOL;
   double nveg = y[1], ndet = y[2], nsoil = y[3];
   double rh_adj = 1.0;
+  double npp_fin_total = npp_t;  // npp_total after any NBP constraint (final_npp weights it)
   if constexpr (CON && !SPIN) {
     // NBP constraint in stashCValues :343-383: fluxes moved by +-diff/2, the pools by
     // diff * yf shared by size, the same amount taken out of the deep ocean
@@ -594,6 +609,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     if ((yc.mask & HXC_NBP) && !isnan(target)) {
       const double diff = target - alf;
       const double npp2 = npp_t + diff / 2.0;
+      npp_fin_total = npp2;
       rh_adj = (rh_t - diff / 2.0) / rh_t;
       const double rh2 = rh_t - diff / 2.0;
       const double pool_diff = diff * yf;
@@ -607,6 +623,8 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     }
   }
   m.nbp = alf;
+  double fin_npp = 0, fin_rh = 0, fin_det = 0, fin_soil = 0;
+
   const double total = y[1] + y[2] + y[3];
   m.cum_luc_va += ((m.luc_e - m.luc_u) * y[1]) / total;  // no yf: :388-393
   const double inv_nr = 1.0 / npp_rh;
@@ -616,6 +634,14 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     const double wt = (B == 1) ? 1.0
         : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
     const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
+    if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
+      const double a = m_rh_fda(m, b) * rh_adj, bb = m_rh_fsa(m, b) * rh_adj;
+      const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
+      fin_npp += npp_fin_total * wt;
+      fin_rh += ((a + bb) + cc) + dd;
+      fin_det += a;
+      fin_soil += bb;
+    }
     if constexpr (CON) m.cum_pf_ch4 += (m_rh_tp_ch4(m, lk, b) * rh_adj) * yf;
     else m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
     m.veg[b] = nveg * wt;
@@ -630,6 +656,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
                      m.cum_pf_ch4;
   if (m.masstot > 0.0 && fabs(sum - m.masstot) > 0.001) m.status |= HX_ERR_MASS;
   m.masstot = sum;
+  double ca_residual = 0.0;
   if (SPIN) {  // pin the atmosphere to C0, residual to the deep box :567-603
     const double match = m.C0 / PGC2PPM;
     const double residual = m.atmos - match;
@@ -640,8 +667,19 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {
       const double match = yc.co2 / PGC2PPM;
       const double residual = m.atmos - match;
+      ca_residual = residual;
       m.cDO = residual + m.cDO;
       m.atmos = m.atmos - residual;
+    }
+  }
+  if constexpr (CON && !SPIN) {
+    if (diag) {  // the last stash of the year is the one that stays
+      const HxBuffers &buf = *m.bufp;
+      if (buf.out[HXO_NPP]) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
+      if (buf.out[HXO_RH]) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
+      if (buf.out[HXO_RH_DET]) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
+      if (buf.out[HXO_RH_SOIL]) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
+      if (buf.out[HXO_CA_RESIDUAL]) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
     }
   }
   m.ode_start = t;
@@ -1310,6 +1348,8 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   put(HXO_HEATFLUX, 0.0); put(HXO_CH4, kc.M0f); put(HXO_O3, 0.0);
   put(HXO_EARTH_C, m.earth); put(HXO_NBP, 0.0); put(HXO_OCEAN_UPTAKE, 0.0);
   put(HXO_NSTASH, 0.0); put(HXO_NSTEPS, 0.0);
+  put(HXO_C_HL, m.cHL); put(HXO_C_LL, m.cLL); put(HXO_C_IO, m.cIO); put(HXO_C_DO, m.cDO);
+  put(HXO_F_FROZEN, 1.0); put(HXO_TAU_OH, kc.TOH0);
   if (spinup_steps) spinup_steps[mem] = steps;
 }
 
@@ -1322,8 +1362,9 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // Year-level state (Tland, SST, forcing[t-1], CH4, Q10 window...) lives in the HBM
 // state table between phases; the solver's pools stay in registers for the launch.
 // ===========================================================================
-// CON: the scenario holds constraints (HxConst::con_mask) or a member a land-ocean warming
-// ratio -- a separate instantiation so that unconstrained runs carry none of it.
+// CON: the extended kernel -- the scenario holds constraints (HxConst::con_mask), a member has
+// a land-ocean warming ratio, or diagnostics beyond HXO_SST_LO are recorded.  A separate
+// instantiation, so that plain runs carry none of it.
 template <int B, bool HF, bool KERPM, bool CON>
 __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
@@ -1350,9 +1391,11 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
+  if constexpr (CON) m.bufp = &args->buf;
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
+    if constexpr (CON) m.iy = iy;
     double ch4, o3;
     // ======================= phase A ========================================
     {
@@ -1415,6 +1458,15 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         toh = ((kc.CCH4 * (log(prev_ch4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
               sh[HXSH_OH_D];
       const double tau_oh = kc.TOH0 * exp(-toh);
+      if constexpr (CON) {
+      if (buf.out[HXO_TAU_OH]) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
+      if (buf.stash_diag) {  // sums over the year's stashes start at zero (oceanbox::new_year)
+        const size_t o = (size_t)iy * buf.npad + mem;
+        if (buf.out[HXO_HL_UPTAKE]) sto_(buf, HXO_HL_UPTAKE, o, 0.0);
+        if (buf.out[HXO_LL_UPTAKE]) sto_(buf, HXO_LL_UPTAKE, o, 0.0);
+        if (buf.out[HXO_HL_DO]) sto_(buf, HXO_HL_DO, o, 0.0);
+      }
+      }
       {
         const double emisTocon =
             ((sh[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
@@ -1560,7 +1612,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         }
       }
       // ---- DOECLIM: history before the block (hx_doeclim_pass_kernel) + in-block terms ----
-      double tl_new, sst_new, heatflux = 0, tgav;
+      double tl_new, sst_new, heatflux = 0, tgav, flux_mixed = 0, flux_interior = 0;
       {
         const int j = jb;
         // Ker is stored with HX_KPAD zeros in front: entry k lives at k + HX_KPAD
@@ -1597,6 +1649,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           const double hmix = D_cas * (sst_new - sst);
           const double hi = dHFS * (2.0 * sst_new - hint);
           heatflux = hmix + D_fso * hi;
+          flux_mixed = hmix;
+          flux_interior = hi;
         }
         s_tblk[j][lane] = sst_new;
       }
@@ -1650,6 +1704,32 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         if (buf.out[HXO_DET_C]) sto_(buf, HXO_DET_C, o, d);
         if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, s);
         if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, th);
+      }
+      if constexpr (CON) {  // diagnostics of the extended kernel
+      if (buf.out[HXO_GMST]) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
+      if (buf.out[HXO_FLUX_MIXED]) sto_(buf, HXO_FLUX_MIXED, o, flux_mixed);
+      if (buf.out[HXO_FLUX_INTERIOR]) sto_(buf, HXO_FLUX_INTERIOR, o, flux_interior);
+      if (buf.out[HXO_C_HL]) sto_(buf, HXO_C_HL, o, m.cHL);
+      if (buf.out[HXO_C_LL]) sto_(buf, HXO_C_LL, o, m.cLL);
+      if (buf.out[HXO_C_IO]) sto_(buf, HXO_C_IO, o, m.cIO);
+      if (buf.out[HXO_C_DO]) sto_(buf, HXO_C_DO, o, m.cDO);
+      if (buf.out[HXO_PCO2_HL]) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
+      if (buf.out[HXO_PCO2_LL]) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
+      if (buf.out[HXO_RH_CH4] || buf.out[HXO_F_FROZEN]) {
+        // record_state: RH_ch4 = rh_ftpa_ch4 of the year-end pools (simpleNbox.cpp:800-812);
+        // f_frozen: permafrost-weighted mean over biomes, 1 without permafrost (:492-514)
+        LandK<B> lk;
+        load_landk<B>(m, lk);
+        double rch4 = 0, ptot = 0, ff = 0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) { rch4 += m_rh_tp_ch4(m, lk, b); ptot += m.pf[b]; }
+        if (ptot > 0.0) {
+#pragma unroll
+          for (int b = 0; b < B; ++b) ff += (m.pf[b] / ptot) * PKM(m, PK_FFROZEN0 + b);
+        } else ff = 1.0;
+        if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rch4);
+        if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);
+      }
       }
       if (buf.hist) {  // Core::reset(date) needs every component's state of every year
         double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(B) * buf.npad;
@@ -1764,6 +1844,120 @@ __global__ __launch_bounds__(256) void hx_doeclim_table_kernel(const double *dif
   ker[(size_t)(i + HX_KPAD) * stride + mem] = KT0 + KTA1 + KTB1 + KTA2 + KTB2 + KTA3 + KTB3;
 }
 
+// ===========================================================================
+// Diagnostics derived from recorded outputs, one (year, member) element per thread.
+// The reference keeps them as members of the carbonate-chemistry object of the last solve
+// (ocean_csys.cpp:328-366) or recomputes them on request (ocean_component.cpp:440-512);
+// here they follow from what the run recorded:
+//   [H+] = 10^-pH and pCO2 of the last solve, the box temperature Tbox = SST(year-1) + 18 +
+//   deltaT (oceanbox.cpp:97-99, 309-323), and the year-end box carbon:
+//   CO2* = pCO2 Kh, CO3 = CO2* K1 K2 / [H+]^2  (identical to DIC / (1 + h/K2 + h^2/(K1 K2)))
+// ===========================================================================
+__device__ __forceinline__ double diag_rf(int kind, const HxDiagArgs &a, int iy, int mem) {
+  hx_ccd sh = HX_CCD(a.shared) + (size_t)iy * HXSH_STRIDE;
+  const size_t o = (size_t)iy * a.npad + mem;
+  const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
+  const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
+  const double sqN = sh[HXSH_SQRT_N2O];
+  if (kind == HXG_RF_O3) return 0.042 * a.o3[o];
+  const double ch4 = a.ch4[o], sqM = sqrt(ch4);
+  if (kind == HXG_RF_H2O) return 0.0485 * ((ch4 - a.M0f) / (1831 - a.M0f));
+  if (kind == HXG_RF_CH4) {
+    const double sarf = (a3 * sqM + b3 * sqN + d3) * (sqM - a.sqrtM0);
+    return (a.delta_ch4 * sarf) + sarf;
+  }
+  const double sqC = sqrt(a.co2[o]);
+  const double sarf = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - a.sqrtN0);
+  return (a.delta_n2o * sarf) + sarf;
+}
+
+__global__ __launch_bounds__(256) void hx_diag_kernel(int kind, HxDiagArgs a, double *out) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  const int iy = a.iy0 + blockIdx.y;
+  if (mem >= a.npad) return;
+  const size_t o = (size_t)iy * a.npad + mem;
+  double r = 0.0;
+  if (kind >= HXG_RF_N2O) {
+    // forcings are reported relative to the base year (forcing_component.cpp:507-527)
+    if (iy >= a.base_idx) r = diag_rf(kind, a, iy, mem) - diag_rf(kind, a, a.base_idx, mem);
+  } else if (kind == HXG_OCEAN_TAS) {
+    const double lo = a.lo_ratio[mem];
+    r = (lo != 0) ? a.tgav[o] / ((lo * D_flnd) + (1 - D_flnd)) : D_bsi * a.sst[o];
+  } else {
+    const double sst_prev = (iy >= 1) ? a.sst[o - a.npad] : 0.0;
+    const double Tc = sst_prev + 18 + a.deltaT;
+    // convertToDIC  ocean_csys.cpp:403-408 (umol/kg)
+    const double dic = ((((a.carbon ? a.carbon[o] : 0.0) * 1e15) * (1.0 / 12.01)) * (1.0 / 1027.0) *
+                        a.inv_vol) * 1e6;
+    if (kind == HXG_TEMP) r = Tc;
+    else if (kind == HXG_DIC) r = dic;
+    else {
+      ChemK k;
+      chem_constants(Tc, k);
+      const double h = exp10(-a.ph[o]);
+      const double co2st = a.pco2[o] * k.Kh;            // umol/kg
+      const double co3 = co2st * ((k.K1 * k.K2) / (h * h));  // umol/kg
+      if (kind == HXG_CO3) r = co3;
+      else if (kind == HXG_REVELLE) r = dic / co3;        // oceanbox.cpp:278-292
+      else {
+        const double S = O_S, Tk = Tc + 273.15, sqrtS = 5.873670062235365,
+                     S15 = 202.64161714712009;
+        double t1, t2, t3;
+        if (kind == HXG_OMEGA_CA) {  // ocean_csys.cpp:266-274
+          t1 = -171.9065 - 0.077993 * Tk + 2839.319 / Tk + 71.595 * log10(Tk);
+          t2 = +(-0.77712 + 0.0028426 * Tk + 178.34 / Tk) * sqrtS;
+          t3 = -0.07711 * S + 0.0041249 * S15;
+        } else {
+          t1 = -171.945 - 0.077993 * Tk + 2903.293 / Tk + 71.595 * log10(Tk);
+          t2 = +(-0.068393 + 0.0017276 * Tk + 88.135 / Tk) * sqrtS;
+          t3 = -0.10018 * S + 0.0059415 * S15;
+        }
+        const double Ksp = exp10(t1 + t2 + t3);
+        const double calcium = 0.02128 / 40.087 * (S / 1.80655);
+        r = (((co3 * 1e-6) * calcium) / Ksp);
+      }
+    }
+  }
+  out[(size_t)blockIdx.y * a.npad + mem] = r;
+}
+
+// slrComponent (slr_component.cpp:116-232, Vermeer & Rahmstorf 2009): sea-level rise from the
+// global tas series of each member; one thread walks one member's years.  Nothing exists
+// before the reference period 1951-1980 has been run; dT/dt is the derivative of the series as
+// known when the date was computed (h_interpolator.cpp:132-167).  out: 4 arrays [ns][npad]
+// (slr, sl_rc, slr_no_ice, sl_rc_no_ice), zero where the reference has no value.
+__global__ __launch_bounds__(64) void hx_slr_kernel(const double *tgav, int npad, int start_year,
+                                                    int iy_to, double *out, size_t var_stride) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mem >= npad) return;
+  const int lo = 1951 - start_year, hi = 1980 - start_year, first = 1;
+  if (lo < first || iy_to < hi) return;
+  auto TG = [&](int iy) { return tgav[(size_t)iy * npad + mem]; };
+  double sum = 0.0;
+  for (int i = lo; i <= hi; ++i) sum += TG(i);
+  const double ref = sum / (hi - lo + 1);
+  double slr = 0.0, slr_ni = 0.0;
+  for (int iy = first; iy <= iy_to; ++iy) {
+    const int last = (iy <= hi) ? hi : iy;  // the series' last date when this date was computed
+    double dTdt = 0.0;
+    if (last - first + 1 > 2) {
+      if (iy == first) dTdt = (TG(first + 1) - TG(first)) / 1.0;
+      else if (iy == last) dTdt = (TG(iy) - TG(iy - 1)) / 1.0;
+      else dTdt = (((TG(iy) - TG(iy - 1)) / 1.0) + ((TG(iy + 1) - TG(iy)) / 1.0)) / 2.0;
+    }
+    const double T = TG(iy) - ref;
+    const double dHdt = 0.56 * (T - (-0.41)) + (-4.9) * dTdt;
+    const double dHdt_ni = 0.08 * (T - (-0.375)) + 2.5 * dTdt;
+    slr = slr + dHdt;
+    slr_ni = slr_ni + dHdt_ni;
+    const size_t o = (size_t)iy * npad + mem;
+    out[o] = slr;
+    out[var_stride + o] = dHdt;
+    out[2 * var_stride + o] = slr_ni;
+    out[3 * var_stride + o] = dHdt_ni;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-callable launchers (the only symbols the host runtime uses)
 // ---------------------------------------------------------------------------
@@ -1826,6 +2020,16 @@ hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, dou
   return hipGetLastError();
 }
 int hx_doeclim_block_years() { return HX_DBLK; }
+hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(hx_diag_kernel, dim3((a.npad + 255) / 256, a.ny), dim3(256), 0, st, kind, a, out);
+  return hipGetLastError();
+}
+hipError_t hx_launch_slr(const double *tgav, int npad, int start_year, int iy_to, double *out,
+                         size_t var_stride, hipStream_t st) {
+  hipLaunchKernelGGL(hx_slr_kernel, dim3((npad + 63) / 64), dim3(64), 0, st, tgav, npad,
+                     start_year, iy_to, out, var_stride);
+  return hipGetLastError();
+}
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st) {
   hipLaunchKernelGGL(hx_broadcast_rows_kernel, dim3((npad + 255) / 256), dim3(256), 0, st,
                      table, nrows, npad);

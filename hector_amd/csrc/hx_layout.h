@@ -73,6 +73,12 @@ enum HxOutVar {
   HXO_NBP, HXO_OCEAN_UPTAKE, HXO_NSTASH, HXO_NSTEPS, HXO_LL_PH,
   HXO_SST_LO,       // D_SST as reported when a land-ocean warming ratio is set (HXO_SST stays
                     // DOECLIM's own history); allocated only then
+  // diagnostics the reference's output stream writes every year (csv_outputstream_visitor.cpp)
+  HXO_NPP, HXO_RH, HXO_RH_DET, HXO_RH_SOIL,    // final_* of the year's last stash
+  HXO_HL_UPTAKE, HXO_LL_UPTAKE, HXO_HL_DO,     // accumulated over the year's stashes
+  HXO_CA_RESIDUAL,
+  HXO_RH_CH4, HXO_F_FROZEN, HXO_GMST, HXO_FLUX_MIXED, HXO_FLUX_INTERIOR,
+  HXO_C_HL, HXO_C_LL, HXO_C_IO, HXO_C_DO, HXO_PCO2_HL, HXO_PCO2_LL, HXO_TAU_OH,
   HXO_NVAR
 };
 
@@ -133,7 +139,25 @@ struct HxBuffers {
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   int n, npad, ker_per_member;
+  int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
 };
+
+// ---- diagnostics derived on the device from recorded outputs (hx_diag_kernel) ----
+enum HxDiagKind {
+  HXG_TEMP = 0, HXG_DIC, HXG_CO3, HXG_OMEGA_AR, HXG_OMEGA_CA, HXG_REVELLE, HXG_OCEAN_TAS,
+  HXG_RF_N2O, HXG_RF_CH4, HXG_RF_H2O, HXG_RF_O3
+};
+
+struct HxDiagArgs {
+  const double *sst, *ph, *pco2, *carbon;  // recorded outputs [ns][npad] (null if unused)
+  const double *co2, *ch4, *o3, *tgav;
+  const double *lo_ratio;                  // parameter row (ocean_tas)
+  const double *shared;                    // per-year table
+  double deltaT, inv_vol;                  // of the box
+  double sqrtN0, sqrtM0, M0f, delta_n2o, delta_ch4;
+  int base_idx, npad, iy0, ny;
+};
+
 
 // kernel arguments live in device memory (one copy per core) and are read through
 // wave-uniform scalar loads on demand -- passing them by value would pin ~110 SGPRs

@@ -79,6 +79,10 @@ int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const 
  * component); here it is opt-in because each variable costs 8 B/member-year. */
 int hx_set_outputs(hx_core *core, int nvars, const char *const *capabilities);
 int hx_output_capabilities(const char *const **names, int *count);
+/* Names of the scenario's halocarbon components ("CF4", "HFC23" ...; one
+ * HalocarbonComponent each in the reference, src/core.cpp:120-175): "<name>_concentration",
+ * "<name>_emissions", "RF_<name>" and "<name>_constrain" are fetchvars / setvar capabilities. */
+int hx_halocarbons(hx_core *core, const char *const **names, int *count);
 
 /* Internal lane assignment: by default members are mapped to GPU lanes sorted by their
  * perturbed parameters (wavefronts then follow similar solver schedules); every result is

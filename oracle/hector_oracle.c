@@ -525,6 +525,12 @@ typedef struct {
   double A[4], IB[4], taucfl, taukls, taucfs, tauksl, taudif, powtoheat;
   double tas_land, sst_now; /* undated D_LAND_TAS, D_SST */
   double Ca_residual;
+  double hl_do;                                  /* annual_box_fluxes[HL -> DO] */
+  double final_npp, final_rh, final_rh_det, final_rh_soil;
+  double temp_surface_now, flux_mixed_now, flux_interior_now;
+  double rf_item_v[16];                          /* RF_* relative to the base year, see year_forcing */
+  double rf_base_v[16];
+  double slr[4]; int slr_have; double refperiod_tgav;
 } member_t;
 
 /* tseries::exists for a constraint held as a NaN-filled dense series */
@@ -732,6 +738,9 @@ static void doeclim_run(member_t *m, int tstep, double rf_total) {
     m->heatflux_interior[0] = 0.0;
   }
   /* setoutputs  src/temperature_component.cpp:706-746 */
+  m->temp_surface_now = flnd * m->temp_landair[tstep] + (1.0 - flnd) * m->temp_sst[tstep];
+  m->flux_mixed_now = m->heatflux_mixed[tstep];
+  m->flux_interior_now = m->heatflux_interior[tstep];
   m->tas_land = m->temp_landair[tstep];
   m->sst_now = m->temp_sst[tstep];
   /* land-ocean warming ratio override :722-739; what D_LAND_TAS / D_SST return :586-625 */
@@ -821,6 +830,7 @@ static void box_transfer(member_t *m, int from, int to, double k, double yf) {
   double closs = m->carbon[from] * k * yf; /* oceanbox.cpp:246 */
   m->additions[to] = m->additions[to] + closs;
   m->subtractions[from] = m->subtractions[from] + closs;
+  if (from == HL && to == DO) m->hl_do = m->hl_do + closs; /* annual_box_fluxes :254-255 */
 }
 
 /* oceanbox::compute_fluxes  src/oceanbox.cpp:203-260 */
@@ -945,6 +955,7 @@ static void ocean_run(member_t *m) {
   m->Tbox[LL] = m->SST + 18 + m->deltaT[LL];
   m->atmflux[HL] = 0.0;
   m->atmflux[LL] = 0.0;
+  m->hl_do = 0.0; /* new_year  oceanbox.cpp:309-313 */
   if (!m->sc->spinup_chem && !m->ocean_in_spinup && !m->active_chem) {
     m->active_chem = 1;
     box_chem_equilibrate(m, HL);
@@ -1276,8 +1287,20 @@ static void snb_stash(member_t *m, double t, const double c[]) {
   const double total = c[SNBOX_VEG] + c[SNBOX_DET] + c[SNBOX_SOIL];
   m->cum_luc_va = m->cum_luc_va +
                   ((m->cur_luc_e - m->cur_luc_u) * c[SNBOX_VEG] / total);
+  m->final_npp = m->final_rh = m->final_rh_det = m->final_rh_soil = 0.0;
   for (int b = 0; b < m->B; b++) {
     const double wt = (snb_npp(m, b) + snb_rh(m, b)) / npp_rh_total;
+    /* final_npp / final_rh* :420-440, summed over biomes as D_NPP, D_RH ... report them */
+    m->final_npp = m->final_npp + npp_total * wt;
+    {
+      const double a = snb_rh_fda(m, b) * rh_nbp_constraint_adjust;
+      const double bb = snb_rh_fsa(m, b) * rh_nbp_constraint_adjust;
+      const double cc = snb_rh_ftpa_co2(m, b) * rh_nbp_constraint_adjust;
+      const double dd = snb_rh_ftpa_ch4(m, b) * rh_nbp_constraint_adjust;
+      m->final_rh = m->final_rh + (a + bb + cc + dd);
+      m->final_rh_det = m->final_rh_det + a;
+      m->final_rh_soil = m->final_rh_soil + bb;
+    }
     const double wt_pf =
         permafrost_total > 0 ? m->permafrost_c[b] / permafrost_total : 0;
     double rh_ftpa_ch4_adj = snb_rh_ftpa_ch4(m, b) * rh_nbp_constraint_adjust;
@@ -1538,7 +1561,11 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
   const hxo_scenario *s = m->sc;
   const hxo_params *p = m->pa;
   int iy = year - s->start;
-  if (year < s->baseyear) { m->rf_tot = m->rf_co2 = 0.0; m->rf_ch4 = m->rf_n2o = 0; return; }
+  if (year < s->baseyear) {
+    m->rf_tot = m->rf_co2 = 0.0; m->rf_ch4 = m->rf_n2o = 0;
+    memset(m->rf_item_v, 0, sizeof m->rf_item_v);
+    return;
+  }
   const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
   const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
   const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
@@ -1595,6 +1622,19 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
     m->have_base = 1; m->base_tot = Ftot; m->base_co2 = fco2;
     m->base_ch4 = fch4; m->base_n2o = fn2o;
   }
+  {
+    static const char *const want[] = {"RF_H2O_strat", "RF_O3_trop", "RF_BC", "RF_OC", "RF_SO2",
+                                       "RF_NH3", "RF_aci", "RF_vol", "RF_albedo", "RF_misc"};
+    double v[16] = {0};
+    for (int i = 0; i < nf; i++) {
+      int hit = -1;
+      for (int k = 0; k < 10; k++) if (!strcmp(f[i].name, want[k])) hit = k;
+      if (hit >= 0) v[hit] = f[i].v;
+    }
+    for (int h = 0; h < s->nhalo; h++) v[10] += m->halo_rf[h];
+    if (year == s->baseyear) memcpy(m->rf_base_v, v, sizeof v);
+    for (int k = 0; k < 11; k++) m->rf_item_v[k] = v[k] - m->rf_base_v[k];
+  }
   m->rf_tot = Ftot - m->base_tot;
   m->rf_co2 = fco2 - m->base_co2;
   m->rf_ch4 = fch4 - m->base_ch4;
@@ -1627,6 +1667,33 @@ static void record_outputs(member_t *m, int iy, double *out) {
   O(HXO_NRHS) = (double)m->nrhs_year;
   O(HXO_OCEAN_UPTAKE) = m->annualflux_sum;
   O(HXO_NBP) = m->nbp;
+  O(HXO_NPP) = m->final_npp; O(HXO_RH) = m->final_rh;
+  O(HXO_RH_DET) = m->final_rh_det; O(HXO_RH_SOIL) = m->final_rh_soil;
+  O(HXO_RH_CH4) = m->RH_ch4_sum;
+  {
+    /* f_frozen_weighted_mean  simpleNbox.cpp:492-514 */
+    const double ptot = sum_b(m->permafrost_c, m->B);
+    double ff = 0.0;
+    if (ptot > 0.0) for (int b = 0; b < m->B; b++) ff += (m->permafrost_c[b] / ptot) * m->f_frozen[b];
+    else ff = 1.0;
+    O(HXO_F_FROZEN) = ff;
+  }
+  O(HXO_CA_RESIDUAL) = m->Ca_residual;
+  O(HXO_HL_UPTAKE) = m->annualflux_sumHL; O(HXO_LL_UPTAKE) = m->annualflux_sumLL;
+  O(HXO_C_HL) = m->carbon[HL]; O(HXO_C_LL) = m->carbon[LL];
+  O(HXO_C_IO) = m->carbon[IO]; O(HXO_C_DO) = m->carbon[DO];
+  O(HXO_DIC_HL) = csys_dic_umol(&m->chem[HL], m->carbon[HL]);
+  O(HXO_DIC_LL) = csys_dic_umol(&m->chem[LL], m->carbon[LL]);
+  O(HXO_HL_DO) = m->hl_do;
+  O(HXO_OMEGAAR_HL) = m->chem[HL].OmegaAr; O(HXO_OMEGAAR_LL) = m->chem[LL].OmegaAr;
+  O(HXO_OMEGACA_HL) = m->chem[HL].OmegaCa; O(HXO_OMEGACA_LL) = m->chem[LL].OmegaCa;
+  O(HXO_TEMP_HL) = m->Tbox[HL]; O(HXO_TEMP_LL) = m->Tbox[LL];
+  O(HXO_CO3_HL) = m->chem[HL].CO3; O(HXO_CO3_LL) = m->chem[LL].CO3;
+  if (m->active_chem) { /* calc_revelle  oceanbox.cpp:278-292 */
+    O(HXO_REVELLE_HL) = csys_dic_umol(&m->chem[HL], m->carbon[HL]) / m->chem[HL].CO3;
+    O(HXO_REVELLE_LL) = csys_dic_umol(&m->chem[LL], m->carbon[LL]) / m->chem[LL].CO3;
+  }
+  O(HXO_TAU_OH) = m->tau_oh;
 #undef O
 }
 
@@ -1707,6 +1774,54 @@ static int member_spinup(member_t *m) {
   return step;
 }
 
+/* slrComponent::run + compute_slr  src/slr_component.cpp:116-232 (Vermeer & Rahmstorf 2009).
+ * tgav is recorded from startDate+1; nothing is computed before the end of the reference
+ * period (1980); dT/dt is the interpolator's derivative of the series AS KNOWN WHEN the date
+ * is computed (h_interpolator.cpp:132-167): slope of the only adjacent segment at either end
+ * of the series, the mean of the two adjacent slopes inside it. */
+static void slr_compute(member_t *m, int date, int lastdate, double *out) {
+  const hxo_scenario *s = m->sc;
+  const int ns = m->ns, first = s->start + 1;
+  const double *tg = m->temp;
+#define TG(Y) tg[(Y) - s->start]
+  const double T = TG(date) - m->refperiod_tgav;
+  double dTdt = 0.0;
+  if (lastdate - first + 1 > 2) {
+    if (date == first) dTdt = (TG(first + 1) - TG(first)) / 1.0;
+    else if (date == lastdate) dTdt = (TG(date) - TG(date - 1)) / 1.0;
+    else {
+      double slopePrev = (TG(date) - TG(date - 1)) / 1.0;
+      double slopeNext = (TG(date + 1) - TG(date)) / 1.0;
+      dTdt = (slopePrev + slopeNext) / 2.0;
+    }
+  }
+#undef TG
+  const int iy = date - s->start;
+  const double a = 0.56, b = -4.9, T0 = -0.41;
+  const double dHdt = a * (T - T0) + b * dTdt;
+  out[HXO_SL_RC * ns + iy] = dHdt;
+  double to_date = (date - 1 >= first) ? out[HXO_SLR * ns + iy - 1] : 0.0;
+  out[HXO_SLR * ns + iy] = to_date + dHdt;
+  const double a_ni = 0.08, b_ni = 2.5, T0_ni = -0.375;
+  const double dHdt_ni = a_ni * (T - T0_ni) + b_ni * dTdt;
+  out[HXO_SL_RC_NO_ICE * ns + iy] = dHdt_ni;
+  double to_date_ni = (date - 1 >= first) ? out[HXO_SLR_NO_ICE * ns + iy - 1] : 0.0;
+  out[HXO_SLR_NO_ICE * ns + iy] = to_date_ni + dHdt_ni;
+}
+
+static void slr_run(member_t *m, int year, double *out) {
+  const hxo_scenario *s = m->sc;
+  const int lo = 1951, hi = 1980;
+  if (s->start + 1 > lo) return; /* the reference needs tgav over the reference period */
+  if (year == hi) {
+    double sum = 0.0;
+    for (int i = lo; i <= hi; i++) sum += m->temp[i - s->start];
+    m->refperiod_tgav = sum / (hi - lo + 1);
+    for (int i = s->start + 1; i <= hi; i++) slr_compute(m, i, hi, out);
+  }
+  if (year > hi) slr_compute(m, year, year, out);
+}
+
 /* Core::run core.cpp:483-504, component order SURVEY 3c */
 static void member_main(member_t *m, int run_to, double *out) {
   const hxo_scenario *s = m->sc;
@@ -1746,6 +1861,13 @@ static void member_main(member_t *m, int run_to, double *out) {
     out[HXO_CH4 * ns + iy] = m->ch4;
     out[HXO_N2O * ns + iy] = m->n2o;
     out[HXO_O3 * ns + iy] = m->o3;
+    out[HXO_GMST * ns + iy] = m->temp_surface_now;
+    out[HXO_FLUX_MIXED * ns + iy] = m->flux_mixed_now;
+    out[HXO_FLUX_INTERIOR * ns + iy] = m->flux_interior_now;
+    out[HXO_OCEAN_TAS * ns + iy] =
+        (m->pa->lo_warming_ratio != 0) ? m->sst_now * d_bsi : d_bsi * m->temp_sst[iy];
+    for (int k = 0; k < 11; k++) out[(HXO_RF_H2O + k) * ns + iy] = m->rf_item_v[k];
+    slr_run(m, year, out);
   }
 }
 

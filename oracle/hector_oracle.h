@@ -66,6 +66,17 @@ enum {
   HXO_NBP,
   HXO_RF_CH4,
   HXO_RF_N2O,
+  /* diagnostics (csv_outputstream_visitor.cpp writes all of these every year) */
+  HXO_NPP, HXO_RH, HXO_RH_DET, HXO_RH_SOIL, HXO_RH_CH4, HXO_F_FROZEN, HXO_CA_RESIDUAL,
+  HXO_GMST, HXO_FLUX_MIXED, HXO_FLUX_INTERIOR, HXO_OCEAN_TAS,
+  HXO_HL_UPTAKE, HXO_LL_UPTAKE, HXO_C_HL, HXO_C_LL, HXO_C_IO, HXO_C_DO,
+  HXO_DIC_HL, HXO_DIC_LL, HXO_HL_DO,
+  HXO_OMEGAAR_HL, HXO_OMEGAAR_LL, HXO_OMEGACA_HL, HXO_OMEGACA_LL,
+  HXO_TEMP_HL, HXO_TEMP_LL, HXO_CO3_HL, HXO_CO3_LL, HXO_REVELLE_HL, HXO_REVELLE_LL,
+  HXO_TAU_OH,
+  HXO_RF_H2O, HXO_RF_O3, HXO_RF_BC, HXO_RF_OC, HXO_RF_SO2, HXO_RF_NH3, HXO_RF_ACI,
+  HXO_RF_VOL, HXO_RF_ALBEDO, HXO_RF_MISC, HXO_RF_HALO, /* sum of the halocarbon forcings */
+  HXO_SLR, HXO_SL_RC, HXO_SLR_NO_ICE, HXO_SL_RC_NO_ICE,
   HXO_NVAR
 };
 

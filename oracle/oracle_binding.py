@@ -18,7 +18,16 @@ VARS = ["CO2_concentration", "global_tas", "RF_tot", "RF_CO2", "heatflux", "ocea
         "atmos_co2", "sst", "permafrost_c", "land_tas", "CH4_concentration", "N2O_concentration",
         "O3_concentration", "veg_c", "detritus_c", "soil_c", "thawedp_c", "earth_c", "timesteps",
         "max_timestep", "solver_dt", "solver_steps", "rhs_evals", "LL_pH", "HL_PCO2", "LL_PCO2",
-        "ocean_uptake", "NBP", "RF_CH4", "RF_N2O"]
+        "ocean_uptake", "NBP", "RF_CH4", "RF_N2O",
+        "NPP", "RH", "rh_det", "rh_soil", "rh_ch4", "f_frozen", "atmos_c_residual",
+        "gmst", "heatflux_mixed", "heatflux_interior", "ocean_tas",
+        "HL_ocean_uptake", "LL_ocean_uptake", "HL_ocean_c", "LL_ocean_c", "IO_ocean_c",
+        "DO_ocean_c", "HL_DIC", "LL_DIC", "HL_downwelling",
+        "HL_OmegaAr", "LL_OmegaAr", "HL_OmegaCa", "LL_OmegaCa",
+        "HL_sst", "LL_sst", "HL_CO3", "LL_CO3", "HL_Revelle", "LL_Revelle", "TAU_OH",
+        "RF_H2O_strat", "RF_O3_trop", "RF_BC", "RF_OC", "RF_SO2", "RF_NH3", "RF_aci",
+        "RF_vol", "RF_albedo", "RF_misc", "RF_halocarbons",
+        "slr", "sl_rc", "slr_no_ice", "sl_rc_no_ice"]
 
 
 class Params(ctypes.Structure):

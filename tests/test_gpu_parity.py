@@ -385,3 +385,14 @@ def test_constrained_ensemble_vs_oracle_on_gpu(hip_lib, tmp_path):
         assert err == 0
         assert (np.abs(g[:, i] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < REL_CO2
         assert np.abs(t[:, i] - r["global_tas"]).max() < ABS_T
+
+
+def test_all_output_stream_variables_on_gpu(hip_lib, oracle):
+    """Every variable of the reference's output stream (kernel-recorded, device-derived, host)
+    for 12 members with perturbed ECS, Q10, aerosol and volcanic scaling, vs the oracle."""
+    from test_diagnostics import check_all_diagnostics
+    n = 12
+    S, q10 = ensemble.ecs_q10(n, offset=300)
+    c = check_all_diagnostics(hip_lib, oracle, S, q10, np.linspace(0.5, 1.5, n),
+                              np.linspace(1.3, 0.7, n), device=0)
+    assert c.backend == "hip"
