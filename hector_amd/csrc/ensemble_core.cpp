@@ -926,6 +926,8 @@ bool EnsembleCore::fetch_host(const std::string &capability, int year0, int year
   return true;
 }
 
+std::string EnsembleCore::run_name() const { return scen_.text("core", "run_name", ""); }
+
 bool EnsembleCore::host_output(const std::string &capability) {
   return fetch_host(capability, 0, 0, nullptr);
 }

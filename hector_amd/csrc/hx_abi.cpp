@@ -88,6 +88,10 @@ int hx_halocarbons(hx_core *core, const char *const **names, int *count) {
     if (count) *count = (int)ptrs.size();
   })
 }
+int hx_run_name(hx_core *core, const char **name) {
+  static thread_local std::string rn;
+  HX_TRY({ rn = core->core->run_name(); if (name) *name = rn.c_str(); })
+}
 int hx_enable_history(hx_core *core, int on) { HX_TRY(core->core->enable_history(on != 0)) }
 int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
                     int n, const char *units) {

@@ -1,0 +1,236 @@
+// hx_main.cpp -- command-line front end: `hector-amd <ini>` runs a scenario and writes
+// output/outputstream_<run_name>.csv in the reference's long format, like the reference's
+// wrapper (src/main.cpp:36-128 + CSVOutputStreamVisitor, src/csv_outputstream_visitor.cpp):
+//
+//   # Output from hector-amd ... on <date>
+//   year,run_name,spinup,component,variable,value,units
+//
+// One row per (year, variable).  Differences from the reference, by design of the ensemble
+// path: only post-spinup years are written (spinup = 0; the reference also streams its ~500
+// spinup steps); with --members N > 1 the run_name column is "<run_name>.<member>"; values are
+// printed with 6 significant digits like the reference (forcings with 4,
+// csv_outputstream_visitor.cpp:129) unless --precision is given.
+// Talks to libhector_amd.so through the C ABI only.
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hector_amd.h"
+
+namespace {
+
+struct VarDef { const char *component, *variable, *units; bool forcing; };
+
+// variable -> (component, units) as the visitor prints them (csv_outputstream_visitor.cpp:
+// 126-365; unit names src/unitval.cpp:30-165)
+const VarDef kVars[] = {
+    {"simpleNbox", "NBP", "Pg C/yr", false}, {"simpleNbox", "NPP", "Pg C/yr", false},
+    {"simpleNbox", "RH", "Pg C/yr", false}, {"simpleNbox", "rh_det", "Pg C/yr", false},
+    {"simpleNbox", "rh_soil", "Pg C/yr", false}, {"simpleNbox", "rh_ch4", "Pg C/yr", false},
+    {"simpleNbox", "CO2_concentration", "ppmv CO2", false},
+    {"simpleNbox", "atmos_co2", "Pg C", false}, {"simpleNbox", "atmos_c_residual", "Pg C", false},
+    {"simpleNbox", "veg_c", "Pg C", false}, {"simpleNbox", "detritus_c", "Pg C", false},
+    {"simpleNbox", "soil_c", "Pg C", false}, {"simpleNbox", "permafrost_c", "Pg C", false},
+    {"simpleNbox", "thawedp_c", "Pg C", false}, {"simpleNbox", "f_frozen", "(unitless)", false},
+    {"simpleNbox", "earth_c", "Pg C", false},
+    {"temperature", "global_tas", "degC", false}, {"temperature", "gmst", "degC", false},
+    {"temperature", "heatflux_mixed", "W/m2", false},
+    {"temperature", "heatflux_interior", "W/m2", false},
+    {"temperature", "heatflux", "W/m2", false}, {"temperature", "land_tas", "degC", false},
+    {"temperature", "sst", "degC", false},
+    {"ocean", "HL_ocean_uptake", "Pg C/yr", false}, {"ocean", "LL_ocean_uptake", "Pg C/yr", false},
+    {"ocean", "DO_ocean_c", "Pg C", false}, {"ocean", "HL_ocean_c", "Pg C", false},
+    {"ocean", "IO_ocean_c", "Pg C", false}, {"ocean", "LL_ocean_c", "Pg C", false},
+    {"ocean", "HL_DIC", "umol/kg", false}, {"ocean", "LL_DIC", "umol/kg", false},
+    {"ocean", "HL_downwelling", "Pg C/yr", false}, {"ocean", "ocean_uptake", "Pg C/yr", false},
+    {"ocean", "HL_OmegaAr", "(unitless)", false}, {"ocean", "LL_OmegaAr", "(unitless)", false},
+    {"ocean", "HL_OmegaCa", "(unitless)", false}, {"ocean", "LL_OmegaCa", "(unitless)", false},
+    {"ocean", "HL_PCO2", "uatm", false}, {"ocean", "LL_PCO2", "uatm", false},
+    {"ocean", "HL_pH", "pH", false}, {"ocean", "LL_pH", "pH", false},
+    {"ocean", "HL_sst", "degC", false}, {"ocean", "LL_sst", "degC", false},
+    {"ocean", "ocean_c", "Pg C", false}, {"ocean", "HL_CO3", "umol/kg", false},
+    {"ocean", "LL_CO3", "umol/kg", false}, {"ocean", "HL_Revelle", "(unitless)", false},
+    {"ocean", "LL_Revelle", "(unitless)", false},
+    {"ozone", "O3_concentration", "DU O3", false}, {"OH", "TAU_OH", "Years", false},
+    {"CH4", "CH4_concentration", "ppbv CH4", false}, {"N2O", "N2O_concentration", "ppbv N2O", false},
+};
+const char *const kForcings[] = {"RF_BC", "RF_CH4", "RF_CO2", "RF_H2O_strat", "RF_N2O", "RF_NH3",
+                                 "RF_O3_trop", "RF_OC", "RF_SO2", "RF_aci", "RF_albedo",
+                                 "RF_misc", "RF_tot", "RF_vol"};
+const char *const kSlr[] = {"sl_rc", "slr", "sl_rc_no_ice", "slr_no_ice"};
+
+void die(const std::string &msg, int code) {
+  std::fprintf(stderr, "* Program exception:\n%s\n", msg.c_str());
+  std::exit(code);
+}
+void ck(int rc) { if (rc) die(hx_last_error(), 1); }
+
+std::vector<double> parse_values(const std::string &txt) {
+  std::vector<double> v;
+  size_t p = 0;
+  while (p <= txt.size()) {
+    size_t q = txt.find(',', p);
+    if (q == std::string::npos) q = txt.size();
+    v.push_back(std::strtod(txt.substr(p, q - p).c_str(), nullptr));
+    p = q + 1;
+  }
+  return v;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::string scenario, outdir = "output/";
+  int members = 1, device = 0, precision = 0, runto = -1;
+  std::vector<std::pair<std::string, std::string>> params;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&]() -> std::string {
+      if (i + 1 >= argc) die("missing value after " + a, 1);
+      return argv[++i];
+    };
+    if (a == "--members") members = std::atoi(next().c_str());
+    else if (a == "--device") device = std::atoi(next().c_str());
+    else if (a == "--output-dir") { outdir = next(); if (outdir.back() != '/') outdir += '/'; }
+    else if (a == "--precision") precision = std::atoi(next().c_str());
+    else if (a == "--run-to") runto = std::atoi(next().c_str());
+    else if (a == "--set") {  // --set S=2.5,3.0,4.1   one value, or one per member
+      const std::string kv = next();
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos) die("--set needs capability=value[,value...]", 1);
+      params.emplace_back(kv.substr(0, eq), kv.substr(eq + 1));
+    } else if (a == "-h" || a == "--help") {
+      std::printf("Usage: hector-amd <config file name> [--members N] [--set cap=v[,v...]]...\n"
+                  "       [--run-to year] [--output-dir dir] [--precision digits] [--device i]\n");
+      return 0;
+    } else if (scenario.empty()) scenario = a;
+    else die("unexpected argument " + a, 1);
+  }
+  // src/main.cpp:47-60
+  if (scenario.empty()) die("Usage: <program> <config file name>", 1);
+  if (FILE *f = std::fopen(scenario.c_str(), "r")) std::fclose(f);
+  else die("Couldn't find input file " + scenario, 1);
+
+  hx_core *core = nullptr;
+  ck(hx_newcore(scenario.c_str(), members, device, &core));
+  for (auto &kv : params) {
+    const std::vector<double> v = parse_values(kv.second);
+    if ((int)v.size() != 1 && (int)v.size() != members)
+      die("--set " + kv.first + ": need 1 or " + std::to_string(members) + " values", 1);
+    ck(hx_setvar(core, kv.first.c_str(), v.data(), (int)v.size(), nullptr));
+  }
+  int start = 0, end = 0, cur = 0;
+  ck(hx_dates(core, &start, &end, &cur));
+  if (runto < 0 || runto > end) runto = end;
+
+  const char *const *halo = nullptr;
+  int nhalo = 0;
+  ck(hx_halocarbons(core, &halo, &nhalo));
+  std::vector<std::string> halo_names(halo, halo + nhalo);
+
+  // everything the stream prints
+  std::vector<std::string> wanted;
+  for (const VarDef &v : kVars) wanted.push_back(v.variable);
+  for (const char *f : kForcings) wanted.push_back(f);
+  for (const char *s : kSlr) wanted.push_back(s);
+  {
+    std::vector<const char *> ptr;
+    for (auto &w : wanted) ptr.push_back(w.c_str());
+    ck(hx_set_outputs(core, (int)ptr.size(), ptr.data()));
+  }
+  ck(hx_run(core, (double)runto));
+  ck(hx_sync(core));
+
+  std::vector<unsigned> status((size_t)members);
+  ck(hx_status(core, status.data()));
+  for (int i = 0; i < members; ++i)
+    if (status[(size_t)i])
+      std::fprintf(stderr, "member %d: model error flags 0x%x (see HX_ERR_* in hector_amd.h)\n", i,
+                   status[(size_t)i]);
+
+  // fetch: variable -> [year][member]
+  const int y0 = start + 1, ny = runto - y0 + 1;
+  std::map<std::string, std::vector<double>> data;
+  auto fetch = [&](const std::string &name) {
+    std::vector<double> &d = data[name];
+    d.resize((size_t)ny * members);
+    ck(hx_fetchvars(core, name.c_str(), y0, runto, d.data()));
+  };
+  for (auto &w : wanted) fetch(w);
+  for (auto &h : halo_names) { fetch(h + "_concentration"); fetch("RF_" + h); }
+
+  const char *rn_c = nullptr;
+  ck(hx_run_name(core, &rn_c));
+  const std::string rn = rn_c ? rn_c : "";
+  mkdir(outdir.c_str(), 0777);  // ensure_dir_exists(OUTPUT_DIRECTORY)
+  const std::string path = outdir + (rn.empty() ? "outputstream.csv" : "outputstream_" + rn + ".csv");
+  FILE *out = std::fopen(path.c_str(), "w");
+  if (!out) die("cannot write " + path, 1);
+  {
+    std::time_t t = std::time(nullptr);
+    std::string when = std::ctime(&t);
+    while (!when.empty() && when.back() == '\n') when.pop_back();
+    std::fprintf(out, "# Output from hector-amd (%s) version 3.5.0-compatible on %s\n", hx_backend(),
+                 when.c_str());
+    std::fprintf(out, "year,run_name,spinup,component,variable,value,units\n");
+  }
+  int base = 1750;
+  {
+    // forcing rows start at the base year (csv_outputstream_visitor.cpp:131-132)
+    double b = 0;
+    if (hx_getvar(core, "baseyear", &b) == 0 && b > 0) base = (int)b;
+  }
+  const int slr_from = 1990;  // max(refperiod_high, normalize_year), :300-318
+  auto row = [&](int year, const std::string &run, const char *comp, const std::string &var,
+                 double v, const char *units, int prec) {
+    std::fprintf(out, "%d,%s,0,%s,%s,%.*g,%s\n", year, run.c_str(), comp, var.c_str(), prec, v, units);
+  };
+  const int p_def = precision > 0 ? precision : 6, p_rf = precision > 0 ? precision : 4;
+  for (int mbr = 0; mbr < members; ++mbr) {
+    const std::string run = members > 1 ? rn + "." + std::to_string(mbr) : rn;
+    for (int y = y0; y <= runto; ++y) {
+      const size_t o = (size_t)(y - y0) * members + mbr;
+      if (y >= base) {
+        std::map<std::string, double> rf;  // the reference's map order
+        for (const char *f : kForcings) rf[f] = data[f][o];
+        for (auto &h : halo_names) rf["RF_" + h] = data["RF_" + h][o];
+        for (auto &kv : rf) row(y, run, "forcing", kv.first, kv.second, "W/m2", p_rf);
+      }
+      const char *last_comp = "";
+      for (const VarDef &v : kVars) {
+        if (!std::strcmp(v.component, "temperature") && std::strcmp(last_comp, "temperature"))
+          for (auto &h : halo_names)  // halocarbon components come before temperature
+            row(y, run, (h + "_halocarbon").c_str(), h + "_concentration",
+                data[h + "_concentration"][o], "pptv", p_def);
+        if (!std::strcmp(v.component, "ozone") && std::strcmp(last_comp, "ozone") && ny > 0) {
+          // slrComponent: nothing until 1990, then the back years in one go (:300-318)
+          if (y == slr_from)
+            for (int yy = y0; yy < y; ++yy) {
+              row(yy, run, "slr", "slr", data["slr"][(size_t)(yy - y0) * members + mbr], "cm", p_def);
+              row(yy, run, "slr", "slr_no_ice",
+                  data["slr_no_ice"][(size_t)(yy - y0) * members + mbr], "cm", p_def);
+            }
+          if (y >= slr_from) {
+            row(y, run, "slr", "sl_rc", data["sl_rc"][o], "cm/yr", p_def);
+            row(y, run, "slr", "slr", data["slr"][o], "cm", p_def);
+            row(y, run, "slr", "sl_rc_no_ice", data["sl_rc_no_ice"][o], "cm/yr", p_def);
+            row(y, run, "slr", "slr_no_ice", data["slr_no_ice"][o], "cm", p_def);
+          }
+        }
+        row(y, run, v.component, v.variable, data[v.variable][o], v.units, p_def);
+        last_comp = v.component;
+      }
+    }
+  }
+  std::fclose(out);
+  std::printf("wrote %s (%d member%s, %d-%d)\n", path.c_str(), members, members > 1 ? "s" : "", y0,
+              runto);
+  ck(hx_shutdown(core));
+  return 0;
+}

@@ -112,6 +112,11 @@ double Scenario::scalar(const std::string &section, const std::string &key, doub
   auto it = scalars_.find(section + "." + key);
   return it == scalars_.end() ? dflt : to_double(it->second, section + "." + key);
 }
+std::string Scenario::text(const std::string &section, const std::string &key,
+                           const std::string &dflt) const {
+  auto it = scalars_.find(section + "." + key);
+  return it == scalars_.end() ? dflt : it->second;
+}
 bool Scenario::has_scalar(const std::string &section, const std::string &key) const {
   return scalars_.count(section + "." + key) != 0;
 }

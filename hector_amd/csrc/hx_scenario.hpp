@@ -27,6 +27,8 @@ class Scenario {
   double scalar(const std::string &section, const std::string &key) const;
   double scalar(const std::string &section, const std::string &key, double dflt) const;
   bool has_scalar(const std::string &section, const std::string &key) const;
+  std::string text(const std::string &section, const std::string &key,
+                   const std::string &dflt) const;  // a non-numeric INI value (run_name)
   const std::vector<double> &series(const std::string &section,
                                     const std::string &key) const;
   bool has_series(const std::string &section, const std::string &key) const;

@@ -126,6 +126,8 @@ int hx_spinup_steps(hx_core *core, int member, int *steps);
  * carbon, max timestep: src/ocean_component.cpp:422-512). */
 int hx_state_row(hx_core *core, int row, double *out);
 
+/* Core::getRun_name (src/core.cpp:215-220): the INI's [core] run_name, "" if none */
+int hx_run_name(hx_core *core, const char **name);
 /* core metadata: startDate, endDate, current date, members, biomes */
 int hx_dates(hx_core *core, int *start, int *end, int *current);
 int hx_sizes(hx_core *core, int *n_members, int *n_biomes);

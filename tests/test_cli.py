@@ -1,0 +1,79 @@
+"""The command-line front end (hector_amd/csrc/hx_main.cpp; reference: src/main.cpp +
+src/csv_outputstream_visitor.cpp): runs a scenario file and writes outputstream_<run>.csv
+in the reference's long format.  Here the test-only emulation build of the same source;
+test_gpu_parity.py runs the product binary."""
+import csv
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENARIO
+
+EMUL_CLI = os.path.join(ROOT, "tests", "emul", "hector-amd-emul")
+GOLDEN_TO_STREAM = {"CO2_concentration": "CO2_concentration", "global_tas": "global_tas",
+                    "RF_tot": "RF_tot", "RF_CO2": "RF_CO2", "heatflux": "heatflux",
+                    "ocean_c": "ocean_c", "HL_pH": "HL_pH", "atmos_co2": "atmos_co2",
+                    "sst": "sst", "permafrost_c": "permafrost_c"}
+
+
+def read_stream(path):
+    with open(path) as f:
+        first = f.readline()
+        assert first.startswith("# Output from")
+        rows = list(csv.DictReader(f))
+    assert list(rows[0].keys()) == ["year", "run_name", "spinup", "component", "variable", "value",
+                                    "units"]
+    return rows
+
+
+def check_stream_against_golden(rows, golden, run_name):
+    by = {}
+    for r in rows:
+        assert r["spinup"] == "0"
+        if r["run_name"] == run_name:
+            by.setdefault(r["variable"], {})[int(r["year"])] = float(r["value"])
+    for gv, sv in GOLDEN_TO_STREAM.items():
+        ref = golden[gv]
+        sig = 4 if sv.startswith("RF_") else 6          # digits the reference's stream prints
+        first = 1750 if sv.startswith("RF_") else 1746  # forcings start at the base year
+        for y in range(first, 2301, 7):
+            want = float("%.*g" % (sig, ref[y - 1745]))
+            assert by[sv][y] == pytest.approx(want, rel=2e-6 if sig == 6 else 2e-4, abs=1e-12), (sv, y)
+    return by
+
+
+def test_cli_writes_the_reference_output_stream(emul_lib, golden, tmp_path):
+    assert os.path.exists(EMUL_CLI)
+    r = subprocess.run([EMUL_CLI, SCENARIO, "--output-dir", str(tmp_path)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr
+    rows = read_stream(tmp_path / "outputstream_ssp245.csv")
+    by = check_stream_against_golden(rows, golden, "ssp245")
+    comps = {(r["component"], r["variable"], r["units"]) for r in rows}
+    for want in [("simpleNbox", "NBP", "Pg C/yr"), ("ocean", "HL_Revelle", "(unitless)"),
+                 ("temperature", "gmst", "degC"), ("forcing", "RF_CF4", "W/m2"),
+                 ("CF4_halocarbon", "CF4_concentration", "pptv"), ("slr", "slr", "cm"),
+                 ("OH", "TAU_OH", "Years"), ("ozone", "O3_concentration", "DU O3"),
+                 ("N2O", "N2O_concentration", "ppbv N2O")]:
+        assert want in comps, want
+    assert min(by["RF_tot"]) == 1750 and min(by["slr"]) == 1746 and min(by["sl_rc"]) == 1990
+
+
+def test_cli_ensemble_members_and_errors(emul_lib, golden, tmp_path):
+    r = subprocess.run([EMUL_CLI, SCENARIO, "--members", "3", "--set", "S=2.0,3.0,4.5",
+                        "--run-to", "2100", "--output-dir", str(tmp_path), "--precision", "15"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = read_stream(tmp_path / "outputstream_ssp245.csv")
+    assert {r["run_name"] for r in rows} == {"ssp245.0", "ssp245.1", "ssp245.2"}
+    t = {r["run_name"]: float(r["value"]) for r in rows
+         if r["variable"] == "global_tas" and r["year"] == "2100"}
+    assert t["ssp245.0"] < t["ssp245.1"] < t["ssp245.2"]
+    assert abs(t["ssp245.1"] - golden["global_tas"][2100 - 1745]) < 2e-8   # S = 3 is the default
+    # src/main.cpp:47-60: missing file / no argument -> message and exit code 1
+    r = subprocess.run([EMUL_CLI, str(tmp_path / "nope.ini")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Couldn't find input file" in r.stderr
+    r = subprocess.run([EMUL_CLI], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr

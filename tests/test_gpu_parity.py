@@ -396,3 +396,18 @@ def test_all_output_stream_variables_on_gpu(hip_lib, oracle):
     c = check_all_diagnostics(hip_lib, oracle, S, q10, np.linspace(0.5, 1.5, n),
                               np.linspace(1.3, 0.7, n), device=0)
     assert c.backend == "hip"
+
+
+def test_cli_on_gpu(hip_lib, golden, tmp_path):
+    """hector_amd/bin/hector-amd (the reference's `hector <ini>`): output stream vs the golden
+    trajectory of the reference."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from test_cli import read_stream, check_stream_against_golden
+    cli = os.path.join(ROOT, "hector_amd", "bin", "hector-amd")
+    r = subprocess.run([cli, SCENARIO, "--output-dir", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = read_stream(tmp_path / "outputstream_ssp245.csv")
+    assert "(hip)" in open(tmp_path / "outputstream_ssp245.csv").readline()
+    check_stream_against_golden(rows, golden, "ssp245")
