@@ -411,3 +411,10 @@ def test_cli_on_gpu(hip_lib, golden, tmp_path):
     rows = read_stream(tmp_path / "outputstream_ssp245.csv")
     assert "(hip)" in open(tmp_path / "outputstream_ssp245.csv").readline()
     check_stream_against_golden(rows, golden, "ssp245")
+
+
+def test_reference_science_checks_on_gpu(hip_lib):
+    """test_ocean.R, test_atmosphere.R, test_parameters.R, picontrol: restated (see
+    test_reference_properties.py), on the HIP library."""
+    from test_reference_properties import science_checks
+    science_checks(hip_lib, device=0)
