@@ -287,8 +287,29 @@ enum HxPark {
 // single-biome kernels also park the biome constants (11 more slots)
 enum HxParkB1 { PKB_NPP0 = 0, PKB_F_NPPV, PKB_F_NPPD, PKB_F_LITTERD, PKB_RH_CH4_FRAC,
                 PKB_FPF_STATIC, PKB_BETA, PKB_WF, PKB_LNQ10, PKB_MU, PKB_SIGMA, PKB_N };
-template <int B> constexpr int hx_npark() { return PK_FFROZEN0 + B + (B == 1 ? PKB_N : 0); }
+// multi-biome kernels park the nine per-biome arrays of Member instead (see BiomeArr)
+constexpr int HX_NBIOME_ARR = 9;
+template <int B> constexpr int hx_npark() {
+  return PK_FFROZEN0 + B + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * B);
+}
 template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + B; }
+
+// Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
+// registers, 36 doubles for B = 4 on top of the solver's working set overflow 256 VGPRs +
+// 256 AGPRs and ~100 VGPRs spill to scratch, each reload an exposed memory stall; the solver
+// steps themselves only touch the interval constants, not these arrays.
+struct ParkArr {
+  double (*base)[64];
+  int lane;
+  __device__ __forceinline__ double &operator[](int b) const { return base[b][lane]; }
+};
+struct RegArr1 {
+  double v[1];
+  __device__ __forceinline__ double &operator[](int b) { return v[b]; }
+  __device__ __forceinline__ const double &operator[](int b) const { return v[b]; }
+};
+template <int B> struct BiomeArr { using type = ParkArr; };
+template <> struct BiomeArr<1> { using type = RegArr1; };
 
 // What stays in registers through the carbon-cycle solver of one year.
 template <int B>
@@ -296,14 +317,14 @@ struct Member {
   double C0;
   // state
   double cHL, cLL, cIO, cDO, atmos, earth;
-  double veg[B], det[B], soil[B], pf[B], thawed[B], tempferts[B];
+  typename BiomeArr<B>::type veg, det, soil, pf, thawed, tempferts;
   double cum_luc_va, cum_pf_ch4, masstot;
   double max_ts, lastflux_ann, sdt;
   int ts_timeout;
   double alkH, alkL, hH, hL;
   unsigned status;
   // per-year
-  double co2fert[B], tempfertd[B], f_new_thaw[B];
+  typename BiomeArr<B>::type co2fert, tempfertd, f_new_thaw;
   double luc_e, luc_u, ffi, daccs, npp_luc_adjust;
   ChemK kH, kL;
   double pco2H, pco2L;
@@ -941,6 +962,13 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   m.npad = buf.npad;
   m.pk = park;
   m.lane = lane;
+  if constexpr (B > 1) {
+    constexpr int o = hx_pkb1<B>();
+    ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
+                                   &m.co2fert, &m.tempfertd, &m.f_new_thaw};
+#pragma unroll
+    for (int k = 0; k < HX_NBIOME_ARR; ++k) { arr[k]->base = park + o + k * B; arr[k]->lane = lane; }
+  }
   m.C0 = ldp(buf, HXP_C0, mem);
   // constants -> park
   PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
@@ -1369,7 +1397,9 @@ template <int B, bool HF, bool KERPM, bool CON>
 __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
-  __shared__ double s_tblk[HX_DBLK][64];
+  // (multi-biome kernels need that LDS for the per-biome arrays and re-read the block's SSTs
+  // from the output array instead)
+  __shared__ double s_tblk[B == 1 ? HX_DBLK : 1][64];
   const int lane = threadIdx.x;
   const int mem = blockIdx.x * 64 + lane;
   if (mem >= args->buf.npad) return;
@@ -1622,7 +1652,9 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           else return HX_CCD(buf.ker)[idx];
         };
         for (int i = blk0; i < iy; ++i) {
-          const double T = s_tblk[i - blk0][lane];
+          double T;
+          if constexpr (B == 1) T = s_tblk[i - blk0][lane];
+          else T = HX_GCD(buf.out[HXO_SST])[(size_t)i * buf.npad + mem];
           dpast += T * ldk(kq + i);
           if (want_hf) hint += T * ldk(kq + i + 1);
         }
@@ -1652,7 +1684,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           flux_mixed = hmix;
           flux_interior = hi;
         }
-        s_tblk[j][lane] = sst_new;
+        if constexpr (B == 1) s_tblk[j][lane] = sst_new;
       }
       double tl_seen = tland, tl_rep = tl_new, sst_rep = sst_new;  // what D_LAND_TAS / D_SST return
       if constexpr (CON) {
