@@ -8,6 +8,12 @@
 #include "../../include/hector_amd.h"
 #include "ensemble_core.hpp"
 
+hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, const double *alk,
+                               double inv_vol, double *out, hipStream_t st);
+hipError_t hx_launch_doeclim_kernel(const double *diff_row, double *ker, int ns, int count,
+                                    int stride, hipStream_t st);
+int hx_doeclim_kernel_pad();
+
 #ifndef HX_BACKEND_NAME
 #define HX_BACKEND_NAME "hip"
 #endif
@@ -78,6 +84,43 @@ int hx_output_capabilities(const char *const **names, int *count) {
   return 0;
 }
 int hx_set_member_sorting(hx_core *core, int on) { HX_TRY(core->core->set_member_sorting(on != 0)) }
+// ---- unit vectors (function-level parity tests; SURVEY 8c fixture iv) -------------------
+int hx_unit_csys(int device, int n, const double *Tc, const double *carbon, const double *alk,
+                 double volume, double *out) {
+  if (n <= 0 || !Tc || !carbon || !alk || !out) return fail("hx_unit_csys: bad arguments");
+  double *d = nullptr;
+  try {
+    auto ck = [](hipError_t e) { if (e != hipSuccess) throw std::runtime_error(hipGetErrorString(e)); };
+    ck(hipSetDevice(device));
+    const size_t nb = sizeof(double) * (size_t)n;
+    ck(hipMalloc(&d, nb * 7));
+    ck(hipMemcpy(d, Tc, nb, hipMemcpyHostToDevice));
+    ck(hipMemcpy(d + n, carbon, nb, hipMemcpyHostToDevice));
+    ck(hipMemcpy(d + 2 * (size_t)n, alk, nb, hipMemcpyHostToDevice));
+    ck(hx_launch_unit_csys(n, d, d + n, d + 2 * (size_t)n, 1.0 / volume, d + 3 * (size_t)n, nullptr));
+    ck(hipStreamSynchronize(nullptr));
+    ck(hipMemcpy(out, d + 3 * (size_t)n, nb * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+  } catch (const std::exception &e) { if (d) (void)hipFree(d); return fail(e); }
+}
+int hx_unit_doeclim_kernel(int device, double diff, int ns, double *out) {
+  if (ns <= 1 || !out) return fail("hx_unit_doeclim_kernel: bad arguments");
+  double *d = nullptr;
+  try {
+    auto ck = [](hipError_t e) { if (e != hipSuccess) throw std::runtime_error(hipGetErrorString(e)); };
+    ck(hipSetDevice(device));
+    const int pad = hx_doeclim_kernel_pad();
+    ck(hipMalloc(&d, sizeof(double) * ((size_t)ns + 2 * pad + 1)));
+    ck(hipMemcpy(d, &diff, sizeof(double), hipMemcpyHostToDevice));
+    ck(hx_launch_doeclim_kernel(d, d + 1, ns, 1, 1, nullptr));
+    ck(hipStreamSynchronize(nullptr));
+    ck(hipMemcpy(out, d + 1 + pad, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+  } catch (const std::exception &e) { if (d) (void)hipFree(d); return fail(e); }
+}
+
 int hx_halocarbons(hx_core *core, const char *const **names, int *count) {
   static thread_local std::vector<const char *> ptrs;
   HX_TRY({

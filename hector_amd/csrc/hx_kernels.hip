@@ -1990,6 +1990,25 @@ __global__ __launch_bounds__(64) void hx_slr_kernel(const double *tgav, int npad
   }
 }
 
+// Unit vector of the carbonate chemistry (a7): n independent (T, carbon, alkalinity) triples
+// through chem_constants + chem_solve from a cold start (the Fujiwara bound is not needed: the
+// bracketed Newton accepts any positive start), one per thread.  Test hook for parity at the
+// function level; the run kernel uses the same two functions.
+__global__ void hx_unit_csys_kernel(int n, const double *Tc, const double *carbon,
+                                    const double *alk, double inv_vol, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ChemK k;
+  chem_constants(Tc[i], k);
+  double h = 1e-8;
+  unsigned status = 0;
+  const double pco2 = chem_solve(k, carbon[i], inv_vol, alk[i], h, status);
+  out[4 * i + 0] = pco2;
+  out[4 * i + 1] = -log10(h);
+  out[4 * i + 2] = k.Tr;
+  out[4 * i + 3] = (double)status;
+}
+
 // ---------------------------------------------------------------------------
 // host-callable launchers (the only symbols the host runtime uses)
 // ---------------------------------------------------------------------------
@@ -2052,6 +2071,13 @@ hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, dou
   return hipGetLastError();
 }
 int hx_doeclim_block_years() { return HX_DBLK; }
+int hx_doeclim_kernel_pad() { return HX_KPAD; }
+hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, const double *alk,
+                               double inv_vol, double *out, hipStream_t st) {
+  hipLaunchKernelGGL(hx_unit_csys_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, Tc, carbon, alk,
+                     inv_vol, out);
+  return hipGetLastError();
+}
 hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st) {
   hipLaunchKernelGGL(hx_diag_kernel, dim3((a.npad + 255) / 256, a.ny), dim3(256), 0, st, kind, a, out);
   return hipGetLastError();

@@ -128,6 +128,16 @@ int hx_state_row(hx_core *core, int row, double *out);
 
 /* Core::getRun_name (src/core.cpp:215-220): the INI's [core] run_name, "" if none */
 int hx_run_name(hx_core *core, const char **name);
+/* Unit vectors for function-level parity tests (no core needed).
+ * hx_unit_csys: oceancsys::ocean_csys_run (src/ocean_csys.cpp:166-366) for n independent
+ *   (T degC, box carbon Pg C, alkalinity mol/kg) triples in a box of `volume` m3;
+ *   out[4*i..] = {pCO2 uatm, pH, Tr, status bits}.
+ * hx_unit_doeclim_kernel: TemperatureComponent::prepareToRun's Ker[ns]
+ *   (src/temperature_component.cpp:303-371) for one diffusivity (cm2/s). */
+int hx_unit_csys(int device, int n, const double *Tc, const double *carbon, const double *alk,
+                 double volume, double *out);
+int hx_unit_doeclim_kernel(int device, double diff, int ns, double *out);
+
 /* core metadata: startDate, endDate, current date, members, biomes */
 int hx_dates(hx_core *core, int *start, int *end, int *current);
 int hx_sizes(hx_core *core, int *n_members, int *n_biomes);

@@ -312,3 +312,39 @@ def test_dated_setvar_emissions_vs_oracle(emul_lib, oracle, tmp_path):
         c.setvar_dated("ffi_emissions", years, vals, "Tg C/yr")     # unit check
     with pytest.raises(hector_amd.HectorAmdError):
         c.setvar_dated("no_such_series", years, vals)
+
+
+def unit_vectors_vs_oracle(lib, oracle, device=0):
+    """Function-level parity (SURVEY 8c iv): carbonate solve over a grid of (T, DIC, alk) and
+    the DOECLIM kernel table for several diffusivities, product functions vs the oracle."""
+    import ctypes
+    dp = ctypes.POINTER(ctypes.c_double)
+    rng = np.random.default_rng(7)
+    n = 500
+    vol = 3.6e14 * 0.85 * 100.0
+    Tc = rng.uniform(-1.0, 30.0, n); carbon = rng.uniform(600.0, 1100.0, n)
+    alk = rng.uniform(2100e-6, 2750e-6, n)
+    out = np.zeros((n, 4))
+    as_p = lambda a: np.ascontiguousarray(a).ctypes.data_as(dp)
+    rc = lib.hx_unit_csys(device, n, as_p(Tc), as_p(carbon), as_p(alk), vol, out.ctypes.data_as(dp))
+    assert rc == 0, lib.hx_last_error()
+    assert (out[:, 3] == 0).all()
+    for i in range(n):
+        o = oracle.csys(Tc[i], carbon[i], alk[i], vol)      # PCO2o, pH, Tr, K0, h, CO3
+        # the reference's root is only defined to 2^-30 relative (newton_raphson_iterate with
+        # 31 bits, ocean_csys.cpp:134-156: its last step can be a bracket-halving one); the
+        # kernel's Newton converges quadratically to the exact root
+        assert abs(out[i, 0] - o[0]) < 3e-9 * o[0]
+        assert abs(out[i, 1] - o[1]) < 1e-9
+        assert abs(out[i, 2] - o[2]) < 1e-13 * o[2]
+    for diff in (0.55, 1.16, 2.3, 4.0):
+        ker = np.zeros(556)
+        rc = lib.hx_unit_doeclim_kernel(device, diff, 556, ker.ctypes.data_as(dp))
+        assert rc == 0, lib.hx_last_error()
+        ref = oracle.doeclim_kernel(diff, 556)
+        assert np.abs(ker - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+def test_unit_vectors_vs_oracle(emul_lib, oracle):
+    import hector_amd._lib as L
+    unit_vectors_vs_oracle(L.load(emul_lib, allow_emulation=True), oracle)

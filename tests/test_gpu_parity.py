@@ -418,3 +418,10 @@ def test_reference_science_checks_on_gpu(hip_lib):
     test_reference_properties.py), on the HIP library."""
     from test_reference_properties import science_checks
     science_checks(hip_lib, device=0)
+
+
+def test_unit_vectors_vs_oracle_on_gpu(hip_lib, oracle):
+    """Carbonate solve and DOECLIM kernel table: HIP functions vs the oracle, value by value."""
+    import hector_amd._lib as L
+    from test_emulation_parity import unit_vectors_vs_oracle
+    unit_vectors_vs_oracle(L.load(hip_lib), oracle)
