@@ -120,6 +120,18 @@ class Core:
                                            unit.encode() if unit else None))
         return self
 
+    def setvar_dated_members(self, var, years, values, unit=None):
+        """values[year, member]: a different input series for every member."""
+        y = np.ascontiguousarray(np.atleast_1d(np.asarray(years, dtype=np.int32)))
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64))
+        if v.shape != (y.size, self.n_members):
+            raise HectorAmdError("setvar_dated_members: values must be [n_years, n_members]")
+        self._ck(self._lib.hx_setvar_dated_members(
+            self._h, var.encode(), y.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+            v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), y.size,
+            unit.encode() if unit else None))
+        return self
+
     def set_member_sorting(self, on=True):
         self._ck(self._lib.hx_set_member_sorting(self._h, 1 if on else 0))
         return self

@@ -361,6 +361,7 @@ void EnsembleCore::free_device() {
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   d_hist_ = nullptr;
+  for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
   fr(d_diag_); fr(d_slr_); d_diag_ = d_slr_ = nullptr; diag_cap_ = 0; slr_valid_to_ = -1;
   d_derived_ = nullptr; d_dpart_ = nullptr; d_gather_ = nullptr; d_lane_of_member_ = nullptr;
   gather_cap_ = 0;
@@ -408,6 +409,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.dpart2 = d_dpart_ ? d_dpart_ + (size_t)npad_ * hx_doeclim_block_years() : nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
   b.hist = d_hist_;
+  for (int k = 0; k < HXM_N; ++k) b.mseries[k] = d_mseries_[k];
   b.stash_diag = 0;
   for (int v = HXO_NPP; v <= HXO_CA_RESIDUAL; ++v) if (d_out_[v]) b.stash_diag = 1;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
@@ -632,6 +634,75 @@ void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
   if (target < last_iy_) dirty_from_iy_ = (dirty_from_iy_ < 0) ? target : std::min(dirty_from_iy_, target);
 }
 
+namespace {
+struct MemberSeriesDef { const char *name; int k; const char *section; const char *units; int lag; };
+// lag: the shared table holds the value of date year-1 for what slowparameval reads
+const MemberSeriesDef kMemberSeries[] = {
+    {"ffi_emissions", HXM_FFI, "simpleNbox", "Pg C/yr", 1},
+    {"daccs_uptake", HXM_DACCS, "simpleNbox", "Pg C/yr", 1},
+    {"luc_emissions", HXM_LUC_E, "simpleNbox", "Pg C/yr", 1},
+    {"luc_uptake", HXM_LUC_U, "simpleNbox", "Pg C/yr", 1},
+    {"CH4_emissions", HXM_CH4_EM, "CH4", "Tg CH4", 0},
+};
+}  // namespace
+
+void EnsembleCore::setvar_dated_members(const std::string &capability, const int *years,
+                                        const double *values, int nyears, const char *units) {
+  const MemberSeriesDef *d = nullptr;
+  for (const MemberSeriesDef &m : kMemberSeries) if (capability == m.name) d = &m;
+  if (!d)
+    throw std::runtime_error("per-member dated input not supported for " + capability +
+                             " (ffi_emissions, luc_emissions, daccs_uptake, luc_uptake, "
+                             "CH4_emissions are)");
+  if (units && units[0] && std::string(units) != d->units)
+    throw std::runtime_error("Units: " + std::string(units) + " do not match expected: " +
+                             d->units + " for " + capability);
+  const int ns = scen_.ns();
+  std::vector<double> &ms = member_series_[d->k];
+  if (ms.empty()) {  // start from the scenario's series, the same for every member
+    ms.resize((size_t)ns * n_);
+    const std::vector<double> base = scen_.has_series(d->section, capability)
+                                         ? scen_.series(d->section, capability)
+                                         : std::vector<double>((size_t)ns, 0.0);
+    for (int iy = 0; iy < ns; ++iy)
+      std::fill(ms.begin() + (size_t)iy * n_, ms.begin() + (size_t)(iy + 1) * n_, base[(size_t)iy]);
+  }
+  int miny = scen_.end;
+  for (int i = 0; i < nyears; ++i) {
+    if (years[i] < scen_.start || years[i] > scen_.end)
+      throw std::runtime_error("date outside startDate..endDate");
+    std::copy(values + (size_t)i * n_, values + (size_t)(i + 1) * n_,
+              ms.begin() + (size_t)(years[i] - scen_.start) * n_);
+    miny = std::min(miny, years[i]);
+  }
+  mseries_dirty_ = true;
+  const int target = std::max(0, miny - 1 - scen_.start);
+  if (target < last_iy_) dirty_from_iy_ = (dirty_from_iy_ < 0) ? target : std::min(dirty_from_iy_, target);
+}
+
+void EnsembleCore::upload_member_series() {
+  const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
+  std::vector<double> flat;
+  for (const MemberSeriesDef &d : kMemberSeries) {
+    const std::vector<double> &ms = member_series_[d.k];
+    if (ms.empty()) continue;
+    if (!d_mseries_[d.k]) check(hipMalloc(&d_mseries_[d.k], sizeof(double) * ns * np), "hipMalloc member series");
+    flat.assign(ns * np, 0.0);
+    for (size_t iy = (size_t)d.lag; iy < ns; ++iy)
+      for (size_t l = 0; l < np; ++l)
+        flat[iy * np + l] = ms[(iy - (size_t)d.lag) * n_ + (size_t)std::min(member_of_lane_[l], n_ - 1)];
+    check(hipMemcpyAsync(d_mseries_[d.k], flat.data(), sizeof(double) * flat.size(),
+                         hipMemcpyHostToDevice, stream_), "upload member series");
+    check(hipStreamSynchronize(stream_), "sync member series");
+  }
+  HxArgs a;
+  a.buf = buffers();
+  a.kc = kc_;
+  check(hipMemcpyAsync(d_args_, &a, sizeof a, hipMemcpyHostToDevice, stream_), "upload args");
+  check(hipStreamSynchronize(stream_), "sync args");
+  mseries_dirty_ = false;
+}
+
 void EnsembleCore::lane_of_member(int *out) {
   prepare();
   std::memcpy(out, lane_of_member_.data(), sizeof(int) * (size_t)n_);
@@ -721,7 +792,11 @@ void EnsembleCore::prepare() {
     shared_dirty_ = false;
     params_dirty_ = true;  // HxConst (constraint mask, preindustrial values) is re-uploaded
   }
-  if (params_dirty_) upload_params();
+  if (params_dirty_) {
+    upload_params();
+    for (int k = 0; k < HXM_N; ++k) if (!member_series_[k].empty()) mseries_dirty_ = true;  // lanes may have moved
+  }
+  if (mseries_dirty_) upload_member_series();
   if (!need_spinup_) return;
   // Spinup is independent of every parameter that is not in the spinup set
   // (SURVEY 3f): if those rows are uniform, spin up one prototype wavefront and
@@ -814,6 +889,7 @@ void EnsembleCore::run(double runtodate) {
   const bool hf = d_out_[HXO_HEATFLUX] || d_out_[HXO_FLUX_MIXED] || d_out_[HXO_FLUX_INTERIOR];
   bool ext = kc_.con_mask != 0;  // extended kernel: constraints or the extra diagnostics
   for (int v = HXO_NPP; v < HXO_NVAR; ++v) if (d_out_[v]) ext = true;
+  for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) ext = true;
   check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, ext, last_iy_, target,
                       stream_),
         "run kernel");
@@ -847,6 +923,15 @@ bool EnsembleCore::fetch_host(const std::string &capability, int year0, int year
   auto input = [&](const std::string &sec, const std::string &key, double dflt) {
     return scen_.has_series(sec, key) ? scen_.series(sec, key) : std::vector<double>((size_t)ns, dflt);
   };
+  for (const MemberSeriesDef &d : kMemberSeries)
+    if (capability == d.name && !member_series_[d.k].empty()) {
+      if (!out_host) return true;
+      if (year0 < scen_.start || year1 > scen_.end || year1 < year0)
+        throw std::runtime_error("fetchvars: dates must lie between startDate and endDate");
+      std::copy(member_series_[d.k].begin() + (size_t)(year0 - scen_.start) * n_,
+                member_series_[d.k].begin() + (size_t)(year1 - scen_.start + 1) * n_, out_host);
+      return true;
+    }
   for (const DatedDef &d : kDated)
     if (capability == d.name && scen_.has_series(d.sections[0], capability))
       ser = scen_.series(d.sections[0], capability);

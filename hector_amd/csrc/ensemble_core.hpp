@@ -64,6 +64,12 @@ class EnsembleCore {
   void setvar_dated(const std::string &capability, const int *years, const double *values,
                     int n, const char *units);
   void lane_of_member(int *out);
+  // SETDATA with dates and a different value for every member (ffi_emissions, luc_emissions,
+  // daccs_uptake, luc_uptake, CH4_emissions): values[i * n_members + member] for years[i] --
+  // the reference's pattern of re-running a period with new emissions per run
+  // (vignettes/ex_hector_apply.Rmd), for all members at once.
+  void setvar_dated_members(const std::string &capability, const int *years, const double *values,
+                            int nyears, const char *units);
   static const char *const *output_capabilities(int *count);
 
   void reset(double date);      // Core::reset: date < startDate => redo spinup
@@ -110,6 +116,10 @@ class EnsembleCore {
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
   int last_iy_ = 0;
   HxConst kc_{};
+  std::vector<double> member_series_[HXM_N];  // host [ns][n_], member order; empty = shared
+  double *d_mseries_[HXM_N] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool mseries_dirty_ = false;
+  void upload_member_series();
   std::vector<std::string> halo_names_;
   std::vector<std::vector<double>> halo_conc_;  // [gas][ns] halocarbon concentrations, pptv
   std::vector<double> shared_, ker_;

@@ -141,6 +141,12 @@ int hx_setvar_dated(hx_core *core, const char *capability, const int *years, con
   if (!capability || !years || !values || n < 1) return fail("hx_setvar_dated: bad arguments");
   HX_TRY(core->core->setvar_dated(capability, years, values, n, units))
 }
+int hx_setvar_dated_members(hx_core *core, const char *capability, const int *years,
+                            const double *values, int nyears, const char *units) {
+  if (!capability || !years || !values || nyears < 1)
+    return fail("hx_setvar_dated_members: bad arguments");
+  HX_TRY(core->core->setvar_dated_members(capability, years, values, nyears, units))
+}
 int hx_lane_of_member(hx_core *core, int *out) {
   if (!out) return fail("null argument");
   HX_TRY(core->core->lane_of_member(out))

@@ -1498,8 +1498,13 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       }
       {
+        double ch4_em = sh[HXSH_CH4_EM];
+        if constexpr (CON) {
+          if (buf.mseries[HXM_CH4_EM])
+            ch4_em = HX_GCD(buf.mseries[HXM_CH4_EM])[(size_t)iy * buf.npad + mem];
+        }
         const double emisTocon =
-            ((sh[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
+            ((ch4_em + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
         const double dCH4 = ((emisTocon - prev_ch4 / kc.Tsoil) - prev_ch4 / kc.Tstrat) -
                             prev_ch4 / tau_oh;
         ch4 = prev_ch4 + dCH4;
@@ -1526,6 +1531,13 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       // ---- slowparameval (t = year-1) ----
       m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
       m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
+      if constexpr (CON) {  // emissions that differ between members
+        const size_t o = (size_t)iy * buf.npad + mem;
+        if (buf.mseries[HXM_FFI]) m.ffi = HX_GCD(buf.mseries[HXM_FFI])[o];
+        if (buf.mseries[HXM_DACCS]) m.daccs = HX_GCD(buf.mseries[HXM_DACCS])[o];
+        if (buf.mseries[HXM_LUC_E]) m.luc_e = HX_GCD(buf.mseries[HXM_LUC_E])[o];
+        if (buf.mseries[HXM_LUC_U]) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
+      }
       m.npp_luc_adjust = (eos - m.cum_luc_va) / eos;
       const double lnc = log((m.atmos * PGC2PPM) / m.C0);
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =

@@ -98,6 +98,9 @@ enum HxSharedCol {
   HXSH_STRIDE = 24
 };
 
+// ---- optional per-member input series [ns][npad], overriding the shared column ----------
+enum HxMemberSeries { HXM_FFI = 0, HXM_DACCS, HXM_LUC_E, HXM_LUC_U, HXM_CH4_EM, HXM_N };
+
 // ---- status bits (per member) ---------------------------------------------
 #define HX_ERR_MASS 1u       // mass balance > 1e-3 PgC   simpleNbox-runtime.cpp:553-563
 #define HX_ERR_RETRIES 2u    // > 8 solver retries        carbon-cycle-solver.cpp:242-294
@@ -139,6 +142,7 @@ struct HxBuffers {
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   int n, npad, ker_per_member;
+  const double *mseries[HXM_N];  // per-member emissions (row iy as in the shared table) or nullptr
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
 };
 

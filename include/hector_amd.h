@@ -60,6 +60,13 @@ int hx_setvar(hx_core *core, const char *capability, const double *values, int n
  * (src/rcpp_hector.cpp:160-166). */
 int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
                     int n, const char *units);
+/* The same with a different value for every member -- the reference's "re-run a period with new
+ * emissions per run" pattern (vignettes/ex_hector_apply.Rmd; one reset/setvar/run per run
+ * there), for all members in one run: values[i * n_members + member] is the value of
+ * years[i].  ffi_emissions, luc_emissions, daccs_uptake, luc_uptake, CH4_emissions
+ * (8 B per member-year of HBM each, once used). */
+int hx_setvar_dated_members(hx_core *core, const char *capability, const int *years,
+                            const double *values, int nyears, const char *units);
 /* Keep every year's component state in HBM so hx_reset can return to any computed date --
  * what the reference's per-component tseries records provide (src/simpleNbox.cpp:708-840,
  * src/ocean_component.cpp:767-846).  272 B per member-year (one biome); default off. */

@@ -348,3 +348,60 @@ def unit_vectors_vs_oracle(lib, oracle, device=0):
 def test_unit_vectors_vs_oracle(emul_lib, oracle):
     import hector_amd._lib as L
     unit_vectors_vs_oracle(L.load(emul_lib, allow_emulation=True), oracle)
+
+
+def per_member_emissions_vs_oracle(lib, tmp_path, n=4, **kw):
+    """vignettes/ex_hector_apply.Rmd: run, go back, give every run its own emissions for a
+    period, run again -- all members in one core.  Each member vs the oracle reading a scenario
+    that holds that member's series."""
+    import oracle_binding
+    from conftest import edited_pack
+    years = np.arange(2000, 2101)
+    S = np.linspace(2.2, 4.6, n)
+    c = hector_amd.Core(SCENARIO, n, lib_path=lib, **kw).setvar("S", S, "degC")
+    c.enable_history(True)
+    c.set_outputs(["CO2_concentration", "global_tas", "CH4_concentration"])
+    c.run(2150)
+    before = c.fetchvars("CO2_concentration", (1745, 2150)).copy()
+    base_ffi = c.fetchvars("ffi_emissions", (2000, 2100))          # [year, member]
+    scale = np.linspace(0.2, 1.6, n)
+    ffi = base_ffi * scale[None, :]
+    ch4 = c.fetchvars("CH4_emissions", (2000, 2100)) * scale[::-1][None, :]
+    c.setvar_dated_members("ffi_emissions", years, ffi, "Pg C/yr")
+    c.setvar_dated_members("CH4_emissions", years, ch4, "Tg CH4")
+    assert np.array_equal(c.fetchvars("ffi_emissions", (2000, 2100)), ffi)
+    c.run(2150)                                    # auto-reset to 1999, like the R wrapper
+    assert (c.status() == 0).all()
+    co2 = c.fetchvars("CO2_concentration", (1745, 2150))
+    tg = c.fetchvars("global_tas", (1745, 2150))
+    m4 = c.fetchvars("CH4_concentration", (1745, 2150))
+    assert np.array_equal(co2[:2000 - 1745], before[:2000 - 1745])
+    assert (np.diff(co2[2100 - 1745]) > 0).all()   # more emissions (and higher ECS), more CO2
+    for i in range(n):
+        p1 = edited_pack(tmp_path / ("a%d.hxs" % i), "simpleNbox", "ffi_emissions", years, ffi[:, i])
+        p2 = edited_pack(tmp_path / ("b%d.hxs" % i), "CH4", "CH4_emissions", years, ch4[:, i], base=p1)
+        o = oracle_binding.Oracle(p2)
+        p = o.default_params(); p.S = S[i]
+        r, err, _ = o.run(p, run_to=2150)
+        assert err == 0
+        k = 2150 - 1745 + 1
+        assert (np.abs(co2[:, i] - r["CO2_concentration"][:k]) / r["CO2_concentration"][:k]).max() < REL_CO2
+        assert np.abs(tg[:, i] - r["global_tas"][:k]).max() < ABS_T
+        assert np.abs(m4[:, i] - r["CH4_concentration"][:k]).max() < 1e-6
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar_dated_members("N2O_emissions", years, ffi)        # a shared (host) gas cycle
+    return c
+
+
+def test_per_member_emissions_vs_oracle(emul_lib, tmp_path):
+    c = per_member_emissions_vs_oracle(emul_lib, tmp_path, allow_emulation=True)
+    # member sorting must not mix the series up: same result with sorting off
+    d = hector_amd.Core(SCENARIO, 4, lib_path=emul_lib, allow_emulation=True)
+    d.set_member_sorting(False).setvar("S", np.linspace(2.2, 4.6, 4), "degC")
+    d.set_outputs(["CO2_concentration"])
+    y = np.arange(2000, 2101)
+    d.setvar_dated_members("ffi_emissions", y, c.fetchvars("ffi_emissions", (2000, 2100)))
+    d.setvar_dated_members("CH4_emissions", y, c.fetchvars("CH4_emissions", (2000, 2100)))
+    d.run(2150)
+    assert np.array_equal(d.fetchvars("CO2_concentration", (1745, 2150)),
+                          c.fetchvars("CO2_concentration", (1745, 2150)))

@@ -425,3 +425,9 @@ def test_unit_vectors_vs_oracle_on_gpu(hip_lib, oracle):
     import hector_amd._lib as L
     from test_emulation_parity import unit_vectors_vs_oracle
     unit_vectors_vs_oracle(L.load(hip_lib), oracle)
+
+
+def test_per_member_emissions_on_gpu(hip_lib, tmp_path):
+    """Per-member emission series (ex_hector_apply.Rmd pattern), 24 members vs the oracle."""
+    from test_emulation_parity import per_member_emissions_vs_oracle
+    per_member_emissions_vs_oracle(hip_lib, tmp_path, n=24, device=0)
