@@ -101,6 +101,13 @@ class Core:
         self._ck(self._lib.hx_set_outputs(self._h, n, arr))
         return self
 
+    def biomes(self):
+        """get_biome_list(core)  R/biome.R:8-16"""
+        names = ctypes.POINTER(ctypes.c_char_p)()
+        n = ctypes.c_int()
+        self._ck(self._lib.hx_biomes(self._h, ctypes.byref(names), ctypes.byref(n)))
+        return [names[i].decode() for i in range(n.value)]
+
     def halocarbons(self):
         names = ctypes.POINTER(ctypes.c_char_p)()
         n = ctypes.c_int()

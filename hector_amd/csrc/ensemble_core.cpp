@@ -120,7 +120,7 @@ const DerivedDef *derived_of(const std::string &name) {
 
 const char *const *EnsembleCore::output_capabilities(int *count) {
   for (auto &o : kOutputs) kOutputNames[o.idx] = o.name;
-  if (count) *count = HXO_NVAR;
+  if (count) *count = HXO_BIOME0;  // (per-biome pools "<biome>.veg_c" ... are named by the core's biomes)
   return kOutputNames;
 }
 
@@ -167,21 +167,58 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   setrow(HXP_LO_RATIO, s.scalar("temperature", "lo_warming_ratio", 0.0));
   out_enabled_[HXO_SST_LO] = s.scalar("temperature", "lo_warming_ratio", 0.0) != 0.0;
   const int r = HXP_NGLOBAL;
-  setrow(r + HXPB_BETA, s.scalar("simpleNbox", "beta"));
-  setrow(r + HXPB_Q10, s.scalar("simpleNbox", "q10_rh"));
+  setrow(r + HXPB_BETA, s.scalar("simpleNbox", "beta", 0.0));  // 0 if only biomes define it
+  setrow(r + HXPB_Q10, s.scalar("simpleNbox", "q10_rh", 0.0));  // 0 if only biomes define it
   setrow(r + HXPB_WF, s.scalar("simpleNbox", "warmingfactor", 1.0));
-  setrow(r + HXPB_NPP0, s.scalar("simpleNbox", "npp_flux0"));
-  setrow(r + HXPB_VEG0, s.scalar("simpleNbox", "veg_c"));
-  setrow(r + HXPB_DET0, s.scalar("simpleNbox", "detritus_c"));
-  setrow(r + HXPB_SOIL0, s.scalar("simpleNbox", "soil_c"));
+  setrow(r + HXPB_NPP0, s.scalar("simpleNbox", "npp_flux0", 0.0));  // 0 if only biomes define it
+  setrow(r + HXPB_VEG0, s.scalar("simpleNbox", "veg_c", 0.0));  // 0 if only biomes define it
+  setrow(r + HXPB_DET0, s.scalar("simpleNbox", "detritus_c", 0.0));  // 0 if only biomes define it
+  setrow(r + HXPB_SOIL0, s.scalar("simpleNbox", "soil_c", 0.0));  // 0 if only biomes define it
   setrow(r + HXPB_PF0, s.scalar("simpleNbox", "permafrost_c", 0.0));
-  setrow(r + HXPB_F_NPPV, s.scalar("simpleNbox", "f_nppv"));
-  setrow(r + HXPB_F_NPPD, s.scalar("simpleNbox", "f_nppd"));
-  setrow(r + HXPB_F_LITTERD, s.scalar("simpleNbox", "f_litterd"));
+  setrow(r + HXPB_F_NPPV, s.scalar("simpleNbox", "f_nppv", 0.0));  // 0 if only biomes define it
+  setrow(r + HXPB_F_NPPD, s.scalar("simpleNbox", "f_nppd", 0.0));  // 0 if only biomes define it
+  setrow(r + HXPB_F_LITTERD, s.scalar("simpleNbox", "f_litterd", 0.0));  // 0 if only biomes define it
   setrow(r + HXPB_RH_CH4_FRAC, s.scalar("simpleNbox", "rh_ch4_frac", 0.023));
   setrow(r + HXPB_PF_MU, s.scalar("simpleNbox", "pf_mu", 1.67));
   setrow(r + HXPB_PF_SIGMA, s.scalar("simpleNbox", "pf_sigma", 0.986));
   setrow(r + HXPB_FPF_STATIC, s.scalar("simpleNbox", "fpf_static", 0.74));
+  // Biomes defined in the INI file: "<biome>.<variable>" keys of [simpleNbox]
+  // (src/simpleNbox.cpp:190-330; the checks of simpleNbox-runtime.cpp:64-135)
+  {
+    std::vector<std::string> biomes;
+    for (const std::string &k : s.scalar_keys("simpleNbox")) {
+      const size_t dot = k.find('.');
+      if (dot == std::string::npos) continue;
+      const std::string b = k.substr(0, dot);
+      if (std::find(biomes.begin(), biomes.end(), b) == biomes.end()) biomes.push_back(b);
+    }
+    if (!biomes.empty()) {
+      if ((int)biomes.size() > HX_MAXB)
+        throw std::runtime_error("at most " + std::to_string(HX_MAXB) + " biomes are supported");
+      B_ = (int)biomes.size();
+      biome_names_ = biomes;
+      const std::vector<std::vector<double>> global = params_;
+      params_.assign(HX_NPARAM(B_), std::vector<double>((size_t)npad_, 0.0));
+      row_uniform_.assign(HX_NPARAM(B_), true);
+      for (int g = 0; g < HXP_NGLOBAL; ++g) params_[g] = global[g];
+      for (int b = 0; b < B_; ++b)
+        for (const ParamDef &d : kParams) {
+          if (!d.per_biome) continue;
+          const std::string key = biomes[(size_t)b] + "." + d.name;
+          double v;
+          if (s.has_scalar("simpleNbox", key)) v = s.scalar("simpleNbox", key);
+          else if (d.row == HXPB_WF) v = 1.0;
+          else if (d.row == HXPB_RH_CH4_FRAC) v = 0.023;
+          else if (d.row == HXPB_PF_MU) v = 1.67;
+          else if (d.row == HXPB_PF_SIGMA) v = 0.986;
+          else if (d.row == HXPB_FPF_STATIC) v = 0.74;
+          else
+            throw std::runtime_error(std::string(d.name) + " and veg_c not same size: no " + d.name +
+                                     " data for " + biomes[(size_t)b]);
+          setrow(HXP_NGLOBAL + b * HXPB_N + d.row, v);
+        }
+    }
+  }
   if (s.scalar("ocean", "spinup_chem", 0) != 0)
     throw std::runtime_error("ocean.spinup_chem=1 is not supported by the GPU path");
   if (s.scalar("core", "do_spinup", 1) == 0)
@@ -527,6 +564,17 @@ int EnsembleCore::out_index(const std::string &capability) const {
   // 614-625); the kernel records the reported one separately
   if (capability == "sst" && out_enabled_[HXO_SST_LO]) return HXO_SST_LO;
   if (capability == "ocean_timesteps") return HXO_NSTASH;  // D_TIMESTEPS, component_data.hpp:337
+  const size_t dot = capability.find('.');
+  if (dot != std::string::npos) {  // "<biome>.<pool>"  (SNBOX_PARSECHAR, simpleNbox.cpp:527-540)
+    static const char *const pools[5] = {"veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c"};
+    const std::string biome = capability.substr(0, dot), var = capability.substr(dot + 1);
+    for (int b = 0; b < B_; ++b)
+      if (biome_names_[(size_t)b] == biome)
+        for (int k = 0; k < 5; ++k)
+          if (var == pools[k]) return HXO_BIOME0 + k * HX_MAXB + b;
+    throw std::runtime_error("Biome '" + biome + "' missing from biome list. Hit this error while "
+                             "trying to retrieve variable: '" + capability + "'.");
+  }
   for (auto &o : kOutputs) if (capability == o.name) return o.idx;
   throw std::runtime_error("Caller is requesting unknown variable: " + capability);
 }

@@ -131,6 +131,16 @@ int hx_halocarbons(hx_core *core, const char *const **names, int *count) {
     if (count) *count = (int)ptrs.size();
   })
 }
+int hx_biomes(hx_core *core, const char *const **names, int *count) {
+  static thread_local std::vector<const char *> ptrs;
+  HX_TRY({
+    const auto &b = core->core->biomes();
+    ptrs.clear();
+    for (auto &n : b) ptrs.push_back(n.c_str());
+    if (names) *names = ptrs.data();
+    if (count) *count = (int)ptrs.size();
+  })
+}
 int hx_run_name(hx_core *core, const char **name) {
   static thread_local std::string rn;
   HX_TRY({ rn = core->core->run_name(); if (name) *name = rn.c_str(); })

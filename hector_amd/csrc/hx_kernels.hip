@@ -1378,6 +1378,12 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   put(HXO_NSTASH, 0.0); put(HXO_NSTEPS, 0.0);
   put(HXO_C_HL, m.cHL); put(HXO_C_LL, m.cLL); put(HXO_C_IO, m.cIO); put(HXO_C_DO, m.cDO);
   put(HXO_F_FROZEN, 1.0); put(HXO_TAU_OH, kc.TOH0);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    put(HXO_BIOME0 + 0 * HX_MAXB + b, m.veg[b]); put(HXO_BIOME0 + 1 * HX_MAXB + b, m.det[b]);
+    put(HXO_BIOME0 + 2 * HX_MAXB + b, m.soil[b]); put(HXO_BIOME0 + 3 * HX_MAXB + b, m.pf[b]);
+    put(HXO_BIOME0 + 4 * HX_MAXB + b, m.thawed[b]);
+  }
   if (spinup_steps) spinup_steps[mem] = steps;
 }
 
@@ -1759,6 +1765,16 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if (buf.out[HXO_C_DO]) sto_(buf, HXO_C_DO, o, m.cDO);
       if (buf.out[HXO_PCO2_HL]) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
       if (buf.out[HXO_PCO2_LL]) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
+      if constexpr (B > 1) {  // "<biome>.veg_c" ...: the pools of each biome
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          if (buf.out[HXO_BIOME0 + 0 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 0 * HX_MAXB + b, o, m.veg[b]);
+          if (buf.out[HXO_BIOME0 + 1 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 1 * HX_MAXB + b, o, m.det[b]);
+          if (buf.out[HXO_BIOME0 + 2 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 2 * HX_MAXB + b, o, m.soil[b]);
+          if (buf.out[HXO_BIOME0 + 3 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 3 * HX_MAXB + b, o, m.pf[b]);
+          if (buf.out[HXO_BIOME0 + 4 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 4 * HX_MAXB + b, o, m.thawed[b]);
+        }
+      }
       if (buf.out[HXO_RH_CH4] || buf.out[HXO_F_FROZEN]) {
         // record_state: RH_ch4 = rh_ftpa_ch4 of the year-end pools (simpleNbox.cpp:800-812);
         // f_frozen: permafrost-weighted mean over biomes, 1 without permafrost (:492-514)

@@ -79,7 +79,9 @@ enum HxOutVar {
   HXO_CA_RESIDUAL,
   HXO_RH_CH4, HXO_F_FROZEN, HXO_GMST, HXO_FLUX_MIXED, HXO_FLUX_INTERIOR,
   HXO_C_HL, HXO_C_LL, HXO_C_IO, HXO_C_DO, HXO_PCO2_HL, HXO_PCO2_LL, HXO_TAU_OH,
-  HXO_NVAR
+  // per-biome pools "<biome>.veg_c" ...: index HXO_BIOME0 + pool * HX_MAXB + biome
+  HXO_BIOME0,
+  HXO_NVAR = HXO_BIOME0 + 5 * HX_MAXB
 };
 
 // ---- shared per-year scenario table: row iy = year - startDate ------------

@@ -117,6 +117,13 @@ std::string Scenario::text(const std::string &section, const std::string &key,
   auto it = scalars_.find(section + "." + key);
   return it == scalars_.end() ? dflt : it->second;
 }
+std::vector<std::string> Scenario::scalar_keys(const std::string &section) const {
+  std::vector<std::string> out;
+  const std::string pre = section + ".";
+  for (auto &kv : scalars_)
+    if (kv.first.compare(0, pre.size(), pre) == 0) out.push_back(kv.first.substr(pre.size()));
+  return out;
+}
 bool Scenario::has_scalar(const std::string &section, const std::string &key) const {
   return scalars_.count(section + "." + key) != 0;
 }

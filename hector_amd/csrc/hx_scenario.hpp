@@ -27,6 +27,7 @@ class Scenario {
   double scalar(const std::string &section, const std::string &key) const;
   double scalar(const std::string &section, const std::string &key, double dflt) const;
   bool has_scalar(const std::string &section, const std::string &key) const;
+  std::vector<std::string> scalar_keys(const std::string &section) const;
   std::string text(const std::string &section, const std::string &key,
                    const std::string &dflt) const;  // a non-numeric INI value (run_name)
   const std::vector<double> &series(const std::string &section,

@@ -80,6 +80,12 @@ int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const 
                    const double *fdet, const double *fsoil, const double *fpf,
                    const double *fnpp);
 
+/* get_biome_list(core)  R/biome.R:8-16: "global", the names given to hx_split_biome, or the
+ * biomes an INI file defines with "<biome>.<variable>" keys in [simpleNbox]
+ * (src/simpleNbox.cpp:190-330).  Per-biome parameters are "<biome>.beta" ..., per-biome pools
+ * "<biome>.veg_c", ".detritus_c", ".soil_c", ".permafrost_c", ".thawedp_c" are outputs. */
+int hx_biomes(hx_core *core, const char *const **names, int *count);
+
 /* Select which per-year outputs are recorded (capability strings such as
  * "CO2_concentration", "global_tas", "RF_tot"...).  sst and land_tas are always
  * recorded.  The reference records everything always (tseries in every

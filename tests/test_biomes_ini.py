@@ -1,0 +1,89 @@
+"""Biomes defined in the scenario file ("<biome>.<variable>" keys of [simpleNbox]) and per-biome
+outputs -- tests/testthat/test_biome.R "Hector runs with multiple biomes created via INI file"
+restated, plus parity with the oracle given the same per-biome parameters."""
+import numpy as np
+import pytest
+
+import hector_amd
+from conftest import SCENARIO
+
+BIOME_VARS = ["veg_c", "detritus_c", "soil_c", "permafrost_c", "npp_flux0", "beta", "q10_rh",
+              "f_nppv", "f_nppd", "f_litterd"]
+BIOME_LINES = {
+    "boreal": dict(veg_c=100, detritus_c=15, soil_c=1200, permafrost_c=0, npp_flux0=5.0, beta=0.36,
+                   q10_rh=2.0, f_nppv=0.35, f_nppd=0.60, f_litterd=0.98),
+    "tropical": dict(veg_c=450, detritus_c=45, soil_c=578, permafrost_c=0, npp_flux0=45.0,
+                     beta=0.36, q10_rh=2.0, f_nppv=0.35, f_nppd=0.60, f_litterd=0.98),
+}
+
+
+def biome_pack(path, extra=()):
+    """The packaged scenario with the global pool/flux keys replaced by two biomes."""
+    out = []
+    for line in open(SCENARIO):
+        p = line.split()
+        if len(p) > 3 and p[0] == "scalar" and p[1] == "simpleNbox" and p[2] in BIOME_VARS:
+            continue
+        out.append(line)
+    for b, kv in BIOME_LINES.items():
+        for k, v in kv.items():
+            out.append("scalar simpleNbox %s.%s %r\n" % (b, k, float(v)))
+    for b, k, v in extra:
+        out.append("scalar simpleNbox %s.%s %r\n" % (b, k, float(v)))
+    open(path, "w").writelines(out)
+    return str(path)
+
+
+def oracle_params(oracle, wf=(1.0, 1.0)):
+    p = oracle.default_params()
+    p.nbiome = 2
+    for b, name in enumerate(["boreal", "tropical"]):
+        kv = BIOME_LINES[name]
+        p.veg_c[b] = kv["veg_c"]; p.detritus_c[b] = kv["detritus_c"]; p.soil_c[b] = kv["soil_c"]
+        p.permafrost_c[b] = kv["permafrost_c"]; p.npp_flux0[b] = kv["npp_flux0"]
+        p.beta[b] = kv["beta"]; p.q10_rh[b] = kv["q10_rh"]; p.f_nppv[b] = kv["f_nppv"]
+        p.f_nppd[b] = kv["f_nppd"]; p.f_litterd[b] = kv["f_litterd"]
+        p.warmingfactor[b] = wf[b]; p.rh_ch4_frac[b] = 0.023; p.pf_mu[b] = 1.67
+        p.pf_sigma[b] = 0.986; p.fpf_static[b] = 0.74
+    return p
+
+
+def biome_ini_checks(lib, oracle, tmp_path, **kw):
+    mk = lambda path, n=1: hector_amd.Core(path, n, lib_path=lib, **kw)
+    vars_ = ["CO2_concentration", "RF_tot", "global_tas"]
+    dflt = mk(SCENARIO); dflt.set_outputs(vars_); dflt.run(2300)
+    assert dflt.biomes() == ["global"]
+    bc = mk(biome_pack(tmp_path / "biome.hxs"))
+    assert bc.biomes() == ["boreal", "tropical"]
+    bc.set_outputs(vars_ + ["boreal.veg_c", "tropical.veg_c", "veg_c", "tropical.soil_c"]); bc.run(2300)
+    assert bc.status()[0] == 0
+    for v in vars_:                                     # the biome run differs from the default one
+        assert abs((dflt.fetchvars(v, (2000, 2100)) - bc.fetchvars(v, (2000, 2100))).sum()) > 0
+    assert bc.getvar("boreal.npp_flux0")[0] == 5.0 and bc.getvar("tropical.veg_c")[0] == 450.0
+    veg = bc.fetchvars("veg_c", (1745, 2300))[:, 0]
+    vb, vt = bc.fetchvars("boreal.veg_c", (1745, 2300))[:, 0], bc.fetchvars("tropical.veg_c", (1745, 2300))[:, 0]
+    # (every stash re-apportions the pool totals by each biome's NPP + RH share,
+    # simpleNbox-runtime.cpp:396-520, so the spun-up split is not the INI's 100 : 450)
+    assert np.allclose(vb + vt, veg, rtol=1e-13) and (vt > vb).all()
+    r, err, _ = oracle.run(oracle_params(oracle))
+    assert err == 0
+    for v in vars_:
+        ref = r[v]; got = bc.fetchvars(v, (1745, 2300))[:, 0]
+        assert np.abs(got - ref).max() < 2e-8 * max(1.0, np.abs(ref).max()), v
+    assert np.abs(veg - r["veg_c"]).max() < 2e-8 * r["veg_c"].max()
+    # warming factor tag
+    wc = mk(biome_pack(tmp_path / "warm.hxs", [("boreal", "warmingfactor", 2.5),
+                                                ("tropical", "warmingfactor", 1.0)]))
+    wc.set_outputs(vars_); wc.run(2300)
+    assert wc.fetchvars("global_tas", (2000, 2100)).mean() != dflt.fetchvars("global_tas", (2000, 2100)).mean()
+    r, err, _ = oracle.run(oracle_params(oracle, wf=(2.5, 1.0)))
+    assert np.abs(wc.fetchvars("global_tas", (1745, 2300))[:, 0] - r["global_tas"]).max() < 2e-8
+    # a biome with missing data is refused ("not same size")
+    with pytest.raises(hector_amd.HectorAmdError, match="not same size"):
+        mk(biome_pack(tmp_path / "extra.hxs", [("extra", "veg_c", 1.0)]))
+    with pytest.raises(hector_amd.HectorAmdError):
+        bc.fetchvars("nosuchbiome.veg_c", (2000, 2001))
+
+
+def test_biomes_from_ini_keys(emul_lib, oracle, tmp_path):
+    biome_ini_checks(emul_lib, oracle, tmp_path, allow_emulation=True)

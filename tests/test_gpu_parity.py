@@ -431,3 +431,9 @@ def test_per_member_emissions_on_gpu(hip_lib, tmp_path):
     """Per-member emission series (ex_hector_apply.Rmd pattern), 24 members vs the oracle."""
     from test_emulation_parity import per_member_emissions_vs_oracle
     per_member_emissions_vs_oracle(hip_lib, tmp_path, n=24, device=0)
+
+
+def test_biomes_from_ini_keys_on_gpu(hip_lib, oracle, tmp_path):
+    """test_biome.R 'multiple biomes created via INI file' + per-biome outputs, HIP library."""
+    from test_biomes_ini import biome_ini_checks
+    biome_ini_checks(hip_lib, oracle, tmp_path, device=0)
