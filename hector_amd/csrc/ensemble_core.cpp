@@ -17,6 +17,7 @@ hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, dou
 int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
+hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st);
 hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st);
 hipError_t hx_launch_slr(const double *tgav, int npad, int start_year, int iy_to, double *out,
                          size_t var_stride, hipStream_t st);
@@ -859,6 +860,7 @@ void EnsembleCore::prepare() {
   }
   check(hipEventRecord(ev0_, stream_), "event");
   check(hx_launch_spinup(B_, d_args_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
+  check(hx_launch_alk(d_args_, uniform ? 1 : npad_, stream_), "alkalinity tuning");
   if (uniform) {
     check(hx_launch_broadcast(d_state_, HX_NSTATE(B_), npad_, stream_), "broadcast state");
     check(hx_launch_broadcast_u32(d_status_, npad_, stream_), "broadcast status");

@@ -150,6 +150,106 @@ __device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
   return co2st * 1e6 / k.Kh;  // PCO2o, uatm
 }
 
+// The carbonate solve exactly as the reference iterates it: Fujiwara bound as the start
+// (find_largest_root, src/ocean_csys.cpp:134-156) and boost::math::tools::
+// newton_raphson_iterate (roots.hpp, Boost >= 1.71) with 31 bits, whose last step may be a
+// bracket-halving one -- its root is only good to ~1e-9 relative, and WHICH 1e-9 depends on the
+// iteration path.  The year-by-year solves do not care (chem_solve converges to the exact root),
+// but the alkalinity tuner compares objective values that differ by less than that, so it gets
+// the reference's own iteration.  Used ~120 times per member, once per run.
+__device__ __attribute__((noinline)) double chem_solve_ref(const ChemK &k, double carbon,
+                                                           double inv_vol, double alk,
+                                                           double &h_out, unsigned &status) {
+#pragma clang fp contract(off)
+  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
+  // convertToDIC returns umol/kg, ocean_csys_run divides by 1e6 again
+  const double dic = ((((carbon * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol)) * 1e6) / 1e6;
+  const double K1 = k.K1, K2 = k.K2, Kb = k.Kb, Kw = k.Kw;
+  const double a5 = -1.0;
+  const double a4 = -alk - Kb - K1;
+  const double a3 = dic * K1 - alk * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
+  double tmp = dic * (Kb * K1 + 2.0 * K1 * K2) - alk * (Kb * K1 + K1 * K2) + Kb * bor * K1;
+  const double a2 = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
+  tmp = 2.0 * dic * Kb * K1 * K2 - alk * Kb * K1 * K2 + Kb * bor * K1 * K2;
+  const double a1 = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
+  const double a0 = Kw * Kb * K1 * K2;
+  const double d0 = a1 * 1.0, d1 = a2 * 2.0, d2 = a3 * 3.0, d3 = a4 * 4.0, d4 = a5 * 5.0;
+  auto f_ = [&](double z) {
+    double s = a5;
+    s *= z; s += a4; s *= z; s += a3; s *= z; s += a2; s *= z; s += a1; s *= z; s += a0;
+    return s;
+  };
+  auto fp_ = [&](double z) {
+    double s = d4;
+    s *= z; s += d3; s *= z; s += d2; s *= z; s += d1; s *= z; s += d0;
+    return s;
+  };
+  auto sgn = [](double x) { return (double)((x > 0) - (x < 0)); };
+  double mx = pow(fabs(a0 / (2.0 * a5)), 1.0 / 5);
+  {
+    double m_;
+    m_ = pow(fabs(a1 / a5), 1.0 / 4.0); mx = (mx < m_) ? m_ : mx;
+    m_ = pow(fabs(a2 / a5), 1.0 / 3.0); mx = (mx < m_) ? m_ : mx;
+    m_ = pow(fabs(a3 / a5), 1.0 / 2.0); mx = (mx < m_) ? m_ : mx;
+    m_ = pow(fabs(a4 / a5), 1.0 / 1.0); mx = (mx < m_) ? m_ : mx;
+  }
+  mx *= 2.0;
+  double mn = 0.0, guess = mx - 0.001;
+  double f0 = 0, f1, last_f0 = 0, result = guess;
+  const double factor = 0x1p-30;  // ldexp(1, 1 - 31)
+  const double BIG = 1.7976931348623157e308;
+  double delta = BIG, delta1 = BIG, delta2 = BIG;
+  double max_range_f = 0, min_range_f = 0;
+  int count = 100000;
+  bool go = true;
+  while (go) {
+    last_f0 = f0;
+    delta2 = delta1;
+    delta1 = delta;
+    f0 = f_(result);
+    f1 = fp_(result);
+    --count;
+    if (0 == f0) break;
+    if (f1 == 0) {
+      if (last_f0 == 0) {
+        guess = (result == mn) ? mx : mn;
+        last_f0 = f_(guess);
+        delta = guess - result;
+      }
+      if (sgn(last_f0) * sgn(f0) < 0) delta = (delta < 0) ? (result - mn) / 2 : (result - mx) / 2;
+      else delta = (delta < 0) ? (result - mx) / 2 : (result - mn) / 2;
+    } else {
+      delta = f0 / f1;
+    }
+    if (fabs(delta * 2) > fabs(delta2)) {
+      const double shift = (delta > 0) ? (result - mn) / 2 : (result - mx) / 2;
+      if ((result != 0) && (fabs(shift) > fabs(result))) delta = sgn(delta) * fabs(result) * (double)1.1f;
+      else delta = shift;
+      delta1 = 3 * delta;
+      delta2 = 3 * delta;
+    }
+    guess = result;
+    result -= delta;
+    if (result <= mn) {
+      delta = 0.5 * (guess - mn);
+      result = guess - delta;
+      if ((result == mn) || (result == mx)) break;
+    } else if (result >= mx) {
+      delta = 0.5 * (guess - mx);
+      result = guess - delta;
+      if ((result == mn) || (result == mx)) break;
+    }
+    if (delta > 0) { mx = guess; max_range_f = f0; }
+    else { mn = guess; min_range_f = f0; }
+    if (max_range_f * min_range_f > 0) { status |= HX_ERR_ROOT; result = guess; break; }
+    go = count && (fabs(result * factor) < fabs(delta));
+  }
+  const double h = result;
+  h_out = h;
+  const double co2st = dic / (1.0 + K1 / h + K1 * K2 / h / h);
+  return co2st * 1e6 / k.Kh;
+}
+
 // Both surface boxes at once.  Same formulas as chem_constants / chem_solve; the two
 // boxes are independent, so writing them side by side gives the single resident
 // wavefront two dependency chains to interleave, and the seven divisions by Tk
@@ -884,7 +984,7 @@ __device__ __forceinline__ double equilibrate_alk(const ChemK &k, double carbon,
   // the decision logic exactly the reference's: no FMA contraction in here.
 #pragma clang fp contract(off)
   auto fmin_ = [&](double alk) {
-    const double p = chem_solve(k, carbon, inv_vol, alk, h, status);
+    const double p = chem_solve_ref(k, carbon, inv_vol, alk, h, status);
     return fabs(surf_flux(co2, p, 1.0, k.Tr, As) - f_target);
   };
   const double tolerance = 0x1p-25;  // bits = min(53/2, 31) = 26
@@ -1526,11 +1626,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       // ---- ocean: new year ----
       chem_constants2(sst + 18 + (-16.4), sst + 18 + 2.9, m.kH, m.kL);
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
-      if (m.alkH == 0.0) {  // first year after spinup: turn the chemistry on
-        const double co2 = m.atmos * PGC2PPM;
-        m.alkH = equilibrate_alk(m.kH, m.cHL, 1.0 / O_vHL, O_AsHL, co2, 1.000, m.hH, m.status);
-        m.alkL = equilibrate_alk(m.kL, m.cLL, 1.0 / O_vLL, O_AsLL, co2, -1.000, m.hL, m.status);
-      }
+      // (the alkalinities were tuned once, right after the spinup: hx_alk_kernel)
       chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
                   m.status);
       m.chem_fresh = true;
@@ -1905,6 +2001,31 @@ __global__ __launch_bounds__(256) void hx_doeclim_table_kernel(const double *dif
 }
 
 // ===========================================================================
+// oceanbox::chem_equilibrate for both surface boxes (src/oceanbox.cpp:382-445,
+// ocean_component.cpp:392-400): the first post-spinup ocean.run() turns the chemistry on and
+// tunes each box's alkalinity so that it reproduces the spinup flux at the spun-up CO2.  Its
+// inputs are all spinup results (box carbon, atmosphere, SST = 0), so it runs once, directly
+// after the spinup kernel, and the run kernel finds the alkalinities in the state table.
+// ===========================================================================
+__global__ __launch_bounds__(64) void hx_alk_kernel(const HxArgs *__restrict__ args, int nmem) {
+  const int mem = blockIdx.x * 64 + threadIdx.x;
+  if (mem >= nmem) return;
+  const HxBuffers &buf = args->buf;
+  const double cHL = lds_(buf, HXS_C_HL, mem), cLL = lds_(buf, HXS_C_LL, mem);
+  const double co2 = lds_(buf, HXS_ATMOS, mem) * PGC2PPM;
+  const double sst = lds_(buf, HXS_SST, mem);
+  unsigned status = HX_GU(buf.status)[mem];
+  ChemK kH, kL;
+  chem_constants2(sst + 18 + (-16.4), sst + 18 + 2.9, kH, kL);
+  double hH = 0, hL = 0;
+  const double alkH = equilibrate_alk(kH, cHL, 1.0 / O_vHL, O_AsHL, co2, 1.000, hH, status);
+  const double alkL = equilibrate_alk(kL, cLL, 1.0 / O_vLL, O_AsLL, co2, -1.000, hL, status);
+  sts_(buf, HXS_ALK_HL, mem, alkH); sts_(buf, HXS_ALK_LL, mem, alkL);
+  sts_(buf, HXS_H_HL, mem, hH); sts_(buf, HXS_H_LL, mem, hL);
+  HX_GU(buf.status)[mem] = status;
+}
+
+// ===========================================================================
 // Diagnostics derived from recorded outputs, one (year, member) element per thread.
 // The reference keeps them as members of the carbonate-chemistry object of the last solve
 // (ocean_csys.cpp:328-366) or recomputes them on request (ocean_component.cpp:440-512);
@@ -2051,6 +2172,12 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
     case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) {
+  hipLaunchKernelGGL(hx_alk_kernel, dim3((nmem_launch + 63) / 64), dim3(64), 0, st, d_args,
+                     nmem_launch);
   return hipGetLastError();
 }
 
