@@ -783,7 +783,18 @@ void EnsembleCore::assign_lanes() {
     const std::vector<double> &p = params_[varying[0]];
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p[a] < p[b]; });
     if (varying.size() > 1) {
-      const std::vector<double> &q = params_[varying[1]];
+      // second key: the second perturbed parameter, or -- with more than two -- the sum of
+      // the standardised remaining ones (per-biome Q10s and warming factors act together)
+      std::vector<double> q((size_t)n_, 0.0);
+      for (size_t k = 1; k < varying.size(); ++k) {
+        const std::vector<double> &r = params_[varying[k]];
+        double mean = 0, var = 0;
+        for (int i = 0; i < n_; ++i) mean += r[(size_t)i];
+        mean /= n_;
+        for (int i = 0; i < n_; ++i) var += (r[(size_t)i] - mean) * (r[(size_t)i] - mean);
+        const double sd = std::sqrt(var / n_);
+        if (sd > 0) for (int i = 0; i < n_; ++i) q[(size_t)i] += (r[(size_t)i] - mean) / sd;
+      }
       int nbins = (int)std::lround(std::sqrt((double)n_ / HX_WAVE));
       nbins = std::max(1, nbins);
       const int per = (n_ + nbins - 1) / nbins;
