@@ -1935,11 +1935,36 @@ __global__ __launch_bounds__(256) void hx_stats_kernel(const double *var, int n,
                                                        int iy0, double *stats) {
   const int iy = iy0 + blockIdx.x;
   const double *row = var + (size_t)iy * npad;
-  double s = 0, s2 = 0, mn = INFINITY, mx = -INFINITY, cnt = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double v = row[i];
-    s += v; s2 += v * v; mn = fmin(mn, v); mx = fmax(mx, v); cnt += 1;
+  // pure streaming: four 16-byte loads in flight per lane (rows are 512-byte aligned: npad is a
+  // multiple of 64), four independent accumulator sets
+  double sa[4] = {0, 0, 0, 0}, qa[4] = {0, 0, 0, 0};
+  double mn = INFINITY, mx = -INFINITY;
+  const int n2 = n >> 1;                       // number of double2 elements
+  const double2 *row2 = reinterpret_cast<const double2 *>(row);
+  int i = threadIdx.x;
+  for (; i + 3 * (int)blockDim.x < n2; i += 4 * blockDim.x) {
+    double2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = row2[i + k * (int)blockDim.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sa[k] += v[k].x + v[k].y;
+      qa[k] += v[k].x * v[k].x + v[k].y * v[k].y;
+      mn = fmin(mn, fmin(v[k].x, v[k].y));
+      mx = fmax(mx, fmax(v[k].x, v[k].y));
+    }
   }
+  for (; i < n2; i += blockDim.x) {
+    const double2 v = row2[i];
+    sa[0] += v.x + v.y; qa[0] += v.x * v.x + v.y * v.y;
+    mn = fmin(mn, fmin(v.x, v.y)); mx = fmax(mx, fmax(v.x, v.y));
+  }
+  if ((n & 1) && threadIdx.x == 0) {
+    const double v = row[n - 1];
+    sa[0] += v; qa[0] += v * v; mn = fmin(mn, v); mx = fmax(mx, v);
+  }
+  double s = (sa[0] + sa[1]) + (sa[2] + sa[3]), s2 = (qa[0] + qa[1]) + (qa[2] + qa[3]);
+  double cnt = (threadIdx.x == 0) ? (double)n : 0.0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s += __shfl_down(s, off, 64); s2 += __shfl_down(s2, off, 64);
