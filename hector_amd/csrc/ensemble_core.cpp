@@ -382,12 +382,14 @@ void EnsembleCore::build_shared() {
   const double M0f_old = k.M0f;
   k.M0f = has(ch4_con, 0) ? ch4_con[0] : k.M0;
   k.sqrtM0 = std::sqrt(k.M0f);
+  k.inv_h2o_span = 1.0 / (1831 - k.M0f);
   if (k.M0f != M0f_old) need_spinup_ = true;  // the post-spinup state holds CH4(startDate)
   k.con_mask = (any(co2_con) ? HXC_CO2 : 0) | (any(nbp_con) ? HXC_NBP : 0) |
                (any(tas_con) ? HXC_TAS : 0) | (any(ftot_con) ? HXC_FTOT : 0) |
                (any(ch4_con) ? HXC_CH4 : 0);
   k.Tsoil = s.scalar("CH4", "Tsoil"); k.Tstrat = s.scalar("CH4", "Tstrat");
   k.UC_CH4 = s.scalar("CH4", "UC_CH4");
+  k.inv_UC_CH4 = 1.0 / k.UC_CH4; k.inv_Tsoil = 1.0 / k.Tsoil; k.inv_Tstrat = 1.0 / k.Tstrat;
   k.TOH0 = s.scalar("OH", "TOH0"); k.CCH4 = s.scalar("OH", "CCH4");
   k.N0 = N0f; k.sqrtN0 = std::sqrt(N0f);
   k.delta_co2 = s.scalar("forcing", "delta_co2"); k.delta_ch4 = s.scalar("forcing", "delta_ch4");

@@ -62,6 +62,25 @@ constexpr double O_vD = O_area * (3777.0 - 900.0 - 100.0);
 constexpr double O_AsHL = O_area * O_part_high, O_AsLL = O_area * O_part_low;
 constexpr double O_S = 34.5, O_U = 6.7;
 
+// Division where the last bit does not matter.  clang expands an IEEE fp64 division into 11
+// dependent VALU instructions (div_scale x2, rcp, 4 fma, mul, fma, div_fmas, div_fixup); with
+// one wavefront per SIMD that chain is fully exposed.  v_rcp_f64 is good to 4.6e-8 (measured
+// on gfx950); one Newton step brings it to 2e-15, two to 1.1e-16 (<= 1 ulp), for normal-range
+// operands, which is what the model has.  ~65 divisions per member-year.
+__device__ __forceinline__ double hx_recip(double b) {
+  double r = HX_RCP(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double hx_div(double a, double b) { return a * hx_recip(b); }
+// 2e-15: enough for a Newton correction, whose own error is squared away by the next iteration
+__device__ __forceinline__ double hx_div1(double a, double b) {
+  double r = HX_RCP(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return a * r;
+}
+
 struct ChemK {  // T-dependent equilibrium constants of one surface box
   double K1, K2, Kb, Kw, Kh, Tr;
   double g;  // Tr * As * 12 / 1e15: annual flux per uatm of air-sea pCO2 difference
@@ -333,7 +352,7 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
           done[b] = true;
         } else {
           if (f > 0) lo[b] = x; else hi[b] = x;
-          double delta = f / fp;
+          double delta = hx_div1(f, fp);
           double hn = x - delta;
           if (!(hn > lo[b] && hn < hi[b])) {  // left the bracket (or fp == 0): bisect
             hn = 0.5 * (lo[b] + hi[b]);
@@ -352,8 +371,8 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
   for (int b = 0; b < 2; ++b) {
     // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
     const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
-    const double co2st = (dic[b] * (x * x)) / ((x * x + K1 * x) + K1 * K2);
-    pc[b] = co2st * 1e6 / k[b]->Kh;
+    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
+    pc[b] = hx_div(co2st * 1e6, k[b]->Kh);
   }
   pco2H = pc[0]; pco2L = pc[1];
 }
@@ -491,7 +510,7 @@ template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &
          (1.0 - k.rh_ch4_frac[b]);  // :689-701
 }
 template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, const LandK<B> &k, int b) {
-  return m_rh_tp_co2(m, k, b) / (1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
+  return hx_div(m_rh_tp_co2(m, k, b), 1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
 }
 
 // constraints of one model year, as the solver and the stash see them (CON kernels only)
@@ -521,7 +540,7 @@ __device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F
   K.k7 = -m.ffi + m.daccs;
   K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
   K.surf = m.cLL + m.cHL;
-  K.inv_surf = 1.0 / K.surf;
+  K.inv_surf = hx_recip(K.surf);
 }
 
 // NBP constraint inside calcderivs: NPP and RH moved by +-diff/2, their parts scaled
@@ -614,7 +633,7 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, cons
   const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
   if constexpr (CON) d[5] = K.k5;
   const double total = y[1] + y[2] + y[3];
-  const double r = m.luc_e / total;
+  const double r = hx_div(m.luc_e, total);
   double ao;
   if (SPIN) {
     ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
@@ -673,7 +692,8 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   if (currentflux != 0.0) adj = (solver_flux - currentflux) / 2.0;
   aH += adj;
   aL += adj;
-  const double cdiff = solver_flux / yf - m.lastflux_ann;
+  const double inv_yf = hx_recip(yf);
+  const double cdiff = solver_flux * inv_yf - m.lastflux_ann;
   if (cdiff > 0.1) {  // ocean_component.cpp:703-733
     m.max_ts = fmax(0.3, m.max_ts * 0.5);
     m.ts_timeout = 20;
@@ -698,7 +718,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   }
   const double lastflux = aL + aH;
   m.annualflux_sum += lastflux;
-  m.lastflux_ann = lastflux / yf;
+  m.lastflux_ann = lastflux * inv_yf;
   // update_state: carbon + additions + ao - oa - subtractions (oceanbox.cpp:297-303)
   m.cHL = ((m.cHL + (lLH + lIH)) + aH) - lHD;
   m.cLL = ((m.cLL + lIL) + aL) - (lLH + lLI);
@@ -747,9 +767,9 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   double fin_npp = 0, fin_rh = 0, fin_det = 0, fin_soil = 0;
 
   const double total = y[1] + y[2] + y[3];
-  m.cum_luc_va += ((m.luc_e - m.luc_u) * y[1]) / total;  // no yf: :388-393
-  const double inv_nr = 1.0 / npp_rh;
-  const double inv_pf = (pf_t > 0) ? 1.0 / pf_t : 0.0;
+  m.cum_luc_va += hx_div((m.luc_e - m.luc_u) * y[1], total);  // no yf: :388-393
+  const double inv_nr = hx_recip(npp_rh);
+  const double inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const double wt = (B == 1) ? 1.0
@@ -940,7 +960,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
             if (n * ed > en * d) { en = n; ed = d; }
           }
-          double err = en / ed;
+          double err = hx_div(en, ed);
           if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
             dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
             if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
@@ -1610,9 +1630,9 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
             ch4_em = HX_GCD(buf.mseries[HXM_CH4_EM])[(size_t)iy * buf.npad + mem];
         }
         const double emisTocon =
-            ((ch4_em + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) / kc.UC_CH4;
-        const double dCH4 = ((emisTocon - prev_ch4 / kc.Tsoil) - prev_ch4 / kc.Tstrat) -
-                            prev_ch4 / tau_oh;
+            ((ch4_em + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) * kc.inv_UC_CH4;
+        const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
+                            hx_div(prev_ch4, tau_oh);
         ch4 = prev_ch4 + dCH4;
       }
       if constexpr (CON) {  // ch4_component.cpp:156-157
@@ -1640,8 +1660,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         if (buf.mseries[HXM_LUC_E]) m.luc_e = HX_GCD(buf.mseries[HXM_LUC_E])[o];
         if (buf.mseries[HXM_LUC_U]) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
       }
-      m.npp_luc_adjust = (eos - m.cum_luc_va) / eos;
-      const double lnc = log((m.atmos * PGC2PPM) / m.C0);
+      m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
+      const double lnc = log(hx_div(m.atmos * PGC2PPM, m.C0));
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
       // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
       if (iy >= 3) {
@@ -1653,19 +1673,19 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       for (int b = 0; b < B; ++b) {
         m.co2fert[b] = 1 + p_beta[b] * lnc;
         const double Tb = tland * p_wf[b];
-        m.tempfertd[b] = exp(p_lnq10[b] * (Tb / 10.0));
+        m.tempfertd[b] = exp(p_lnq10[b] * (Tb * 0.1));
         m.f_new_thaw[b] = 0.0;
         if (m.pf[b] != 0.0) {
           double ff = 1.0;
           if (Tb > 0) {
-            const double d = (log(Tb) - p_mu[b]) / (p_sigma[b] * 1.4142135623730951);
+            const double d = hx_div(log(Tb) - p_mu[b], p_sigma[b] * 1.4142135623730951);
             ff = 1 - erfc(-d) / 2;
           }
           m.f_new_thaw[b] = s_ffrozen[b] - ff;
           PKM(m, PK_FFROZEN0 + b) = ff;
         }
-        const double Trm = (iy > 1) ? (twin * p_wf[b]) / 200 : 0.0;
-        const double tfs = exp(p_lnq10[b] * (Trm / 10.0));
+        const double Trm = (iy > 1) ? (twin * p_wf[b]) * 0.005 : 0.0;
+        const double tfs = exp(p_lnq10[b] * (Trm * 0.1));
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
         m.tempferts[b] = fmax(tfs, last);  // sticky :1054-1059
       }
@@ -1729,13 +1749,13 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         else if (m.C0 < co2c && co2c < C_alpha_max)
           alpha_prime = d1 + a1 * ((co2c - m.C0) * (co2c - m.C0)) + b1 * (co2c - m.C0);
         else alpha_prime = d1;
-        const double sarf_co2 = (alpha_prime + c1 * sqN) * log(co2c / m.C0);
+        const double sarf_co2 = (alpha_prime + c1 * sqN) * log(hx_div(co2c, m.C0));
         const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
         const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - kc.sqrtN0);
         const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
         const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
         const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
-        const double fh2o = 0.0485 * ((ch4 - kc.M0f) / (1831 - kc.M0f));
+        const double fh2o = 0.0485 * ((ch4 - kc.M0f) * kc.inv_h2o_span);
         const double fo3 = 0.042 * o3;
         double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
                        p_aero * sh[HXSH_RF_AERO]) +

@@ -126,6 +126,7 @@ struct HxConst {
   double eps_abs, eps_rel, dt0, eps_spinup;
   double M0, lnM0, Tsoil, Tstrat, UC_CH4, TOH0, CCH4;  // M0: the INI value (OH component)
   double M0f, sqrtM0;  // preindustrial CH4 as the forcing sees it (CH4 constraint at startDate)
+  double inv_UC_CH4, inv_Tsoil, inv_Tstrat, inv_h2o_span;  // reciprocals of uniform divisors
   int con_mask;        // HXC_* bits: which constraint columns hold values
   double N0, sqrtN0;
   double delta_co2, delta_ch4, delta_n2o;

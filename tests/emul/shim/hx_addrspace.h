@@ -10,3 +10,4 @@ typedef const double *hx_ccd;
 #define HX_GCD(p) ((hx_gcd)(p))
 #define HX_GD(p) ((hx_gd)(p))
 #define HX_GU(p) ((hx_gu)(p))
+#define HX_RCP(x) (1.0 / (x))
