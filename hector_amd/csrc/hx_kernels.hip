@@ -283,7 +283,7 @@ __device__ __forceinline__ void chem_constants2(double TcH, double TcL, ChemK &k
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const double Tk = Tc[b] + 273.15;
-    const double rTk = 1.0 / Tk;
+    const double rTk = hx_recip(Tk);
     const double T100 = Tk * 0.01;
     const double lnTk = log(Tk);
     const double lnTk100 = lnTk - 4.605170185988092;  // ln(Tk/100)
@@ -398,6 +398,8 @@ __device__ __forceinline__ double surf_flux(double co2, double pco2, double scal
 enum HxPark {
   PK_CH4 = 0, PK_SST, PK_EOS, PK_TLAND, PK_TWIN, PK_TL_M1, PK_TL_M2, PK_F_PREV,
   PK_BASE_TOT, PK_BASE_CO2,            // <- year-level state (HBM state rows)
+  PK_LN_CH4, PK_LN_CO2R,               // ln CH4 and ln(CO2/C0) of the year just finished: the
+                                       // next year needs exactly these logarithms again
   PK_AERO, PK_VOL,
   PK_D0,                               // 14 DOECLIM constants HXD_A0..HXD_HFSCALE
   PK_K0 = PK_D0 + 14,                  // 7 ocean exchange coefficients HXD_KLH..HXD_KDI
@@ -1541,6 +1543,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     PKM(m, PK_TL_M2) = lds_(buf, HXS_TL_M2, mem); PKM(m, PK_F_PREV) = lds_(buf, HXS_F_PREV, mem);
     PKM(m, PK_BASE_TOT) = lds_(buf, HXS_BASE_TOT, mem);
     PKM(m, PK_BASE_CO2) = lds_(buf, HXS_BASE_CO2, mem);
+    PKM(m, PK_LN_CH4) = log(lds_(buf, HXS_CH4, mem));
+    PKM(m, PK_LN_CO2R) = log(hx_div(m.atmos * PGC2PPM, m.C0));
 #pragma unroll
     for (int b = 0; b < B; ++b)
       PKM(m, PK_FFROZEN0 + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
@@ -1611,7 +1615,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       double toh = 0.0;
       if (prev_ch4 != kc.M0)
-        toh = ((kc.CCH4 * (log(prev_ch4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
+        toh = ((kc.CCH4 * (PKM(m, PK_LN_CH4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
               sh[HXSH_OH_D];
       const double tau_oh = kc.TOH0 * exp(-toh);
       if constexpr (CON) {
@@ -1642,7 +1646,9 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         }
       }
       PKM(m, PK_CH4) = ch4;
-      o3 = ((5 * log(ch4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
+      const double ln_ch4 = log(ch4);
+      PKM(m, PK_LN_CH4) = ln_ch4;
+      o3 = ((5 * ln_ch4 + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
       // ---- ocean: new year ----
       chem_constants2(sst + 18 + (-16.4), sst + 18 + 2.9, m.kH, m.kL);
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
@@ -1661,7 +1667,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         if (buf.mseries[HXM_LUC_U]) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
       }
       m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
-      const double lnc = log(hx_div(m.atmos * PGC2PPM, m.C0));
+      const double lnc = PKM(m, PK_LN_CO2R);  // = log((atmos C * PGC2PPM) / C0), from last year's phase C
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
       // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
       if (iy >= 3) {
@@ -1737,6 +1743,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
       // ---- forcing ----
       const double co2c = m.atmos * PGC2PPM;
+      const double ln_co2r = log(hx_div(co2c, m.C0));
+      PKM(m, PK_LN_CO2R) = ln_co2r;
       double rf_tot = 0, rf_co2 = 0;
       if (iy >= kc.baseyear_idx) {
         const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
@@ -1749,7 +1757,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         else if (m.C0 < co2c && co2c < C_alpha_max)
           alpha_prime = d1 + a1 * ((co2c - m.C0) * (co2c - m.C0)) + b1 * (co2c - m.C0);
         else alpha_prime = d1;
-        const double sarf_co2 = (alpha_prime + c1 * sqN) * log(hx_div(co2c, m.C0));
+        const double sarf_co2 = (alpha_prime + c1 * sqN) * ln_co2r;
         const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
         const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - kc.sqrtN0);
         const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
