@@ -337,6 +337,8 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
     p0[b] = Kw * Kb * K1 * K2;
   }
   const double factor = 0x1p-30;
+  const double q4[2] = {4.0 * p4[0], 4.0 * p4[1]}, q3[2] = {3.0 * p3[0], 3.0 * p3[1]},
+               q2[2] = {2.0 * p2[0], 2.0 * p2[1]};
   for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -345,7 +347,7 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
       f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
       f = f * x + p0[b];
       double fp = -5.0;
-      fp = fp * x + 4.0 * p4[b]; fp = fp * x + 3.0 * p3[b]; fp = fp * x + 2.0 * p2[b];
+      fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
       fp = fp * x + p1[b];
       if (!done[b]) {
         if (f == 0.0) {
@@ -635,7 +637,7 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, cons
   const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
   if constexpr (CON) d[5] = K.k5;
   const double total = y[1] + y[2] + y[3];
-  const double r = hx_div(m.luc_e, total);
+  const double r = hx_div1(m.luc_e, total);  // 2e-15 on a term that is itself ~1e-3 of the flux
   double ao;
   if (SPIN) {
     ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
