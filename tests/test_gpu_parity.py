@@ -2,7 +2,7 @@
 the C ABI) against the CPU oracle on seeded ensembles, against the reference's
 golden trajectory, and -- at BASELINE.json's full sizes -- through size-independent
 properties.  Tolerances as in test_emulation_parity.py (the north star asks for
-1e-6 relative on CO2 and Tgav; we hold 2e-8 -- measured on 2 048 members: max 5.5e-9,
+1e-6 relative on CO2 and Tgav; we hold 2e-8 -- measured on 2 048 members: max 3.3e-9,
 median 6e-11.  That level is only reachable because the alkalinity tuner's decision logic
 is compiled without FMA contraction: Brent's resolution is 3e-6 of the alkalinity
 (oceanbox.cpp:382-445, tol/4 absolute), so a different branch path moves CO2 by ~3e-6)."""
