@@ -222,8 +222,6 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   }
   if (s.scalar("ocean", "spinup_chem", 0) != 0)
     throw std::runtime_error("ocean.spinup_chem=1 is not supported by the GPU path");
-  if (s.scalar("core", "do_spinup", 1) == 0)
-    throw std::runtime_error("core.do_spinup=0 is not supported by the GPU path");
   build_shared();
 }
 
@@ -373,6 +371,7 @@ void EnsembleCore::build_shared() {
   k.start_year = s.start; k.ns = ns;
   k.baseyear_idx = (int)s.scalar("forcing", "baseyear", 1750) - s.start;
   k.max_spinup = (int)s.scalar("core", "max_spinup", 2000);
+  if (s.scalar("core", "do_spinup", 1) == 0) k.max_spinup = 1;  // core.cpp:378-384: no spinup steps
   k.spinup_chem = 0;
   k.eps_abs = s.scalar("carbon-cycle-solver", "eps_abs", 1e-6);
   k.eps_rel = s.scalar("carbon-cycle-solver", "eps_rel", 1e-6);

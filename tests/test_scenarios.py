@@ -80,3 +80,18 @@ def test_luc_pulse_like_reference_test(emul_lib, oracle):
     luc = c.fetchvars("luc_emissions", (1745, 1850))[:, 0]
     assert luc[1800 - 1745] > 0 and np.count_nonzero(luc) == 1
     assert abs((v[1799 - 1745] - v[1801 - 1745])) > 0.01     # the pulse did hit the pool
+
+
+def test_do_spinup_0(emul_lib, tmp_path):
+    """[core] do_spinup=0 (core.cpp:378-384): the run starts from the INI pools as they are."""
+    from conftest import edited_pack, SCENARIO
+    import oracle_binding
+    path = edited_pack(tmp_path / "nospin.hxs", None, None, [], [], scalars={("core", "do_spinup"): 0})
+    c = check_scenario_vs_oracle(emul_lib, path, np.array([3.0, 4.2]), np.array([2.0, 2.6]),
+                                 allow_emulation=True)
+    assert c.spinup_steps(0) == 0
+    d = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    d.set_outputs(["CO2_concentration"]); d.run(1800)
+    c.set_outputs(["CO2_concentration"]); c.run(1800)
+    assert abs(c.fetchvars("CO2_concentration", (1800, 1800))[0, 0] -
+               d.fetchvars("CO2_concentration", (1800, 1800))[0, 0]) > 1e-3     # it matters
