@@ -4,6 +4,6 @@ hector_amd/csrc; this package only binds them."""
 from ._lib import HectorAmdError, DEFAULT_SCENARIO, DEFAULT_LIB  # noqa: F401
 from .core import (Core, newcore, run, reset, shutdown, setvar, fetchvars,  # noqa: F401
                    split_biome)
-from . import core as capabilities  # noqa: F401
+from . import capabilities  # noqa: F401
 
 __version__ = "0.1.0"

@@ -484,8 +484,52 @@ static const ParamDef &def_of(const std::string &capability) {
   throw std::runtime_error("Unknown variable name while parsing: " + capability);
 }
 
+namespace {
+// Parameters of the member-independent components (forcing efficiencies, CH4/N2O/O3
+// preindustrial values and lifetimes, halocarbon rho/delta/tau): one value for the whole core.
+struct SharedParamDef { const char *name, *section, *units; };
+const SharedParamDef kSharedParams[] = {
+    {"M0", "CH4", "ppbv CH4"}, {"Tsoil", "CH4", "Years"}, {"Tstrat", "CH4", "Years"},
+    {"N0", "N2O", "ppbv N2O"}, {"PO3", "ozone", "DU O3"}, {"TOH0", "OH", "Years"},
+    {"delta_co2", "forcing", "(unitless)"}, {"delta_ch4", "forcing", "(unitless)"},
+    {"delta_n2o", "forcing", "(unitless)"}, {"rho_bc", "forcing", "W/m2/Tg"},
+    {"rho_oc", "forcing", "W/m2/Tg"}, {"rho_so2", "forcing", "W/m2/Gg"},
+    {"rho_nh3", "forcing", "W/m2/Tg"},
+};
+}  // namespace
+
+// -> section of a shared scalar parameter ("" if `capability` is not one); *units gets its unit
+static std::string shared_param_section(const Scenario &scen, const std::string &capability,
+                                        std::string *units) {
+  for (const SharedParamDef &d : kSharedParams)
+    if (capability == d.name) { if (units) *units = d.units; return d.section; }
+  for (const Halocarbon &h : scen.halocarbons) {
+    if (capability == "rho_" + h.name) { if (units) *units = "W/m2/pptv"; return h.name + "_halocarbon"; }
+    if (capability == "delta_" + h.name) { if (units) *units = "(unitless)"; return h.name + "_halocarbon"; }
+  }
+  return "";
+}
+
 void EnsembleCore::setvar(const std::string &capability, const double *values, int nvalues,
                           const char *units) {
+  {
+    std::string expect;
+    const std::string sec = shared_param_section(scen_, capability, &expect);
+    if (!sec.empty()) {
+      if (units && units[0] && expect != units)
+        throw std::runtime_error("Units: " + std::string(units) + " do not match expected: " +
+                                 expect + " for " + capability);
+      for (int i = 1; i < nvalues; ++i)
+        if (values[i] != values[0])
+          throw std::runtime_error(capability + " belongs to a member-independent component: one "
+                                   "value for the whole core");
+      scen_.set_scalar(sec, capability, values[0]);
+      shared_dirty_ = true;
+      last_iy_ = 0;
+      need_spinup_ = true;
+      return;
+    }
+  }
   const int row = resolve_param(capability, nullptr);
   const ParamDef &d = def_of(capability);
   if (units && units[0] && std::string(units) != d.units)
@@ -514,6 +558,13 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
 }
 
 void EnsembleCore::getvar(const std::string &capability, double *out) const {
+  {
+    const std::string sec = shared_param_section(scen_, capability, nullptr);
+    if (!sec.empty()) {
+      std::fill(out, out + n_, scen_.scalar(sec, capability));
+      return;
+    }
+  }
   const int row = resolve_param(capability, nullptr);
   std::memcpy(out, params_[row].data(), sizeof(double) * (size_t)n_);
 }
@@ -592,6 +643,15 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
       continue;
     }
     if (host_output(c)) continue;  // answered from the scenario / the shared gas cycles
+    if (c == "pH" || c == "PCO2" || c == "DIC" || c == "CO3" || c == "ML_ocean_c") {
+      const std::string base = c == "ML_ocean_c" ? "ocean_c" : c;
+      for (const char *box : {"LL_", "HL_"}) {
+        const std::string part = box + base;
+        if (const DerivedDef *d = derived_of(part)) { for (const char *dep : d->deps) if (dep) want[out_index(dep)] = true; }
+        else want[out_index(part)] = true;
+      }
+      continue;
+    }
     want[out_index(c)] = true;
   }
   bool changed = false;
@@ -976,8 +1036,12 @@ void EnsembleCore::sync() {
 // (N2O, halocarbons: run while the per-year table is built) and the forcings that are a
 // member's scalar times a shared series.  Returns false if `capability` is not one of them;
 // with out_host == nullptr only answers the question.
-bool EnsembleCore::fetch_host(const std::string &capability, int year0, int year1,
+bool EnsembleCore::fetch_host(const std::string &capability_in, int year0, int year1,
                               double *out_host) {
+  // the R accessors RF_CF4() ... return "Fadj<gas>", which the forcing component maps to
+  // "RF_<gas>" (forcing_component.cpp:56-75, 577-583)
+  const std::string capability = capability_in.compare(0, 4, "Fadj") == 0
+                                     ? "RF_" + capability_in.substr(4) : capability_in;
   const int ns = scen_.ns();
   std::vector<double> ser;          // member-independent series [ns]
   const std::vector<double> *scale = nullptr;  // per-member factor (parameter row)
@@ -1134,6 +1198,23 @@ void EnsembleCore::compute_derived(const std::string &capability, int iy0, int n
 void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
                              double *out_host) {
   if (fetch_host(capability, year0, year1, out_host)) return;
+  {  // whole-surface values: area-weighted low/high latitude (ocean_component.cpp:466-503)
+    static const char *const combos[][3] = {{"pH", "LL_pH", "HL_pH"}, {"PCO2", "LL_PCO2", "HL_PCO2"},
+                                            {"DIC", "LL_DIC", "HL_DIC"}, {"CO3", "LL_CO3", "HL_CO3"},
+                                            {"ML_ocean_c", "LL_ocean_c", "HL_ocean_c"}};
+    for (auto &c : combos)
+      if (capability == c[0]) {
+        const size_t cnt = (size_t)(year1 - year0 + 1) * (size_t)n_;
+        std::vector<double> hl(cnt);
+        fetchvars(c[1], year0, year1, out_host);
+        fetchvars(c[2], year0, year1, hl.data());
+        const bool sum = capability == "ML_ocean_c";
+        const double part_high = 0.15, part_low = 1 - 0.15;
+        for (size_t i = 0; i < cnt; ++i)
+          out_host[i] = sum ? out_host[i] + hl[i] : part_low * out_host[i] + part_high * hl[i];
+        return;
+      }
+  }
   const DerivedDef *dd = derived_of(capability);
   const int v = dd ? -1 : out_index(capability);
   if (!dd && !d_out_[v])

@@ -13,6 +13,7 @@
 #include "hx_scenario.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -123,6 +124,19 @@ std::vector<std::string> Scenario::scalar_keys(const std::string &section) const
   for (auto &kv : scalars_)
     if (kv.first.compare(0, pre.size(), pre) == 0) out.push_back(kv.first.substr(pre.size()));
   return out;
+}
+void Scenario::set_scalar(const std::string &section, const std::string &key, double v) {
+  char buf[40];
+  std::snprintf(buf, sizeof buf, "%.17g", v);
+  scalars_[section + "." + key] = buf;
+  for (auto &h : halocarbons)
+    if (section == h.name + "_halocarbon") {
+      if (key == "tau") h.tau = v;
+      else if (key == "rho_" + h.name) h.rho = v;
+      else if (key == "delta_" + h.name) h.delta = v;
+      else if (key == "H0") h.H0 = v;
+      else if (key == "molarMass") h.molarMass = v;
+    }
 }
 bool Scenario::has_scalar(const std::string &section, const std::string &key) const {
   return scalars_.count(section + "." + key) != 0;

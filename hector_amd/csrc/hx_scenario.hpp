@@ -28,6 +28,7 @@ class Scenario {
   double scalar(const std::string &section, const std::string &key, double dflt) const;
   bool has_scalar(const std::string &section, const std::string &key) const;
   std::vector<std::string> scalar_keys(const std::string &section) const;
+  void set_scalar(const std::string &section, const std::string &key, double v);
   std::string text(const std::string &section, const std::string &key,
                    const std::string &dflt) const;  // a non-numeric INI value (run_name)
   const std::vector<double> &series(const std::string &section,

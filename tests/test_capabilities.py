@@ -1,0 +1,63 @@
+"""The R package's capability accessors (src/rcpp_constants.cpp: ECS(), RF_CF4(), PH() ...) as
+hector_amd.capabilities, and what they address: aliases, whole-surface ocean values, and the
+parameters of the member-independent components (one value per core)."""
+import numpy as np
+import pytest
+
+import hector_amd
+from hector_amd import capabilities as cap
+from conftest import SCENARIO, edited_pack
+
+
+def test_capability_table_is_complete():
+    assert len(cap.__all__) == 256
+    assert cap.ECS() == "S" and cap.GLOBAL_TAS() == "global_tas" and cap.RF_TOTAL() == "RF_tot"
+    assert cap.BETA() == "beta" and cap.BETA("boreal") == "boreal.beta"
+    assert cap.EMISSIONS_CF4() == "CF4_emissions" and cap.HFC23_CONSTRAIN() == "HFC23_constrain"
+    assert cap.RF_CF4() == "FadjCF4" and cap.PH_HL() == "HL_pH" and cap.BIOME_SPLIT_CHAR() == "."
+
+
+def capability_checks(lib, tmp_path, **kw):
+    import oracle_binding
+    c = hector_amd.Core(SCENARIO, 2, lib_path=lib, **kw).setvar(cap.ECS(), np.array([2.5, 4.0]), "degC")
+    outs = [cap.PH(), cap.PCO2(), cap.DIC(), cap.CO3(), cap.OCEAN_C_ML(), cap.PH_HL(), cap.PH_LL(),
+            cap.OCEAN_C_HL(), cap.OCEAN_C_LL(), cap.RF_CO2(), cap.RF_TOTAL(), cap.GLOBAL_TAS(),
+            cap.RF_CF4(), cap.CONCENTRATIONS_CO2()]
+    c.set_outputs(outs); c.run(2100)
+    f = lambda v: c.fetchvars(v, (1746, 2100))
+    assert np.array_equal(f(cap.RF_CF4()), f("RF_CF4"))                       # "FadjCF4" alias
+    assert np.allclose(f(cap.PH()), 0.85 * f(cap.PH_LL()) + 0.15 * f(cap.PH_HL()), rtol=1e-15)
+    assert np.allclose(f(cap.OCEAN_C_ML()), f(cap.OCEAN_C_LL()) + f(cap.OCEAN_C_HL()), rtol=1e-15)
+    assert (f(cap.PCO2()) > 200).all() and (f(cap.DIC()) > 1500).all() and (f(cap.CO3()) > 50).all()
+    rf0, cf40 = f(cap.RF_CO2()).copy(), f(cap.RF_CF4()).copy()
+    # parameters of the shared components: one value per core
+    assert c.getvar(cap.DELTA_CO2())[0] == pytest.approx(0.05)
+    c.setvar(cap.DELTA_CO2(), 0.2, "(unitless)")
+    c.setvar(cap.RHO_CF4(), 2 * c.getvar(cap.RHO_CF4())[0], "W/m2/pptv")
+    c.setvar(cap.PREINDUSTRIAL_CH4(), 700.0, "ppbv CH4")
+    c.run(2100)
+    # RF = sarf (1 + delta); the CO2 path itself shifts a little with the stronger forcing
+    assert np.allclose(f(cap.RF_CO2())[100:] / rf0[100:], 1.2 / 1.05, rtol=3e-2)
+    assert np.allclose(f(cap.RF_CF4())[10:], 2 * cf40[10:], rtol=1e-12)
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar(cap.DELTA_CO2(), np.array([0.1, 0.2]))                        # not per member
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar(cap.RHO_BC(), 1.0, "degC")
+    # the same three edits in the scenario file, through the oracle
+    rho = c.getvar(cap.RHO_CF4())[0]
+    path = edited_pack(tmp_path / "p.hxs", None, None, [], [], scalars={
+        ("forcing", "delta_co2"): 0.2, ("CF4_halocarbon", "rho_CF4"): rho, ("CH4", "M0"): 700.0})
+    o = oracle_binding.Oracle(path)
+    for i, s in enumerate((2.5, 4.0)):
+        p = o.default_params(); p.S = s
+        r, err, _ = o.run(p, run_to=2100)
+        assert err == 0
+        n = 2100 - 1745 + 1
+        assert np.abs(c.fetchvars("global_tas", (1745, 2100))[:, i] - r["global_tas"][:n]).max() < 2e-8
+        assert np.abs(c.fetchvars("RF_tot", (1745, 2100))[:, i] - r["RF_tot"][:n]).max() < 2e-8
+        g = c.fetchvars("CO2_concentration", (1745, 2100))[:, i]
+        assert (np.abs(g - r["CO2_concentration"][:n]) / g).max() < 2e-8
+
+
+def test_capabilities_and_shared_parameters(emul_lib, tmp_path):
+    capability_checks(emul_lib, tmp_path, allow_emulation=True)

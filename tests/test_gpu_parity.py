@@ -437,3 +437,9 @@ def test_biomes_from_ini_keys_on_gpu(hip_lib, oracle, tmp_path):
     """test_biome.R 'multiple biomes created via INI file' + per-biome outputs, HIP library."""
     from test_biomes_ini import biome_ini_checks
     biome_ini_checks(hip_lib, oracle, tmp_path, device=0)
+
+
+def test_capabilities_and_shared_parameters_on_gpu(hip_lib, tmp_path):
+    """R capability accessors, aliases, whole-surface ocean values, shared-component parameters."""
+    from test_capabilities import capability_checks
+    capability_checks(hip_lib, tmp_path, device=0)
