@@ -101,6 +101,17 @@ class Core:
         self._ck(self._lib.hx_set_outputs(self._h, n, arr))
         return self
 
+    def getunits(self, var):
+        """getunits(var)  R/units.R"""
+        u = ctypes.c_char_p()
+        self._ck(self._lib.hx_var_info(self._h, var.encode(), None, ctypes.byref(u)))
+        return u.value.decode()
+
+    def component_of(self, var):
+        comp = ctypes.c_char_p()
+        self._ck(self._lib.hx_var_info(self._h, var.encode(), ctypes.byref(comp), None))
+        return comp.value.decode()
+
     def biomes(self):
         """get_biome_list(core)  R/biome.R:8-16"""
         names = ctypes.POINTER(ctypes.c_char_p)()

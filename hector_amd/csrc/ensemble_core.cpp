@@ -1137,6 +1137,80 @@ bool EnsembleCore::fetch_host(const std::string &capability_in, int year0, int y
   return true;
 }
 
+namespace {
+// component and unit of every output variable, as the reference's output stream prints them
+// (src/csv_outputstream_visitor.cpp:126-365; unit names src/unitval.cpp:30-165)
+struct VarInfo { const char *variable, *component, *units; };
+const VarInfo kVarInfo[] = {
+    {"NBP", "simpleNbox", "Pg C/yr"}, {"NPP", "simpleNbox", "Pg C/yr"}, {"RH", "simpleNbox", "Pg C/yr"},
+    {"rh_det", "simpleNbox", "Pg C/yr"}, {"rh_soil", "simpleNbox", "Pg C/yr"},
+    {"rh_ch4", "simpleNbox", "Pg C/yr"}, {"CO2_concentration", "simpleNbox", "ppmv CO2"},
+    {"atmos_co2", "simpleNbox", "Pg C"}, {"atmos_c_residual", "simpleNbox", "Pg C"},
+    {"veg_c", "simpleNbox", "Pg C"}, {"detritus_c", "simpleNbox", "Pg C"},
+    {"soil_c", "simpleNbox", "Pg C"}, {"permafrost_c", "simpleNbox", "Pg C"},
+    {"thawedp_c", "simpleNbox", "Pg C"}, {"f_frozen", "simpleNbox", "(unitless)"},
+    {"earth_c", "simpleNbox", "Pg C"},
+    {"global_tas", "temperature", "degC"}, {"gmst", "temperature", "degC"},
+    {"heatflux_mixed", "temperature", "W/m2"}, {"heatflux_interior", "temperature", "W/m2"},
+    {"heatflux", "temperature", "W/m2"}, {"land_tas", "temperature", "degC"},
+    {"sst", "temperature", "degC"}, {"ocean_tas", "temperature", "degC"},
+    {"HL_ocean_uptake", "ocean", "Pg C/yr"}, {"LL_ocean_uptake", "ocean", "Pg C/yr"},
+    {"DO_ocean_c", "ocean", "Pg C"}, {"HL_ocean_c", "ocean", "Pg C"}, {"IO_ocean_c", "ocean", "Pg C"},
+    {"LL_ocean_c", "ocean", "Pg C"}, {"ML_ocean_c", "ocean", "Pg C"},
+    {"HL_DIC", "ocean", "umol/kg"}, {"LL_DIC", "ocean", "umol/kg"}, {"DIC", "ocean", "umol/kg"},
+    {"HL_downwelling", "ocean", "Pg C/yr"}, {"ocean_uptake", "ocean", "Pg C/yr"},
+    {"HL_OmegaAr", "ocean", "(unitless)"}, {"LL_OmegaAr", "ocean", "(unitless)"},
+    {"HL_OmegaCa", "ocean", "(unitless)"}, {"LL_OmegaCa", "ocean", "(unitless)"},
+    {"HL_PCO2", "ocean", "uatm"}, {"LL_PCO2", "ocean", "uatm"}, {"PCO2", "ocean", "uatm"},
+    {"HL_pH", "ocean", "pH"}, {"LL_pH", "ocean", "pH"}, {"pH", "ocean", "pH"},
+    {"HL_sst", "ocean", "degC"}, {"LL_sst", "ocean", "degC"}, {"ocean_c", "ocean", "Pg C"},
+    {"HL_CO3", "ocean", "umol/kg"}, {"LL_CO3", "ocean", "umol/kg"}, {"CO3", "ocean", "umol/kg"},
+    {"HL_Revelle", "ocean", "(unitless)"}, {"LL_Revelle", "ocean", "(unitless)"},
+    {"ocean_timesteps", "ocean", "(unitless)"}, {"timesteps", "ocean", "(unitless)"},
+    {"solver_steps", "carbon-cycle-solver", "(unitless)"},
+    {"slr", "slr", "cm"}, {"slr_no_ice", "slr", "cm"}, {"sl_rc", "slr", "cm/yr"},
+    {"sl_rc_no_ice", "slr", "cm/yr"},
+    {"O3_concentration", "ozone", "DU O3"}, {"TAU_OH", "OH", "Years"},
+    {"CH4_concentration", "CH4", "ppbv CH4"}, {"N2O_concentration", "N2O", "ppbv N2O"},
+};
+}  // namespace
+
+// getunits(var) of the R package (R/units.R) and the component that owns the variable
+void EnsembleCore::var_info(const std::string &capability_in, std::string *component,
+                            std::string *units) const {
+  std::string cap = capability_in;
+  const size_t dot = cap.find('.');
+  if (dot != std::string::npos) cap = cap.substr(dot + 1);  // "<biome>.<variable>"
+  if (cap.compare(0, 4, "Fadj") == 0) cap = "RF_" + cap.substr(4);
+  auto set = [&](const std::string &c, const std::string &u) {
+    if (component) *component = c;
+    if (units) *units = u;
+  };
+  for (const VarInfo &v : kVarInfo) if (cap == v.variable) return set(v.component, v.units);
+  if (cap.compare(0, 3, "RF_") == 0 && cap.find("_constrain") == std::string::npos)
+    return set("forcing", "W/m2");
+  for (const ParamDef &d : kParams)
+    if (cap == d.name) {
+      const bool temp = d.row == HXP_S || d.row == HXP_DIFF || d.row == HXP_QCO2 || d.row == HXP_LO_RATIO;
+      const bool forc = d.row == HXP_AERO || d.row == HXP_VOL;
+      const bool ocean = !d.per_biome && d.row >= HXP_TT && d.row <= HXP_PRE_ID;
+      return set(d.per_biome ? "simpleNbox" : temp ? "temperature" : forc ? "forcing" : ocean ? "ocean" : "simpleNbox",
+                 d.units);
+    }
+  {
+    std::string u;
+    const std::string sec = shared_param_section(scen_, cap, &u);
+    if (!sec.empty()) return set(sec, u);
+  }
+  for (const DatedDef &d : kDated) if (cap == d.name) return set(d.sections[0], d.units);
+  for (const Halocarbon &h : scen_.halocarbons) {
+    if (cap == h.name + "_emissions") return set(h.name + "_halocarbon", "Gg");
+    if (cap == h.name + "_concentration" || cap == h.name + "_constrain")
+      return set(h.name + "_halocarbon", "pptv");
+  }
+  throw std::runtime_error("Caller is requesting unknown variable: " + capability_in);
+}
+
 std::string EnsembleCore::run_name() const { return scen_.text("core", "run_name", ""); }
 
 bool EnsembleCore::host_output(const std::string &capability) {

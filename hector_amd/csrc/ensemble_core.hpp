@@ -79,6 +79,7 @@ class EnsembleCore {
   void fetchvars(const std::string &capability, int year0, int year1, double *out_host);
   bool host_output(const std::string &capability);
   std::string run_name() const;
+  void var_info(const std::string &capability, std::string *component, std::string *units) const;
   const std::vector<std::string> &halocarbon_names() const { return halo_names_; }
   // device pointer to the [ns][npad] array of an output variable
   const double *device_var(const std::string &capability, int *npad) const;

@@ -141,6 +141,15 @@ int hx_biomes(hx_core *core, const char *const **names, int *count) {
     if (count) *count = (int)ptrs.size();
   })
 }
+int hx_var_info(hx_core *core, const char *capability, const char **component, const char **units) {
+  static thread_local std::string comp, un;
+  if (!capability) return fail("hx_var_info: null argument");
+  HX_TRY({
+    core->core->var_info(capability, &comp, &un);
+    if (component) *component = comp.c_str();
+    if (units) *units = un.c_str();
+  })
+}
 int hx_run_name(hx_core *core, const char **name) {
   static thread_local std::string rn;
   HX_TRY({ rn = core->core->run_name(); if (name) *name = rn.c_str(); })

@@ -25,40 +25,17 @@
 
 namespace {
 
-struct VarDef { const char *component, *variable, *units; bool forcing; };
-
-// variable -> (component, units) as the visitor prints them (csv_outputstream_visitor.cpp:
-// 126-365; unit names src/unitval.cpp:30-165)
-const VarDef kVars[] = {
-    {"simpleNbox", "NBP", "Pg C/yr", false}, {"simpleNbox", "NPP", "Pg C/yr", false},
-    {"simpleNbox", "RH", "Pg C/yr", false}, {"simpleNbox", "rh_det", "Pg C/yr", false},
-    {"simpleNbox", "rh_soil", "Pg C/yr", false}, {"simpleNbox", "rh_ch4", "Pg C/yr", false},
-    {"simpleNbox", "CO2_concentration", "ppmv CO2", false},
-    {"simpleNbox", "atmos_co2", "Pg C", false}, {"simpleNbox", "atmos_c_residual", "Pg C", false},
-    {"simpleNbox", "veg_c", "Pg C", false}, {"simpleNbox", "detritus_c", "Pg C", false},
-    {"simpleNbox", "soil_c", "Pg C", false}, {"simpleNbox", "permafrost_c", "Pg C", false},
-    {"simpleNbox", "thawedp_c", "Pg C", false}, {"simpleNbox", "f_frozen", "(unitless)", false},
-    {"simpleNbox", "earth_c", "Pg C", false},
-    {"temperature", "global_tas", "degC", false}, {"temperature", "gmst", "degC", false},
-    {"temperature", "heatflux_mixed", "W/m2", false},
-    {"temperature", "heatflux_interior", "W/m2", false},
-    {"temperature", "heatflux", "W/m2", false}, {"temperature", "land_tas", "degC", false},
-    {"temperature", "sst", "degC", false},
-    {"ocean", "HL_ocean_uptake", "Pg C/yr", false}, {"ocean", "LL_ocean_uptake", "Pg C/yr", false},
-    {"ocean", "DO_ocean_c", "Pg C", false}, {"ocean", "HL_ocean_c", "Pg C", false},
-    {"ocean", "IO_ocean_c", "Pg C", false}, {"ocean", "LL_ocean_c", "Pg C", false},
-    {"ocean", "HL_DIC", "umol/kg", false}, {"ocean", "LL_DIC", "umol/kg", false},
-    {"ocean", "HL_downwelling", "Pg C/yr", false}, {"ocean", "ocean_uptake", "Pg C/yr", false},
-    {"ocean", "HL_OmegaAr", "(unitless)", false}, {"ocean", "LL_OmegaAr", "(unitless)", false},
-    {"ocean", "HL_OmegaCa", "(unitless)", false}, {"ocean", "LL_OmegaCa", "(unitless)", false},
-    {"ocean", "HL_PCO2", "uatm", false}, {"ocean", "LL_PCO2", "uatm", false},
-    {"ocean", "HL_pH", "pH", false}, {"ocean", "LL_pH", "pH", false},
-    {"ocean", "HL_sst", "degC", false}, {"ocean", "LL_sst", "degC", false},
-    {"ocean", "ocean_c", "Pg C", false}, {"ocean", "HL_CO3", "umol/kg", false},
-    {"ocean", "LL_CO3", "umol/kg", false}, {"ocean", "HL_Revelle", "(unitless)", false},
-    {"ocean", "LL_Revelle", "(unitless)", false},
-    {"ozone", "O3_concentration", "DU O3", false}, {"OH", "TAU_OH", "Years", false},
-    {"CH4", "CH4_concentration", "ppbv CH4", false}, {"N2O", "N2O_concentration", "ppbv N2O", false},
+// the variables of one year in the order the visitor prints them (csv_outputstream_visitor.cpp:
+// 126-365); component and unit strings come from the library (hx_var_info)
+const char *const kStreamVars[] = {
+    "NBP", "NPP", "RH", "rh_det", "rh_soil", "rh_ch4", "CO2_concentration", "atmos_co2",
+    "atmos_c_residual", "veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c", "f_frozen",
+    "earth_c", "global_tas", "gmst", "heatflux_mixed", "heatflux_interior", "heatflux",
+    "land_tas", "sst", "HL_ocean_uptake", "LL_ocean_uptake", "DO_ocean_c", "HL_ocean_c",
+    "IO_ocean_c", "LL_ocean_c", "HL_DIC", "LL_DIC", "HL_downwelling", "ocean_uptake",
+    "HL_OmegaAr", "LL_OmegaAr", "HL_OmegaCa", "LL_OmegaCa", "HL_PCO2", "LL_PCO2", "HL_pH",
+    "LL_pH", "HL_sst", "LL_sst", "ocean_c", "HL_CO3", "LL_CO3", "HL_Revelle", "LL_Revelle",
+    "O3_concentration", "TAU_OH", "CH4_concentration", "N2O_concentration",
 };
 const char *const kForcings[] = {"RF_BC", "RF_CH4", "RF_CO2", "RF_H2O_strat", "RF_N2O", "RF_NH3",
                                  "RF_O3_trop", "RF_OC", "RF_SO2", "RF_aci", "RF_albedo",
@@ -136,7 +113,7 @@ int main(int argc, char **argv) {
 
   // everything the stream prints
   std::vector<std::string> wanted;
-  for (const VarDef &v : kVars) wanted.push_back(v.variable);
+  for (const char *v : kStreamVars) wanted.push_back(v);
   for (const char *f : kForcings) wanted.push_back(f);
   for (const char *s : kSlr) wanted.push_back(s);
   {
@@ -192,6 +169,13 @@ int main(int argc, char **argv) {
     std::fprintf(out, "%d,%s,0,%s,%s,%.*g,%s\n", year, run.c_str(), comp, var.c_str(), prec, v, units);
   };
   const int p_def = precision > 0 ? precision : 6, p_rf = precision > 0 ? precision : 4;
+  struct Info { std::string component, units; };
+  std::map<std::string, Info> info;
+  for (const char *v : kStreamVars) {
+    const char *c = nullptr, *u = nullptr;
+    ck(hx_var_info(core, v, &c, &u));
+    info[v] = Info{c, u};
+  }
   for (int mbr = 0; mbr < members; ++mbr) {
     const std::string run = members > 1 ? rn + "." + std::to_string(mbr) : rn;
     for (int y = y0; y <= runto; ++y) {
@@ -202,13 +186,14 @@ int main(int argc, char **argv) {
         for (auto &h : halo_names) rf["RF_" + h] = data["RF_" + h][o];
         for (auto &kv : rf) row(y, run, "forcing", kv.first, kv.second, "W/m2", p_rf);
       }
-      const char *last_comp = "";
-      for (const VarDef &v : kVars) {
-        if (!std::strcmp(v.component, "temperature") && std::strcmp(last_comp, "temperature"))
+      std::string last_comp;
+      for (const char *vname : kStreamVars) {
+        const Info &vi = info[vname];
+        if (vi.component == "temperature" && last_comp != "temperature")
           for (auto &h : halo_names)  // halocarbon components come before temperature
             row(y, run, (h + "_halocarbon").c_str(), h + "_concentration",
                 data[h + "_concentration"][o], "pptv", p_def);
-        if (!std::strcmp(v.component, "ozone") && std::strcmp(last_comp, "ozone") && ny > 0) {
+        if (vi.component == "ozone" && last_comp != "ozone" && ny > 0) {
           // slrComponent: nothing until 1990, then the back years in one go (:300-318)
           if (y == slr_from)
             for (int yy = y0; yy < y; ++yy) {
@@ -223,8 +208,8 @@ int main(int argc, char **argv) {
             row(y, run, "slr", "slr_no_ice", data["slr_no_ice"][o], "cm", p_def);
           }
         }
-        row(y, run, v.component, v.variable, data[v.variable][o], v.units, p_def);
-        last_comp = v.component;
+        row(y, run, vi.component.c_str(), vname, data[vname][o], vi.units.c_str(), p_def);
+        last_comp = vi.component;
       }
     }
   }

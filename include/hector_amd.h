@@ -139,6 +139,11 @@ int hx_spinup_steps(hx_core *core, int member, int *steps);
  * carbon, max timestep: src/ocean_component.cpp:422-512). */
 int hx_state_row(hx_core *core, int row, double *out);
 
+/* getunits(var)  R/units.R (unit strings of src/unitval.cpp:30-165) and the component that owns
+ * the variable (IModelComponent::getComponentName, as printed by the output stream): for
+ * parameters, inputs, constraints and outputs.  The strings stay valid until the next call on
+ * this thread. */
+int hx_var_info(hx_core *core, const char *capability, const char **component, const char **units);
 /* Core::getRun_name (src/core.cpp:215-220): the INI's [core] run_name, "" if none */
 int hx_run_name(hx_core *core, const char **name);
 /* Unit vectors for function-level parity tests (no core needed).

@@ -61,3 +61,37 @@ def capability_checks(lib, tmp_path, **kw):
 
 def test_capabilities_and_shared_parameters(emul_lib, tmp_path):
     capability_checks(emul_lib, tmp_path, allow_emulation=True)
+
+
+def test_units_and_set_get_of_every_emission(emul_lib):
+    """test_units.R (getunits) and test_set_get_data.R (every emissions series can be set at a
+    date and read back) restated."""
+    c = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    units = {cap.ECS(): "degC", cap.DIFFUSIVITY(): "cm2/s", cap.BETA(): "(unitless)",
+             cap.PREINDUSTRIAL_CO2(): "ppmv CO2", cap.FFI_EMISSIONS(): "Pg C/yr",
+             cap.EMISSIONS_SO2(): "Gg S", cap.EMISSIONS_CF4(): "Gg", cap.EMISSIONS_CH4(): "Tg CH4",
+             cap.EMISSIONS_NOX(): "Tg N", cap.NAT_EMISSIONS_N2O(): "Tg N", cap.RHO_BC(): "W/m2/Tg",
+             cap.RHO_SO2(): "W/m2/Gg", cap.DELTA_CO2(): "(unitless)", cap.TT(): "m3/s",
+             cap.OCEAN_PREIND_C_SURF(): "Pg C", cap.CO2_CONSTRAIN(): "ppmv CO2",
+             cap.TAS_CONSTRAIN(): "degC", cap.HFC23_CONSTRAIN(): "pptv", cap.GLOBAL_TAS(): "degC",
+             cap.RF_TOTAL(): "W/m2", cap.RF_CF4(): "W/m2", cap.PH_HL(): "pH", cap.PCO2_LL(): "uatm",
+             cap.CONCENTRATIONS_CH4(): "ppbv CH4", cap.OCEAN_UPTAKE(): "Pg C/yr", cap.NBP(): "Pg C/yr",
+             cap.VOLCANIC_SO2(): "W/m2", cap.LIFETIME_SOIL(): "Years", "boreal." + cap.VEG_C(): "Pg C"}
+    for v, u in units.items():
+        assert c.getunits(v) == u, v
+    assert c.component_of(cap.GLOBAL_TAS()) == "temperature" and c.component_of(cap.NBP()) == "simpleNbox"
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.getunits("no_such_variable")
+    emissions = [n for n in cap.__all__ if n.startswith("EMISSIONS_")] + \
+        ["FFI_EMISSIONS", "LUC_EMISSIONS", "NAT_EMISSIONS_N2O", "DACCS_UPTAKE", "LUC_UPTAKE"]
+    assert len(emissions) >= 37
+    rng = np.random.default_rng(3)
+    for name in emissions:
+        v = getattr(cap, name)()
+        val = float(rng.exponential(5.0))
+        c.setvar_dated(v, [1800], [val], c.getunits(v))
+        assert c.fetchvars(v, (1800, 1800))[0, 0] == val, v
+    c.run(1800)
+    assert c.status()[0] == 0
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.setvar_dated(cap.FFI_EMISSIONS(), [1800], [1.0], "boogedyboo")
