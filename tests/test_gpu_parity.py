@@ -443,3 +443,21 @@ def test_capabilities_and_shared_parameters_on_gpu(hip_lib, tmp_path):
     """R capability accessors, aliases, whole-surface ocean values, shared-component parameters."""
     from test_capabilities import capability_checks
     capability_checks(hip_lib, tmp_path, device=0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 1001, 4097])
+def test_stats_kernel_on_ragged_member_counts(hip_lib, n):
+    """hx_stats_kernel (16-byte loads, tail handling) against numpy for odd ensemble sizes."""
+    import torch
+    S, q10 = ensemble.ecs_q10(n, offset=77)
+    c = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    c.run(1900)
+    d = torch.zeros((156, 5), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()   # the fill runs on torch's stream, the statistics on the core's
+    c.stats_device("global_tas", 1745, 1900, d.data_ptr())
+    tg = c.fetchvars("global_tas", (1745, 1900))
+    ref = stats_numpy(tg)
+    got = d.cpu().numpy()
+    assert np.array_equal(got[:, 0], ref[:, 0])
+    assert np.allclose(got[:, 1:3], ref[:, 1:3], rtol=1e-12, atol=1e-13)
+    assert np.array_equal(got[:, 3:], ref[:, 3:])
