@@ -175,6 +175,7 @@ def test_full_size_ensemble_properties(hip_lib, oracle):
     # statistics kernel (wave shuffles) vs numpy
     import torch
     d = torch.zeros((556, 5), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()   # torch fills on its own stream; the core's stream writes next
     c.stats_device("global_tas", 1745, 2300, d.data_ptr())
     torch.cuda.synchronize()
     ref = stats_numpy(tg)
