@@ -125,7 +125,9 @@ int hx_fetchvars(hx_core *core, const char *capability, int year0, int year1, do
 int hx_device_var(hx_core *core, const char *capability, const double **d_ptr, int *npad);
 /* Per-year ensemble statistics {count, sum, sum of squares, min, max} of one
  * variable into a caller-owned DEVICE buffer of (year1-year0+1)*5 doubles --
- * the sufficient statistics that a multi-GPU job all-reduces over RCCL. */
+ * the sufficient statistics that a multi-GPU job all-reduces over RCCL.  The kernel runs on the
+ * core's stream (hx_stream) and has finished when the call returns; work the caller queued on
+ * d_stats on another stream (e.g. a fill) must have completed before the call. */
 int hx_stats_device(hx_core *core, const char *capability, int year0, int year1,
                     double *d_stats);
 
