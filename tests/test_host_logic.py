@@ -82,3 +82,16 @@ def test_ini_reader_equals_pack(emul_lib):
     b = hector_amd.Core(ini, 1, lib_path=emul_lib, allow_emulation=True).run(1800)
     for v in ("CO2_concentration", "global_tas"):
         assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
+
+
+def test_example_script_runs(emul_lib):
+    """examples/ensemble_ecs_q10.py end to end (through the emulation build here)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HECTOR_AMD_EMULATION_LIB=emul_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ensemble_ecs_q10.py"), "8"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "2100 warming" in r.stdout and "halved fossil emissions" in r.stdout
