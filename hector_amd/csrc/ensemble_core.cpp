@@ -398,6 +398,7 @@ void EnsembleCore::build_shared() {
 void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
+  fr(d_uparams_); d_uparams_ = nullptr;
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   d_hist_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
@@ -414,6 +415,7 @@ void EnsembleCore::alloc_device() {
   free_device();
   const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
+  check(hipMalloc(&d_uparams_, sizeof(double) * HX_NPARAM(B_)), "hipMalloc uniform params");
   check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
   check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
   // DOECLIM kernel table, zero-padded by HX_KPAD (= 32) entries on both sides
@@ -449,6 +451,15 @@ HxBuffers EnsembleCore::buffers() const {
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
   b.hist = d_hist_;
   for (int k = 0; k < HXM_N; ++k) b.mseries[k] = d_mseries_[k];
+  b.uparams = d_uparams_;
+  b.uni_landk = b.uni_bio = 1;
+  for (int bb = 0; bb < B_; ++bb) {
+    const int r = HXP_NGLOBAL + bb * HXPB_N;
+    for (int k : {HXPB_NPP0, HXPB_F_NPPV, HXPB_F_NPPD, HXPB_F_LITTERD, HXPB_RH_CH4_FRAC, HXPB_FPF_STATIC})
+      if (!row_uniform_[r + k]) b.uni_landk = 0;
+    for (int k : {HXPB_BETA, HXPB_PF_MU, HXPB_PF_SIGMA})
+      if (!row_uniform_[r + k]) b.uni_bio = 0;
+  }
   b.stash_diag = 0;
   for (int v = HXO_NPP; v <= HXO_CA_RESIDUAL; ++v) if (d_out_[v]) b.stash_diag = 1;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
@@ -878,6 +889,13 @@ void EnsembleCore::upload_params() {
                        hipMemcpyHostToDevice, stream_), "upload lane map");
   check(hipMemcpyAsync(d_params_, flat.data(), sizeof(double) * flat.size(),
                        hipMemcpyHostToDevice, stream_), "upload params");
+  {
+    std::vector<double> u((size_t)HX_NPARAM(B_));
+    for (int r = 0; r < HX_NPARAM(B_); ++r) u[(size_t)r] = params_[r][0];
+    check(hipMemcpyAsync(d_uparams_, u.data(), sizeof(double) * u.size(), hipMemcpyHostToDevice,
+                         stream_), "upload uniform params");
+    check(hipStreamSynchronize(stream_), "sync uniform params");
+  }
   check(hipStreamSynchronize(stream_), "sync params");
   // DOECLIM convolution kernel: one shared table when every member has the same
   // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]

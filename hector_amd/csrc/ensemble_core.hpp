@@ -131,6 +131,7 @@ class EnsembleCore {
   unsigned *d_status_ = nullptr;
   int *d_spin_steps_ = nullptr;
   HxArgs *d_args_ = nullptr;
+  double *d_uparams_ = nullptr;
   double *d_derived_ = nullptr, *d_dpart_ = nullptr, *d_gather_ = nullptr, *d_hist_ = nullptr;
   bool history_ = false, shared_dirty_ = false;
   int hist_valid_to_ = 0;   // history slabs 1..hist_valid_to_ are valid

@@ -461,6 +461,7 @@ struct Member {
   int npad;
   double (*pk)[64];  // LDS park
   int lane;
+  hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
   const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
   int iy;                 // year index being integrated
 };
@@ -479,6 +480,18 @@ __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
     k.npp0[0] = PKM(m, o + PKB_NPP0); k.f_nppv[0] = PKM(m, o + PKB_F_NPPV);
     k.f_nppd[0] = PKM(m, o + PKB_F_NPPD); k.f_litterd[0] = PKM(m, o + PKB_F_LITTERD);
     k.rh_ch4_frac[0] = PKM(m, o + PKB_RH_CH4_FRAC); k.fpf_static[0] = PKM(m, o + PKB_FPF_STATIC);
+    return;
+  }
+  if (m.upar) {
+    // every member has the same biome constants (the usual case: ensembles perturb Q10, beta,
+    // warming factors): wave-uniform scalar loads instead of 6 B vector loads from HBM
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      hx_ccd r = m.upar + (HXP_NGLOBAL + b * HXPB_N);
+      k.npp0[b] = r[HXPB_NPP0]; k.f_nppv[b] = r[HXPB_F_NPPV]; k.f_nppd[b] = r[HXPB_F_NPPD];
+      k.f_litterd[b] = r[HXPB_F_LITTERD]; k.rh_ch4_frac[b] = r[HXPB_RH_CH4_FRAC];
+      k.fpf_static[b] = r[HXPB_FPF_STATIC];
+    }
     return;
   }
 #pragma unroll
@@ -1086,6 +1099,7 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   m.npad = buf.npad;
   m.pk = park;
   m.lane = lane;
+  m.upar = (B > 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
   if constexpr (B > 1) {
     constexpr int o = hx_pkb1<B>();
     ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
@@ -1600,13 +1614,23 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           lk.rh_ch4_frac[b] = PKM(m, o + PKB_RH_CH4_FRAC);
         } else {
           const int pr = HXP_NGLOBAL + b * HXPB_N;
-          p_beta[b] = ldp(buf, pr + HXPB_BETA, mem);
           p_wf[b] = ldp(buf, pr + HXPB_WF, mem);
-          p_mu[b] = ldp(buf, pr + HXPB_PF_MU, mem);
-          p_sigma[b] = ldp(buf, pr + HXPB_PF_SIGMA, mem);
+          if (buf.uni_bio) {  // beta, permafrost mu/sigma uniform over members: scalar loads
+            hx_ccd u = HX_CCD(buf.uparams) + pr;
+            p_beta[b] = u[HXPB_BETA]; p_mu[b] = u[HXPB_PF_MU]; p_sigma[b] = u[HXPB_PF_SIGMA];
+          } else {
+            p_beta[b] = ldp(buf, pr + HXPB_BETA, mem);
+            p_mu[b] = ldp(buf, pr + HXPB_PF_MU, mem);
+            p_sigma[b] = ldp(buf, pr + HXPB_PF_SIGMA, mem);
+          }
           p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
-          lk.fpf_static[b] = ldp(buf, pr + HXPB_FPF_STATIC, mem);
-          lk.rh_ch4_frac[b] = ldp(buf, pr + HXPB_RH_CH4_FRAC, mem);
+          if (m.upar) {
+            lk.fpf_static[b] = m.upar[pr + HXPB_FPF_STATIC];
+            lk.rh_ch4_frac[b] = m.upar[pr + HXPB_RH_CH4_FRAC];
+          } else {
+            lk.fpf_static[b] = ldp(buf, pr + HXPB_FPF_STATIC, mem);
+            lk.rh_ch4_frac[b] = ldp(buf, pr + HXPB_RH_CH4_FRAC, mem);
+          }
         }
       }
       // ---- OH, CH4, O3 ----

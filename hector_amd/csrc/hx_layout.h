@@ -146,6 +146,8 @@ struct HxBuffers {
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   int n, npad, ker_per_member;
   const double *mseries[HXM_N];  // per-member emissions (row iy as in the shared table) or nullptr
+  const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
+  int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
 };
 
