@@ -1,0 +1,260 @@
+// hx_dev_member.h -- what a lane holds: Member, the LDS park, biome constants, SoA load/store helpers
+// Part of the device code of hx_kernels.hip (one translation unit; see its header for the
+// reference file:line map).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// A compiler-only fence: values cached from memory may not be carried across it.
+// The year loop is split into phases by these so that per-member constants that a
+// phase needs are (re)loaded from HBM / L2 inside the phase instead of being kept
+// in registers across the whole solver -- register pressure, not bandwidth, is what
+// limits this kernel (DESIGN.md "registers").
+#define HX_FENCE() asm volatile("" ::: "memory")
+
+// Per-lane LDS scratchpad ("park"): year-level state and the constants that the
+// phases and the stash block need a few times per year.  One wavefront per SIMD
+// means every HBM/L2 access is an exposed ~1-2k-cycle stall; LDS answers in ~64.
+// Filled from the HBM tables at kernel entry, state slots written back at exit.
+enum HxPark {
+  PK_CH4 = 0, PK_SST, PK_EOS, PK_TLAND, PK_TWIN, PK_TL_M1, PK_TL_M2, PK_F_PREV,
+  PK_BASE_TOT, PK_BASE_CO2,            // <- year-level state (HBM state rows)
+  PK_LN_CH4, PK_LN_CO2R,               // ln CH4 and ln(CO2/C0) of the year just finished: the
+                                       // next year needs exactly these logarithms again
+  PK_AERO, PK_VOL,
+  PK_D0,                               // 14 DOECLIM constants HXD_A0..HXD_HFSCALE
+  PK_K0 = PK_D0 + 14,                  // 7 ocean exchange coefficients HXD_KLH..HXD_KDI
+  PK_FFROZEN0 = PK_K0 + 7,             // f_frozen per biome
+};
+// single-biome kernels also park the biome constants (11 more slots)
+enum HxParkB1 { PKB_NPP0 = 0, PKB_F_NPPV, PKB_F_NPPD, PKB_F_LITTERD, PKB_RH_CH4_FRAC,
+                PKB_FPF_STATIC, PKB_BETA, PKB_WF, PKB_LNQ10, PKB_MU, PKB_SIGMA, PKB_N };
+// multi-biome kernels park the nine per-biome arrays of Member instead (see BiomeArr)
+constexpr int HX_NBIOME_ARR = 9;
+template <int B> constexpr int hx_npark() {
+  return PK_FFROZEN0 + B + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * B);
+}
+template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + B; }
+
+// Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
+// registers, 36 doubles for B = 4 on top of the solver's working set overflow 256 VGPRs +
+// 256 AGPRs and ~100 VGPRs spill to scratch, each reload an exposed memory stall; the solver
+// steps themselves only touch the interval constants, not these arrays.
+struct ParkArr {
+  double (*base)[64];
+  int lane;
+  __device__ __forceinline__ double &operator[](int b) const { return base[b][lane]; }
+};
+struct RegArr1 {
+  double v[1];
+  __device__ __forceinline__ double &operator[](int b) { return v[b]; }
+  __device__ __forceinline__ const double &operator[](int b) const { return v[b]; }
+};
+template <int B> struct BiomeArr { using type = ParkArr; };
+template <> struct BiomeArr<1> { using type = RegArr1; };
+
+// What stays in registers through the carbon-cycle solver of one year.
+template <int B>
+struct Member {
+  double C0;
+  // state
+  double cHL, cLL, cIO, cDO, atmos, earth;
+  typename BiomeArr<B>::type veg, det, soil, pf, thawed, tempferts;
+  double cum_luc_va, cum_pf_ch4, masstot;
+  double max_ts, lastflux_ann, sdt;
+  int ts_timeout;
+  double alkH, alkL, hH, hL;
+  unsigned status;
+  // per-year
+  typename BiomeArr<B>::type co2fert, tempfertd, f_new_thaw;
+  double luc_e, luc_u, ffi, daccs, npp_luc_adjust;
+  ChemK kH, kL;
+  double pco2H, pco2L;
+  double annualflux_sum, nbp;
+  int nstash, nsteps;
+  double ode_start;
+  bool chem_fresh;  // pco2H/L already computed for the current box carbon
+  // where this lane's constants live
+  hx_gcd par;  // params + mem   (row stride npad)
+  hx_gcd der;  // derived + mem
+  int npad;
+  double (*pk)[64];  // LDS park
+  int lane;
+  hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
+  const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
+  int iy;                 // year index being integrated
+};
+#define PKM(m, slot) ((m).pk[(slot)][(m).lane])
+
+// biome constants of the land model, fetched where they are used
+template <int B>
+struct LandK {
+  double npp0[B], f_nppv[B], f_nppd[B], f_litterd[B], rh_ch4_frac[B], fpf_static[B];
+};
+template <int B>
+__device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
+  HX_FENCE();
+  if constexpr (B == 1) {
+    constexpr int o = hx_pkb1<B>();
+    k.npp0[0] = PKM(m, o + PKB_NPP0); k.f_nppv[0] = PKM(m, o + PKB_F_NPPV);
+    k.f_nppd[0] = PKM(m, o + PKB_F_NPPD); k.f_litterd[0] = PKM(m, o + PKB_F_LITTERD);
+    k.rh_ch4_frac[0] = PKM(m, o + PKB_RH_CH4_FRAC); k.fpf_static[0] = PKM(m, o + PKB_FPF_STATIC);
+    return;
+  }
+  if (m.upar) {
+    // every member has the same biome constants (the usual case: ensembles perturb Q10, beta,
+    // warming factors): wave-uniform scalar loads instead of 6 B vector loads from HBM
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      hx_ccd r = m.upar + (HXP_NGLOBAL + b * HXPB_N);
+      k.npp0[b] = r[HXPB_NPP0]; k.f_nppv[b] = r[HXPB_F_NPPV]; k.f_nppd[b] = r[HXPB_F_NPPD];
+      k.f_litterd[b] = r[HXPB_F_LITTERD]; k.rh_ch4_frac[b] = r[HXPB_RH_CH4_FRAC];
+      k.fpf_static[b] = r[HXPB_FPF_STATIC];
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
+    k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
+    k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
+    k.f_nppd[b] = r[(size_t)HXPB_F_NPPD * m.npad];
+    k.f_litterd[b] = r[(size_t)HXPB_F_LITTERD * m.npad];
+    k.rh_ch4_frac[b] = r[(size_t)HXPB_RH_CH4_FRAC * m.npad];
+    k.fpf_static[b] = r[(size_t)HXPB_FPF_STATIC * m.npad];
+  }
+}
+
+// ---- SoA helpers ------------------------------------------------------------
+__device__ __forceinline__ double ldp(const HxBuffers &b, int row, int mem) {
+  return HX_GCD(b.params)[(size_t)row * b.npad + mem];
+}
+__device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
+  return HX_GCD(b.derived)[(size_t)row * b.npad + mem];
+}
+__device__ __forceinline__ double lds_(const HxBuffers &b, int row, int mem) {
+  return HX_GCD(b.state)[(size_t)row * b.npad + mem];
+}
+__device__ __forceinline__ void sts_(const HxBuffers &b, int row, int mem, double v) {
+  HX_GD(b.state)[(size_t)row * b.npad + mem] = v;
+}
+__device__ __forceinline__ void sto_(const HxBuffers &b, int var, size_t off, double v) {
+  HX_GD(b.out[var])[off] = v;
+}
+
+template <int B>
+__device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Member<B> &m,
+                                            double (*park)[64], int lane) {
+  m.par = HX_GCD(buf.params) + mem;
+  m.der = HX_GCD(buf.derived) + mem;
+  m.npad = buf.npad;
+  m.pk = park;
+  m.lane = lane;
+  m.upar = (B > 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
+  if constexpr (B > 1) {
+    constexpr int o = hx_pkb1<B>();
+    ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
+                                   &m.co2fert, &m.tempfertd, &m.f_new_thaw};
+#pragma unroll
+    for (int k = 0; k < HX_NBIOME_ARR; ++k) { arr[k]->base = park + o + k * B; arr[k]->lane = lane; }
+  }
+  m.C0 = ldp(buf, HXP_C0, mem);
+  // constants -> park
+  PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
+  PKM(m, PK_VOL) = ldp(buf, HXP_VOL, mem);
+#pragma unroll
+  for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) PKM(m, PK_K0 + k) = ldd(buf, HXD_KLH + k, mem);
+  if constexpr (B == 1) {
+    constexpr int o = hx_pkb1<B>();
+    const int r = HXP_NGLOBAL;
+    PKM(m, o + PKB_NPP0) = ldp(buf, r + HXPB_NPP0, mem);
+    PKM(m, o + PKB_F_NPPV) = ldp(buf, r + HXPB_F_NPPV, mem);
+    PKM(m, o + PKB_F_NPPD) = ldp(buf, r + HXPB_F_NPPD, mem);
+    PKM(m, o + PKB_F_LITTERD) = ldp(buf, r + HXPB_F_LITTERD, mem);
+    PKM(m, o + PKB_RH_CH4_FRAC) = ldp(buf, r + HXPB_RH_CH4_FRAC, mem);
+    PKM(m, o + PKB_FPF_STATIC) = ldp(buf, r + HXPB_FPF_STATIC, mem);
+    PKM(m, o + PKB_BETA) = ldp(buf, r + HXPB_BETA, mem);
+    PKM(m, o + PKB_WF) = ldp(buf, r + HXPB_WF, mem);
+    PKM(m, o + PKB_LNQ10) = ldd(buf, HXD_NGLOBAL, mem);
+    PKM(m, o + PKB_MU) = ldp(buf, r + HXPB_PF_MU, mem);
+    PKM(m, o + PKB_SIGMA) = ldp(buf, r + HXPB_PF_SIGMA, mem);
+  }
+}
+
+// solver-resident state <-> HBM state table
+template <int B>
+__device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member<B> &m) {
+  m.cHL = lds_(buf, HXS_C_HL, mem); m.cLL = lds_(buf, HXS_C_LL, mem);
+  m.cIO = lds_(buf, HXS_C_IO, mem); m.cDO = lds_(buf, HXS_C_DO, mem);
+  m.atmos = lds_(buf, HXS_ATMOS, mem); m.earth = lds_(buf, HXS_EARTH, mem);
+  m.cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem);
+  m.cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem);
+  m.masstot = lds_(buf, HXS_MASSTOT, mem);
+  m.max_ts = lds_(buf, HXS_MAX_TS, mem);
+  m.ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
+  m.lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
+  m.sdt = lds_(buf, HXS_SOLVER_DT, mem);
+  m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem);
+  m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int r = HXS_NGLOBAL + b * HXSB_N;
+    m.veg[b] = lds_(buf, r + HXSB_VEG, mem); m.det[b] = lds_(buf, r + HXSB_DET, mem);
+    m.soil[b] = lds_(buf, r + HXSB_SOIL, mem); m.pf[b] = lds_(buf, r + HXSB_PF, mem);
+    m.thawed[b] = lds_(buf, r + HXSB_THAWED, mem);
+    m.tempferts[b] = lds_(buf, r + HXSB_TEMPFERTS, mem);
+  }
+  m.status = HX_GU(buf.status)[mem];
+}
+
+template <int B>
+__device__ __forceinline__ void store_state(const HxBuffers &buf_, int mem,
+                                            const Member<B> &m, double *base = nullptr) {
+  // base == nullptr: the live state table; otherwise a per-year history slab
+  HxBuffers buf = buf_;
+  if (base) buf.state = base;
+  sts_(buf, HXS_C_HL, mem, m.cHL); sts_(buf, HXS_C_LL, mem, m.cLL);
+  sts_(buf, HXS_C_IO, mem, m.cIO); sts_(buf, HXS_C_DO, mem, m.cDO);
+  sts_(buf, HXS_ATMOS, mem, m.atmos); sts_(buf, HXS_EARTH, mem, m.earth);
+  sts_(buf, HXS_CUM_LUC_VA, mem, m.cum_luc_va);
+  sts_(buf, HXS_CUM_PF_CH4, mem, m.cum_pf_ch4);
+  sts_(buf, HXS_MASSTOT, mem, m.masstot);
+  sts_(buf, HXS_MAX_TS, mem, m.max_ts);
+  sts_(buf, HXS_TS_TIMEOUT, mem, (double)m.ts_timeout);
+  sts_(buf, HXS_LASTFLUX_ANN, mem, m.lastflux_ann);
+  sts_(buf, HXS_SOLVER_DT, mem, m.sdt);
+  sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
+  sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const int r = HXS_NGLOBAL + b * HXSB_N;
+    sts_(buf, r + HXSB_VEG, mem, m.veg[b]); sts_(buf, r + HXSB_DET, mem, m.det[b]);
+    sts_(buf, r + HXSB_SOIL, mem, m.soil[b]); sts_(buf, r + HXSB_PF, mem, m.pf[b]);
+    sts_(buf, r + HXSB_THAWED, mem, m.thawed[b]);
+    sts_(buf, r + HXSB_TEMPFERTS, mem, m.tempferts[b]);
+  }
+  if (!base) HX_GU(buf.status)[mem] = m.status;
+}
+
+// year-level state: park -> state rows of `base` (live table or history slab)
+template <int B>
+__device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
+                                                 const Member<B> &m, double *base = nullptr) {
+  HxBuffers buf = buf_;
+  if (base) buf.state = base;
+  sts_(buf, HXS_CH4, mem, PKM(m, PK_CH4)); sts_(buf, HXS_SST, mem, PKM(m, PK_SST));
+  sts_(buf, HXS_TLAND, mem, PKM(m, PK_TLAND)); sts_(buf, HXS_TWIN, mem, PKM(m, PK_TWIN));
+  sts_(buf, HXS_TL_M1, mem, PKM(m, PK_TL_M1)); sts_(buf, HXS_TL_M2, mem, PKM(m, PK_TL_M2));
+  sts_(buf, HXS_F_PREV, mem, PKM(m, PK_F_PREV));
+  sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
+  sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
+  if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
+}
+
+}  // namespace

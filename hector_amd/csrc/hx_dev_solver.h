@@ -1,0 +1,509 @@
+// hx_dev_solver.h -- CarbonCycleSolver::run for one lane: interval constants, RHS, stash, dopri5 + controller + retry logic
+// Part of the device code of hx_kernels.hip (one translation unit; see its header for the
+// reference file:line map).
+#pragma once
+
+namespace {
+
+// rhs constants that only change at a stash (pools frozen in between,
+// src/simpleNbox-runtime.cpp:809-840)
+struct Interval {
+  double P, npp, rh, v1, d2, s3, k4, k5, k7;
+  double totC, surf, inv_surf;
+};
+
+template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, const LandK<B> &k, int b) {
+  return (k.npp0[b] * m.co2fert[b]) * m.npp_luc_adjust;  // :622-635
+}
+template <int B> __device__ __forceinline__ double m_rh_fda(const Member<B> &m, int b) {
+  return (m.det[b] * 0.25) * m.tempfertd[b];  // :653-665
+}
+template <int B> __device__ __forceinline__ double m_rh_fsa(const Member<B> &m, int b) {
+  return (m.soil[b] * 0.02) * m.tempferts[b];  // :671-683
+}
+template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &m, const LandK<B> &k, int b) {
+  return ((m.thawed[b] * (1 - k.fpf_static[b])) * 0.02) * m.tempferts[b] *
+         (1.0 - k.rh_ch4_frac[b]);  // :689-701
+}
+template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, const LandK<B> &k, int b) {
+  return hx_div(m_rh_tp_co2(m, k, b), 1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
+}
+
+// constraints of one model year, as the solver and the stash see them (CON kernels only)
+struct YearCon {
+  int mask;          // HXC_* bits
+  double co2;        // CO2 constraint of the year that ends at tnew (NaN = none)
+  double nbp_lo;     // NBP constraint of date tnew - 1  (round(t) for t < tnew - 0.5)
+  double nbp_hi;     // NBP constraint of date tnew
+  double t_half;     // tnew - 0.5: round(t) switches from tnew - 1 to tnew here
+};
+
+// the land flows of an interval with frozen pools
+struct Flows {
+  double npp, rh, fav, fad, fas, fda, fsa, tpc, tpm, litter, lfvd, lfvs, detsoil, thaw, refr;
+};
+
+template <int B>
+__device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F, Interval &K) {
+  K.npp = F.npp;
+  K.rh = F.rh;
+  K.P = ((m.ffi - m.daccs) + m.luc_e) - m.luc_u;
+  K.v1 = F.fav - F.litter;
+  K.d2 = ((F.fad + F.lfvd) - F.detsoil) - F.fda;
+  K.s3 = ((F.fas + F.lfvs) + F.detsoil) - F.fsa;
+  K.k4 = -F.thaw + F.refr;
+  K.k5 = ((F.thaw - F.refr) - F.tpm) - F.tpc;
+  K.k7 = -m.ffi + m.daccs;
+  K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
+  K.surf = m.cLL + m.cHL;
+  K.inv_surf = hx_recip(K.surf);
+}
+
+// NBP constraint inside calcderivs: NPP and RH moved by +-diff/2, their parts scaled
+// (simpleNbox-runtime.cpp:871-898)
+template <int B>
+__device__ __forceinline__ void make_interval_nbp(const Member<B> &m, Flows F, double target,
+                                                  Interval &K) {
+  if (!isnan(target)) {
+    const double nbp = ((F.npp - F.rh) - m.luc_e) + m.luc_u;
+    const double diff = target - nbp;
+    const double npp_old = F.npp;
+    F.npp = F.npp + diff / 2.0;
+    const double npp_ratio = F.npp / npp_old;
+    F.fav = F.fav * npp_ratio; F.fad = F.fad * npp_ratio; F.fas = F.fas * npp_ratio;
+    const double rh_old = F.rh;
+    F.rh = F.rh - diff / 2.0;
+    const double rh_ratio = F.rh / rh_old;
+    F.fda = F.fda * rh_ratio; F.fsa = F.fsa * rh_ratio; F.tpc = F.tpc * rh_ratio;
+  }
+  make_interval<B>(m, F, K);
+}
+
+template <int B, bool SPIN>
+__device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B> &lk,
+                                              Flows &F) {
+  double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
+  double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const double n = m_npp(m, lk, b);
+    npp_c += n;
+    fav += n * lk.f_nppv[b];
+    fad += n * lk.f_nppd[b];
+    fas += n * (1 - lk.f_nppv[b] - lk.f_nppd[b]);
+    fda += m_rh_fda(m, b);
+    fsa += m_rh_fsa(m, b);
+    const double co2 = m_rh_tp_co2(m, lk, b), ch4 = m_rh_tp_ch4(m, lk, b);
+    tpc += co2;
+    tpm += ch4;
+    const double v = m.veg[b] * 0.035;
+    litter += v;
+    lfvd += v * lk.f_litterd[b];
+    lfvs += v * (1 - lk.f_litterd[b]);
+    detsoil += m.det[b] * 0.6;
+    if (!SPIN) {  // compute_pf_thaw_refreeze :744-772
+      double c_thaw = m.pf[b] * m.f_new_thaw[b];
+      double r_tp = 0.0;
+      if (c_thaw < 0) {
+        const double want = -c_thaw;
+        c_thaw = 0.0;
+        r_tp = fmin(want, m.thawed[b] - co2 - ch4);
+      }
+      thaw += c_thaw;
+      refr += r_tp;
+    }
+  }
+  F.npp = npp_c; F.rh = fda + fsa + tpc;
+  F.fav = fav; F.fad = fad; F.fas = fas; F.fda = fda; F.fsa = fsa; F.tpc = tpc; F.tpm = tpm;
+  F.litter = litter; F.lfvd = lfvd; F.lfvs = lfvs; F.detsoil = detsoil;
+  F.thaw = thaw; F.refr = refr;
+}
+
+// K: the interval's constants; K2 (CON kernels): the same for the second half of the year,
+// where round(t) picks the next date's NBP constraint
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
+                                              Interval &K, Interval &K2, const YearCon &yc) {
+  Flows F;
+  compute_flows<B, SPIN>(m, lk, F);
+  if constexpr (CON && !SPIN) {
+    if (yc.mask & HXC_NBP) {
+      make_interval_nbp<B>(m, F, yc.nbp_lo, K);
+      make_interval_nbp<B>(m, F, yc.nbp_hi, K2);
+      return;
+    }
+    make_interval<B>(m, F, K);
+    K2 = K;
+    return;
+  }
+  make_interval<B>(m, F, K);
+}
+
+// SimpleNbox::calcderivs + OceanComponent::calcderivs restricted to the five
+// pools whose derivative depends on c[] (atmos, veg, det, soil, ocean)
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, const Interval &K2,
+                                    const YearCon &yc, double t, const double *y, double *d) {
+  // CON kernels carry the thawed-permafrost pool as a sixth solver variable: with an NBP
+  // constraint its derivative changes where round(t) does, so it is no longer constant
+  const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
+  if constexpr (CON) d[5] = K.k5;
+  const double total = y[1] + y[2] + y[3];
+  const double r = hx_div1(m.luc_e, total);  // 2e-15 on a term that is itself ~1e-3 of the flux
+  double ao;
+  if (SPIN) {
+    ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
+  } else {
+    const double scale = (K.surf + (y[4] - K.totC)) * K.inv_surf;
+    const double co2 = y[0] * PGC2PPM;
+    ao = (co2 - m.pco2H * scale) * m.kH.g + (co2 - m.pco2L * scale) * m.kL.g;
+  }
+  d[0] = ((K.P - ao) - K.npp) + K.rh;
+  d[1] = (K.v1 - r * y[1]) + m.luc_u;
+  d[2] = K.d2 - r * y[2];
+  d[3] = K.s3 - r * y[3];
+  d[4] = ao;
+}
+
+// OceanComponent::stashCValues + SimpleNbox::stashCValues for one lane
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
+                                      double c4, double c5, double c7, Interval &K,
+                                      Interval &K2, const YearCon &yc, bool more) {
+  LandK<B> lk;
+  load_landk<B>(m, lk);
+  const double kHD = PKM(m, PK_K0 + (HXD_KHD - HXD_KLH)), kLH = PKM(m, PK_K0 + 0),
+               kLI = PKM(m, PK_K0 + (HXD_KLI - HXD_KLH)), kIL = PKM(m, PK_K0 + (HXD_KIL - HXD_KLH)),
+               kIH = PKM(m, PK_K0 + (HXD_KIH - HXD_KLH)), kID = PKM(m, PK_K0 + (HXD_KID - HXD_KLH)),
+               kDI = PKM(m, PK_K0 + (HXD_KDI - HXD_KLH));
+  const double yf = t - m.ode_start;
+  m.nstash++;
+  const bool in_partial_year = (t != floor(t));
+  const double co2 = y[0] * PGC2PPM;
+  double aH, aL;
+  if (SPIN) {
+    aH = 1.000 * yf;
+    aL = -1.000 * yf;
+  } else {
+    // compute_fluxes re-runs the chemistry with the PRE-update carbon; at the
+    // first stash of a year that is the carbon the year-start solve already used
+    // (same T, DIC, alk -> same result), so only later stashes need a new solve
+    if (!m.chem_fresh)
+      chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
+                  m.status);
+    m.chem_fresh = false;
+    aH = ((co2 - m.pco2H) * m.kH.g) * yf;
+    aL = ((co2 - m.pco2L) * m.kL.g) * yf;
+  }
+  // box-to-box transports, oceanbox.cpp:244-257 (order: HL, LL, IO, DO)
+  const double lHD = m.cHL * kHD * yf;
+  const double lLH = m.cLL * kLH * yf, lLI = m.cLL * kLI * yf;
+  const double lIL = m.cIO * kIL * yf, lIH = m.cIO * kIH * yf,
+               lID = m.cIO * kID * yf;
+  const double lDI = m.cDO * kDI * yf;
+  const double currentflux = aH + aL;
+  const double totC = m.cDO + m.cIO + m.cLL + m.cHL;
+  const double solver_flux = y[4] - totC;
+  double adj = 0.0;
+  if (currentflux != 0.0) adj = (solver_flux - currentflux) / 2.0;
+  aH += adj;
+  aL += adj;
+  const double inv_yf = hx_recip(yf);
+  const double cdiff = solver_flux * inv_yf - m.lastflux_ann;
+  if (cdiff > 0.1) {  // ocean_component.cpp:703-733
+    m.max_ts = fmax(0.3, m.max_ts * 0.5);
+    m.ts_timeout = 20;
+  } else if (!in_partial_year && m.ts_timeout) {
+    m.ts_timeout = max(0, m.ts_timeout - 1);
+    if (!m.ts_timeout) {
+      m.max_ts = fmin(1.0, m.max_ts / 0.5);
+      if (m.max_ts < 1.0) m.ts_timeout = 20;
+    }
+  }
+  bool diag = false;
+  size_t dgo = 0;
+  if constexpr (CON && !SPIN) {
+    diag = m.bufp->stash_diag != 0;
+    if (diag) {  // annualflux_sumHL/LL, annual_box_fluxes[HL->DO]: sums over the year's stashes
+      const HxBuffers &buf = *m.bufp;
+      dgo = (size_t)m.iy * buf.npad + (blockIdx.x * 64 + m.lane);
+      if (buf.out[HXO_HL_UPTAKE]) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
+      if (buf.out[HXO_LL_UPTAKE]) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
+      if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
+    }
+  }
+  const double lastflux = aL + aH;
+  m.annualflux_sum += lastflux;
+  m.lastflux_ann = lastflux * inv_yf;
+  // update_state: carbon + additions + ao - oa - subtractions (oceanbox.cpp:297-303)
+  m.cHL = ((m.cHL + (lLH + lIH)) + aH) - lHD;
+  m.cLL = ((m.cLL + lIL) + aL) - (lLH + lLI);
+  m.cIO = (m.cIO + (lLI + lDI)) - ((lIL + lIH) + lID);
+  m.cDO = (m.cDO + (lHD + lID)) - lDI;
+
+  // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
+  double npp_t = 0, rh_t = 0, pf_t = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) npp_t += m_npp(m, lk, b);
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+    rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
+#pragma unroll
+  for (int b = 0; b < B; ++b) pf_t += m.pf[b];
+  double alf = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
+  const double npp_rh = npp_t + rh_t;
+  double tpf = c5;
+  if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
+  if (y[0] < 0 || y[1] < 0 || y[2] < 0 || y[3] < 0 || c4 < 0 || tpf < 0)
+    m.status |= HX_ERR_NEGPOOL;
+  double nveg = y[1], ndet = y[2], nsoil = y[3];
+  double rh_adj = 1.0;
+  double npp_fin_total = npp_t;  // npp_total after any NBP constraint (final_npp weights it)
+  if constexpr (CON && !SPIN) {
+    // NBP constraint in stashCValues :343-383: fluxes moved by +-diff/2, the pools by
+    // diff * yf shared by size, the same amount taken out of the deep ocean
+    const double target = (t >= yc.t_half) ? yc.nbp_hi : yc.nbp_lo;
+    if ((yc.mask & HXC_NBP) && !isnan(target)) {
+      const double diff = target - alf;
+      const double npp2 = npp_t + diff / 2.0;
+      npp_fin_total = npp2;
+      rh_adj = (rh_t - diff / 2.0) / rh_t;
+      const double rh2 = rh_t - diff / 2.0;
+      const double pool_diff = diff * yf;
+      const double total_land = ((y[2] + y[1]) + y[3]) + c5;
+      ndet = ndet + pool_diff * y[2] / total_land;
+      nveg = nveg + pool_diff * y[1] / total_land;
+      nsoil = nsoil + pool_diff * y[3] / total_land;
+      tpf = tpf + pool_diff * c5 / total_land;
+      m.cDO = (-pool_diff) + m.cDO;
+      alf = ((npp2 - rh2) - m.luc_e) + m.luc_u;
+    }
+  }
+  m.nbp = alf;
+  double fin_npp = 0, fin_rh = 0, fin_det = 0, fin_soil = 0;
+
+  const double total = y[1] + y[2] + y[3];
+  m.cum_luc_va += hx_div((m.luc_e - m.luc_u) * y[1], total);  // no yf: :388-393
+  const double inv_nr = hx_recip(npp_rh);
+  const double inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const double wt = (B == 1) ? 1.0
+        : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
+    const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
+    if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
+      const double a = m_rh_fda(m, b) * rh_adj, bb = m_rh_fsa(m, b) * rh_adj;
+      const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
+      fin_npp += npp_fin_total * wt;
+      fin_rh += ((a + bb) + cc) + dd;
+      fin_det += a;
+      fin_soil += bb;
+    }
+    if constexpr (CON) m.cum_pf_ch4 += (m_rh_tp_ch4(m, lk, b) * rh_adj) * yf;
+    else m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
+    m.veg[b] = nveg * wt;
+    m.det[b] = ndet * wt;
+    m.soil[b] = nsoil * wt;
+    m.pf[b] = c4 * wt_pf;
+    m.thawed[b] = tpf * wt_pf;
+  }
+  m.earth = c7;
+  m.atmos = y[0];
+  const double sum = ((((((y[0] + y[1]) + y[2]) + y[3]) + c4) + c5) + y[4]) + c7 +
+                     m.cum_pf_ch4;
+  if (m.masstot > 0.0 && fabs(sum - m.masstot) > 0.001) m.status |= HX_ERR_MASS;
+  m.masstot = sum;
+  double ca_residual = 0.0;
+  if (SPIN) {  // pin the atmosphere to C0, residual to the deep box :567-603
+    const double match = m.C0 / PGC2PPM;
+    const double residual = m.atmos - match;
+    m.cDO = residual + m.cDO;
+    m.atmos = m.atmos - residual;
+  } else if constexpr (CON) {
+    // user-supplied [CO2] at this date: same transfer (:567-603); only whole dates exist
+    if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {
+      const double match = yc.co2 / PGC2PPM;
+      const double residual = m.atmos - match;
+      ca_residual = residual;
+      m.cDO = residual + m.cDO;
+      m.atmos = m.atmos - residual;
+    }
+  }
+  if constexpr (CON && !SPIN) {
+    if (diag) {  // the last stash of the year is the one that stays
+      const HxBuffers &buf = *m.bufp;
+      if (buf.out[HXO_NPP]) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
+      if (buf.out[HXO_RH]) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
+      if (buf.out[HXO_RH_DET]) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
+      if (buf.out[HXO_RH_SOIL]) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
+      if (buf.out[HXO_CA_RESIDUAL]) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
+    }
+  }
+  m.ode_start = t;
+  if (more) prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);  // constants of the next segment
+}
+
+// exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
+// scales the next trial step, so ~1e-15 relative error is immaterial.
+__device__ __forceinline__ double powr(double x, double p) { return exp(p * log(x)); }
+
+// x^(-1/5) for the step-growth rule: single-precision seed, two Newton steps on
+// y^-5 = x in fp64 (relative error e -> 3e^2: 1e-6 -> 3e-12 -> ~1e-16).  The
+// fp64 log/exp pair it replaces is a ~75-instruction dependent chain, the longest
+// in the step block, and a single resident wavefront cannot hide it.
+__device__ __forceinline__ double pow_m15(double x) {
+  double y = (double)exp2f(-0.2f * log2f((float)x));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double y2 = y * y;
+    const double y5 = y2 * y2 * y;
+    y = y + y * ((1.0 - x * y5) * 0.2);
+  }
+  return y;
+}
+
+// CarbonCycleSolver::run for one model year t0 -> tnew (carbon-cycle-solver.cpp:
+// 222-303).  The 64 lanes walk the reference's control flow in lock-step over
+// SEGMENTS (one stash interval each): inner loop = dopri5 attempts until every
+// lane has reached its own t_target (retries only move t_target), then ONE stash
+// block for all lanes.  Lanes in reduced-timestep mode take up to 4 segments a
+// year, the others idle through the extra ones; the expensive step and stash
+// blocks are never interleaved lane by lane.
+template <int B, bool SPIN, bool CON = false>
+__device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
+                                           double t0, double tnew, const YearCon &yc) {
+  constexpr int NP = CON ? 6 : 5;  // solver variables (see rhs)
+  // dopri5 tableau (odeint runge_kutta_dopri5)
+  constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
+                   b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
+                   b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+                   b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247,
+                   b64 = 49.0 / 176, b65 = -5103.0 / 18656;
+  constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
+                   c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+  constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
+                   dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
+                   dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+  constexpr double EPS = 2.220446049250313e-16;
+
+  Interval K, K2s;
+  Interval &K2 = CON ? K2s : K;
+  {
+    LandK<B> lk;
+    load_landk<B>(m, lk);
+    prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);
+  }
+  // getCValues  simpleNbox-runtime.cpp:247-258
+  double y[NP], l4, l5, l7;
+  auto load_pools = [&]() {
+    double v = 0, d = 0, s = 0, p = 0, th = 0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+                                   p += m.pf[b]; th += m.thawed[b]; }
+    y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;
+    l4 = p; l5 = th; l7 = m.earth;
+    if constexpr (CON) y[5] = th;
+  };
+  load_pools();
+  m.ode_start = t0;
+  double t = t0;   // time reached by accepted steps
+  int retry = 0;
+  bool alive = true;
+  while (__any(alive && t < tnew)) {
+    const bool seg = alive && t < tnew;
+    // fresh integrate_adaptive call: by-value dt, fresh controlled stepper
+    const double t_start = t;
+    double t_target = tnew, dtl = m.sdt;
+    double dxdt[NP];
+    bool first_call = true;
+    int fails = 0;
+    bool stepping = seg;
+    while (__any(stepping)) {
+      if (stepping) {
+        if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
+        if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
+        // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
+        // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
+        // attempt throws CARBON_CYCLE_RETRY iff its last stage does.
+        if (((t + dtl) - m.ode_start) > m.max_ts) {
+          ++retry;  // carbon-cycle-solver.cpp:266-276
+          t_target = t_start + (t_target - t_start) / 2.0;
+          t = t_start;
+          m.sdt = t_target - t;
+          dtl = m.sdt;
+          load_pools();
+          first_call = true;
+          fails = 0;
+          if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
+        } else {
+          double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
+#pragma unroll
+          for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (1.0 / 5), xt, k2);
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (3.0 / 10), xt, k3);
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (4.0 / 5), xt, k4);
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] +
+                    dtl * b53 * k3[i] + dtl * b54 * k4[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (8.0 / 9), xt, k5);
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] +
+                    dtl * b63 * k3[i] + dtl * b64 * k4[i] + dtl * b65 * k5[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xt, k6);
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
+                    dtl * c5 * k5[i] + dtl * c6 * k6[i];
+          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xn, dn);
+          // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
+          // The maximum of the five quotients is found by cross-multiplication
+          // (all denominators > 0) and divided once.
+          double en = 0.0, ed = 1.0;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
+                              dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
+                              dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
+            const double n = fabs(xe);
+            const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
+            if (n * ed > en * d) { en = n; ed = d; }
+          }
+          double err = hx_div(en, ed);
+          if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
+            dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
+            if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
+          } else {          // accept
+            // pools with a constant derivative over the interval advance exactly
+            l4 += dtl * K.k4; l7 += dtl * K.k7;
+            if constexpr (!CON) l5 += dtl * K.k5;
+            t += dtl;
+            // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
+            const double grow = 0.9 * pow_m15(fmax(0.00032, err));
+            if (err < 0.5) dtl *= grow;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
+            fails = 0;
+            m.nsteps++;
+            if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
+          }
+        }
+      }
+    }
+    if (seg && alive) {
+      // the solver keeps integrating its own c[] afterwards (no getCValues,
+      // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
+      retry = 0;
+      stash<B, SPIN, CON>(m, t, y, l4, CON ? y[NP - 1] : l5, l7, K, K2, yc, t < tnew);
+    }
+  }
+}
+
+}  // namespace

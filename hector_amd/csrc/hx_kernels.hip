@@ -40,1172 +40,10 @@
 #define HX_DJT 8    // block years per thread in the history-pass kernel
 #define HX_KPAD 32  // zero entries in front of / behind the Ker table
 
-namespace {
-
-constexpr double PGC2PPM = 1.0 / 2.13;  // carbon-cycle-model.hpp:29
-constexpr double PG_C_TO_TG_CH4 = 1000.0 * 16.04 / 12.01;
-
-// ---- DOECLIM constants  inst/include/temperature_component.hpp:77-98 -------
-constexpr double D_ak = 0.31, D_bk = 1.59, D_csw = 0.13, D_earth_area = 5100656E8,
-                 D_secs = 60.0 * 60.0 * 24.0 * 365.2422, D_rlam = 1.43,
-                 D_zbot = 4000.0, D_bsi = 1.3, D_cal = 0.52, D_cas = 7.80,
-                 D_flnd = 0.29, D_fso = 0.95;
-
-// ---- ocean geometry  src/ocean_component.cpp:202-303 -----------------------
-constexpr double O_part_high = 0.15, O_part_low = 1 - 0.15;
-constexpr double O_spy = 60.0 * 60 * 24 * 365.25;
-constexpr double O_area = 3.6e14;
-constexpr double O_vLL = O_area * O_part_low * 100.0;
-constexpr double O_vHL = O_area * O_part_high * 100.0;
-constexpr double O_vI = O_area * 900.0;
-constexpr double O_vD = O_area * (3777.0 - 900.0 - 100.0);
-constexpr double O_AsHL = O_area * O_part_high, O_AsLL = O_area * O_part_low;
-constexpr double O_S = 34.5, O_U = 6.7;
-
-// Division where the last bit does not matter.  clang expands an IEEE fp64 division into 11
-// dependent VALU instructions (div_scale x2, rcp, 4 fma, mul, fma, div_fmas, div_fixup); with
-// one wavefront per SIMD that chain is fully exposed.  v_rcp_f64 is good to 4.6e-8 (measured
-// on gfx950); one Newton step brings it to 2e-15, two to 1.1e-16 (<= 1 ulp), for normal-range
-// operands, which is what the model has.  ~65 divisions per member-year.
-__device__ __forceinline__ double hx_recip(double b) {
-  double r = HX_RCP(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ double hx_div(double a, double b) { return a * hx_recip(b); }
-// 2e-15: enough for a Newton correction, whose own error is squared away by the next iteration
-__device__ __forceinline__ double hx_div1(double a, double b) {
-  double r = HX_RCP(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  return a * r;
-}
-
-struct ChemK {  // T-dependent equilibrium constants of one surface box
-  double K1, K2, Kb, Kw, Kh, Tr;
-  double g;  // Tr * As * 12 / 1e15: annual flux per uatm of air-sea pCO2 difference
-};
-
-// oceancsys::ocean_csys_run, the part that depends only on T (S = 34.5, U = 6.7)
-// src/ocean_csys.cpp:205-287, 349
-__device__ __forceinline__ void chem_constants(double Tc, ChemK &k) {
-  const double S = O_S;
-  const double sqrtS = 5.873670062235365;      // sqrt(34.5)
-  const double S15 = 202.64161714712009;       // 34.5^1.5
-  const double Tk = Tc + 273.15;
-  const double lnTk = log(Tk);
-  const double lnTk100 = log(Tk / 100);
-  double tmp1 = -58.0931 + 90.5069 * (100 / Tk) + 22.2940 * lnTk100;
-  double tmp2 = S * (0.027766 - 0.025888 * (Tk / 100) +
-                     0.0050578 * ((Tk / 100) * (Tk / 100)));
-  const double K0 = exp(tmp1 + tmp2);
-  const double Sc =
-      2073.1 - (125.62 * Tc) + (3.6276 * Tc * Tc) - (0.043219 * Tc * Tc * Tc);
-  tmp1 = -13847.26 / Tk + 148.96502 - 23.6521 * lnTk;
-  tmp2 = +(118.67 / Tk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S;
-  k.Kw = exp(tmp1 + tmp2);
-  double tmp = 9345.17 / Tk - 60.2409 + 23.3585 * lnTk100;
-  k.Kh = exp(tmp + S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk));
-  const double pK1 = 3633.86 / Tk - 61.2172 + 9.6777 * lnTk - 0.011555 * S +
-                     0.0001152 * S * S;
-  k.K1 = exp10(-pK1);
-  const double pK2 = 471.78 / Tk + 25.9290 - 3.16967 * lnTk - 0.01781 * S +
-                     0.0001122 * S * S;
-  k.K2 = exp10(-pK2);
-  tmp1 = (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 -
-          0.0996 * S * S) / Tk;
-  tmp2 = +148.0248 + 137.1942 * sqrtS + 1.62142 * S;
-  double tmp3 = +(-24.4344 - 25.085 * sqrtS - 0.2474 * S) * lnTk +
-                0.053105 * sqrtS * Tk;
-  k.Kb = exp(tmp1 + tmp2 + tmp3);
-  k.Tr = (0.585 * K0 * rsqrt(Sc) * O_U * O_U);
-}
-
-// Carbonate solve for one box: DIC + alk -> [H+] (largest real root of the
-// quintic, src/ocean_csys.cpp:289-325) and pCO2 (:328-343).  The quintic has
-// exactly one positive root (one sign change: p5,p4 < 0 < p2,p1,p0), so f > 0
-// left of it and f < 0 right of it for h > 0; Newton from the previous [H+]
-// with a sign-maintained bracket reaches the same root the reference's
-// Fujiwara-bound Newton does.  Stop rule = Boost's (|delta| <= |h| 2^-30).
-__device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
-                                             double inv_vol, double alk,
-                                             double &h_io, unsigned &status) {
-  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
-  const double dic = ((carbon * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol);
-  const double K1 = k.K1, K2 = k.K2, Kb = k.Kb, Kw = k.Kw;
-  const double p4 = -alk - Kb - K1;
-  const double p3 = dic * K1 - alk * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
-  double tmp = dic * (Kb * K1 + 2.0 * K1 * K2) - alk * (Kb * K1 + K1 * K2) +
-               Kb * bor * K1;
-  const double p2 = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
-  tmp = 2.0 * dic * Kb * K1 * K2 - alk * Kb * K1 * K2 + Kb * bor * K1 * K2;
-  const double p1 = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
-  const double p0 = Kw * Kb * K1 * K2;
-  double h = h_io;
-  double lo = 0.0, hi = 1.0;  // f(lo) > 0 > f(hi)
-  const double factor = 0x1p-30;
-  bool done = false;
-  for (int it = 0; it < 200 && !done; ++it) {
-    // Horner, top coefficient first (boost polynomial::evaluate)
-    double f = -1.0;
-    f = f * h + p4; f = f * h + p3; f = f * h + p2; f = f * h + p1; f = f * h + p0;
-    double fp = -5.0;
-    fp = fp * h + 4.0 * p4; fp = fp * h + 3.0 * p3; fp = fp * h + 2.0 * p2;
-    fp = fp * h + p1;
-    if (f == 0.0) { done = true; break; }
-    if (f > 0) lo = h; else hi = h;
-    double delta = f / fp;
-    double hn = h - delta;
-    if (!(hn > lo && hn < hi)) {  // left the bracket (or fp == 0): bisect
-      hn = 0.5 * (lo + hi);
-      delta = h - hn;
-    }
-    done = !(fabs(hn * factor) < fabs(delta));
-    h = hn;
-  }
-  if (!done) status |= HX_ERR_ROOT;
-  h_io = h;
-  const double co2st = dic / (1.0 + K1 / h + K1 * K2 / h / h);
-  return co2st * 1e6 / k.Kh;  // PCO2o, uatm
-}
-
-// The carbonate solve exactly as the reference iterates it: Fujiwara bound as the start
-// (find_largest_root, src/ocean_csys.cpp:134-156) and boost::math::tools::
-// newton_raphson_iterate (roots.hpp, Boost >= 1.71) with 31 bits, whose last step may be a
-// bracket-halving one -- its root is only good to ~1e-9 relative, and WHICH 1e-9 depends on the
-// iteration path.  The year-by-year solves do not care (chem_solve converges to the exact root),
-// but the alkalinity tuner compares objective values that differ by less than that, so it gets
-// the reference's own iteration.  Used ~120 times per member, once per run.
-__device__ __attribute__((noinline)) double chem_solve_ref(const ChemK &k, double carbon,
-                                                           double inv_vol, double alk,
-                                                           double &h_out, unsigned &status) {
-#pragma clang fp contract(off)
-  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
-  // convertToDIC returns umol/kg, ocean_csys_run divides by 1e6 again
-  const double dic = ((((carbon * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol)) * 1e6) / 1e6;
-  const double K1 = k.K1, K2 = k.K2, Kb = k.Kb, Kw = k.Kw;
-  const double a5 = -1.0;
-  const double a4 = -alk - Kb - K1;
-  const double a3 = dic * K1 - alk * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
-  double tmp = dic * (Kb * K1 + 2.0 * K1 * K2) - alk * (Kb * K1 + K1 * K2) + Kb * bor * K1;
-  const double a2 = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
-  tmp = 2.0 * dic * Kb * K1 * K2 - alk * Kb * K1 * K2 + Kb * bor * K1 * K2;
-  const double a1 = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
-  const double a0 = Kw * Kb * K1 * K2;
-  const double d0 = a1 * 1.0, d1 = a2 * 2.0, d2 = a3 * 3.0, d3 = a4 * 4.0, d4 = a5 * 5.0;
-  auto f_ = [&](double z) {
-    double s = a5;
-    s *= z; s += a4; s *= z; s += a3; s *= z; s += a2; s *= z; s += a1; s *= z; s += a0;
-    return s;
-  };
-  auto fp_ = [&](double z) {
-    double s = d4;
-    s *= z; s += d3; s *= z; s += d2; s *= z; s += d1; s *= z; s += d0;
-    return s;
-  };
-  auto sgn = [](double x) { return (double)((x > 0) - (x < 0)); };
-  double mx = pow(fabs(a0 / (2.0 * a5)), 1.0 / 5);
-  {
-    double m_;
-    m_ = pow(fabs(a1 / a5), 1.0 / 4.0); mx = (mx < m_) ? m_ : mx;
-    m_ = pow(fabs(a2 / a5), 1.0 / 3.0); mx = (mx < m_) ? m_ : mx;
-    m_ = pow(fabs(a3 / a5), 1.0 / 2.0); mx = (mx < m_) ? m_ : mx;
-    m_ = pow(fabs(a4 / a5), 1.0 / 1.0); mx = (mx < m_) ? m_ : mx;
-  }
-  mx *= 2.0;
-  double mn = 0.0, guess = mx - 0.001;
-  double f0 = 0, f1, last_f0 = 0, result = guess;
-  const double factor = 0x1p-30;  // ldexp(1, 1 - 31)
-  const double BIG = 1.7976931348623157e308;
-  double delta = BIG, delta1 = BIG, delta2 = BIG;
-  double max_range_f = 0, min_range_f = 0;
-  int count = 100000;
-  bool go = true;
-  while (go) {
-    last_f0 = f0;
-    delta2 = delta1;
-    delta1 = delta;
-    f0 = f_(result);
-    f1 = fp_(result);
-    --count;
-    if (0 == f0) break;
-    if (f1 == 0) {
-      if (last_f0 == 0) {
-        guess = (result == mn) ? mx : mn;
-        last_f0 = f_(guess);
-        delta = guess - result;
-      }
-      if (sgn(last_f0) * sgn(f0) < 0) delta = (delta < 0) ? (result - mn) / 2 : (result - mx) / 2;
-      else delta = (delta < 0) ? (result - mx) / 2 : (result - mn) / 2;
-    } else {
-      delta = f0 / f1;
-    }
-    if (fabs(delta * 2) > fabs(delta2)) {
-      const double shift = (delta > 0) ? (result - mn) / 2 : (result - mx) / 2;
-      if ((result != 0) && (fabs(shift) > fabs(result))) delta = sgn(delta) * fabs(result) * (double)1.1f;
-      else delta = shift;
-      delta1 = 3 * delta;
-      delta2 = 3 * delta;
-    }
-    guess = result;
-    result -= delta;
-    if (result <= mn) {
-      delta = 0.5 * (guess - mn);
-      result = guess - delta;
-      if ((result == mn) || (result == mx)) break;
-    } else if (result >= mx) {
-      delta = 0.5 * (guess - mx);
-      result = guess - delta;
-      if ((result == mn) || (result == mx)) break;
-    }
-    if (delta > 0) { mx = guess; max_range_f = f0; }
-    else { mn = guess; min_range_f = f0; }
-    if (max_range_f * min_range_f > 0) { status |= HX_ERR_ROOT; result = guess; break; }
-    go = count && (fabs(result * factor) < fabs(delta));
-  }
-  const double h = result;
-  h_out = h;
-  const double co2st = dic / (1.0 + K1 / h + K1 * K2 / h / h);
-  return co2st * 1e6 / k.Kh;
-}
-
-// Both surface boxes at once.  Same formulas as chem_constants / chem_solve; the two
-// boxes are independent, so writing them side by side gives the single resident
-// wavefront two dependency chains to interleave, and the seven divisions by Tk
-// share one reciprocal.
-__device__ __forceinline__ void chem_constants2(double TcH, double TcL, ChemK &kH, ChemK &kL) {
-  const double S = O_S;
-  const double sqrtS = 5.873670062235365;      // sqrt(34.5)
-  const double S15 = 202.64161714712009;       // 34.5^1.5
-  const double Tc[2] = {TcH, TcL};
-  const double As[2] = {O_AsHL, O_AsLL};
-  ChemK *k[2] = {&kH, &kL};
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const double Tk = Tc[b] + 273.15;
-    const double rTk = hx_recip(Tk);
-    const double T100 = Tk * 0.01;
-    const double lnTk = log(Tk);
-    const double lnTk100 = lnTk - 4.605170185988092;  // ln(Tk/100)
-    double tmp1 = -58.0931 + 9050.69 * rTk + 22.2940 * lnTk100;
-    double tmp2 = S * (0.027766 - 0.025888 * T100 + 0.0050578 * (T100 * T100));
-    const double K0 = exp(tmp1 + tmp2);
-    const double Sc = 2073.1 - (125.62 * Tc[b]) + (3.6276 * Tc[b] * Tc[b]) -
-                      (0.043219 * Tc[b] * Tc[b] * Tc[b]);
-    tmp1 = -13847.26 * rTk + 148.96502 - 23.6521 * lnTk;
-    tmp2 = +(118.67 * rTk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S;
-    k[b]->Kw = exp(tmp1 + tmp2);
-    double tmp = 9345.17 * rTk - 60.2409 + 23.3585 * lnTk100;
-    k[b]->Kh = exp(tmp + S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk));
-    const double pK1 = 3633.86 * rTk - 61.2172 + 9.6777 * lnTk - 0.011555 * S +
-                       0.0001152 * S * S;
-    k[b]->K1 = exp10(-pK1);
-    const double pK2 = 471.78 * rTk + 25.9290 - 3.16967 * lnTk - 0.01781 * S +
-                       0.0001122 * S * S;
-    k[b]->K2 = exp10(-pK2);
-    tmp1 = (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 - 0.0996 * S * S) * rTk;
-    tmp2 = +148.0248 + 137.1942 * sqrtS + 1.62142 * S;
-    double tmp3 = +(-24.4344 - 25.085 * sqrtS - 0.2474 * S) * lnTk + 0.053105 * sqrtS * Tk;
-    k[b]->Kb = exp(tmp1 + tmp2 + tmp3);
-    k[b]->Tr = (0.585 * K0 * rsqrt(Sc) * O_U * O_U);
-    k[b]->g = k[b]->Tr * As[b] * (12.0 / 1e15);
-  }
-}
-
-__device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, double cH,
-                                            double cL, double alkH, double alkL, double &hH,
-                                            double &hL, double &pco2H, double &pco2L,
-                                            unsigned &status) {
-  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
-  const ChemK *k[2] = {&kH, &kL};
-  const double carbon[2] = {cH, cL}, alk[2] = {alkH, alkL};
-  const double inv_vol[2] = {1.0 / O_vHL, 1.0 / O_vLL};
-  double dic[2], p4[2], p3[2], p2[2], p1[2], p0[2], h[2] = {hH, hL};
-  double lo[2] = {0.0, 0.0}, hi[2] = {1.0, 1.0};
-  bool done[2] = {false, false};
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const double K1 = k[b]->K1, K2 = k[b]->K2, Kb = k[b]->Kb, Kw = k[b]->Kw;
-    dic[b] = ((carbon[b] * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol[b]);
-    p4[b] = -alk[b] - Kb - K1;
-    p3[b] = dic[b] * K1 - alk[b] * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
-    double tmp = dic[b] * (Kb * K1 + 2.0 * K1 * K2) - alk[b] * (Kb * K1 + K1 * K2) +
-                 Kb * bor * K1;
-    p2[b] = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
-    tmp = 2.0 * dic[b] * Kb * K1 * K2 - alk[b] * Kb * K1 * K2 + Kb * bor * K1 * K2;
-    p1[b] = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
-    p0[b] = Kw * Kb * K1 * K2;
-  }
-  const double factor = 0x1p-30;
-  const double q4[2] = {4.0 * p4[0], 4.0 * p4[1]}, q3[2] = {3.0 * p3[0], 3.0 * p3[1]},
-               q2[2] = {2.0 * p2[0], 2.0 * p2[1]};
-  for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const double x = h[b];
-      double f = -1.0;
-      f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
-      f = f * x + p0[b];
-      double fp = -5.0;
-      fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
-      fp = fp * x + p1[b];
-      if (!done[b]) {
-        if (f == 0.0) {
-          done[b] = true;
-        } else {
-          if (f > 0) lo[b] = x; else hi[b] = x;
-          double delta = hx_div1(f, fp);
-          double hn = x - delta;
-          if (!(hn > lo[b] && hn < hi[b])) {  // left the bracket (or fp == 0): bisect
-            hn = 0.5 * (lo[b] + hi[b]);
-            delta = x - hn;
-          }
-          done[b] = !(fabs(hn * factor) < fabs(delta));
-          h[b] = hn;
-        }
-      }
-    }
-  }
-  if (!(done[0] && done[1])) status |= HX_ERR_ROOT;
-  hH = h[0]; hL = h[1];
-  double pc[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
-    const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
-    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
-    pc[b] = hx_div(co2st * 1e6, k[b]->Kh);
-  }
-  pco2H = pc[0]; pco2L = pc[1];
-}
-
-// calc_annual_surface_flux  src/ocean_csys.cpp:375-396
-__device__ __forceinline__ double surf_flux(double co2, double pco2, double scale,
-                                            double Tr, double As) {
-  return (((co2 - pco2 * scale) * Tr) * As * 12.0) / 1e15;
-}
-
-// ---------------------------------------------------------------------------
-// A compiler-only fence: values cached from memory may not be carried across it.
-// The year loop is split into phases by these so that per-member constants that a
-// phase needs are (re)loaded from HBM / L2 inside the phase instead of being kept
-// in registers across the whole solver -- register pressure, not bandwidth, is what
-// limits this kernel (DESIGN.md "registers").
-#define HX_FENCE() asm volatile("" ::: "memory")
-
-// Per-lane LDS scratchpad ("park"): year-level state and the constants that the
-// phases and the stash block need a few times per year.  One wavefront per SIMD
-// means every HBM/L2 access is an exposed ~1-2k-cycle stall; LDS answers in ~64.
-// Filled from the HBM tables at kernel entry, state slots written back at exit.
-enum HxPark {
-  PK_CH4 = 0, PK_SST, PK_EOS, PK_TLAND, PK_TWIN, PK_TL_M1, PK_TL_M2, PK_F_PREV,
-  PK_BASE_TOT, PK_BASE_CO2,            // <- year-level state (HBM state rows)
-  PK_LN_CH4, PK_LN_CO2R,               // ln CH4 and ln(CO2/C0) of the year just finished: the
-                                       // next year needs exactly these logarithms again
-  PK_AERO, PK_VOL,
-  PK_D0,                               // 14 DOECLIM constants HXD_A0..HXD_HFSCALE
-  PK_K0 = PK_D0 + 14,                  // 7 ocean exchange coefficients HXD_KLH..HXD_KDI
-  PK_FFROZEN0 = PK_K0 + 7,             // f_frozen per biome
-};
-// single-biome kernels also park the biome constants (11 more slots)
-enum HxParkB1 { PKB_NPP0 = 0, PKB_F_NPPV, PKB_F_NPPD, PKB_F_LITTERD, PKB_RH_CH4_FRAC,
-                PKB_FPF_STATIC, PKB_BETA, PKB_WF, PKB_LNQ10, PKB_MU, PKB_SIGMA, PKB_N };
-// multi-biome kernels park the nine per-biome arrays of Member instead (see BiomeArr)
-constexpr int HX_NBIOME_ARR = 9;
-template <int B> constexpr int hx_npark() {
-  return PK_FFROZEN0 + B + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * B);
-}
-template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + B; }
-
-// Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
-// registers, 36 doubles for B = 4 on top of the solver's working set overflow 256 VGPRs +
-// 256 AGPRs and ~100 VGPRs spill to scratch, each reload an exposed memory stall; the solver
-// steps themselves only touch the interval constants, not these arrays.
-struct ParkArr {
-  double (*base)[64];
-  int lane;
-  __device__ __forceinline__ double &operator[](int b) const { return base[b][lane]; }
-};
-struct RegArr1 {
-  double v[1];
-  __device__ __forceinline__ double &operator[](int b) { return v[b]; }
-  __device__ __forceinline__ const double &operator[](int b) const { return v[b]; }
-};
-template <int B> struct BiomeArr { using type = ParkArr; };
-template <> struct BiomeArr<1> { using type = RegArr1; };
-
-// What stays in registers through the carbon-cycle solver of one year.
-template <int B>
-struct Member {
-  double C0;
-  // state
-  double cHL, cLL, cIO, cDO, atmos, earth;
-  typename BiomeArr<B>::type veg, det, soil, pf, thawed, tempferts;
-  double cum_luc_va, cum_pf_ch4, masstot;
-  double max_ts, lastflux_ann, sdt;
-  int ts_timeout;
-  double alkH, alkL, hH, hL;
-  unsigned status;
-  // per-year
-  typename BiomeArr<B>::type co2fert, tempfertd, f_new_thaw;
-  double luc_e, luc_u, ffi, daccs, npp_luc_adjust;
-  ChemK kH, kL;
-  double pco2H, pco2L;
-  double annualflux_sum, nbp;
-  int nstash, nsteps;
-  double ode_start;
-  bool chem_fresh;  // pco2H/L already computed for the current box carbon
-  // where this lane's constants live
-  hx_gcd par;  // params + mem   (row stride npad)
-  hx_gcd der;  // derived + mem
-  int npad;
-  double (*pk)[64];  // LDS park
-  int lane;
-  hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
-  const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
-  int iy;                 // year index being integrated
-};
-#define PKM(m, slot) ((m).pk[(slot)][(m).lane])
-
-// biome constants of the land model, fetched where they are used
-template <int B>
-struct LandK {
-  double npp0[B], f_nppv[B], f_nppd[B], f_litterd[B], rh_ch4_frac[B], fpf_static[B];
-};
-template <int B>
-__device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
-  HX_FENCE();
-  if constexpr (B == 1) {
-    constexpr int o = hx_pkb1<B>();
-    k.npp0[0] = PKM(m, o + PKB_NPP0); k.f_nppv[0] = PKM(m, o + PKB_F_NPPV);
-    k.f_nppd[0] = PKM(m, o + PKB_F_NPPD); k.f_litterd[0] = PKM(m, o + PKB_F_LITTERD);
-    k.rh_ch4_frac[0] = PKM(m, o + PKB_RH_CH4_FRAC); k.fpf_static[0] = PKM(m, o + PKB_FPF_STATIC);
-    return;
-  }
-  if (m.upar) {
-    // every member has the same biome constants (the usual case: ensembles perturb Q10, beta,
-    // warming factors): wave-uniform scalar loads instead of 6 B vector loads from HBM
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      hx_ccd r = m.upar + (HXP_NGLOBAL + b * HXPB_N);
-      k.npp0[b] = r[HXPB_NPP0]; k.f_nppv[b] = r[HXPB_F_NPPV]; k.f_nppd[b] = r[HXPB_F_NPPD];
-      k.f_litterd[b] = r[HXPB_F_LITTERD]; k.rh_ch4_frac[b] = r[HXPB_RH_CH4_FRAC];
-      k.fpf_static[b] = r[HXPB_FPF_STATIC];
-    }
-    return;
-  }
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
-    k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
-    k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
-    k.f_nppd[b] = r[(size_t)HXPB_F_NPPD * m.npad];
-    k.f_litterd[b] = r[(size_t)HXPB_F_LITTERD * m.npad];
-    k.rh_ch4_frac[b] = r[(size_t)HXPB_RH_CH4_FRAC * m.npad];
-    k.fpf_static[b] = r[(size_t)HXPB_FPF_STATIC * m.npad];
-  }
-}
-
-// rhs constants that only change at a stash (pools frozen in between,
-// src/simpleNbox-runtime.cpp:809-840)
-struct Interval {
-  double P, npp, rh, v1, d2, s3, k4, k5, k7;
-  double totC, surf, inv_surf;
-};
-
-template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, const LandK<B> &k, int b) {
-  return (k.npp0[b] * m.co2fert[b]) * m.npp_luc_adjust;  // :622-635
-}
-template <int B> __device__ __forceinline__ double m_rh_fda(const Member<B> &m, int b) {
-  return (m.det[b] * 0.25) * m.tempfertd[b];  // :653-665
-}
-template <int B> __device__ __forceinline__ double m_rh_fsa(const Member<B> &m, int b) {
-  return (m.soil[b] * 0.02) * m.tempferts[b];  // :671-683
-}
-template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &m, const LandK<B> &k, int b) {
-  return ((m.thawed[b] * (1 - k.fpf_static[b])) * 0.02) * m.tempferts[b] *
-         (1.0 - k.rh_ch4_frac[b]);  // :689-701
-}
-template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, const LandK<B> &k, int b) {
-  return hx_div(m_rh_tp_co2(m, k, b), 1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
-}
-
-// constraints of one model year, as the solver and the stash see them (CON kernels only)
-struct YearCon {
-  int mask;          // HXC_* bits
-  double co2;        // CO2 constraint of the year that ends at tnew (NaN = none)
-  double nbp_lo;     // NBP constraint of date tnew - 1  (round(t) for t < tnew - 0.5)
-  double nbp_hi;     // NBP constraint of date tnew
-  double t_half;     // tnew - 0.5: round(t) switches from tnew - 1 to tnew here
-};
-
-// the land flows of an interval with frozen pools
-struct Flows {
-  double npp, rh, fav, fad, fas, fda, fsa, tpc, tpm, litter, lfvd, lfvs, detsoil, thaw, refr;
-};
-
-template <int B>
-__device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F, Interval &K) {
-  K.npp = F.npp;
-  K.rh = F.rh;
-  K.P = ((m.ffi - m.daccs) + m.luc_e) - m.luc_u;
-  K.v1 = F.fav - F.litter;
-  K.d2 = ((F.fad + F.lfvd) - F.detsoil) - F.fda;
-  K.s3 = ((F.fas + F.lfvs) + F.detsoil) - F.fsa;
-  K.k4 = -F.thaw + F.refr;
-  K.k5 = ((F.thaw - F.refr) - F.tpm) - F.tpc;
-  K.k7 = -m.ffi + m.daccs;
-  K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
-  K.surf = m.cLL + m.cHL;
-  K.inv_surf = hx_recip(K.surf);
-}
-
-// NBP constraint inside calcderivs: NPP and RH moved by +-diff/2, their parts scaled
-// (simpleNbox-runtime.cpp:871-898)
-template <int B>
-__device__ __forceinline__ void make_interval_nbp(const Member<B> &m, Flows F, double target,
-                                                  Interval &K) {
-  if (!isnan(target)) {
-    const double nbp = ((F.npp - F.rh) - m.luc_e) + m.luc_u;
-    const double diff = target - nbp;
-    const double npp_old = F.npp;
-    F.npp = F.npp + diff / 2.0;
-    const double npp_ratio = F.npp / npp_old;
-    F.fav = F.fav * npp_ratio; F.fad = F.fad * npp_ratio; F.fas = F.fas * npp_ratio;
-    const double rh_old = F.rh;
-    F.rh = F.rh - diff / 2.0;
-    const double rh_ratio = F.rh / rh_old;
-    F.fda = F.fda * rh_ratio; F.fsa = F.fsa * rh_ratio; F.tpc = F.tpc * rh_ratio;
-  }
-  make_interval<B>(m, F, K);
-}
-
-template <int B, bool SPIN>
-__device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B> &lk,
-                                              Flows &F) {
-  double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
-  double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const double n = m_npp(m, lk, b);
-    npp_c += n;
-    fav += n * lk.f_nppv[b];
-    fad += n * lk.f_nppd[b];
-    fas += n * (1 - lk.f_nppv[b] - lk.f_nppd[b]);
-    fda += m_rh_fda(m, b);
-    fsa += m_rh_fsa(m, b);
-    const double co2 = m_rh_tp_co2(m, lk, b), ch4 = m_rh_tp_ch4(m, lk, b);
-    tpc += co2;
-    tpm += ch4;
-    const double v = m.veg[b] * 0.035;
-    litter += v;
-    lfvd += v * lk.f_litterd[b];
-    lfvs += v * (1 - lk.f_litterd[b]);
-    detsoil += m.det[b] * 0.6;
-    if (!SPIN) {  // compute_pf_thaw_refreeze :744-772
-      double c_thaw = m.pf[b] * m.f_new_thaw[b];
-      double r_tp = 0.0;
-      if (c_thaw < 0) {
-        const double want = -c_thaw;
-        c_thaw = 0.0;
-        r_tp = fmin(want, m.thawed[b] - co2 - ch4);
-      }
-      thaw += c_thaw;
-      refr += r_tp;
-    }
-  }
-  F.npp = npp_c; F.rh = fda + fsa + tpc;
-  F.fav = fav; F.fad = fad; F.fas = fas; F.fda = fda; F.fsa = fsa; F.tpc = tpc; F.tpm = tpm;
-  F.litter = litter; F.lfvd = lfvd; F.lfvs = lfvs; F.detsoil = detsoil;
-  F.thaw = thaw; F.refr = refr;
-}
-
-// K: the interval's constants; K2 (CON kernels): the same for the second half of the year,
-// where round(t) picks the next date's NBP constraint
-template <int B, bool SPIN, bool CON = false>
-__device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
-                                              Interval &K, Interval &K2, const YearCon &yc) {
-  Flows F;
-  compute_flows<B, SPIN>(m, lk, F);
-  if constexpr (CON && !SPIN) {
-    if (yc.mask & HXC_NBP) {
-      make_interval_nbp<B>(m, F, yc.nbp_lo, K);
-      make_interval_nbp<B>(m, F, yc.nbp_hi, K2);
-      return;
-    }
-    make_interval<B>(m, F, K);
-    K2 = K;
-    return;
-  }
-  make_interval<B>(m, F, K);
-}
-
-// SimpleNbox::calcderivs + OceanComponent::calcderivs restricted to the five
-// pools whose derivative depends on c[] (atmos, veg, det, soil, ocean)
-template <int B, bool SPIN, bool CON = false>
-__device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, const Interval &K2,
-                                    const YearCon &yc, double t, const double *y, double *d) {
-  // CON kernels carry the thawed-permafrost pool as a sixth solver variable: with an NBP
-  // constraint its derivative changes where round(t) does, so it is no longer constant
-  const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
-  if constexpr (CON) d[5] = K.k5;
-  const double total = y[1] + y[2] + y[3];
-  const double r = hx_div1(m.luc_e, total);  // 2e-15 on a term that is itself ~1e-3 of the flux
-  double ao;
-  if (SPIN) {
-    ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
-  } else {
-    const double scale = (K.surf + (y[4] - K.totC)) * K.inv_surf;
-    const double co2 = y[0] * PGC2PPM;
-    ao = (co2 - m.pco2H * scale) * m.kH.g + (co2 - m.pco2L * scale) * m.kL.g;
-  }
-  d[0] = ((K.P - ao) - K.npp) + K.rh;
-  d[1] = (K.v1 - r * y[1]) + m.luc_u;
-  d[2] = K.d2 - r * y[2];
-  d[3] = K.s3 - r * y[3];
-  d[4] = ao;
-}
-
-// OceanComponent::stashCValues + SimpleNbox::stashCValues for one lane
-template <int B, bool SPIN, bool CON = false>
-__device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
-                                      double c4, double c5, double c7, Interval &K,
-                                      Interval &K2, const YearCon &yc, bool more) {
-  LandK<B> lk;
-  load_landk<B>(m, lk);
-  const double kHD = PKM(m, PK_K0 + (HXD_KHD - HXD_KLH)), kLH = PKM(m, PK_K0 + 0),
-               kLI = PKM(m, PK_K0 + (HXD_KLI - HXD_KLH)), kIL = PKM(m, PK_K0 + (HXD_KIL - HXD_KLH)),
-               kIH = PKM(m, PK_K0 + (HXD_KIH - HXD_KLH)), kID = PKM(m, PK_K0 + (HXD_KID - HXD_KLH)),
-               kDI = PKM(m, PK_K0 + (HXD_KDI - HXD_KLH));
-  const double yf = t - m.ode_start;
-  m.nstash++;
-  const bool in_partial_year = (t != floor(t));
-  const double co2 = y[0] * PGC2PPM;
-  double aH, aL;
-  if (SPIN) {
-    aH = 1.000 * yf;
-    aL = -1.000 * yf;
-  } else {
-    // compute_fluxes re-runs the chemistry with the PRE-update carbon; at the
-    // first stash of a year that is the carbon the year-start solve already used
-    // (same T, DIC, alk -> same result), so only later stashes need a new solve
-    if (!m.chem_fresh)
-      chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
-                  m.status);
-    m.chem_fresh = false;
-    aH = ((co2 - m.pco2H) * m.kH.g) * yf;
-    aL = ((co2 - m.pco2L) * m.kL.g) * yf;
-  }
-  // box-to-box transports, oceanbox.cpp:244-257 (order: HL, LL, IO, DO)
-  const double lHD = m.cHL * kHD * yf;
-  const double lLH = m.cLL * kLH * yf, lLI = m.cLL * kLI * yf;
-  const double lIL = m.cIO * kIL * yf, lIH = m.cIO * kIH * yf,
-               lID = m.cIO * kID * yf;
-  const double lDI = m.cDO * kDI * yf;
-  const double currentflux = aH + aL;
-  const double totC = m.cDO + m.cIO + m.cLL + m.cHL;
-  const double solver_flux = y[4] - totC;
-  double adj = 0.0;
-  if (currentflux != 0.0) adj = (solver_flux - currentflux) / 2.0;
-  aH += adj;
-  aL += adj;
-  const double inv_yf = hx_recip(yf);
-  const double cdiff = solver_flux * inv_yf - m.lastflux_ann;
-  if (cdiff > 0.1) {  // ocean_component.cpp:703-733
-    m.max_ts = fmax(0.3, m.max_ts * 0.5);
-    m.ts_timeout = 20;
-  } else if (!in_partial_year && m.ts_timeout) {
-    m.ts_timeout = max(0, m.ts_timeout - 1);
-    if (!m.ts_timeout) {
-      m.max_ts = fmin(1.0, m.max_ts / 0.5);
-      if (m.max_ts < 1.0) m.ts_timeout = 20;
-    }
-  }
-  bool diag = false;
-  size_t dgo = 0;
-  if constexpr (CON && !SPIN) {
-    diag = m.bufp->stash_diag != 0;
-    if (diag) {  // annualflux_sumHL/LL, annual_box_fluxes[HL->DO]: sums over the year's stashes
-      const HxBuffers &buf = *m.bufp;
-      dgo = (size_t)m.iy * buf.npad + (blockIdx.x * 64 + m.lane);
-      if (buf.out[HXO_HL_UPTAKE]) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
-      if (buf.out[HXO_LL_UPTAKE]) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
-      if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
-    }
-  }
-  const double lastflux = aL + aH;
-  m.annualflux_sum += lastflux;
-  m.lastflux_ann = lastflux * inv_yf;
-  // update_state: carbon + additions + ao - oa - subtractions (oceanbox.cpp:297-303)
-  m.cHL = ((m.cHL + (lLH + lIH)) + aH) - lHD;
-  m.cLL = ((m.cLL + lIL) + aL) - (lLH + lLI);
-  m.cIO = (m.cIO + (lLI + lDI)) - ((lIL + lIH) + lID);
-  m.cDO = (m.cDO + (lHD + lID)) - lDI;
-
-  // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
-  double npp_t = 0, rh_t = 0, pf_t = 0;
-#pragma unroll
-  for (int b = 0; b < B; ++b) npp_t += m_npp(m, lk, b);
-#pragma unroll
-  for (int b = 0; b < B; ++b)
-    rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
-#pragma unroll
-  for (int b = 0; b < B; ++b) pf_t += m.pf[b];
-  double alf = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
-  const double npp_rh = npp_t + rh_t;
-  double tpf = c5;
-  if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
-  if (y[0] < 0 || y[1] < 0 || y[2] < 0 || y[3] < 0 || c4 < 0 || tpf < 0)
-    m.status |= HX_ERR_NEGPOOL;
-  double nveg = y[1], ndet = y[2], nsoil = y[3];
-  double rh_adj = 1.0;
-  double npp_fin_total = npp_t;  // npp_total after any NBP constraint (final_npp weights it)
-  if constexpr (CON && !SPIN) {
-    // NBP constraint in stashCValues :343-383: fluxes moved by +-diff/2, the pools by
-    // diff * yf shared by size, the same amount taken out of the deep ocean
-    const double target = (t >= yc.t_half) ? yc.nbp_hi : yc.nbp_lo;
-    if ((yc.mask & HXC_NBP) && !isnan(target)) {
-      const double diff = target - alf;
-      const double npp2 = npp_t + diff / 2.0;
-      npp_fin_total = npp2;
-      rh_adj = (rh_t - diff / 2.0) / rh_t;
-      const double rh2 = rh_t - diff / 2.0;
-      const double pool_diff = diff * yf;
-      const double total_land = ((y[2] + y[1]) + y[3]) + c5;
-      ndet = ndet + pool_diff * y[2] / total_land;
-      nveg = nveg + pool_diff * y[1] / total_land;
-      nsoil = nsoil + pool_diff * y[3] / total_land;
-      tpf = tpf + pool_diff * c5 / total_land;
-      m.cDO = (-pool_diff) + m.cDO;
-      alf = ((npp2 - rh2) - m.luc_e) + m.luc_u;
-    }
-  }
-  m.nbp = alf;
-  double fin_npp = 0, fin_rh = 0, fin_det = 0, fin_soil = 0;
-
-  const double total = y[1] + y[2] + y[3];
-  m.cum_luc_va += hx_div((m.luc_e - m.luc_u) * y[1], total);  // no yf: :388-393
-  const double inv_nr = hx_recip(npp_rh);
-  const double inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const double wt = (B == 1) ? 1.0
-        : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
-    const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
-    if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
-      const double a = m_rh_fda(m, b) * rh_adj, bb = m_rh_fsa(m, b) * rh_adj;
-      const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
-      fin_npp += npp_fin_total * wt;
-      fin_rh += ((a + bb) + cc) + dd;
-      fin_det += a;
-      fin_soil += bb;
-    }
-    if constexpr (CON) m.cum_pf_ch4 += (m_rh_tp_ch4(m, lk, b) * rh_adj) * yf;
-    else m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
-    m.veg[b] = nveg * wt;
-    m.det[b] = ndet * wt;
-    m.soil[b] = nsoil * wt;
-    m.pf[b] = c4 * wt_pf;
-    m.thawed[b] = tpf * wt_pf;
-  }
-  m.earth = c7;
-  m.atmos = y[0];
-  const double sum = ((((((y[0] + y[1]) + y[2]) + y[3]) + c4) + c5) + y[4]) + c7 +
-                     m.cum_pf_ch4;
-  if (m.masstot > 0.0 && fabs(sum - m.masstot) > 0.001) m.status |= HX_ERR_MASS;
-  m.masstot = sum;
-  double ca_residual = 0.0;
-  if (SPIN) {  // pin the atmosphere to C0, residual to the deep box :567-603
-    const double match = m.C0 / PGC2PPM;
-    const double residual = m.atmos - match;
-    m.cDO = residual + m.cDO;
-    m.atmos = m.atmos - residual;
-  } else if constexpr (CON) {
-    // user-supplied [CO2] at this date: same transfer (:567-603); only whole dates exist
-    if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {
-      const double match = yc.co2 / PGC2PPM;
-      const double residual = m.atmos - match;
-      ca_residual = residual;
-      m.cDO = residual + m.cDO;
-      m.atmos = m.atmos - residual;
-    }
-  }
-  if constexpr (CON && !SPIN) {
-    if (diag) {  // the last stash of the year is the one that stays
-      const HxBuffers &buf = *m.bufp;
-      if (buf.out[HXO_NPP]) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
-      if (buf.out[HXO_RH]) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
-      if (buf.out[HXO_RH_DET]) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
-      if (buf.out[HXO_RH_SOIL]) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
-      if (buf.out[HXO_CA_RESIDUAL]) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
-    }
-  }
-  m.ode_start = t;
-  if (more) prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);  // constants of the next segment
-}
-
-// exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
-// scales the next trial step, so ~1e-15 relative error is immaterial.
-__device__ __forceinline__ double powr(double x, double p) { return exp(p * log(x)); }
-
-// x^(-1/5) for the step-growth rule: single-precision seed, two Newton steps on
-// y^-5 = x in fp64 (relative error e -> 3e^2: 1e-6 -> 3e-12 -> ~1e-16).  The
-// fp64 log/exp pair it replaces is a ~75-instruction dependent chain, the longest
-// in the step block, and a single resident wavefront cannot hide it.
-__device__ __forceinline__ double pow_m15(double x) {
-  double y = (double)exp2f(-0.2f * log2f((float)x));
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const double y2 = y * y;
-    const double y5 = y2 * y2 * y;
-    y = y + y * ((1.0 - x * y5) * 0.2);
-  }
-  return y;
-}
-
-// CarbonCycleSolver::run for one model year t0 -> tnew (carbon-cycle-solver.cpp:
-// 222-303).  The 64 lanes walk the reference's control flow in lock-step over
-// SEGMENTS (one stash interval each): inner loop = dopri5 attempts until every
-// lane has reached its own t_target (retries only move t_target), then ONE stash
-// block for all lanes.  Lanes in reduced-timestep mode take up to 4 segments a
-// year, the others idle through the extra ones; the expensive step and stash
-// blocks are never interleaved lane by lane.
-template <int B, bool SPIN, bool CON = false>
-__device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
-                                           double t0, double tnew, const YearCon &yc) {
-  constexpr int NP = CON ? 6 : 5;  // solver variables (see rhs)
-  // dopri5 tableau (odeint runge_kutta_dopri5)
-  constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
-                   b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
-                   b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
-                   b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247,
-                   b64 = 49.0 / 176, b65 = -5103.0 / 18656;
-  constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
-                   c5 = -2187.0 / 6784, c6 = 11.0 / 84;
-  constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
-                   dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
-                   dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
-  constexpr double EPS = 2.220446049250313e-16;
-
-  Interval K, K2s;
-  Interval &K2 = CON ? K2s : K;
-  {
-    LandK<B> lk;
-    load_landk<B>(m, lk);
-    prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);
-  }
-  // getCValues  simpleNbox-runtime.cpp:247-258
-  double y[NP], l4, l5, l7;
-  auto load_pools = [&]() {
-    double v = 0, d = 0, s = 0, p = 0, th = 0;
-#pragma unroll
-    for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
-                                   p += m.pf[b]; th += m.thawed[b]; }
-    y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;
-    l4 = p; l5 = th; l7 = m.earth;
-    if constexpr (CON) y[5] = th;
-  };
-  load_pools();
-  m.ode_start = t0;
-  double t = t0;   // time reached by accepted steps
-  int retry = 0;
-  bool alive = true;
-  while (__any(alive && t < tnew)) {
-    const bool seg = alive && t < tnew;
-    // fresh integrate_adaptive call: by-value dt, fresh controlled stepper
-    const double t_start = t;
-    double t_target = tnew, dtl = m.sdt;
-    double dxdt[NP];
-    bool first_call = true;
-    int fails = 0;
-    bool stepping = seg;
-    while (__any(stepping)) {
-      if (stepping) {
-        if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
-        if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
-        // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
-        // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
-        // attempt throws CARBON_CYCLE_RETRY iff its last stage does.
-        if (((t + dtl) - m.ode_start) > m.max_ts) {
-          ++retry;  // carbon-cycle-solver.cpp:266-276
-          t_target = t_start + (t_target - t_start) / 2.0;
-          t = t_start;
-          m.sdt = t_target - t;
-          dtl = m.sdt;
-          load_pools();
-          first_call = true;
-          fails = 0;
-          if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
-        } else {
-          double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
-#pragma unroll
-          for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (1.0 / 5), xt, k2);
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (3.0 / 10), xt, k3);
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (4.0 / 5), xt, k4);
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] +
-                    dtl * b53 * k3[i] + dtl * b54 * k4[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (8.0 / 9), xt, k5);
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] +
-                    dtl * b63 * k3[i] + dtl * b64 * k4[i] + dtl * b65 * k5[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xt, k6);
-#pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
-                    dtl * c5 * k5[i] + dtl * c6 * k6[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xn, dn);
-          // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
-          // The maximum of the five quotients is found by cross-multiplication
-          // (all denominators > 0) and divided once.
-          double en = 0.0, ed = 1.0;
-#pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
-                              dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
-                              dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
-            const double n = fabs(xe);
-            const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
-            if (n * ed > en * d) { en = n; ed = d; }
-          }
-          double err = hx_div(en, ed);
-          if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
-            dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
-            if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
-          } else {          // accept
-            // pools with a constant derivative over the interval advance exactly
-            l4 += dtl * K.k4; l7 += dtl * K.k7;
-            if constexpr (!CON) l5 += dtl * K.k5;
-            t += dtl;
-            // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
-            const double grow = 0.9 * pow_m15(fmax(0.00032, err));
-            if (err < 0.5) dtl *= grow;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
-            fails = 0;
-            m.nsteps++;
-            if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
-          }
-        }
-      }
-    }
-    if (seg && alive) {
-      // the solver keeps integrating its own c[] afterwards (no getCValues,
-      // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
-      retry = 0;
-      stash<B, SPIN, CON>(m, t, y, l4, CON ? y[NP - 1] : l5, l7, K, K2, yc, t < tnew);
-    }
-  }
-}
-
-// oceanbox::chem_equilibrate: tune alkalinity so that the chemistry reproduces
-// the spinup flux at CO2 = co2 (src/oceanbox.cpp:382-445).  Boost's
-// brent_find_minima restated; the alkalinity kept is the LAST point evaluated.
-__device__ __forceinline__ double equilibrate_alk(const ChemK &k, double carbon,
-                                                  double inv_vol, double As,
-                                                  double co2, double f_target,
-                                                  double &h, unsigned &status) {
-  // Brent's branch decisions hinge on differences of nearly equal numbers (it is
-  // minimising a V-shaped |flux - target|); its resolution here is only
-  // tol/4 = 7.5e-9 absolute = 3e-6 of the alkalinity, so a different path ends
-  // 1e-6..1e-5 away and moves CO2 by up to ~3e-6 relative.  Keep the arithmetic of
-  // the decision logic exactly the reference's: no FMA contraction in here.
-#pragma clang fp contract(off)
-  auto fmin_ = [&](double alk) {
-    const double p = chem_solve_ref(k, carbon, inv_vol, alk, h, status);
-    return fabs(surf_flux(co2, p, 1.0, k.Tr, As) - f_target);
-  };
-  const double tolerance = 0x1p-25;  // bits = min(53/2, 31) = 26
-  double mn = 2100e-6, mx = 2750e-6;
-  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
-  const double golden = 0.3819660f;
-  x = w = v = mx;
-  fw = fv = fx = fmin_(x);
-  delta2 = delta = 0;
-  u = x;
-  for (int count = 0; count < 1000; ++count) {
-    mid = (mn + mx) / 2;
-    fract1 = tolerance * fabs(x) + tolerance / 4;
-    fract2 = 2 * fract1;
-    if (fabs(x - mid) <= (fract2 - (mx - mn) / 2)) break;
-    if (fabs(delta2) > fract1) {
-      double r = (x - w) * (fx - fv);
-      double q = (x - v) * (fx - fw);
-      double p = (x - v) * q - (x - w) * r;
-      q = 2 * (q - r);
-      if (q > 0) p = -p;
-      q = fabs(q);
-      const double td = delta2;
-      delta2 = delta;
-      if ((fabs(p) >= fabs(q * td / 2)) || (p <= q * (mn - x)) || (p >= q * (mx - x))) {
-        delta2 = (x >= mid) ? mn - x : mx - x;
-        delta = golden * delta2;
-      } else {
-        delta = p / q;
-        u = x + delta;
-        if (((u - mn) < fract2) || ((mx - u) < fract2))
-          delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
-      }
-    } else {
-      delta2 = (x >= mid) ? mn - x : mx - x;
-      delta = golden * delta2;
-    }
-    u = (fabs(delta) >= fract1) ? (x + delta)
-                                : (delta > 0 ? (x + fabs(fract1)) : (x - fabs(fract1)));
-    fu = fmin_(u);
-    if (fu <= fx) {
-      if (u >= x) mn = x; else mx = x;
-      v = w; w = x; x = u; fv = fw; fw = fx; fx = fu;
-    } else {
-      if (u < x) mn = u; else mx = u;
-      if ((fu <= fw) || (w == x)) { v = w; w = u; fv = fw; fw = fu; }
-      else if ((fu <= fv) || (v == x) || (v == w)) { v = u; fv = fu; }
-    }
-  }
-  return u;
-}
-
-// ---- SoA helpers ------------------------------------------------------------
-__device__ __forceinline__ double ldp(const HxBuffers &b, int row, int mem) {
-  return HX_GCD(b.params)[(size_t)row * b.npad + mem];
-}
-__device__ __forceinline__ double ldd(const HxBuffers &b, int row, int mem) {
-  return HX_GCD(b.derived)[(size_t)row * b.npad + mem];
-}
-__device__ __forceinline__ double lds_(const HxBuffers &b, int row, int mem) {
-  return HX_GCD(b.state)[(size_t)row * b.npad + mem];
-}
-__device__ __forceinline__ void sts_(const HxBuffers &b, int row, int mem, double v) {
-  HX_GD(b.state)[(size_t)row * b.npad + mem] = v;
-}
-__device__ __forceinline__ void sto_(const HxBuffers &b, int var, size_t off, double v) {
-  HX_GD(b.out[var])[off] = v;
-}
-
-template <int B>
-__device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Member<B> &m,
-                                            double (*park)[64], int lane) {
-  m.par = HX_GCD(buf.params) + mem;
-  m.der = HX_GCD(buf.derived) + mem;
-  m.npad = buf.npad;
-  m.pk = park;
-  m.lane = lane;
-  m.upar = (B > 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
-  if constexpr (B > 1) {
-    constexpr int o = hx_pkb1<B>();
-    ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
-                                   &m.co2fert, &m.tempfertd, &m.f_new_thaw};
-#pragma unroll
-    for (int k = 0; k < HX_NBIOME_ARR; ++k) { arr[k]->base = park + o + k * B; arr[k]->lane = lane; }
-  }
-  m.C0 = ldp(buf, HXP_C0, mem);
-  // constants -> park
-  PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
-  PKM(m, PK_VOL) = ldp(buf, HXP_VOL, mem);
-#pragma unroll
-  for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
-#pragma unroll
-  for (int k = 0; k < 7; ++k) PKM(m, PK_K0 + k) = ldd(buf, HXD_KLH + k, mem);
-  if constexpr (B == 1) {
-    constexpr int o = hx_pkb1<B>();
-    const int r = HXP_NGLOBAL;
-    PKM(m, o + PKB_NPP0) = ldp(buf, r + HXPB_NPP0, mem);
-    PKM(m, o + PKB_F_NPPV) = ldp(buf, r + HXPB_F_NPPV, mem);
-    PKM(m, o + PKB_F_NPPD) = ldp(buf, r + HXPB_F_NPPD, mem);
-    PKM(m, o + PKB_F_LITTERD) = ldp(buf, r + HXPB_F_LITTERD, mem);
-    PKM(m, o + PKB_RH_CH4_FRAC) = ldp(buf, r + HXPB_RH_CH4_FRAC, mem);
-    PKM(m, o + PKB_FPF_STATIC) = ldp(buf, r + HXPB_FPF_STATIC, mem);
-    PKM(m, o + PKB_BETA) = ldp(buf, r + HXPB_BETA, mem);
-    PKM(m, o + PKB_WF) = ldp(buf, r + HXPB_WF, mem);
-    PKM(m, o + PKB_LNQ10) = ldd(buf, HXD_NGLOBAL, mem);
-    PKM(m, o + PKB_MU) = ldp(buf, r + HXPB_PF_MU, mem);
-    PKM(m, o + PKB_SIGMA) = ldp(buf, r + HXPB_PF_SIGMA, mem);
-  }
-}
-
-// solver-resident state <-> HBM state table
-template <int B>
-__device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member<B> &m) {
-  m.cHL = lds_(buf, HXS_C_HL, mem); m.cLL = lds_(buf, HXS_C_LL, mem);
-  m.cIO = lds_(buf, HXS_C_IO, mem); m.cDO = lds_(buf, HXS_C_DO, mem);
-  m.atmos = lds_(buf, HXS_ATMOS, mem); m.earth = lds_(buf, HXS_EARTH, mem);
-  m.cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem);
-  m.cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem);
-  m.masstot = lds_(buf, HXS_MASSTOT, mem);
-  m.max_ts = lds_(buf, HXS_MAX_TS, mem);
-  m.ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
-  m.lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
-  m.sdt = lds_(buf, HXS_SOLVER_DT, mem);
-  m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem);
-  m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const int r = HXS_NGLOBAL + b * HXSB_N;
-    m.veg[b] = lds_(buf, r + HXSB_VEG, mem); m.det[b] = lds_(buf, r + HXSB_DET, mem);
-    m.soil[b] = lds_(buf, r + HXSB_SOIL, mem); m.pf[b] = lds_(buf, r + HXSB_PF, mem);
-    m.thawed[b] = lds_(buf, r + HXSB_THAWED, mem);
-    m.tempferts[b] = lds_(buf, r + HXSB_TEMPFERTS, mem);
-  }
-  m.status = HX_GU(buf.status)[mem];
-}
-
-template <int B>
-__device__ __forceinline__ void store_state(const HxBuffers &buf_, int mem,
-                                            const Member<B> &m, double *base = nullptr) {
-  // base == nullptr: the live state table; otherwise a per-year history slab
-  HxBuffers buf = buf_;
-  if (base) buf.state = base;
-  sts_(buf, HXS_C_HL, mem, m.cHL); sts_(buf, HXS_C_LL, mem, m.cLL);
-  sts_(buf, HXS_C_IO, mem, m.cIO); sts_(buf, HXS_C_DO, mem, m.cDO);
-  sts_(buf, HXS_ATMOS, mem, m.atmos); sts_(buf, HXS_EARTH, mem, m.earth);
-  sts_(buf, HXS_CUM_LUC_VA, mem, m.cum_luc_va);
-  sts_(buf, HXS_CUM_PF_CH4, mem, m.cum_pf_ch4);
-  sts_(buf, HXS_MASSTOT, mem, m.masstot);
-  sts_(buf, HXS_MAX_TS, mem, m.max_ts);
-  sts_(buf, HXS_TS_TIMEOUT, mem, (double)m.ts_timeout);
-  sts_(buf, HXS_LASTFLUX_ANN, mem, m.lastflux_ann);
-  sts_(buf, HXS_SOLVER_DT, mem, m.sdt);
-  sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
-  sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const int r = HXS_NGLOBAL + b * HXSB_N;
-    sts_(buf, r + HXSB_VEG, mem, m.veg[b]); sts_(buf, r + HXSB_DET, mem, m.det[b]);
-    sts_(buf, r + HXSB_SOIL, mem, m.soil[b]); sts_(buf, r + HXSB_PF, mem, m.pf[b]);
-    sts_(buf, r + HXSB_THAWED, mem, m.thawed[b]);
-    sts_(buf, r + HXSB_TEMPFERTS, mem, m.tempferts[b]);
-  }
-  if (!base) HX_GU(buf.status)[mem] = m.status;
-}
-
-// year-level state: park -> state rows of `base` (live table or history slab)
-template <int B>
-__device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
-                                                 const Member<B> &m, double *base = nullptr) {
-  HxBuffers buf = buf_;
-  if (base) buf.state = base;
-  sts_(buf, HXS_CH4, mem, PKM(m, PK_CH4)); sts_(buf, HXS_SST, mem, PKM(m, PK_SST));
-  sts_(buf, HXS_TLAND, mem, PKM(m, PK_TLAND)); sts_(buf, HXS_TWIN, mem, PKM(m, PK_TWIN));
-  sts_(buf, HXS_TL_M1, mem, PKM(m, PK_TL_M1)); sts_(buf, HXS_TL_M2, mem, PKM(m, PK_TL_M2));
-  sts_(buf, HXS_F_PREV, mem, PKM(m, PK_F_PREV));
-  sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
-  sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
-  if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
-#pragma unroll
-  for (int b = 0; b < B; ++b)
-    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
-}
-
-}  // namespace
+#include "hx_dev_const.h"
+#include "hx_dev_chem.h"
+#include "hx_dev_member.h"
+#include "hx_dev_solver.h"
 
 // ===========================================================================
 // Per-member derived constants, once per parameter upload: DOECLIM matrices and
