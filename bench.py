@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target wall time of the bounded CPU-baseline sample")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
+                         "multi-process flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,11 +127,16 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the integrator has no CPU path")
+    if args.dist_backend != "nccl":  # rehearsal: ranks may share a GPU
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     n = args.members
     offset = rank * n  # weak scaling: contiguous member blocks, SURVEY.md 8(e)
