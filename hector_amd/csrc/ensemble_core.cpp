@@ -142,8 +142,20 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
   check(hipSetDevice(device_), "hipSetDevice");
   check(hipStreamCreate(&stream_), "hipStreamCreate");
-  check(hipEventCreate(&ev0_), "hipEventCreate");
-  check(hipEventCreate(&ev1_), "hipEventCreate");
+  try {  // a constructor that throws gets no destructor: release the stream and events here
+    check(hipEventCreate(&ev0_), "hipEventCreate");
+    check(hipEventCreate(&ev1_), "hipEventCreate");
+    init_from_scenario();
+  } catch (...) {
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    (void)hipStreamDestroy(stream_);
+    throw;
+  }
+}
+
+// parameter rows, biomes and the per-year table from the scenario (INI) values
+void EnsembleCore::init_from_scenario() {
   for (int v = 0; v < HXO_NVAR; ++v) { d_out_[v] = nullptr; out_enabled_[v] = false; }
   out_enabled_[HXO_SST] = out_enabled_[HXO_TLAND] = true;
   out_enabled_[HXO_CO2] = out_enabled_[HXO_TGAV] = true;

@@ -121,6 +121,7 @@ class EnsembleCore {
   double *d_mseries_[HXM_N] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool mseries_dirty_ = false;
   void upload_member_series();
+  void init_from_scenario();
   std::vector<std::string> halo_names_;
   std::vector<std::vector<double>> halo_conc_;  // [gas][ns] halocarbon concentrations, pptv
   std::vector<double> shared_, ker_;
