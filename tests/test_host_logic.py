@@ -84,14 +84,16 @@ def test_ini_reader_equals_pack(emul_lib):
         assert np.array_equal(a.fetchvars(v), b.fetchvars(v))
 
 
-def test_example_script_runs(emul_lib):
-    """examples/ensemble_ecs_q10.py end to end (through the emulation build here)."""
+def test_example_script_runs(emul_lib, capsys):
+    """examples/ensemble_ecs_q10.py end to end (its main() on the emulation build here)."""
+    import importlib.util
     import os
-    import subprocess
-    import sys
     from conftest import ROOT
-    env = dict(os.environ, HECTOR_AMD_EMULATION_LIB=emul_lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ensemble_ecs_q10.py"), "8"],
-                       capture_output=True, text=True, env=env)
-    assert r.returncode == 0, r.stderr
-    assert "2100 warming" in r.stdout and "halved fossil emissions" in r.stdout
+    spec = importlib.util.spec_from_file_location(
+        "example_ecs_q10", os.path.join(ROOT, "examples", "ensemble_ecs_q10.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tas, tas2 = mod.main(8, lib_path=emul_lib, allow_emulation=True)
+    assert (tas2 < tas).all()
+    out = capsys.readouterr().out
+    assert "2100 warming" in out and "halved fossil emissions" in out
