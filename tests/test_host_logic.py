@@ -39,6 +39,13 @@ def test_loader_refuses_emulation_as_product(emul_lib):
     with pytest.raises(hector_amd.HectorAmdError):
         _lib.load(emul_lib)
     assert _lib.load(emul_lib, allow_emulation=True).hx_backend() == b"host-emulation"
+    # ... and only from where the tests build it: a copy elsewhere is refused even on request
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        other = shutil.copy(emul_lib, d)
+        with pytest.raises(_lib.HectorAmdError):
+            _lib.load(other, allow_emulation=True)
 
 
 def test_ensemble_generator_is_counter_based():
