@@ -172,11 +172,17 @@ class Core:
     def sync(self):
         self._ck(self._lib.hx_sync(self._h))
 
-    def fetchvars(self, var, dates=None):
-        """-> ndarray [n_years, n_members] for dates = (year0, year1) inclusive."""
+    def fetchvars(self, var, dates=None, out=None):
+        """-> ndarray [n_years, n_members] for dates = (year0, year1) inclusive.  `out`: a
+        C-contiguous float64 array of that shape to reuse (a buffer the host has already touched
+        takes the device-to-host copy ~3x faster than a fresh allocation)."""
         y0, y1 = (self.strtdate, self.current_date) if dates is None else \
             (int(min(dates)), int(max(dates)))
-        out = np.empty((y1 - y0 + 1, self.n_members))
+        shape = (y1 - y0 + 1, self.n_members)
+        if out is None:
+            out = np.empty(shape)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+            raise HectorAmdError("fetchvars: out must be a C-contiguous float64 array of shape %r" % (shape,))
         self._ck(self._lib.hx_fetchvars(self._h, var.encode(), y0, y1,
                                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
