@@ -11,9 +11,6 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
                             hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, bool con,
                          int iy_from, int iy_to, hipStream_t st);
-hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, double *part,
-                                  double *part2, int ns, int npad, int blk0, int nyears,
-                                  bool heatflux, bool kpm, hipStream_t st);
 int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);

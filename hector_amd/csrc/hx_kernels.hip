@@ -37,7 +37,6 @@
 #include "hx_layout.h"
 
 #define HX_DBLK 32  // DOECLIM block length = years per run-kernel launch
-#define HX_DJT 8    // block years per thread in the history-pass kernel
 #define HX_KPAD 32  // zero entries in front of / behind the Ker table
 
 #include "hx_dev_const.h"
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(256) void hx_derive_kernel(const double *params, do
 }
 
 
-// In-kernel form of the DOECLIM history pass (see hx_doeclim_pass_kernel below for
+// The DOECLIM history pass (in-kernel device call; see DESIGN.md section 4 for
 // the algorithm): one lane = one member, all HX_DBLK block years, two sweeps of 16
 // accumulators.  Deliberately NOT inlined: as a real call it gets its own register
 // allocation (16 loads in flight need landing registers the year loop does not have),
@@ -184,66 +183,6 @@ __device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_his
       HX_GD(part)[(size_t)(j0 + j) * np + mem] = acc[j];
       if (HF) HX_GD(part2)[(size_t)(j0 + j) * np + mem] = acc2[j];
     }
-  }
-}
-
-// ===========================================================================
-// DOECLIM history pass.  sum_{i<t} Tsst[i] * Ker[ns - t + i - 1]
-// (temperature_component.cpp:488-491; :534-537 for the heat-flux diagnostic, Ker
-// index + 1) is a causal convolution: evaluated per year it re-reads the whole SST
-// history every year (83 % of the algorithmic HBM bytes).  The run
-// kernel is launched per block of <= HX_DBLK years; before each launch this kernel
-// reads the history BEFORE the block once and leaves, for every year of the block,
-// the partial sum over that history in part[j][member] -- same ascending summation
-// order per year as the reference; the run kernel appends the in-block terms.
-// Thread = (member, HX_DJT block years); history in chunks of 16 years: 16 coalesced
-// loads in flight + a 23-entry window of Ker (scalar loads when the diffusivity is
-// shared) per 128 FMAs.  Ker is zero-padded by HX_KPAD entries on both sides, so
-// block years beyond the end of the run and the ragged last chunk need no branches.
-// ===========================================================================
-template <bool KERPM, bool HF>
-__global__ __launch_bounds__(64) void hx_doeclim_pass_kernel(const double *sst_hist,
-                                                             const double *ker, double *part,
-                                                             double *part2, int ns, int npad,
-                                                             int blk0) {
-  const int mem = blockIdx.x * 64 + threadIdx.x;
-  const int j0 = blockIdx.y * HX_DJT;
-  if (mem >= npad) return;
-  double acc[HX_DJT], acc2[HX_DJT];
-#pragma unroll
-  for (int j = 0; j < HX_DJT; ++j) { acc[j] = 0; acc2[j] = 0; }
-  hx_gcd hist = HX_GCD(sst_hist) + mem;
-  const size_t np = (size_t)npad;
-  // window entry w of chunk i0 = Ker[(ns - (blk0 + j0) - 1) + i0 - (HX_DJT - 1) + w]
-  const int k0 = ns - (blk0 + j0) - 1 - (HX_DJT - 1) + HX_KPAD;
-  auto ldk = [&](int idx) -> double {
-    if constexpr (KERPM) return HX_GCD(ker)[(size_t)idx * np + mem];
-    else return HX_CCD(ker)[idx];
-  };
-  for (int i0 = 0; i0 < blk0; i0 += 16) {
-    double T[16], kw[HX_DJT + 16];
-#pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-      const int i = i0 + ii;
-      // rows >= blk0 may hold stale values of an earlier run: mask them
-      const double v = hist[(size_t)(i < ns ? i : ns - 1) * np];
-      T[ii] = (i < blk0) ? v : 0.0;
-    }
-#pragma unroll
-    for (int w = 0; w < HX_DJT + 16; ++w) kw[w] = ldk(k0 + i0 + w);
-#pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-#pragma unroll
-      for (int j = 0; j < HX_DJT; ++j) {
-        acc[j] += T[ii] * kw[HX_DJT - 1 + ii - j];
-        if (HF) acc2[j] += T[ii] * kw[HX_DJT + ii - j];
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < HX_DJT; ++j) {
-    HX_GD(part)[(size_t)(j0 + j) * np + mem] = acc[j];
-    if (HF) HX_GD(part2)[(size_t)(j0 + j) * np + mem] = acc2[j];
   }
 }
 
@@ -647,7 +586,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           rf_co2 = fco2 - base_co2;
         }
       }
-      // ---- DOECLIM: history before the block (hx_doeclim_pass_kernel) + in-block terms ----
+      // ---- DOECLIM: history before the block (doeclim_pass_dev) + in-block terms ----
       double tl_new, sst_new, heatflux = 0, tgav, flux_mixed = 0, flux_interior = 0;
       {
         const int j = jb;
@@ -1128,20 +1067,6 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
   return hipGetLastError();
 }
 
-hipError_t hx_launch_doeclim_pass(const double *sst_hist, const double *ker, double *part,
-                                  double *part2, int ns, int npad, int blk0, int nyears,
-                                  bool heatflux, bool kpm, hipStream_t st) {
-  const dim3 grid(npad / 64, (nyears + HX_DJT - 1) / HX_DJT), block(64);
-  if (heatflux && kpm)
-    hipLaunchKernelGGL((hx_doeclim_pass_kernel<true, true>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
-  else if (heatflux)
-    hipLaunchKernelGGL((hx_doeclim_pass_kernel<false, true>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
-  else if (kpm)
-    hipLaunchKernelGGL((hx_doeclim_pass_kernel<true, false>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
-  else
-    hipLaunchKernelGGL((hx_doeclim_pass_kernel<false, false>), grid, block, 0, st, sst_hist, ker, part, part2, ns, npad, blk0);
-  return hipGetLastError();
-}
 int hx_doeclim_block_years() { return HX_DBLK; }
 int hx_doeclim_kernel_pad() { return HX_KPAD; }
 hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, const double *alk,
