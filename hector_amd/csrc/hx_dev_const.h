@@ -9,7 +9,7 @@ constexpr double PGC2PPM = 1.0 / 2.13;  // carbon-cycle-model.hpp:29
 constexpr double PG_C_TO_TG_CH4 = 1000.0 * 16.04 / 12.01;
 
 // ---- DOECLIM constants  inst/include/temperature_component.hpp:77-98 -------
-constexpr double D_ak = 0.31, D_bk = 1.59, D_csw = 0.13, D_earth_area = 5100656E8,
+constexpr double D_ak = 0.31, D_bk = 1.59, D_csw = 0.13,
                  D_secs = 60.0 * 60.0 * 24.0 * 365.2422, D_rlam = 1.43,
                  D_zbot = 4000.0, D_bsi = 1.3, D_cal = 0.52, D_cas = 7.80,
                  D_flnd = 0.29, D_fso = 0.95;
