@@ -39,7 +39,8 @@ const char *hx_last_error(void);
 /* newcore(inifile, ...)  R/hector.R:81-87, src/rcpp_hector.cpp:31-86.
  * `scenario` is a Hector INI file (csv: tables resolved like the reference) or
  * a dense scenario pack (.hxs).  Creates an n_members ensemble on GPU `device`,
- * all members at the INI's parameter values, one biome "global". */
+ * all members at the INI's parameter values; one biome "global", or the biomes the INI
+ * defines with "<biome>.<variable>" keys (at most 4). */
 int hx_newcore(const char *scenario, int n_members, int device, hx_core **out);
 
 /* shutdown(core)  src/rcpp_hector.cpp:88-101 (Core::shutDown + delcore) */
@@ -50,12 +51,15 @@ int hx_shutdown(hx_core *core);
  * capability: component_data.hpp string, optionally "<biome>.<capability>".
  * nvalues is 1 (every member) or n_members.  units: NULL/"" = unchecked, else it
  * must match the reference's unit string (e.g. "degC" for S).  Like the R
- * wrapper this invalidates results from date 0 (the next run respins if needed). */
+ * wrapper this invalidates results from date 0 (the next run respins if needed).
+ * Parameters of the member-independent components (delta_co2, rho_bc, rho_<gas>, M0, N0,
+ * Tsoil, Tstrat ...) take one value for the whole core. */
 int hx_setvar(hx_core *core, const char *capability, const double *values, int nvalues,
               const char *units);
 /* setvar(core, dates, var, values, unit) for a scenario INPUT series (emissions, SV,
- * RF_albedo, RF_misc ...; R/messages.R:107-140 with dates): the same new values for every
- * member.  Marks the core dirty from min(year)-1: the next hx_run first resets there (if the
+ * RF_albedo, RF_misc ...) or a constraint (CO2_constrain, NBP_constrain, tas_constrain,
+ * RF_tot_constrain, CH4_constrain, N2O_constrain, <gas>_constrain; NaN removes a date);
+ * R/messages.R:107-140 with dates: the same new values for every member.  Marks the core dirty from min(year)-1: the next hx_run first resets there (if the
  * state history is enabled, else to startDate), like run() does for a core that is not clean
  * (src/rcpp_hector.cpp:160-166). */
 int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
@@ -106,7 +110,7 @@ int hx_lane_of_member(hx_core *core, int *out /* n_members */);
 
 /* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.
  * date < startDate (e.g. 0): rerun the spinup on the next run; date == startDate:
- * back to the post-spinup state; any earlier computed date if hx_enable_history is on. */
+ * back to the post-spinup state; any other computed date if hx_enable_history is on. */
 int hx_reset(hx_core *core, double date);
 
 /* run(core, runtodate)  src/rcpp_hector.cpp:153-181 -> Core::run src/core.cpp:448-509.
