@@ -469,8 +469,11 @@ HxBuffers EnsembleCore::buffers() const {
     for (int k : {HXPB_BETA, HXPB_PF_MU, HXPB_PF_SIGMA})
       if (!row_uniform_[r + k]) b.uni_bio = 0;
   }
-  b.stash_diag = 0;
+  b.stash_diag = b.biome_diag = 0;
   for (int v = HXO_NPP; v <= HXO_CA_RESIDUAL; ++v) if (d_out_[v]) b.stash_diag = 1;
+  for (int v = HXO_BIOME0; v < HXO_NVAR; ++v) if (d_out_[v]) b.biome_diag = 1;
+  for (int bb = 0; bb < HX_MAXB; ++bb)
+    if (d_out_[HXO_B(HXOB_NPP, bb)] || d_out_[HXO_B(HXOB_RH, bb)]) b.stash_diag = 1;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   return b;
 }
@@ -639,12 +642,14 @@ int EnsembleCore::out_index(const std::string &capability) const {
   if (capability == "ocean_timesteps") return HXO_NSTASH;  // D_TIMESTEPS, component_data.hpp:337
   const size_t dot = capability.find('.');
   if (dot != std::string::npos) {  // "<biome>.<pool>"  (SNBOX_PARSECHAR, simpleNbox.cpp:527-540)
-    static const char *const pools[5] = {"veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c"};
+    static const char *const pools[HXOB_N] = {"veg_c", "detritus_c", "soil_c", "permafrost_c",
+                                               "thawedp_c", "NPP", "RH", "rh_ch4", "f_frozen",
+                                               "detritus_tempfert", "soil_tempfert"};
     const std::string biome = capability.substr(0, dot), var = capability.substr(dot + 1);
     for (int b = 0; b < B_; ++b)
       if (biome_names_[(size_t)b] == biome)
-        for (int k = 0; k < 5; ++k)
-          if (var == pools[k]) return HXO_BIOME0 + k * HX_MAXB + b;
+        for (int k = 0; k < HXOB_N; ++k)
+          if (var == pools[k]) return HXO_B(k, b);
     throw std::runtime_error("Biome '" + biome + "' missing from biome list. Hit this error while "
                              "trying to retrieve variable: '" + capability + "'.");
   }
@@ -1176,7 +1181,8 @@ const VarInfo kVarInfo[] = {
     {"veg_c", "simpleNbox", "Pg C"}, {"detritus_c", "simpleNbox", "Pg C"},
     {"soil_c", "simpleNbox", "Pg C"}, {"permafrost_c", "simpleNbox", "Pg C"},
     {"thawedp_c", "simpleNbox", "Pg C"}, {"f_frozen", "simpleNbox", "(unitless)"},
-    {"earth_c", "simpleNbox", "Pg C"},
+    {"earth_c", "simpleNbox", "Pg C"}, {"detritus_tempfert", "simpleNbox", "(unitless)"},
+    {"soil_tempfert", "simpleNbox", "(unitless)"},
     {"global_tas", "temperature", "degC"}, {"gmst", "temperature", "degC"},
     {"heatflux_mixed", "temperature", "W/m2"}, {"heatflux_interior", "temperature", "W/m2"},
     {"heatflux", "temperature", "W/m2"}, {"land_tas", "temperature", "degC"},

@@ -296,6 +296,9 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
       fin_npp += npp_fin_total * wt;
       fin_rh += ((a + bb) + cc) + dd;
+      const HxBuffers &buf = *m.bufp;  // "<biome>.NPP", "<biome>.RH"
+      if (buf.out[HXO_B(HXOB_NPP, b)]) HX_GD(buf.out[HXO_B(HXOB_NPP, b)])[dgo] = npp_fin_total * wt;
+      if (buf.out[HXO_B(HXOB_RH, b)]) HX_GD(buf.out[HXO_B(HXOB_RH, b)])[dgo] = ((a + bb) + cc) + dd;
       fin_det += a;
       fin_soil += bb;
     }

@@ -295,9 +295,10 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   put(HXO_F_FROZEN, 1.0); put(HXO_TAU_OH, kc.TOH0);
 #pragma unroll
   for (int b = 0; b < B; ++b) {
-    put(HXO_BIOME0 + 0 * HX_MAXB + b, m.veg[b]); put(HXO_BIOME0 + 1 * HX_MAXB + b, m.det[b]);
-    put(HXO_BIOME0 + 2 * HX_MAXB + b, m.soil[b]); put(HXO_BIOME0 + 3 * HX_MAXB + b, m.pf[b]);
-    put(HXO_BIOME0 + 4 * HX_MAXB + b, m.thawed[b]);
+    put(HXO_B(HXOB_VEG, b), m.veg[b]); put(HXO_B(HXOB_DET, b), m.det[b]);
+    put(HXO_B(HXOB_SOIL, b), m.soil[b]); put(HXO_B(HXOB_PF, b), m.pf[b]);
+    put(HXO_B(HXOB_THAWED, b), m.thawed[b]); put(HXO_B(HXOB_F_FROZEN, b), 1.0);
+    put(HXO_B(HXOB_TEMPFERTD, b), 1.0); put(HXO_B(HXOB_TEMPFERTS, b), 1.0);
   }
   if (spinup_steps) spinup_steps[mem] = steps;
 }
@@ -692,14 +693,17 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if (buf.out[HXO_C_DO]) sto_(buf, HXO_C_DO, o, m.cDO);
       if (buf.out[HXO_PCO2_HL]) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
       if (buf.out[HXO_PCO2_LL]) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
-      if constexpr (B > 1) {  // "<biome>.veg_c" ...: the pools of each biome
+      if (buf.biome_diag) {  // "<biome>.veg_c" ...: pools and factors of each biome
+        LandK<B> lkb;
+        load_landk<B>(m, lkb);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-          if (buf.out[HXO_BIOME0 + 0 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 0 * HX_MAXB + b, o, m.veg[b]);
-          if (buf.out[HXO_BIOME0 + 1 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 1 * HX_MAXB + b, o, m.det[b]);
-          if (buf.out[HXO_BIOME0 + 2 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 2 * HX_MAXB + b, o, m.soil[b]);
-          if (buf.out[HXO_BIOME0 + 3 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 3 * HX_MAXB + b, o, m.pf[b]);
-          if (buf.out[HXO_BIOME0 + 4 * HX_MAXB + b]) sto_(buf, HXO_BIOME0 + 4 * HX_MAXB + b, o, m.thawed[b]);
+          auto putb = [&](int k, double v) { if (buf.out[HXO_B(k, b)]) sto_(buf, HXO_B(k, b), o, v); };
+          putb(HXOB_VEG, m.veg[b]); putb(HXOB_DET, m.det[b]); putb(HXOB_SOIL, m.soil[b]);
+          putb(HXOB_PF, m.pf[b]); putb(HXOB_THAWED, m.thawed[b]);
+          putb(HXOB_RH_CH4, m_rh_tp_ch4(m, lkb, b));
+          putb(HXOB_F_FROZEN, PKM(m, PK_FFROZEN0 + b));
+          putb(HXOB_TEMPFERTD, m.tempfertd[b]); putb(HXOB_TEMPFERTS, m.tempferts[b]);
         }
       }
       if (buf.out[HXO_RH_CH4] || buf.out[HXO_F_FROZEN]) {

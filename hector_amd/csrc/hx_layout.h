@@ -79,10 +79,14 @@ enum HxOutVar {
   HXO_CA_RESIDUAL,
   HXO_RH_CH4, HXO_F_FROZEN, HXO_GMST, HXO_FLUX_MIXED, HXO_FLUX_INTERIOR,
   HXO_C_HL, HXO_C_LL, HXO_C_IO, HXO_C_DO, HXO_PCO2_HL, HXO_PCO2_LL, HXO_TAU_OH,
-  // per-biome pools "<biome>.veg_c" ...: index HXO_BIOME0 + pool * HX_MAXB + biome
+  // per-biome "<biome>.veg_c" ...: index HXO_BIOME0 + k * HX_MAXB + biome, k = HxBiomeOut
   HXO_BIOME0,
-  HXO_NVAR = HXO_BIOME0 + 5 * HX_MAXB
+  HXO_NVAR = HXO_BIOME0 + 11 * HX_MAXB
 };
+
+enum HxBiomeOut { HXOB_VEG = 0, HXOB_DET, HXOB_SOIL, HXOB_PF, HXOB_THAWED, HXOB_NPP, HXOB_RH,
+                   HXOB_RH_CH4, HXOB_F_FROZEN, HXOB_TEMPFERTD, HXOB_TEMPFERTS, HXOB_N };
+#define HXO_B(k, b) (HXO_BIOME0 + (k) * HX_MAXB + (b))
 
 // ---- shared per-year scenario table: row iy = year - startDate ------------
 enum HxSharedCol {
@@ -148,6 +152,7 @@ struct HxBuffers {
   const double *mseries[HXM_N];  // per-member emissions (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
   int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)
+  int biome_diag;          // some "<biome>.<variable>" output is recorded
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
 };
 

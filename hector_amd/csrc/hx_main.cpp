@@ -41,6 +41,9 @@ const char *const kForcings[] = {"RF_BC", "RF_CH4", "RF_CO2", "RF_H2O_strat", "R
                                  "RF_O3_trop", "RF_OC", "RF_SO2", "RF_aci", "RF_albedo",
                                  "RF_misc", "RF_tot", "RF_vol"};
 const char *const kSlr[] = {"sl_rc", "slr", "sl_rc_no_ice", "slr_no_ice"};
+// with more than one biome the visitor adds these per biome (:169-198)
+const char *const kBiomeVars[] = {"NPP", "RH", "rh_ch4", "veg_c", "detritus_c", "soil_c", "permafrost_c",
+                                  "thawedp_c", "f_frozen", "detritus_tempfert", "soil_tempfert"};
 
 void die(const std::string &msg, int code) {
   std::fprintf(stderr, "* Program exception:\n%s\n", msg.c_str());
@@ -111,8 +114,17 @@ int main(int argc, char **argv) {
   ck(hx_halocarbons(core, &halo, &nhalo));
   std::vector<std::string> halo_names(halo, halo + nhalo);
 
+  const char *const *bio = nullptr;
+  int nbio = 0;
+  ck(hx_biomes(core, &bio, &nbio));
+  std::vector<std::string> biome_vars;  // "<biome>.<variable>" rows, only with several biomes
+  if (nbio > 1)
+    for (int b = 0; b < nbio; ++b)
+      for (const char *v : kBiomeVars) biome_vars.push_back(std::string(bio[b]) + "." + v);
+
   // everything the stream prints
   std::vector<std::string> wanted;
+  for (auto &bv : biome_vars) wanted.push_back(bv);
   for (const char *v : kStreamVars) wanted.push_back(v);
   for (const char *f : kForcings) wanted.push_back(f);
   for (const char *s : kSlr) wanted.push_back(s);
@@ -209,6 +221,12 @@ int main(int argc, char **argv) {
           }
         }
         row(y, run, vi.component.c_str(), vname, data[vname][o], vi.units.c_str(), p_def);
+        if (!std::strcmp(vname, "earth_c"))  // biome rows close the simpleNbox block
+          for (auto &bv : biome_vars) {
+            const char *u = nullptr;
+            ck(hx_var_info(core, bv.c_str(), nullptr, &u));
+            row(y, run, "simpleNbox", bv, data[bv][o], u, p_def);
+          }
         last_comp = vi.component;
       }
     }

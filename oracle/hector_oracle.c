@@ -527,6 +527,7 @@ typedef struct {
   double Ca_residual;
   double hl_do;                                  /* annual_box_fluxes[HL -> DO] */
   double final_npp, final_rh, final_rh_det, final_rh_soil;
+  double final_npp_b[HXO_MAXB], final_rh_b[HXO_MAXB];
   double temp_surface_now, flux_mixed_now, flux_interior_now;
   double rf_item_v[16];                          /* RF_* relative to the base year, see year_forcing */
   double rf_base_v[16];
@@ -1292,12 +1293,14 @@ static void snb_stash(member_t *m, double t, const double c[]) {
     const double wt = (snb_npp(m, b) + snb_rh(m, b)) / npp_rh_total;
     /* final_npp / final_rh* :420-440, summed over biomes as D_NPP, D_RH ... report them */
     m->final_npp = m->final_npp + npp_total * wt;
+    m->final_npp_b[b] = npp_total * wt;
     {
       const double a = snb_rh_fda(m, b) * rh_nbp_constraint_adjust;
       const double bb = snb_rh_fsa(m, b) * rh_nbp_constraint_adjust;
       const double cc = snb_rh_ftpa_co2(m, b) * rh_nbp_constraint_adjust;
       const double dd = snb_rh_ftpa_ch4(m, b) * rh_nbp_constraint_adjust;
       m->final_rh = m->final_rh + (a + bb + cc + dd);
+      m->final_rh_b[b] = a + bb + cc + dd;
       m->final_rh_det = m->final_rh_det + a;
       m->final_rh_soil = m->final_rh_soil + bb;
     }
@@ -1694,6 +1697,14 @@ static void record_outputs(member_t *m, int iy, double *out) {
     O(HXO_REVELLE_LL) = csys_dic_umol(&m->chem[LL], m->carbon[LL]) / m->chem[LL].CO3;
   }
   O(HXO_TAU_OH) = m->tau_oh;
+  for (int b = 0; b < m->B && b < 4; b++) {
+    const int k0 = HXO_BIOME0 + 11 * b;
+    O(k0 + 0) = m->veg_c[b]; O(k0 + 1) = m->detritus_c[b]; O(k0 + 2) = m->soil_c[b];
+    O(k0 + 3) = m->permafrost_c[b]; O(k0 + 4) = m->thawed_c[b];
+    O(k0 + 5) = m->final_npp_b[b]; O(k0 + 6) = m->final_rh_b[b];
+    O(k0 + 7) = m->snbox_in_spinup ? 0.0 : snb_rh_ftpa_ch4(m, b);
+    O(k0 + 8) = m->f_frozen[b]; O(k0 + 9) = m->tempfertd[b]; O(k0 + 10) = m->tempferts[b];
+  }
 #undef O
 }
 

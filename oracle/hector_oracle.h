@@ -77,7 +77,11 @@ enum {
   HXO_RF_H2O, HXO_RF_O3, HXO_RF_BC, HXO_RF_OC, HXO_RF_SO2, HXO_RF_NH3, HXO_RF_ACI,
   HXO_RF_VOL, HXO_RF_ALBEDO, HXO_RF_MISC, HXO_RF_HALO, /* sum of the halocarbon forcings */
   HXO_SLR, HXO_SL_RC, HXO_SLR_NO_ICE, HXO_SL_RC_NO_ICE,
-  HXO_NVAR
+  /* per biome (first 4 biomes): 11 variables each, index HXO_BIOME0 + 11 * biome + k, k in the
+   * order veg_c, detritus_c, soil_c, permafrost_c, thawedp_c, NPP, RH, rh_ch4, f_frozen,
+   * detritus_tempfert, soil_tempfert */
+  HXO_BIOME0,
+  HXO_NVAR = HXO_BIOME0 + 44
 };
 
 typedef struct hxo_scenario hxo_scenario;

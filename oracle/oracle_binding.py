@@ -27,7 +27,10 @@ VARS = ["CO2_concentration", "global_tas", "RF_tot", "RF_CO2", "heatflux", "ocea
         "HL_sst", "LL_sst", "HL_CO3", "LL_CO3", "HL_Revelle", "LL_Revelle", "TAU_OH",
         "RF_H2O_strat", "RF_O3_trop", "RF_BC", "RF_OC", "RF_SO2", "RF_NH3", "RF_aci",
         "RF_vol", "RF_albedo", "RF_misc", "RF_halocarbons",
-        "slr", "sl_rc", "slr_no_ice", "sl_rc_no_ice"]
+        "slr", "sl_rc", "slr_no_ice", "sl_rc_no_ice"] + \
+    ["b%d.%s" % (b, v) for b in range(4) for v in
+     ("veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c", "NPP", "RH", "rh_ch4", "f_frozen",
+      "detritus_tempfert", "soil_tempfert")]
 
 
 class Params(ctypes.Structure):

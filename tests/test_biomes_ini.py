@@ -71,6 +71,17 @@ def biome_ini_checks(lib, oracle, tmp_path, **kw):
         ref = r[v]; got = bc.fetchvars(v, (1745, 2300))[:, 0]
         assert np.abs(got - ref).max() < 2e-8 * max(1.0, np.abs(ref).max()), v
     assert np.abs(veg - r["veg_c"]).max() < 2e-8 * r["veg_c"].max()
+    # every per-biome variable of the output stream, biome by biome
+    per_biome = ["veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c", "NPP", "RH", "rh_ch4",
+                 "f_frozen", "detritus_tempfert", "soil_tempfert"]
+    bc.set_outputs([b + "." + v for b in ("boreal", "tropical") for v in per_biome] + vars_)
+    bc.run(2300)
+    for bi, b in enumerate(("boreal", "tropical")):
+        for v in per_biome:
+            got = bc.fetchvars(b + "." + v, (1746, 2300))[:, 0]
+            ref = r["b%d.%s" % (bi, v)][1:]
+            assert np.abs(got - ref).max() < 2e-8 * max(1.0, np.abs(ref).max()), (b, v)
+    assert bc.getunits("boreal.NPP") == "Pg C/yr" and bc.getunits("tropical.soil_tempfert") == "(unitless)"
     # warming factor tag
     wc = mk(biome_pack(tmp_path / "warm.hxs", [("boreal", "warmingfactor", 2.5),
                                                 ("tropical", "warmingfactor", 1.0)]))

@@ -77,3 +77,20 @@ def test_cli_ensemble_members_and_errors(emul_lib, golden, tmp_path):
     assert r.returncode == 1 and "Couldn't find input file" in r.stderr
     r = subprocess.run([EMUL_CLI], capture_output=True, text=True)
     assert r.returncode == 1 and "Usage" in r.stderr
+
+
+def test_cli_prints_biome_rows_for_multi_biome_scenarios(emul_lib, tmp_path):
+    """csv_outputstream_visitor.cpp:169-198: per-biome rows when the core has several biomes."""
+    from test_biomes_ini import biome_pack
+    path = biome_pack(tmp_path / "biome.hxs")
+    r = subprocess.run([EMUL_CLI, path, "--run-to", "1800", "--output-dir", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = read_stream(tmp_path / "outputstream_ssp245.csv")
+    names = {r["variable"] for r in rows if r["year"] == "1800"}
+    for b in ("boreal", "tropical"):
+        for v in ("NPP", "RH", "rh_ch4", "veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c",
+                  "f_frozen", "detritus_tempfert", "soil_tempfert"):
+            assert b + "." + v in names
+    veg = {r["variable"]: float(r["value"]) for r in rows if r["year"] == "1800" and r["variable"].endswith("veg_c")}
+    assert veg["boreal.veg_c"] + veg["tropical.veg_c"] == pytest.approx(veg["veg_c"], rel=1e-5)
