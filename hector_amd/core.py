@@ -101,6 +101,28 @@ class Core:
         self._ck(self._lib.hx_set_outputs(self._h, n, arr))
         return self
 
+    def tracking_pools(self):
+        names = ctypes.POINTER(ctypes.c_char_p)()
+        n = ctypes.c_int()
+        self._ck(self._lib.hx_tracking_pools(self._h, ctypes.byref(names), ctypes.byref(n)))
+        return [names[i].decode() for i in range(n.value)]
+
+    def tracking_data(self, member, dates, masks=False):
+        """-> (values[ny, TP], fractions[ny, TP, TP]) for dates = (year0, year1); with masks=True
+        also in_map[ny, TP, TP] (bool: the source is in the pool's map)."""
+        y0, y1 = int(min(dates)), int(max(dates))
+        tp = len(self.tracking_pools())
+        v = np.zeros((y1 - y0 + 1, tp)); f = np.zeros((y1 - y0 + 1, tp, tp))
+        dp = ctypes.POINTER(ctypes.c_double)
+        mk = np.zeros((y1 - y0 + 1, tp), dtype=np.uint64)
+        self._ck(self._lib.hx_tracking_data(self._h, int(member), y0, y1, v.ctypes.data_as(dp),
+                                            f.ctypes.data_as(dp),
+                                            mk.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))))
+        if masks:
+            bits = (mk[:, :, None] >> np.arange(tp, dtype=np.uint64)[None, None, :]) & np.uint64(1)
+            return v, f, bits.astype(bool)
+        return v, f
+
     def getunits(self, var):
         """getunits(var)  R/units.R"""
         u = ctypes.c_char_p()
@@ -262,6 +284,24 @@ def fetchvars(core, dates, variables):
     if isinstance(variables, str):
         variables = [variables]
     return {v: core.fetchvars(v, dates) for v in variables}
+
+
+def get_tracking_data(core, member=0):
+    """get_tracking_data(core)  R/hector.R: rows (year, component, pool_name, pool_value,
+    pool_units, source_name, source_fraction) for one member, trackingDate .. current date."""
+    start = int(core.getvar("trackingDate")[0])
+    if start == 9999 or core.current_date < start:
+        return []
+    names = core.tracking_pools()
+    v, f, held = core.tracking_data(member, (start, core.current_date), masks=True)
+    rows = []
+    for iy in range(v.shape[0]):
+        for p, pn in enumerate(names):
+            comp = "ocean" if pn in ("HL", "LL", "intermediate", "deep") else "simpleNbox"
+            for s, sn in enumerate(names):
+                if held[iy, p, s]:
+                    rows.append((start + iy, comp, pn, v[iy, p], "Pg C", sn, f[iy, p, s]))
+    return rows
 
 
 def split_biome(core, old_biome, new_biomes, **fractions):

@@ -9,7 +9,8 @@
 // launchers defined in hx_kernels.hip
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st);
-hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, bool con,
+int hx_track_rows(int B);
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st);
 int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
@@ -162,6 +163,8 @@ void EnsembleCore::init_from_scenario() {
   row_uniform_.assign(HX_NPARAM(1), true);
   auto setrow = [&](int row, double v) { std::fill(params_[row].begin(), params_[row].end(), v); };
   const Scenario &s = scen_;
+  tracking_year_ = (int)s.scalar("core", "trackingDate", 0.0);  // [core] trackingDate
+  if (tracking_year_ >= 9999 || tracking_year_ < 0) tracking_year_ = 0;
   setrow(HXP_S, s.scalar("temperature", "S"));
   setrow(HXP_DIFF, s.scalar("temperature", "diff"));
   setrow(HXP_QCO2, s.scalar("temperature", "qco2"));
@@ -408,6 +411,8 @@ void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
   fr(d_uparams_); d_uparams_ = nullptr;
+  fr(d_track_); fr(d_track_out_f_); fr(d_track_out_v_);
+  d_track_ = d_track_out_f_ = d_track_out_v_ = nullptr;
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   d_hist_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
@@ -425,6 +430,15 @@ void EnsembleCore::alloc_device() {
   const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
   check(hipMalloc(&d_uparams_, sizeof(double) * HX_NPARAM(B_)), "hipMalloc uniform params");
+  if (trk_iy() >= 0) {  // carbon tracking: origin matrix + its yearly record from the tracking date
+    const size_t TP = (size_t)(2 + 5 * B_ + 4), nyt = ns - (size_t)trk_iy();
+    check(hipMalloc(&d_track_, sizeof(double) * (size_t)hx_track_rows(B_) * np), "hipMalloc track");
+    check(hipMemsetAsync(d_track_, 0, sizeof(double) * (size_t)hx_track_rows(B_) * np, stream_), "zero");
+    check(hipMalloc(&d_track_out_f_, sizeof(double) * nyt * TP * TP * np), "hipMalloc tracking record");
+    check(hipMalloc(&d_track_out_v_, sizeof(double) * nyt * 2 * TP * np), "hipMalloc tracking record");
+    check(hipMemsetAsync(d_track_out_f_, 0, sizeof(double) * nyt * TP * TP * np, stream_), "zero");
+    check(hipMemsetAsync(d_track_out_v_, 0, sizeof(double) * nyt * 2 * TP * np, stream_), "zero");
+  }
   check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
   check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
   // DOECLIM kernel table, zero-padded by HX_KPAD (= 32) entries on both sides
@@ -461,6 +475,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.hist = d_hist_;
   for (int k = 0; k < HXM_N; ++k) b.mseries[k] = d_mseries_[k];
   b.uparams = d_uparams_;
+  b.track = d_track_; b.track_out_f = d_track_out_f_; b.track_out_v = d_track_out_v_;
   b.uni_landk = b.uni_bio = 1;
   for (int bb = 0; bb < B_; ++bb) {
     const int r = HXP_NGLOBAL + bb * HXPB_N;
@@ -535,6 +550,10 @@ static std::string shared_param_section(const Scenario &scen, const std::string 
 
 void EnsembleCore::setvar(const std::string &capability, const double *values, int nvalues,
                           const char *units) {
+  if (capability == "trackingDate") {  // Core::setData  core.cpp:230-236
+    set_tracking_date((int)values[0]);
+    return;
+  }
   {
     std::string expect;
     const std::string sec = shared_param_section(scen_, capability, &expect);
@@ -581,6 +600,10 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
 }
 
 void EnsembleCore::getvar(const std::string &capability, double *out) const {
+  if (capability == "trackingDate") {  // 9999 = never, like Core's default (core.cpp:60)
+    std::fill(out, out + n_, tracking_year_ > 0 ? (double)tracking_year_ : 9999.0);
+    return;
+  }
   {
     const std::string sec = shared_param_section(scen_, capability, nullptr);
     if (!sec.empty()) {
@@ -925,6 +948,7 @@ void EnsembleCore::upload_params() {
     bool lo_any = false;
     for (double v : params_[HXP_LO_RATIO]) if (v != 0.0) lo_any = true;
     kc_.con_mask = (kc_.con_mask & ~HXC_LO) | (lo_any ? HXC_LO : 0);
+    kc_.trk_iy = trk_iy();
     HxArgs a;
     a.buf = buffers();
     a.kc = kc_;
@@ -1044,7 +1068,14 @@ void EnsembleCore::run(double runtodate) {
   bool ext = kc_.con_mask != 0;  // extended kernel: constraints or the extra diagnostics
   for (int v = HXO_NPP; v < HXO_NVAR; ++v) if (d_out_[v]) ext = true;
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) ext = true;
-  check(hx_launch_run(B_, d_args_, npad_, hf, ker_per_member_, ext, last_iy_, target,
+  int con = ext ? 1 : 0;
+  if (d_track_) {
+    if (kc_.con_mask & (HXC_CO2 | HXC_NBP))
+      throw std::runtime_error("carbon tracking together with a CO2 or NBP constraint is not "
+                               "supported (the constraint residual is an untracked source)");
+    con = 2;
+  }
+  check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
                       stream_),
         "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
@@ -1242,6 +1273,55 @@ void EnsembleCore::var_info(const std::string &capability_in, std::string *compo
       return set(h.name + "_halocarbon", "pptv");
   }
   throw std::runtime_error("Caller is requesting unknown variable: " + capability_in);
+}
+
+void EnsembleCore::set_tracking_date(int year) {
+  if (year <= 0) year = 0;
+  const int before = trk_iy();
+  tracking_year_ = year;
+  if (trk_iy() == before) return;
+  layout_dirty_ = true;
+  need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+std::vector<std::string> EnsembleCore::tracking_pools() const {
+  // pool names as the fluxpools carry them (simpleNbox.cpp:45-79, ocean_component.cpp:246-258)
+  std::vector<std::string> n = {"atmos_c", "earth_c"};
+  for (int b = 0; b < B_; ++b) {
+    const std::string pre = (B_ == 1 && biome_names_[0] == "global") ? "" : biome_names_[(size_t)b] + ".";
+    for (const char *k : {"veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c"}) n.push_back(pre + k);
+  }
+  for (const char *k : {"HL", "LL", "intermediate", "deep"}) n.push_back(k);
+  return n;
+}
+
+void EnsembleCore::tracking_data(int member, int year0, int year1, double *values,
+                                 double *fractions, unsigned long long *source_masks) {
+  if (!d_track_out_f_) throw std::runtime_error("carbon tracking is off (set trackingDate first)");
+  if (member < 0 || member >= n_) throw std::runtime_error("tracking_data: bad member index");
+  if (year0 < tracking_year_ || year1 > last_date() || year1 < year0)
+    throw std::runtime_error("tracking_data: dates must lie between trackingDate and the current date");
+  sync();
+  const size_t TP = (size_t)(2 + 5 * B_ + 4), np = (size_t)npad_;
+  const size_t k0 = (size_t)(year0 - tracking_year_), ny = (size_t)(year1 - year0 + 1);
+  const int lane = lane_of_member_[(size_t)member];
+  // one column (this member's lane) of the [rows][npad] records (per year: TP values, TP masks)
+  check(hipMemcpy2D(fractions, sizeof(double), d_track_out_f_ + k0 * TP * TP * np + lane,
+                    np * sizeof(double), sizeof(double), ny * TP * TP, hipMemcpyDeviceToHost),
+        "tracking fractions");
+  for (size_t y = 0; y < ny; ++y)
+    check(hipMemcpy2D(values + y * TP, sizeof(double), d_track_out_v_ + (k0 + y) * 2 * TP * np + lane,
+                      np * sizeof(double), sizeof(double), TP, hipMemcpyDeviceToHost),
+          "tracking values");
+  if (source_masks) {  // which sources a pool's map holds (a held source can have fraction 0)
+    std::vector<double> mk(ny * TP);
+    for (size_t y = 0; y < ny; ++y)
+      check(hipMemcpy2D(mk.data() + y * TP, sizeof(double),
+                        d_track_out_v_ + ((k0 + y) * 2 + 1) * TP * np + lane, np * sizeof(double),
+                        sizeof(double), TP, hipMemcpyDeviceToHost), "tracking masks");
+    for (size_t i = 0; i < ny * TP; ++i) source_masks[i] = (unsigned long long)mk[i];
+  }
 }
 
 std::string EnsembleCore::run_name() const { return scen_.text("core", "run_name", ""); }

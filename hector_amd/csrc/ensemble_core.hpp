@@ -78,6 +78,15 @@ class EnsembleCore {
   // GETDATA with dates: out[(year - year0) * n + member]
   void fetchvars(const std::string &capability, int year0, int year1, double *out_host);
   bool host_output(const std::string &capability);
+  // Carbon tracking (Core::trackingDate, get_tracking_data): origins of every pool's carbon from
+  // `year` on.  year <= 0 or beyond endDate switches it off.
+  void set_tracking_date(int year);
+  int tracking_date() const { return tracking_year_; }
+  std::vector<std::string> tracking_pools() const;
+  // values[ny][TP], fractions[ny][TP][TP], source_masks[ny][TP] (bit s: source s is in the pool's
+  // map; optional) of one member for year0..year1 (>= the tracking date)
+  void tracking_data(int member, int year0, int year1, double *values, double *fractions,
+                     unsigned long long *source_masks = nullptr);
   std::string run_name() const;
   void var_info(const std::string &capability, std::string *component, std::string *units) const;
   const std::vector<std::string> &halocarbon_names() const { return halo_names_; }
@@ -133,6 +142,13 @@ class EnsembleCore {
   int *d_spin_steps_ = nullptr;
   HxArgs *d_args_ = nullptr;
   double *d_uparams_ = nullptr;
+  int tracking_year_ = 0;  // 0 = off
+  double *d_track_ = nullptr, *d_track_out_f_ = nullptr, *d_track_out_v_ = nullptr;
+  // SimpleNbox::run starts tracking when runToDate == trackingDate (simpleNbox-runtime.cpp:215-220):
+  // a date at or before startDate, or past endDate, never engages
+  int trk_iy() const {
+    return (tracking_year_ > scen_.start && tracking_year_ <= scen_.end) ? tracking_year_ - scen_.start : -1;
+  }
   double *d_derived_ = nullptr, *d_dpart_ = nullptr, *d_gather_ = nullptr, *d_hist_ = nullptr;
   bool history_ = false, shared_dirty_ = false;
   int hist_valid_to_ = 0;   // history slabs 1..hist_valid_to_ are valid

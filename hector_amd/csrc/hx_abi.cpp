@@ -150,6 +150,22 @@ int hx_var_info(hx_core *core, const char *capability, const char **component, c
     if (units) *units = un.c_str();
   })
 }
+int hx_tracking_pools(hx_core *core, const char *const **names, int *count) {
+  static thread_local std::vector<std::string> store;
+  static thread_local std::vector<const char *> ptrs;
+  HX_TRY({
+    store = core->core->tracking_pools();
+    ptrs.clear();
+    for (auto &n : store) ptrs.push_back(n.c_str());
+    if (names) *names = ptrs.data();
+    if (count) *count = (int)ptrs.size();
+  })
+}
+int hx_tracking_data(hx_core *core, int member, int year0, int year1, double *values,
+                     double *fractions, unsigned long long *source_masks) {
+  if (!values || !fractions) return fail("hx_tracking_data: null argument");
+  HX_TRY(core->core->tracking_data(member, year0, year1, values, fractions, source_masks))
+}
 int hx_run_name(hx_core *core, const char **name) {
   static thread_local std::string rn;
   HX_TRY({ rn = core->core->run_name(); if (name) *name = rn.c_str(); })

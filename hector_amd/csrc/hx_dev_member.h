@@ -84,6 +84,7 @@ struct Member {
   hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
   const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
   int iy;                 // year index being integrated
+  int trk_iy;             // first tracked year index (tracking kernels)
 };
 #define PKM(m, slot) ((m).pk[(slot)][(m).lane])
 

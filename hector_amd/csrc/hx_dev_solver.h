@@ -121,7 +121,7 @@ __device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B>
 
 // K: the interval's constants; K2 (CON kernels): the same for the second half of the year,
 // where round(t) picks the next date's NBP constraint
-template <int B, bool SPIN, bool CON = false>
+template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
                                               Interval &K, Interval &K2, const YearCon &yc) {
   Flows F;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B>
 
 // SimpleNbox::calcderivs + OceanComponent::calcderivs restricted to the five
 // pools whose derivative depends on c[] (atmos, veg, det, soil, ocean)
-template <int B, bool SPIN, bool CON = false>
+template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, const Interval &K2,
                                     const YearCon &yc, double t, const double *y, double *d) {
   // CON kernels carry the thawed-permafrost pool as a sixth solver variable: with an NBP
@@ -165,8 +165,12 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, cons
   d[4] = ao;
 }
 
+}  // namespace
+#include "hx_dev_track.h"
+namespace {
+
 // OceanComponent::stashCValues + SimpleNbox::stashCValues for one lane
-template <int B, bool SPIN, bool CON = false>
+template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
                                       double c4, double c5, double c7, Interval &K,
                                       Interval &K2, const YearCon &yc, bool more) {
@@ -232,6 +236,14 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
     }
   }
+  [[maybe_unused]] TrkStashIn<B> tk;
+  if constexpr (CON == 2 && !SPIN) {
+    tk.yf = yf;
+    tk.pre[0] = m.cHL; tk.pre[1] = m.cLL; tk.pre[2] = m.cIO; tk.pre[3] = m.cDO;
+    tk.closs[0] = lHD; tk.closs[1] = lLH; tk.closs[2] = lLI; tk.closs[3] = lIL;
+    tk.closs[4] = lIH; tk.closs[5] = lID; tk.closs[6] = lDI;
+    tk.aH = aH; tk.aL = aL;
+  }
   const double lastflux = aL + aH;
   m.annualflux_sum += lastflux;
   m.lastflux_ann = lastflux * inv_yf;
@@ -240,6 +252,9 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   m.cLL = ((m.cLL + lIL) + aL) - (lLH + lLI);
   m.cIO = (m.cIO + (lLI + lDI)) - ((lIL + lIH) + lID);
   m.cDO = (m.cDO + (lHD + lID)) - lDI;
+  if constexpr (CON == 2 && !SPIN) {
+    tk.post[0] = m.cHL; tk.post[1] = m.cLL; tk.post[2] = m.cIO; tk.post[3] = m.cDO;
+  }
 
   // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
   double npp_t = 0, rh_t = 0, pf_t = 0;
@@ -302,6 +317,13 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       fin_det += a;
       fin_soil += bb;
     }
+    if constexpr (CON == 2 && !SPIN) {
+      tk.veg[b] = m.veg[b]; tk.det[b] = m.det[b]; tk.soil[b] = m.soil[b]; tk.pf[b] = m.pf[b];
+      tk.tp[b] = m.thawed[b]; tk.wt[b] = wt; tk.wt_pf[b] = wt_pf;
+      tk.f_new_thaw[b] = m.f_new_thaw[b];
+      tk.rh_fda[b] = m_rh_fda(m, b); tk.rh_fsa[b] = m_rh_fsa(m, b);
+      tk.rh_co2[b] = m_rh_tp_co2(m, lk, b); tk.rh_ch4[b] = m_rh_tp_ch4(m, lk, b);
+    }
     if constexpr (CON) m.cum_pf_ch4 += (m_rh_tp_ch4(m, lk, b) * rh_adj) * yf;
     else m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
     m.veg[b] = nveg * wt;
@@ -309,6 +331,16 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     m.soil[b] = nsoil * wt;
     m.pf[b] = c4 * wt_pf;
     m.thawed[b] = tpf * wt_pf;
+  }
+  if constexpr (CON == 2 && !SPIN) {
+    if (m.bufp->track && m.iy >= m.trk_iy) {
+      tk.atmos = m.atmos; tk.earth = m.earth;
+      tk.npp_total = npp_fin_total; tk.rh_adj = rh_adj; tk.total = total;
+      tk.nveg = nveg; tk.ndet = ndet; tk.nsoil = nsoil; tk.npf = c4; tk.ntp = tpf;
+      tk.natm = y[0]; tk.nearth = c7;
+      tk.ffi = m.ffi; tk.daccs = m.daccs; tk.luc_e = m.luc_e; tk.luc_u = m.luc_u;
+      track_stash<B>(*m.bufp, blockIdx.x * 64 + m.lane, lk, tk);
+    }
   }
   m.earth = c7;
   m.atmos = y[0];
@@ -372,7 +404,7 @@ __device__ __forceinline__ double pow_m15(double x) {
 // block for all lanes.  Lanes in reduced-timestep mode take up to 4 segments a
 // year, the others idle through the extra ones; the expensive step and stash
 // blocks are never interleaved lane by lane.
-template <int B, bool SPIN, bool CON = false>
+template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                                            double t0, double tnew, const YearCon &yc) {
   constexpr int NP = CON ? 6 : 5;  // solver variables (see rhs)

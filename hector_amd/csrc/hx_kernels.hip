@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // CON: the extended kernel -- the scenario holds constraints (HxConst::con_mask), a member has
 // a land-ocean warming ratio, or diagnostics beyond HXO_SST_LO are recorded.  A separate
 // instantiation, so that plain runs carry none of it.
-template <int B, bool HF, bool KERPM, bool CON>
+template <int B, bool HF, bool KERPM, int CON>
 __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                     int iy_from, int iy_to) {
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
   if constexpr (CON) m.bufp = &args->buf;
+  if constexpr (CON == 2) m.trk_iy = args->kc.trk_iy;
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
@@ -358,6 +359,38 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
       // every HBM value this phase needs, issued back to back (one exposed latency:
       // with one wavefront per SIMD nothing else hides it)
+      if constexpr (CON == 2) {
+        // carbon tracking: start_tracking() at Core::trackingDate (every pool 100 % itself),
+        // then every year the ocean's copy of the atmosphere's origins
+        // (SimpleNbox::run, simpleNbox-runtime.cpp:215-227)
+        if (buf.track && kc.trk_iy >= 0 && iy >= kc.trk_iy) {
+          constexpr int TP = hx_tp<B>();
+          hx_gd tr = HX_GD(buf.track) + mem;
+          const size_t np = (size_t)buf.npad;
+          if (iy == kc.trk_iy) {
+#pragma unroll 1
+            for (int p = 0; p < TP; ++p) {
+              for (int s2 = 0; s2 < TP; ++s2) tr[(size_t)trk_row_f<B>(p, s2) * np] = (p == s2) ? 1.0 : 0.0;
+              tr[(size_t)trk_row_mask<B>(p) * np] = (double)(1ull << p);
+            }
+          } else if (iy == iy_from + 1) {
+            // resuming past the tracking date (run() again, or reset(date) -- the reference's
+            // pools come back from their time series with their maps, simpleNbox.cpp reset):
+            // the maps of the end of last year are in the record
+            const size_t k1 = (size_t)(iy - 1 - kc.trk_iy);
+            hx_gd pf = HX_GD(buf.track_out_f) + k1 * (size_t)(TP * TP) * np + mem;
+            hx_gd pm = HX_GD(buf.track_out_v) + (k1 * 2 + 1) * (size_t)TP * np + mem;
+#pragma unroll 1
+            for (int r = 0; r < TP * TP; ++r) tr[(size_t)r * np] = pf[(size_t)r * np];
+#pragma unroll 1
+            for (int p = 0; p < TP; ++p) tr[(size_t)trk_row_mask<B>(p) * np] = pm[(size_t)p * np];
+          }
+#pragma unroll 1
+          for (int s2 = 0; s2 < TP; ++s2)
+            tr[(size_t)trk_row_atmcopy<B>(s2) * np] = tr[(size_t)trk_row_f<B>(TKP_ATM, s2) * np];
+          tr[(size_t)trk_row_atmcopy_mask<B>() * np] = tr[(size_t)trk_row_mask<B>(TKP_ATM) * np];
+        }
+      }
       const double prev_ch4 = PKM(m, PK_CH4);
       double sst = PKM(m, PK_SST);
       const double eos = PKM(m, PK_EOS);
@@ -722,6 +755,29 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);
       }
       }
+      if constexpr (CON == 2) {  // CSVFluxPoolVisitor: pools and their origins, once a year
+        if (buf.track_out_f && kc.trk_iy >= 0 && iy >= kc.trk_iy) {
+          constexpr int TP = hx_tp<B>();
+          hx_gd tr = HX_GD(buf.track) + mem;
+          const size_t np = (size_t)buf.npad, k = (size_t)(iy - kc.trk_iy);
+          hx_gd of = HX_GD(buf.track_out_f) + k * (size_t)(TP * TP) * np + mem;
+#pragma unroll 1
+          for (int r = 0; r < TP * TP; ++r) of[(size_t)r * np] = tr[(size_t)r * np];
+          hx_gd ov = HX_GD(buf.track_out_v) + k * 2 * (size_t)TP * np + mem;  // values, then masks
+#pragma unroll 1
+          for (int p = 0; p < TP; ++p)
+            ov[(size_t)(TP + p) * np] = tr[(size_t)trk_row_mask<B>(p) * np];
+          ov[(size_t)TKP_ATM * np] = m.atmos; ov[(size_t)TKP_EARTH * np] = m.earth;
+#pragma unroll
+          for (int b = 0; b < B; ++b) {
+            ov[(size_t)tkp_land<B>(b, 0) * np] = m.veg[b]; ov[(size_t)tkp_land<B>(b, 1) * np] = m.det[b];
+            ov[(size_t)tkp_land<B>(b, 2) * np] = m.soil[b]; ov[(size_t)tkp_land<B>(b, 3) * np] = m.pf[b];
+            ov[(size_t)tkp_land<B>(b, 4) * np] = m.thawed[b];
+          }
+          ov[(size_t)tkp_ocean<B>(0) * np] = m.cHL; ov[(size_t)tkp_ocean<B>(1) * np] = m.cLL;
+          ov[(size_t)tkp_ocean<B>(2) * np] = m.cIO; ov[(size_t)tkp_ocean<B>(3) * np] = m.cDO;
+        }
+      }
       if (buf.hist) {  // Core::reset(date) needs every component's state of every year
         double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(B) * buf.npad;
         store_state<B>(buf, mem, m, slab);
@@ -1042,24 +1098,28 @@ hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) 
 }
 
 template <int B>
-static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, bool con,
+static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st) {
   const int blocks = npad / 64;
   const size_t lds = 0;
-  if (con && kpm)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, true, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  if (con == 2 && kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (con == 2)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (con && kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (con)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, false, true>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (hf && kpm)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, true, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (hf)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, false, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (kpm)
-    hipLaunchKernelGGL((hx_run_kernel<B, false, true, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, false, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else
-    hipLaunchKernelGGL((hx_run_kernel<B, false, false, false>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
 }
-hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, bool con,
+hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st) {
   switch (B) {
     case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
@@ -1072,6 +1132,10 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
 }
 
 int hx_doeclim_block_years() { return HX_DBLK; }
+int hx_track_rows(int B) {
+  switch (B) { case 1: return hx_trk_rows<1>(); case 2: return hx_trk_rows<2>();
+               case 3: return hx_trk_rows<3>(); default: return hx_trk_rows<4>(); }
+}
 int hx_doeclim_kernel_pad() { return HX_KPAD; }
 hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, const double *alk,
                                double inv_vol, double *out, hipStream_t st) {

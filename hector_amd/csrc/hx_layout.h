@@ -132,6 +132,7 @@ struct HxConst {
   double M0f, sqrtM0;  // preindustrial CH4 as the forcing sees it (CH4 constraint at startDate)
   double inv_UC_CH4, inv_Tsoil, inv_Tstrat, inv_h2o_span;  // reciprocals of uniform divisors
   int con_mask;        // HXC_* bits: which constraint columns hold values
+  int trk_iy;          // year index of Core::trackingDate, -1 = no tracking
   double N0, sqrtN0;
   double delta_co2, delta_ch4, delta_n2o;
 };
@@ -152,6 +153,10 @@ struct HxBuffers {
   const double *mseries[HXM_N];  // per-member emissions (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
   int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)
+  // carbon tracking (CON == 2 kernels): per-member origin matrix and its yearly record
+  double *track;         // [hx_trk_rows(B)][npad]
+  double *track_out_f;   // [ns - trk_iy][TP*TP][npad] fractions from the tracking date on
+  double *track_out_v;   // [ns - trk_iy][TP][npad] pool values
   int biome_diag;          // some "<biome>.<variable>" output is recorded
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
 };

@@ -234,6 +234,40 @@ int main(int argc, char **argv) {
   std::fclose(out);
   std::printf("wrote %s (%d member%s, %d-%d)\n", path.c_str(), members, members > 1 ? "s" : "", y0,
               runto);
+  // tracking_<run_name>.csv (src/main.cpp:91-105, CSVFluxPoolVisitor): when the INI's
+  // [core] trackingDate falls inside the run
+  double tdate = 9999.0;
+  {
+    std::vector<double> td((size_t)members);
+    ck(hx_getvar(core, "trackingDate", td.data()));
+    tdate = td[0];
+  }
+  if (tdate > y0 && tdate <= runto) {
+    const char *const *pools = nullptr;
+    int tp = 0;
+    ck(hx_tracking_pools(core, &pools, &tp));
+    const int t0 = (int)tdate, nyt = runto - t0 + 1;
+    std::vector<double> tv((size_t)nyt * tp), tfr((size_t)nyt * tp * tp);
+    std::vector<unsigned long long> tm((size_t)nyt * tp);
+    for (int mbr = 0; mbr < members; ++mbr) {  // one file per member ("<run_name>.<member>")
+      const std::string run = members > 1 ? rn + "." + std::to_string(mbr) : rn;
+      const std::string tpath = outdir + (run.empty() ? "tracking.csv" : "tracking_" + run + ".csv");
+      FILE *tf = std::fopen(tpath.c_str(), "w");
+      if (!tf) die("cannot write " + tpath, 1);
+      std::fprintf(tf, "year,component,pool_name,pool_value,pool_units,source_name,source_fraction\n");
+      ck(hx_tracking_data(core, mbr, t0, runto, tv.data(), tfr.data(), tm.data()));
+      for (int y = 0; y < nyt; ++y)
+        for (int p = 0; p < tp; ++p)
+          for (int s2 = 0; s2 < tp; ++s2)
+            if (tm[(size_t)y * tp + p] >> s2 & 1ull)
+              std::fprintf(tf, "%d,%s,%s,%.*g,Pg C,%s,%.*g\n", t0 + y,
+                           p >= tp - 4 ? "ocean" : "simpleNbox", pools[p], p_def,
+                           tv[(size_t)y * tp + p], pools[s2], p_def,
+                           tfr[((size_t)y * tp + p) * tp + s2]);
+      std::fclose(tf);
+      std::printf("wrote %s\n", tpath.c_str());
+    }
+  }
   ck(hx_shutdown(core));
   return 0;
 }

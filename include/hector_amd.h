@@ -145,6 +145,22 @@ int hx_spinup_steps(hx_core *core, int member, int *steps);
  * carbon, max timestep: src/ocean_component.cpp:422-512). */
 int hx_state_row(hx_core *core, int row, double *out);
 
+/* Carbon tracking: get_tracking_data(core)  R/hector.R -> Core::getTrackingData
+ * (src/core.cpp:199-209, src/csv_tracking_visitor.cpp): where the carbon of every pool
+ * originated, from Core::trackingDate on.  Switch it on with
+ * hx_setvar(core, "trackingDate", &year, 1, NULL) before running.  Pools (hx_tracking_pools):
+ * atmos_c, earth_c, [<biome>.]veg_c/detritus_c/soil_c/permafrost_c/thawedp_c, and the ocean
+ * boxes HL, LL, intermediate, deep.  hx_tracking_data: for one member and year0..year1,
+ * values[(y-year0)*TP + pool] (Pg C), fractions[((y-year0)*TP + pool)*TP + source] and, if
+ * source_masks is not NULL, source_masks[(y-year0)*TP + pool] with bit s set where source s is
+ * in the pool's map (the rows CSVFluxPoolVisitor::print_pool writes).  A [core] trackingDate in
+ * the INI switches tracking on as well; hector-amd then writes tracking_<run_name>.csv.
+ * Costs TP*TP*8 B per member-year of HBM (968 B for one biome); not combinable with a CO2 or
+ * NBP constraint. */
+int hx_tracking_pools(hx_core *core, const char *const **names, int *count);
+int hx_tracking_data(hx_core *core, int member, int year0, int year1, double *values,
+                     double *fractions, unsigned long long *source_masks);
+
 /* getunits(var)  R/units.R (unit strings of src/unitval.cpp:30-165) and the component that owns
  * the variable (IModelComponent::getComponentName, as printed by the output stream): for
  * parameters, inputs, constraints and outputs.  The strings stay valid until the next call on

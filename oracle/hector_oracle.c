@@ -476,6 +476,14 @@ enum { HL = 0, LL = 1, IO = 2, DO = 3 };
 #define MB_EPSILON 0.001                 /* simpleNbox.hpp:37 */
 #define Q10_TEMPN 200                    /* simpleNbox-runtime.cpp:1042 */
 
+/* ---- carbon tracking: a pool or flux with the origin of its carbon (fluxpool.hpp) ---- */
+#define TP_MAX (2 + 5 * HXO_MAXB + 4) /* atmos, earth, 5 pools per biome, 4 ocean boxes */
+typedef struct {
+  double val;
+  double f[TP_MAX]; /* fraction that originated in pool s (0 if s is not in the map) */
+  unsigned long mask; /* which sources are in the map (ctmap keys) */
+} tv_t;
+
 typedef struct {
   const hxo_scenario *sc;
   const hxo_params *pa;
@@ -525,6 +533,14 @@ typedef struct {
   double A[4], IB[4], taucfl, taukls, taucfs, tauksl, taudif, powtoheat;
   double tas_land, sst_now; /* undated D_LAND_TAS, D_SST */
   double Ca_residual;
+  /* carbon tracking shadow (values mirror the fluxpools' running values) */
+  int trk_on, trk_iy, TP;
+  tv_t trk[TP_MAX];      /* the pools */
+  tv_t trk_addn[4];      /* oceanbox::CarbonAdditions */
+  double trk_subn[4];    /* oceanbox::CarbonSubtractions (value only) */
+  tv_t trk_atm_copy;     /* OceanComponent::atmosphere_cpool: the atmosphere as of SimpleNbox::run */
+  tv_t trk_ao[2], trk_oa[2];
+  double *trk_out_f, *trk_out_v; /* [ns][TP][TP], [ns][TP] or NULL */
   double hl_do;                                  /* annual_box_fluxes[HL -> DO] */
   double final_npp, final_rh, final_rh_det, final_rh_soil;
   double final_npp_b[HXO_MAXB], final_rh_b[HXO_MAXB];
@@ -756,6 +772,39 @@ static void doeclim_run(member_t *m, int tstep, double rf_total) {
 }
 
 /* ------------------------------------------------------------------ */
+/* carbon tracking arithmetic   inst/include/fluxpool.hpp:166-298     */
+/* ------------------------------------------------------------------ */
+enum { TP_ATM = 0, TP_EARTH = 1 };
+#define TP_LAND(b, k) (2 + 5 * (b) + (k)) /* k: 0 veg 1 det 2 soil 3 permafrost 4 thawed */
+#define TP_OCEAN(m, box) (2 + 5 * (m)->B + (box))
+
+static tv_t tv_self(int self, double val) { /* fluxpool::set: ctmap[name] = 1 */
+  tv_t r;
+  memset(&r, 0, sizeof r);
+  r.val = val; r.f[self] = 1.0; r.mask = 1ul << self;
+  return r;
+}
+/* flux_from_fluxpool / flux_from_unitval: the pool's origins, another value */
+static tv_t tv_from(const tv_t *pool, double val) { tv_t r = *pool; r.val = val; return r; }
+/* operator+ : origins mixed by value; a zero total shares equally among the sources */
+static tv_t tv_add(tv_t a, tv_t b, int TP) {
+  tv_t r;
+  memset(&r, 0, sizeof r);
+  r.val = a.val + b.val;
+  r.mask = a.mask | b.mask;
+  int nsrc = 0;
+  for (int s = 0; s < TP; s++) if (r.mask >> s & 1ul) nsrc++;
+  for (int s = 0; s < TP; s++) {
+    if (!(r.mask >> s & 1ul)) continue;
+    const double pool_s = a.val * a.f[s] + b.val * b.f[s];
+    r.f[s] = (r.val != 0.0) ? pool_s / r.val : 1.0 / nsrc;
+  }
+  return r;
+}
+static tv_t tv_sub(tv_t a, tv_t b) { a.val = a.val - b.val; return a; } /* operator- */
+static tv_t tv_mul(tv_t a, double k) { a.val = a.val * k; return a; }   /* operator* */
+
+/* ------------------------------------------------------------------ */
 /* ocean component                                                     */
 /* ------------------------------------------------------------------ */
 static double ocean_totalcpool(const member_t *m) {
@@ -985,6 +1034,45 @@ static int ocean_calcderivs(const member_t *m, double t, const double c[],
   return 0;
 }
 
+/* The origins side of OceanComponent::stashCValues: oceanbox::compute_fluxes step 4
+ * (oceanbox.cpp:240-257), separate_surface_fluxes (:262-271) and update_state (:297-303),
+ * boxes in the order HL, LL, intermediate, deep.  Called with the pre-update box carbon. */
+static void trk_ocean_stash(member_t *m, double yf) {
+  const int TP = m->TP;
+  static const int from_[7] = {HL, LL, LL, IO, IO, IO, DO};
+  static const int to_[7] = {DO, HL, IO, LL, HL, DO, IO};
+  const double k_[7] = {m->k_HL_DO, m->k_LL_HL, m->k_LL_IO, m->k_IO_LL,
+                        m->k_IO_HL, m->k_IO_DO, m->k_DO_IO};
+  for (int b = 0; b < 4; b++) m->trk[TP_OCEAN(m, b)].val = m->carbon[b];
+  for (int i = 0; i < 7; i++) {
+    tv_t closs = tv_mul(tv_mul(m->trk[TP_OCEAN(m, from_[i])], k_[i]), yf); /* carbon * k * yf */
+    m->trk_addn[to_[i]] = tv_add(m->trk_addn[to_[i]], closs, TP);        /* add_carbon */
+    m->trk_subn[from_[i]] = m->trk_subn[from_[i]] + closs.val;
+  }
+  for (int b = 0; b < 2; b++) { /* surface boxes: final separate_surface_fluxes */
+    if (m->atmflux[b] > 0) {
+      m->trk_ao[b] = tv_from(&m->trk_atm_copy, m->atmflux[b]);
+      m->trk_oa[b] = tv_from(&m->trk[TP_OCEAN(m, b)], 0.0);
+    } else {
+      m->trk_ao[b] = tv_from(&m->trk_atm_copy, 0.0);
+      m->trk_oa[b] = tv_from(&m->trk[TP_OCEAN(m, b)], -m->atmflux[b]);
+    }
+  }
+  for (int b = 0; b < 4; b++) { /* carbon + CarbonAdditions + ao_flux - oa_flux - CarbonSubtractions */
+    tv_t c = tv_add(m->trk[TP_OCEAN(m, b)], m->trk_addn[b], TP);
+    if (b < 2) {
+      c = tv_add(c, m->trk_ao[b], TP);
+      c = tv_sub(c, m->trk_oa[b]);
+    } else { /* ao/oa of the deeper boxes: zero-valued fluxpools named after the box */
+      c = tv_add(c, tv_from(&m->trk_atm_copy, 0.0), TP);
+    }
+    c.val = c.val - m->trk_subn[b];
+    m->trk[TP_OCEAN(m, b)] = c;
+    m->trk_addn[b] = tv_self(TP_OCEAN(m, b), 0.0);
+    m->trk_subn[b] = 0.0;
+  }
+}
+
 /* OceanComponent::stashCValues  src/ocean_component.cpp:653-763 */
 static void ocean_stash(member_t *m, double t, const double c[]) {
   const double yearfraction = (t - m->ocean_ODEstartdate);
@@ -1022,10 +1110,13 @@ static void ocean_stash(member_t *m, double t, const double c[]) {
   m->annualflux_sumLL = m->annualflux_sumLL + m->atmflux[LL];
   m->annualflux_sum = m->annualflux_sum + lastflux;
   m->lastflux_annualized = lastflux / yearfraction;
+  if (m->trk_on) trk_ocean_stash(m, yearfraction);
   box_update_state(m, HL);
   box_update_state(m, LL);
   box_update_state(m, IO);
   box_update_state(m, DO);
+  if (m->trk_on)
+    for (int b = 0; b < 4; b++) m->trk[TP_OCEAN(m, b)].val = m->carbon[b];
   m->ocean_ODEstartdate = t;
 }
 
@@ -1245,6 +1336,104 @@ static void snb_slowparameval(member_t *m, double t) {
   }
 }
 
+/* The origins side of SimpleNbox::stashCValues (simpleNbox-runtime.cpp:289-540): the same
+ * sequence of fluxpool operations, pool by pool and biome by biome; called with the pools as
+ * they are when the stash begins (the ocean's part has already run, like omodel->stashCValues). */
+static void trk_land_stash(member_t *m, const double c[], double yf, double npp_total,
+                           double npp_rh_total, double rh_adj, double newveg, double newdet,
+                           double newsoil, double newpermafrost, double newthawedpf,
+                           double newatmos) {
+  const hxo_params *p = m->pa;
+  const int TP = m->TP;
+  tv_t *T = m->trk;
+  T[TP_ATM].val = m->atmos_c; T[TP_EARTH].val = m->earth_c;
+  for (int b = 0; b < m->B; b++) {
+    T[TP_LAND(b, 0)].val = m->veg_c[b]; T[TP_LAND(b, 1)].val = m->detritus_c[b];
+    T[TP_LAND(b, 2)].val = m->soil_c[b]; T[TP_LAND(b, 3)].val = m->permafrost_c[b];
+    T[TP_LAND(b, 4)].val = m->thawed_c[b];
+  }
+  const tv_t ffi_flux = tv_from(&T[TP_EARTH], m->cur_ffi);  /* :295-296 */
+  const tv_t ccs_flux = tv_from(&T[TP_ATM], m->cur_daccs);
+  const tv_t oa_flux = tv_add(m->trk_oa[LL], m->trk_oa[HL], TP);  /* get_oaflux: LL + HL */
+  const tv_t ao_flux = tv_add(m->trk_ao[LL], m->trk_ao[HL], TP);
+  const double permafrost_total = sum_b(m->permafrost_c, m->B);
+  const double total = c[SNBOX_VEG] + c[SNBOX_DET] + c[SNBOX_SOIL];
+  for (int b = 0; b < m->B; b++) {
+    tv_t *veg = &T[TP_LAND(b, 0)], *det = &T[TP_LAND(b, 1)], *soil = &T[TP_LAND(b, 2)],
+         *pf = &T[TP_LAND(b, 3)], *tp = &T[TP_LAND(b, 4)], *atm = &T[TP_ATM];
+    const double wt = (snb_npp(m, b) + snb_rh(m, b)) / npp_rh_total;
+    const double wt_pf = permafrost_total > 0 ? m->permafrost_c[b] / permafrost_total : 0;
+    const double veg_frac = veg->val / total, det_frac = det->val / total,
+                 soil_frac = soil->val / total;
+    /* every flux of this biome is drawn before any pool moves (:414-452) */
+    const tv_t luc_fva = tv_mul(tv_from(veg, m->cur_luc_e * veg_frac), yf);
+    const tv_t luc_fda = tv_mul(tv_from(det, m->cur_luc_e * det_frac), yf);
+    const tv_t luc_fsa = tv_mul(tv_from(soil, m->cur_luc_e * soil_frac), yf);
+    const tv_t luc_fav = tv_mul(tv_from(atm, m->cur_luc_u), yf);
+    const double npp_biome = npp_total * wt;
+    const tv_t npp_fav = tv_mul(tv_from(atm, npp_biome * p->f_nppv[b]), yf);
+    const tv_t npp_fad = tv_mul(tv_from(atm, npp_biome * p->f_nppd[b]), yf);
+    const tv_t npp_fas = tv_mul(tv_from(atm, npp_biome * (1 - p->f_nppv[b] - p->f_nppd[b])), yf);
+    const double rh_fda_adj = snb_rh_fda(m, b) * rh_adj, rh_fsa_adj = snb_rh_fsa(m, b) * rh_adj,
+                 rh_co2_adj = snb_rh_ftpa_co2(m, b) * rh_adj, rh_ch4_adj = snb_rh_ftpa_ch4(m, b) * rh_adj;
+    const tv_t rh_fda_flux = tv_mul(tv_from(det, rh_fda_adj), yf);
+    const tv_t rh_fsa_flux = tv_mul(tv_from(soil, rh_fsa_adj), yf);
+    const tv_t rh_fpa_co2 = tv_mul(tv_from(tp, rh_co2_adj), yf);
+    const tv_t rh_fpa_ch4 = tv_mul(tv_from(tp, rh_ch4_adj), yf);
+    /* luc fluxes :455-460 (the detritus line of the reference has no effect: an expression
+     * statement without assignment) */
+    *atm = tv_add(tv_add(tv_sub(tv_add(*atm, luc_fva, TP), luc_fav), luc_fda, TP), luc_fsa, TP);
+    *veg = tv_sub(tv_add(*veg, luc_fav, TP), luc_fva);
+    *soil = tv_sub(*soil, luc_fsa);
+    /* npp fluxes :463-467 */
+    *veg = tv_add(*veg, npp_fav, TP);
+    *det = tv_add(*det, npp_fad, TP);
+    *soil = tv_add(*soil, npp_fas, TP);
+    *atm = tv_sub(tv_sub(tv_sub(*atm, npp_fav), npp_fad), npp_fas);
+    /* rh fluxes :470-476 */
+    *atm = tv_add(tv_add(tv_add(*atm, rh_fda_flux, TP), rh_fsa_flux, TP), rh_fpa_co2, TP);
+    *det = tv_sub(*det, rh_fda_flux);
+    *soil = tv_sub(*soil, rh_fsa_flux);
+    *tp = tv_sub(tv_sub(*tp, rh_fpa_co2), rh_fpa_ch4);
+    if (!m->snbox_in_spinup) { /* permafrost thaw and refreeze :484-503 */
+      /* compute_pf_thaw_refreeze :744-772 on the pools as they are at this point (the thawed
+       * pool has already lost this stash's respiration) */
+      double x = pf->val * m->f_new_thaw[b], y = 0.0, z = 0.0;
+      if (x < 0) {
+        const double pf_refreeze = -x;
+        x = 0.0;
+        const double thawed_remaining = tp->val - rh_co2_adj - rh_ch4_adj;
+        y = (thawed_remaining < pf_refreeze) ? thawed_remaining : pf_refreeze;
+      }
+      const tv_t pf_thaw = tv_mul(tv_from(pf, x), yf);
+      const tv_t pf_refreeze_tp = tv_mul(tv_from(tp, y), yf);
+      const tv_t pf_refreeze_soil = tv_mul(tv_from(soil, z), yf);
+      *pf = tv_add(tv_add(tv_sub(*pf, pf_thaw), pf_refreeze_tp, TP), pf_refreeze_soil, TP);
+      *tp = tv_sub(tv_add(*tp, pf_thaw, TP), pf_refreeze_tp);
+      *soil = tv_sub(*soil, pf_refreeze_soil);
+    }
+    /* litter :506-511, detritus -> soil :514-521 */
+    const tv_t litter = tv_mul(*veg, 0.035 * yf);
+    const tv_t litter_fvd = tv_mul(litter, p->f_litterd[b]);
+    const tv_t litter_fvs = tv_mul(litter, 1 - p->f_litterd[b]);
+    *det = tv_add(*det, litter_fvd, TP);
+    *soil = tv_add(*soil, litter_fvs, TP);
+    *veg = tv_sub(*veg, litter);
+    const tv_t detsoil = tv_mul(*det, 0.6 * yf);
+    *soil = tv_add(*soil, detsoil, TP);
+    *det = tv_sub(*det, detsoil);
+    /* adjust_pool_to_val(solver value, false): the value only :524-530 */
+    veg->val = newveg * wt; det->val = newdet * wt; soil->val = newsoil * wt;
+    pf->val = newpermafrost * wt_pf; tp->val = newthawedpf * wt_pf;
+  }
+  /* :534-541 */
+  T[TP_EARTH] = tv_add(tv_sub(T[TP_EARTH], ffi_flux), ccs_flux, TP);
+  T[TP_ATM] = tv_sub(tv_add(T[TP_ATM], ffi_flux, TP), ccs_flux);
+  T[TP_ATM] = tv_sub(tv_add(T[TP_ATM], oa_flux, TP), ao_flux);
+  T[TP_EARTH].val = c[SNBOX_EARTH];
+  T[TP_ATM].val = newatmos;
+}
+
 /* SimpleNbox::stashCValues  runtime.cpp:270-609 (no tracking, no constraints) */
 static void snb_stash(member_t *m, double t, const double c[]) {
   const hxo_params *p = m->pa;
@@ -1288,6 +1477,9 @@ static void snb_stash(member_t *m, double t, const double c[]) {
   const double total = c[SNBOX_VEG] + c[SNBOX_DET] + c[SNBOX_SOIL];
   m->cum_luc_va = m->cum_luc_va +
                   ((m->cur_luc_e - m->cur_luc_u) * c[SNBOX_VEG] / total);
+  if (m->trk_on)
+    trk_land_stash(m, c, yf, npp_total, npp_rh_total, rh_nbp_constraint_adjust, newveg, newdet,
+                   newsoil, newpermafrost, solver_tpf, c[SNBOX_ATMOS]);
   m->final_npp = m->final_rh = m->final_rh_det = m->final_rh_soil = 0.0;
   for (int b = 0; b < m->B; b++) {
     const double wt = (snb_npp(m, b) + snb_rh(m, b)) / npp_rh_total;
@@ -1720,6 +1912,7 @@ static void member_prepare(member_t *m, const hxo_scenario *s, const hxo_params 
   m->heatflux_mixed = buf + 5 * ns; m->heatflux_interior = buf + 6 * ns;
   m->Tland_record = buf + 7 * ns;
   m->Tland_first = -1;
+  m->trk_iy = -1;
   ocean_prepare(m);
   /* SimpleNbox: simpleNbox.cpp:45-79, runtime.cpp:66-190 */
   m->earth_c = 5500;
@@ -1855,6 +2048,28 @@ static void member_main(member_t *m, int run_to, double *out) {
     }
     m->Tland_record[iy] = m->tas_land;
     if (m->Tland_first < 0) m->Tland_first = iy;
+    if (iy == m->trk_iy && !m->trk_on) { /* start_tracking: every pool is 100 % itself */
+      m->trk_on = 1;
+      m->TP = 2 + 5 * m->B + 4;
+      m->trk[TP_ATM] = tv_self(TP_ATM, m->atmos_c);
+      m->trk[TP_EARTH] = tv_self(TP_EARTH, m->earth_c);
+      for (int b = 0; b < m->B; b++) {
+        m->trk[TP_LAND(b, 0)] = tv_self(TP_LAND(b, 0), m->veg_c[b]);
+        m->trk[TP_LAND(b, 1)] = tv_self(TP_LAND(b, 1), m->detritus_c[b]);
+        m->trk[TP_LAND(b, 2)] = tv_self(TP_LAND(b, 2), m->soil_c[b]);
+        m->trk[TP_LAND(b, 3)] = tv_self(TP_LAND(b, 3), m->permafrost_c[b]);
+        m->trk[TP_LAND(b, 4)] = tv_self(TP_LAND(b, 4), m->thawed_c[b]);
+      }
+      for (int b = 0; b < 4; b++) {
+        m->trk[TP_OCEAN(m, b)] = tv_self(TP_OCEAN(m, b), m->carbon[b]);
+        m->trk_addn[b] = tv_self(TP_OCEAN(m, b), 0.0);
+        m->trk_subn[b] = 0.0;
+      }
+    }
+    if (m->trk_on) { /* set_atmosphere_sources(atmos_c)  runtime.cpp:225-227 */
+      m->trk_atm_copy = m->trk[TP_ATM];
+      m->trk_atm_copy.val = m->atmos_c;
+    }
     solver_run(m, (double)year);
     double CO2_conc = m->atmos_c * PGC_TO_PPMVCO2;
     year_forcing(m, year, CO2_conc);
@@ -1879,16 +2094,33 @@ static void member_main(member_t *m, int run_to, double *out) {
         (m->pa->lo_warming_ratio != 0) ? m->sst_now * d_bsi : d_bsi * m->temp_sst[iy];
     for (int k = 0; k < 11; k++) out[(HXO_RF_H2O + k) * ns + iy] = m->rf_item_v[k];
     slr_run(m, year, out);
+    if (m->trk_on && m->trk_out_f) { /* CSVFluxPoolVisitor: pools and their source fractions */
+      const int TP = m->TP;
+      for (int pl = 0; pl < TP; pl++) {
+        m->trk_out_v[(size_t)iy * TP + pl] = m->trk[pl].val;
+        for (int sc = 0; sc < TP; sc++)
+          m->trk_out_f[((size_t)iy * TP + pl) * TP + sc] = m->trk[pl].f[sc];
+      }
+    }
   }
 }
 
 int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,
                    double *out, int *spinup_steps) {
+  return hxo_run_member_tracking(s, p, run_to, -1, out, spinup_steps, NULL, NULL);
+}
+
+int hxo_run_member_tracking(const hxo_scenario *s, const hxo_params *p, int run_to,
+                            int tracking_date, double *out, int *spinup_steps, double *trk_f,
+                            double *trk_v) {
   member_t M, *m = &M;
   const int ns = s->ns;
   memset(out, 0, sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
   double *buf = (double *)malloc(sizeof(double) * (size_t)ns * 8);
   member_prepare(m, s, p, buf);
+  m->trk_iy = tracking_date - s->start; /* Core::trackingDate, 9999 = never */
+  if (tracking_date < 0) m->trk_iy = -1;
+  m->trk_out_f = trk_f; m->trk_out_v = trk_v;
   int step = member_spinup(m);
   if (spinup_steps) *spinup_steps = step;
   member_main(m, run_to, out);

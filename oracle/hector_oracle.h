@@ -128,6 +128,16 @@ void hxo_params_split_equal(hxo_params *p, int n);
 int hxo_run_member(const hxo_scenario *, const hxo_params *, int run_to,
                    double *out, int *spinup_steps);
 
+/* The same with carbon tracking from `tracking_date` on (Core::trackingDate; fluxpool source
+ * maps, inst/include/fluxpool.hpp): TP = 2 + 5 * nbiome + 4 pools in the order atmos_c, earth_c,
+ * per biome {veg_c, detritus_c, soil_c, permafrost_c, thawedp_c}, ocean {HL, LL, intermediate,
+ * deep}; trk_v[ns][TP] pool values, trk_f[ns][TP][TP] fraction of pool p that originated in
+ * pool s (rows of years before tracking_date stay untouched).  PARITY UNPINNED: the reference
+ * ships no tracking vectors; its own tests check structure and that fractions sum to one. */
+int hxo_run_member_tracking(const hxo_scenario *, const hxo_params *, int run_to,
+                            int tracking_date, double *out, int *spinup_steps, double *trk_f,
+                            double *trk_v);
+
 /* Run members [0,n) whose parameters differ from *base only in S and q10_rh[0]
  * (the BASELINE config 2-4 ensemble); writes co2[n*ns], tgav[n*ns] (may be
  * NULL).  Used as bench.py's cpu_baseline leg.  Returns OR of error masks. */

@@ -93,6 +93,27 @@ class Oracle:
                                       out.ctypes.data, ctypes.byref(steps))
         return {v: out[i] for i, v in enumerate(VARS)}, err, steps.value
 
+    def run_tracking(self, p, tracking_date, run_to=None):
+        """-> (values[ns, TP], fractions[ns, TP, TP], pool names, err); see hector_oracle.h"""
+        p = p or self.default_params()
+        run_to = run_to or self.end
+        tp = 2 + 5 * p.nbiome + 4
+        out = np.zeros((len(VARS), self.ns))
+        f = np.zeros((self.ns, tp, tp)); v = np.zeros((self.ns, tp))
+        dp = ctypes.POINTER(ctypes.c_double)
+        fn = self.lib.hxo_run_member_tracking
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int, dp,
+                       ctypes.POINTER(ctypes.c_int), dp, dp]
+        err = fn(self.sc, ctypes.byref(p), int(run_to), int(tracking_date), out.ctypes.data_as(dp),
+                 None, f.ctypes.data_as(dp), v.ctypes.data_as(dp))
+        names = ["atmos_c", "earth_c"]
+        for b in range(p.nbiome):
+            names += ["b%d.%s" % (b, k) for k in ("veg_c", "detritus_c", "soil_c", "permafrost_c",
+                                                    "thawedp_c")]
+        names += ["HL", "LL", "intermediate", "deep"]
+        return v, f, names, err
+
     def run_ecs_q10(self, S, q10, run_to=None, base=None):
         """-> co2[n, ns], tgav[n, ns], err"""
         S = np.ascontiguousarray(S, dtype=np.float64)

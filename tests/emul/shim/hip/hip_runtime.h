@@ -48,6 +48,7 @@ inline const char *hipGetErrorString(hipError_t) { return "host-emulation error"
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 struct double2 { double x, y; };
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

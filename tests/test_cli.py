@@ -94,3 +94,26 @@ def test_cli_prints_biome_rows_for_multi_biome_scenarios(emul_lib, tmp_path):
             assert b + "." + v in names
     veg = {r["variable"]: float(r["value"]) for r in rows if r["year"] == "1800" and r["variable"].endswith("veg_c")}
     assert veg["boreal.veg_c"] + veg["tropical.veg_c"] == pytest.approx(veg["veg_c"], rel=1e-5)
+
+
+def test_cli_writes_tracking_csv(emul_lib, tmp_path):
+    """src/main.cpp:91-105 + CSVFluxPoolVisitor: [core] trackingDate inside the run ->
+    tracking_<run_name>.csv, rows year,component,pool_name,pool_value,pool_units,source_name,
+    source_fraction for trackingDate..end; fractions of every (year, pool) sum to 1."""
+    from conftest import edited_pack
+    pack = edited_pack(tmp_path / "t.hxs", None, None, [], [], scalars={("core", "trackingDate"): 1850})
+    r = subprocess.run([EMUL_CLI, pack, "--run-to", "1900", "--output-dir", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "tracking_ssp245.csv") as f:
+        head = f.readline().strip()
+        rows = [l.strip().split(",") for l in f]
+    assert head == "year,component,pool_name,pool_value,pool_units,source_name,source_fraction"
+    assert sorted({int(r[0]) for r in rows}) == list(range(1850, 1901))
+    tot = {}
+    for r in rows:
+        tot[(r[0], r[2])] = tot.get((r[0], r[2]), 0.0) + float(r[6])
+    assert len(tot) == 51 * 11 and max(abs(v - 1.0) for v in tot.values()) < 1e-4
+    assert {r[1] for r in rows if r[2] in ("HL", "LL", "intermediate", "deep")} == {"ocean"}
+    # without a tracking date no tracking file (the reference writes an empty one)
+    assert not os.path.exists(tmp_path / "tracking_ssp245.0.csv")

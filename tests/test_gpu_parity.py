@@ -446,6 +446,32 @@ def test_capabilities_and_shared_parameters_on_gpu(hip_lib, tmp_path):
     capability_checks(hip_lib, tmp_path, device=0)
 
 
+def test_carbon_tracking_on_gpu(hip_lib, oracle):
+    """Origin maps of every pool (get_tracking_data) from the tracking instantiation of the run
+    kernel: vs the oracle for 1 and 4 biomes, reset/resume, and sum-to-one for 300 members."""
+    from test_tracking import (check_tracking_vs_oracle, tracking_reset_checks,
+                               tracking_four_biomes, tracked_core)
+    c = check_tracking_vs_oracle(hip_lib, oracle, device=0)
+    assert c.backend == "hip"
+    tracking_reset_checks(hip_lib, device=0)
+    tracking_four_biomes(hip_lib, oracle, device=0)
+    n = 300
+    S, q10 = ensemble.ecs_q10(n, offset=77)
+    c = tracked_core(hip_lib, n, date=1850, device=0)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10).run(2100)
+    assert (c.status() == 0).all()
+    plain = hector_amd.Core(SCENARIO, n, lib_path=hip_lib, device=0)
+    plain.setvar("S", S, "degC").setvar("q10_rh", q10).run(2100)
+    co2 = plain.fetchvars("CO2_concentration", (1850, 2100))
+    for i in (0, 63, 64, 177, 299):
+        v, f = c.tracking_data(i, (1850, 2100))
+        assert np.abs(f.sum(axis=2) - 1.0).max() < 1e-12 and f.min() >= 0.0
+        # the tracked atmosphere is the plain run's atmosphere
+        assert (np.abs(v[:, 0] / 2.13 - co2[:, i]) / co2[:, i]).max() < 1e-9
+    # two instantiations of the run kernel: same run to the parity tolerance
+    assert (np.abs(c.fetchvars("CO2_concentration", (1850, 2100)) - co2) / co2).max() < REL_CO2
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 65, 1001, 4097])
 def test_stats_kernel_on_ragged_member_counts(hip_lib, n):
     """hx_stats_kernel (16-byte loads, tail handling) against numpy for odd ensemble sizes."""

@@ -1,0 +1,152 @@
+"""Carbon tracking (fluxpool origin maps, inst/include/fluxpool.hpp; SimpleNbox::stashCValues
+src/simpleNbox-runtime.cpp:289-540; oceanbox.cpp:240-303; CSVFluxPoolVisitor) on the kernel
+source compiled for the host, against the oracle's restatement, plus the properties
+tests/testthat/test_tracking.R states.  The GPU suite repeats the comparison through HIP."""
+import numpy as np
+import pytest
+
+import hector_amd
+from conftest import SCENARIO
+
+T0, END = 1770, 2100
+FRAC_TOL = 1e-8
+
+
+def tracked_core(lib, n, date=T0, **kw):
+    c = hector_amd.Core(SCENARIO, n, lib_path=lib, **kw)
+    c.setvar("trackingDate", [date])
+    return c
+
+
+def check_tracking_vs_oracle(lib, oracle, **kw):
+    c = tracked_core(lib, 3, **kw)
+    q10 = c.getvar("q10_rh"); q10[1] *= 0.9; q10[2] = 2.6
+    S = np.array([3.0, 3.0, 4.5])
+    c.setvar("q10_rh", q10).setvar("S", S, "degC")
+    c.set_outputs(["CO2_concentration", "HL_ocean_c", "DO_ocean_c"])
+    c.run(END)
+    assert (c.status() == 0).all()
+    assert c.getvar("trackingDate")[0] == T0
+    names = c.tracking_pools()
+    assert names == ["atmos_c", "earth_c", "veg_c", "detritus_c", "soil_c", "permafrost_c",
+                     "thawedp_c", "HL", "LL", "intermediate", "deep"]
+    for i in range(3):
+        p = oracle.default_params(); p.q10_rh[0] = q10[i]; p.S = S[i]
+        ov, of, _, err = oracle.run_tracking(p, T0, END)
+        assert err == 0
+        gv, gf = c.tracking_data(i, (T0, END))
+        k0, k1 = T0 - 1745, END - 1745 + 1
+        # pools to ~1e-11 relative like every other output; fractions are ratios of sums of
+        # fluxes, and in small pools (thawed permafrost, detritus) the 1e-11 differences of the
+        # fluxes are amplified: FRAC_TOL absolute on numbers in [0, 1]
+        assert np.abs(gv - ov[k0:k1]).max() < 1e-10 * np.abs(ov).max()
+        assert np.abs(gf - of[k0:k1]).max() < FRAC_TOL
+        # every pool's origins sum to 1 (test_tracking.R:96-101)
+        assert np.abs(gf.sum(axis=2) - 1.0).max() < 1e-12
+        # first tracked year: mostly itself; the pool values are the model's (test_tracking.R:163-)
+        assert gf[0, 1, 1] == 1.0
+        assert np.abs(gv[:, 7] - c.fetchvars("HL_ocean_c", (T0, END))[:, i]).max() == 0.0
+        assert np.abs(gv[:, 10] - c.fetchvars("DO_ocean_c", (T0, END))[:, i]).max() == 0.0
+    return c
+
+
+def test_tracking_vs_oracle(emul_lib, oracle):
+    c = check_tracking_vs_oracle(emul_lib, oracle, allow_emulation=True)
+    # a changed parameter changes the origins (test_tracking.R:30-50)
+    _, f0 = c.tracking_data(0, (T0, END)); _, f1 = c.tracking_data(1, (T0, END))
+    assert np.abs(f0 - f1).max() > 1e-4
+    rows = hector_amd.get_tracking_data(c, 0)
+    years = sorted({r[0] for r in rows})
+    assert years == list(range(T0, END + 1))  # test_tracking.R:70-90
+    assert {r[1] for r in rows} == {"simpleNbox", "ocean"} and {r[4] for r in rows} == {"Pg C"}
+
+
+def test_tracking_changes_nothing_else(emul_lib):
+    """Tracking only observes: the run itself is the untracked run (to the rounding differences
+    between two instantiations of the run kernel)."""
+    a = hector_amd.Core(SCENARIO, 2, lib_path=emul_lib, allow_emulation=True)
+    b = tracked_core(emul_lib, 2, allow_emulation=True)
+    for c in (a, b):
+        c.setvar("S", [2.5, 4.0], "degC"); c.run(2100)
+    for v in ("CO2_concentration", "global_tas"):
+        d = np.abs(a.fetchvars(v, (1745, 2100)) - b.fetchvars(v, (1745, 2100))).max()
+        print(v, d)
+        assert d < 1e-10
+
+
+def test_no_tracking_is_empty(emul_lib):
+    c = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    c.run(1760)
+    assert hector_amd.get_tracking_data(c) == []          # test_tracking.R:12-20
+    assert c.getvar("trackingDate")[0] == 9999            # core.cpp:60
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.tracking_data(0, (1750, 1760))
+    # a tracking date that a run can never reach (simpleNbox-runtime.cpp:217: runToDate == tdate)
+    c.setvar("trackingDate", [1745]); c.run(1760)
+    assert c.getvar("trackingDate")[0] == 1745
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.tracking_data(0, (1750, 1760))
+
+
+def test_tracking_with_reset(emul_lib):
+    tracking_reset_checks(emul_lib, allow_emulation=True)
+
+
+def tracking_reset_checks(lib, **kw):
+    """test_tracking.R:104-160: reset below the tracking date empties the record, a reset at or
+    past it resumes with the maps of that date; a run-reset-run reproduces the straight run."""
+    c = tracked_core(lib, 2, date=1760, **kw)
+    c.enable_history(True)
+    c.setvar("S", [3.0, 4.0], "degC")
+    c.run(1800)
+    v0, f0 = c.tracking_data(1, (1760, 1800))
+    c.reset(1750)
+    assert hector_amd.get_tracking_data(c) == []
+    assert c.getvar("trackingDate")[0] == 1760
+    c.run(1770)
+    rows = hector_amd.get_tracking_data(c, 1)
+    assert min(r[0] for r in rows) == 1760 and max(r[0] for r in rows) == 1770
+    c.reset(1765)                       # >= trackingDate
+    c.run(1800)
+    v1, f1 = c.tracking_data(1, (1760, 1800))
+    assert np.array_equal(v0, v1) and np.array_equal(f0, f1)
+    c.reset(1760); c.run(1780); c.run(1800)
+    v2, f2 = c.tracking_data(1, (1760, 1800))
+    assert np.array_equal(v0, v2) and np.array_equal(f0, f2)
+    with pytest.raises(hector_amd.HectorAmdError):
+        c.tracking_data(1, (1750, 1800))
+
+
+def test_tracking_four_biomes(emul_lib, oracle):
+    tracking_four_biomes(emul_lib, oracle, allow_emulation=True)
+
+
+def tracking_four_biomes(lib, oracle, **kw):
+    c = tracked_core(lib, 2, date=1800, **kw)
+    names = ["b1", "b2", "b3", "b4"]
+    c.split_biome(names)
+    q = [[1.8, 2.2], [2.0, 2.0], [2.4, 1.7], [2.1, 2.6]]
+    for b, nm in enumerate(names):
+        c.setvar(nm + ".q10_rh", q[b])
+    c.run(2050)
+    pools = c.tracking_pools()
+    assert len(pools) == 26 and pools[2] == "b1.veg_c" and pools[21] == "b4.thawedp_c"
+    for i in range(2):
+        p = oracle.split_equal(oracle.default_params(), 4)
+        for b in range(4):
+            p.q10_rh[b] = q[b][i]
+        ov, of, _, err = oracle.run_tracking(p, 1800, 2050)
+        assert err == 0
+        gv, gf = c.tracking_data(i, (1800, 2050))
+        assert np.abs(gv - ov[55:306]).max() < 1e-10 * np.abs(ov).max()
+        assert np.abs(gf - of[55:306]).max() < FRAC_TOL
+        assert np.abs(gf.sum(axis=2) - 1.0).max() < 1e-12
+
+
+def test_tracking_refuses_carbon_constraints(emul_lib, tmp_path):
+    from conftest import edited_pack
+    pack = edited_pack(tmp_path / "c.hxs", "simpleNbox", "CO2_constrain", [1800, 1801], [285.0, 285.2])
+    c = hector_amd.Core(str(pack), 1, lib_path=emul_lib, allow_emulation=True)
+    c.setvar("trackingDate", [1770])
+    with pytest.raises(hector_amd.HectorAmdError, match="constraint"):
+        c.run(1850)
