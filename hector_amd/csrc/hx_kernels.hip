@@ -630,12 +630,27 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * buf.npad + mem];
           else return HX_CCD(buf.ker)[idx];
         };
-        for (int i = blk0; i < iy; ++i) {
-          double T;
-          if constexpr (B == 1) T = s_tblk[i - blk0][lane];
-          else T = HX_GCD(buf.out[HXO_SST])[(size_t)i * buf.npad + mem];
-          dpast += T * ldk(kq + i);
-          if (want_hf) hint += T * ldk(kq + i + 1);
+        // in chunks of 8 so that the loads of a chunk are in flight together (one exposed
+        // latency per chunk instead of per entry); entries from this year on enter as 0 * Ker,
+        // which leaves the sums bit for bit what the entry-by-entry loop gives
+        const int nchunk = (jb + 7) >> 3;
+        for (int c = 0; c < nchunk; ++c) {
+          const int i0 = blk0 + 8 * c;
+          double T[8], K[8], K2[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int i = i0 + r;
+            if constexpr (B == 1) T[r] = s_tblk[8 * c + r][lane];
+            else T[r] = HX_GCD(buf.out[HXO_SST])[(size_t)(i < ns ? i : ns - 1) * buf.npad + mem];
+            K[r] = ldk(kq + i);
+            K2[r] = want_hf ? ldk(kq + i + 1) : 0.0;
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const double t = (i0 + r < iy) ? T[r] : 0.0;
+            dpast += t * K[r];
+            if (want_hf) hint += t * K2[r];
+          }
         }
         dpast *= dDPS;
         const double DelQ = rf_tot - f_prev;
