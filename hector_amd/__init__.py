@@ -3,7 +3,8 @@ carbon-cycle / climate year loop.  HIP kernels + C ABI in
 hector_amd/csrc; this package only binds them."""
 from ._lib import HectorAmdError, DEFAULT_SCENARIO, DEFAULT_LIB  # noqa: F401
 from .core import (Core, newcore, run, reset, shutdown, setvar, fetchvars,  # noqa: F401
-                   split_biome, get_tracking_data)
+                   split_biome, get_tracking_data, create_biome, rename_biome,
+                   get_biome_inits)
 from . import capabilities  # noqa: F401
 
 __version__ = "0.1.0"

@@ -78,8 +78,20 @@ class Core:
                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
         return out
 
+    def create_biome(self, biome):
+        self._ck(self._lib.hx_create_biome(self._h, biome.encode()))
+        return self
+
+    def delete_biome(self, biome):
+        self._ck(self._lib.hx_delete_biome(self._h, biome.encode()))
+        return self
+
+    def rename_biome(self, oldname, newname):
+        self._ck(self._lib.hx_rename_biome(self._h, oldname.encode(), newname.encode()))
+        return self
+
     def split_biome(self, names, fveg_c=None, fdetritus_c=None, fsoil_c=None,
-                    fpermafrost_c=None, fnpp_flux0=None):
+                    fpermafrost_c=None, fnpp_flux0=None, old_biome=None):
         n = len(names)
         arr = (ctypes.c_char_p * n)(*[s.encode() for s in names])
 
@@ -91,8 +103,13 @@ class Core:
             keep.append(a)
             return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         keep = []
-        self._ck(self._lib.hx_split_biome(self._h, n, arr, f(fveg_c), f(fdetritus_c), f(fsoil_c),
-                                          f(fpermafrost_c), f(fnpp_flux0)))
+        if old_biome is None:
+            self._ck(self._lib.hx_split_biome(self._h, n, arr, f(fveg_c), f(fdetritus_c),
+                                              f(fsoil_c), f(fpermafrost_c), f(fnpp_flux0)))
+        else:
+            self._ck(self._lib.hx_split_biome_of(self._h, old_biome.encode(), n, arr, f(fveg_c),
+                                                 f(fdetritus_c), f(fsoil_c), f(fpermafrost_c),
+                                                 f(fnpp_flux0)))
         return self
 
     def set_outputs(self, variables):
@@ -304,7 +321,58 @@ def get_tracking_data(core, member=0):
     return rows
 
 
-def split_biome(core, old_biome, new_biomes, **fractions):
-    if old_biome != "global":
-        raise HectorAmdError("only the default biome can be split")
-    return core.split_biome(list(new_biomes), **fractions)
+_BIOME_PARAMS = ("warmingfactor", "beta", "q10_rh", "f_nppv", "f_nppd", "f_litterd")
+
+
+def split_biome(core, old_biome, new_biomes, fveg_c=None, fdetritus_c=None, fsoil_c=None,
+                fpermafrost_c=None, fnpp_flux0=None, **params):
+    """split_biome(core, old_biome, new_biomes, ...)  R/biome.R:61-130.  `params`: warmingfactor,
+    beta, q10_rh, f_nppv, f_nppd, f_litterd for the new biomes (a scalar, or one value per new
+    biome); default: the old biome's."""
+    new_biomes = list(new_biomes)
+    bad = set(params) - set(_BIOME_PARAMS)
+    if bad:
+        raise HectorAmdError("split_biome: unknown biome parameter(s) %s" % sorted(bad))
+    for name, f in (("fveg_c", fveg_c), ("fdetritus_c", fdetritus_c), ("fsoil_c", fsoil_c),
+                    ("fpermafrost_c", fpermafrost_c), ("fnpp_flux0", fnpp_flux0)):
+        if f is None:
+            continue
+        f = np.asarray(f, dtype=float)  # the stopifnot block of the R function
+        lo_ok = (f >= 0).all() if name == "fpermafrost_c" else (f > 0).all()
+        if f.size != len(new_biomes) or abs(f.sum() - 1.0) > 1e-12 or not lo_ok:
+            raise HectorAmdError("split_biome: %s must be %d positive fractions summing to 1"
+                                 % (name, len(new_biomes)))
+    core.split_biome(new_biomes, fveg_c, fdetritus_c, fsoil_c, fpermafrost_c, fnpp_flux0,
+                     old_biome=old_biome)
+    for key, val in params.items():
+        vals = np.broadcast_to(np.asarray(val, dtype=float), (len(new_biomes),))
+        for b, v in zip(new_biomes, vals):
+            core.setvar("%s.%s" % (b, key), [v])
+    return core
+
+
+def create_biome(core, biome, veg_c0, detritus_c0, soil_c0, permafrost_c0, npp_flux0,
+                 warmingfactor, beta, q10_rh, f_nppv, f_nppd, f_litterd):
+    """create_biome(core, biome, ...)  R/biome.R:20-40 (values: a scalar or one per member)."""
+    core.create_biome(biome)
+    for key, val in (("veg_c", veg_c0), ("detritus_c", detritus_c0), ("soil_c", soil_c0),
+                     ("permafrost_c", permafrost_c0), ("npp_flux0", npp_flux0),
+                     ("warmingfactor", warmingfactor), ("beta", beta), ("q10_rh", q10_rh),
+                     ("f_nppv", f_nppv), ("f_nppd", f_nppd), ("f_litterd", f_litterd)):
+        core.setvar("%s.%s" % (biome, key), np.atleast_1d(np.asarray(val, dtype=float)))
+    return core
+
+
+def rename_biome(core, oldname, newname):
+    return core.rename_biome(oldname, newname)
+
+
+def get_biome_inits(core, biome):
+    """get_biome_inits(core, biome)  R/biome.R:140-170: initial pools and parameters of a biome
+    (per member)."""
+    pre = "" if (biome == "global" and core.biomes() == ["global"]) else biome + "."
+    out = {k: core.getvar(pre + k) for k in ("veg_c", "detritus_c", "soil_c", "permafrost_c",
+                                             "npp_flux0", "f_litterd", "f_nppd", "f_nppv", "beta",
+                                             "q10_rh", "warmingfactor")}
+    out["thawedp_c"] = np.zeros(core.n_members)  # always empty at t = 0 (simpleNbox.cpp:146)
+    return out

@@ -618,44 +618,136 @@ void EnsembleCore::getvar(const std::string &capability, double *out) const {
 void EnsembleCore::split_biome(const std::vector<std::string> &names, const double *fveg,
                                const double *fdet, const double *fsoil, const double *fpf,
                                const double *fnpp) {
-  const int nb = (int)names.size();
-  if (B_ != 1) throw std::runtime_error("split_biome: only a single existing biome can be split");
-  if (nb < 1 || nb > HX_MAXB)
-    throw std::runtime_error("split_biome: 1.." + std::to_string(HX_MAXB) + " biomes supported");
+  if (B_ != 1) throw std::runtime_error("split_biome: name the biome to split (several exist)");
+  split_biome_of(biome_names_[0], names, fveg, fdet, fsoil, fpf, fnpp);
+}
+
+// split_biome(core, old_biome, new_biomes, ...)  R/biome.R:61-130: the new biomes are appended
+// to the list (create_biome), the old one is deleted.  Pools and npp_flux0 are the old biome's
+// times the fractions; warmingfactor, beta, q10_rh, f_nppv, f_nppd, f_litterd the old biome's;
+// what create_biome leaves alone (rh_ch4_frac, permafrost parameters) comes from the last biome
+// of the list, as in SimpleNbox::createBiome.
+void EnsembleCore::split_biome_of(const std::string &old_biome,
+                                  const std::vector<std::string> &names, const double *fveg,
+                                  const double *fdet, const double *fsoil, const double *fpf,
+                                  const double *fnpp) {
+  const int nb = (int)names.size(), ob = biome_index(old_biome);
+  if (ob < 0) throw std::runtime_error("Biome '" + old_biome + "' missing from biome list.");
+  if (nb < 1 || B_ - 1 + nb > HX_MAXB)
+    throw std::runtime_error("split_biome: at most " + std::to_string(HX_MAXB) + " biomes supported");
+  for (int a = 0; a < nb; ++a) {
+    if (names[(size_t)a].empty() || names[(size_t)a].find('.') != std::string::npos)
+      throw std::runtime_error("split_biome: bad biome name '" + names[(size_t)a] + "'");
+    if (biome_index(names[(size_t)a]) >= 0 && names[(size_t)a] != old_biome)
+      throw std::runtime_error("Biome '" + names[(size_t)a] + "' is already in `biome_list`.");
+    for (int c = 0; c < a; ++c)
+      if (names[(size_t)a] == names[(size_t)c])
+        throw std::runtime_error("Biome '" + names[(size_t)a] + "' is already in `biome_list`.");
+  }
   std::vector<double> eq((size_t)nb, 1.0 / nb);
   if (!fveg) fveg = eq.data();
   if (!fdet) fdet = fveg;
   if (!fsoil) fsoil = fveg;
   if (!fpf) fpf = fveg;
   if (!fnpp) fnpp = fveg;
-  std::vector<std::vector<double>> np(HX_NPARAM(nb), std::vector<double>((size_t)npad_, 0.0));
-  std::vector<bool> nu(HX_NPARAM(nb), true);
+  const int nB = B_ - 1 + nb;
+  std::vector<std::vector<double>> np(HX_NPARAM(nB), std::vector<double>((size_t)npad_, 0.0));
+  std::vector<bool> nu(HX_NPARAM(nB), true);
+  std::vector<std::string> nn;
   for (int r = 0; r < HXP_NGLOBAL; ++r) { np[r] = params_[r]; nu[r] = row_uniform_[r]; }
-  for (int b = 0; b < nb; ++b)
+  int dstb = 0;
+  for (int b = 0; b < B_; ++b) {  // the biomes that stay, in order
+    if (b == ob) continue;
     for (int k = 0; k < HXPB_N; ++k) {
-      const int dst = HXP_NGLOBAL + b * HXPB_N + k, src = HXP_NGLOBAL + k;
+      np[HXP_NGLOBAL + dstb * HXPB_N + k] = params_[HXP_NGLOBAL + b * HXPB_N + k];
+      nu[HXP_NGLOBAL + dstb * HXPB_N + k] = row_uniform_[HXP_NGLOBAL + b * HXPB_N + k];
+    }
+    nn.push_back(biome_names_[(size_t)b]);
+    ++dstb;
+  }
+  const int lastb = B_ - 1;  // createBiome copies the untouched parameters from the list's last biome
+  for (int a = 0; a < nb; ++a, ++dstb) {
+    for (int k = 0; k < HXPB_N; ++k) {
+      const int dst = HXP_NGLOBAL + dstb * HXPB_N + k;
+      int src = HXP_NGLOBAL + ob * HXPB_N + k;
       double f = 1.0;
       bool scaled = true;
       switch (k) {
-        case HXPB_VEG0: f = fveg[b]; break;
-        case HXPB_DET0: f = fdet[b]; break;
-        case HXPB_SOIL0: f = fsoil[b]; break;
-        case HXPB_PF0: f = fpf[b]; break;
-        case HXPB_NPP0: f = fnpp[b]; break;
+        case HXPB_VEG0: f = fveg[a]; break;
+        case HXPB_DET0: f = fdet[a]; break;
+        case HXPB_SOIL0: f = fsoil[a]; break;
+        case HXPB_PF0: f = fpf[a]; break;
+        case HXPB_NPP0: f = fnpp[a]; break;
+        case HXPB_RH_CH4_FRAC: case HXPB_PF_MU: case HXPB_PF_SIGMA: case HXPB_FPF_STATIC:
+          scaled = false; src = HXP_NGLOBAL + lastb * HXPB_N + k; break;
         default: scaled = false;
       }
       for (int i = 0; i < npad_; ++i)
         np[dst][(size_t)i] = scaled ? params_[src][(size_t)i] * f : params_[src][(size_t)i];
       nu[dst] = row_uniform_[src];
     }
+    nn.push_back(names[(size_t)a]);
+  }
   params_.swap(np);
   row_uniform_.swap(nu);
-  B_ = nb;
-  biome_names_ = names;
+  B_ = nB;
+  biome_names_ = nn;
   layout_dirty_ = true;
   params_dirty_ = true;
   need_spinup_ = true;
   last_iy_ = 0;
+}
+
+int EnsembleCore::biome_index(const std::string &biome) const {
+  for (int b = 0; b < B_; ++b) if (biome_names_[(size_t)b] == biome) return b;
+  return -1;
+}
+
+// SimpleNbox::createBiome (simpleNbox.cpp:864-932): empty pools, zero npp_flux0, every other
+// parameter like the most recent biome; appended to the biome list.
+void EnsembleCore::create_biome(const std::string &biome) {
+  if (biome_index(biome) >= 0)
+    throw std::runtime_error("Biome '" + biome + "' is already in `biome_list`.");
+  if (biome.empty() || biome.find('.') != std::string::npos)
+    throw std::runtime_error("create_biome: bad biome name '" + biome + "'");
+  if (B_ >= HX_MAXB)
+    throw std::runtime_error("create_biome: at most " + std::to_string(HX_MAXB) + " biomes supported");
+  const int last = HXP_NGLOBAL + (B_ - 1) * HXPB_N;
+  for (int k = 0; k < HXPB_N; ++k) {
+    const bool pool = k == HXPB_VEG0 || k == HXPB_DET0 || k == HXPB_SOIL0 || k == HXPB_PF0 ||
+                      k == HXPB_NPP0;
+    params_.push_back(pool ? std::vector<double>((size_t)npad_, 0.0) : params_[(size_t)(last + k)]);
+    row_uniform_.push_back(pool ? true : (bool)row_uniform_[(size_t)(last + k)]);
+  }
+  ++B_;
+  biome_names_.push_back(biome);
+  layout_dirty_ = params_dirty_ = need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+// SimpleNbox::deleteBiome (simpleNbox.cpp:934-990): the biome and everything it holds go away
+void EnsembleCore::delete_biome(const std::string &biome) {
+  const int b = biome_index(biome);
+  if (b < 0) throw std::runtime_error("Biome '" + biome + "' missing from biome list.");
+  if (B_ == 1) throw std::runtime_error("delete_biome: the core needs at least one biome");
+  const auto first = HXP_NGLOBAL + b * HXPB_N;
+  params_.erase(params_.begin() + first, params_.begin() + first + HXPB_N);
+  row_uniform_.erase(row_uniform_.begin() + first, row_uniform_.begin() + first + HXPB_N);
+  biome_names_.erase(biome_names_.begin() + b);
+  --B_;
+  layout_dirty_ = params_dirty_ = need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+// SimpleNbox::renameBiome (simpleNbox.cpp:992-1060)
+void EnsembleCore::rename_biome(const std::string &oldname, const std::string &newname) {
+  const int b = biome_index(oldname);
+  if (b < 0) throw std::runtime_error("Biome '" + oldname + "' missing from biome list.");
+  if (biome_index(newname) >= 0)
+    throw std::runtime_error("Biome '" + newname + "' already exists in biome list.");
+  if (newname.empty() || newname.find('.') != std::string::npos)
+    throw std::runtime_error("rename_biome: bad biome name '" + newname + "'");
+  biome_names_[(size_t)b] = newname;
 }
 
 int EnsembleCore::out_index(const std::string &capability) const {
@@ -669,6 +761,9 @@ int EnsembleCore::out_index(const std::string &capability) const {
                                                "thawedp_c", "NPP", "RH", "rh_ch4", "f_frozen",
                                                "detritus_tempfert", "soil_tempfert"};
     const std::string biome = capability.substr(0, dot), var = capability.substr(dot + 1);
+    // "global.<pool>" of a core without a biome of that name is the total over the biomes
+    // (SimpleNbox::sum_fluxpool_biome_ts, simpleNbox.cpp:463-485)
+    if (biome == "global" && biome_index(biome) < 0) return out_index(var);
     for (int b = 0; b < B_; ++b)
       if (biome_names_[(size_t)b] == biome)
         for (int k = 0; k < HXOB_N; ++k)

@@ -48,6 +48,15 @@ class EnsembleCore {
   void split_biome(const std::vector<std::string> &names, const double *fveg,
                    const double *fdet, const double *fsoil, const double *fpf,
                    const double *fnpp);
+  void split_biome_of(const std::string &old_biome, const std::vector<std::string> &names,
+                      const double *fveg, const double *fdet, const double *fsoil,
+                      const double *fpf, const double *fnpp);
+  // create_biome_impl / delete_biome_impl / rename_biome (src/rcpp_hector.cpp; SimpleNbox::
+  // createBiome, deleteBiome, renameBiome): at most HX_MAXB biomes
+  void create_biome(const std::string &biome);
+  void delete_biome(const std::string &biome);
+  void rename_biome(const std::string &oldname, const std::string &newname);
+  int biome_index(const std::string &biome) const;
 
   // which output variables are recorded per year (capability strings);
   // sst and land_tas are always recorded (the model needs their history).

@@ -65,6 +65,26 @@ int hx_getvar(hx_core *core, const char *capability, double *out) {
   if (!capability || !out) return fail("hx_getvar: null argument");
   HX_TRY(core->core->getvar(capability, out))
 }
+int hx_split_biome_of(hx_core *core, const char *old_biome, int n_biomes,
+                       const char *const *names, const double *fveg, const double *fdet,
+                       const double *fsoil, const double *fpf, const double *fnpp) {
+  if (!old_biome || !names || n_biomes < 1) return fail("hx_split_biome_of: bad arguments");
+  std::vector<std::string> nm;
+  for (int i = 0; i < n_biomes; ++i) nm.push_back(names[i] ? names[i] : "");
+  HX_TRY(core->core->split_biome_of(old_biome, nm, fveg, fdet, fsoil, fpf, fnpp))
+}
+int hx_create_biome(hx_core *core, const char *biome) {
+  if (!biome) return fail("hx_create_biome: null name");
+  HX_TRY(core->core->create_biome(biome))
+}
+int hx_delete_biome(hx_core *core, const char *biome) {
+  if (!biome) return fail("hx_delete_biome: null name");
+  HX_TRY(core->core->delete_biome(biome))
+}
+int hx_rename_biome(hx_core *core, const char *oldname, const char *newname) {
+  if (!oldname || !newname) return fail("hx_rename_biome: null name");
+  HX_TRY(core->core->rename_biome(oldname, newname))
+}
 int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const double *fveg,
                    const double *fdet, const double *fsoil, const double *fpf,
                    const double *fnpp) {

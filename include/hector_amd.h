@@ -84,6 +84,21 @@ int hx_split_biome(hx_core *core, int n_biomes, const char *const *names, const 
                    const double *fdet, const double *fsoil, const double *fpf,
                    const double *fnpp);
 
+/* split_biome(core, old_biome, new_biomes, ...) for a core that already has several biomes:
+ * the new biomes are appended to the biome list, old_biome is deleted (R/biome.R:61-130). */
+int hx_split_biome_of(hx_core *core, const char *old_biome, int n_biomes,
+                      const char *const *names, const double *fveg, const double *fdet,
+                      const double *fsoil, const double *fpf, const double *fnpp);
+
+/* create_biome_impl / delete_biome_impl / rename_biome  (src/rcpp_hector.cpp:359-400;
+ * SimpleNbox::createBiome / deleteBiome / renameBiome, src/simpleNbox.cpp:864-1060).  A created
+ * biome has empty pools and npp_flux0 = 0 and the other parameters of the most recent biome
+ * (set them with hx_setvar("<biome>.veg_c", ...), like R's create_biome does); at most 4 biomes.
+ * All three invalidate the run (spinup again), like any parameter change. */
+int hx_create_biome(hx_core *core, const char *biome);
+int hx_delete_biome(hx_core *core, const char *biome);
+int hx_rename_biome(hx_core *core, const char *oldname, const char *newname);
+
 /* get_biome_list(core)  R/biome.R:8-16: "global", the names given to hx_split_biome, or the
  * biomes an INI file defines with "<biome>.<variable>" keys in [simpleNbox]
  * (src/simpleNbox.cpp:190-330).  Per-biome parameters are "<biome>.beta" ..., per-biome pools

@@ -1,0 +1,129 @@
+"""create_biome / delete_biome / rename_biome / split_biome of any biome / get_biome_inits
+(R/biome.R, SimpleNbox::createBiome ... renameBiome): tests/testthat/test_biome.R:127-300
+restated, on the kernel source compiled for the host; the oracle for the numbers."""
+import numpy as np
+import pytest
+
+import hector_amd
+from conftest import SCENARIO
+
+Y = (2000, 2100)
+VARS = ["CO2_concentration", "RF_tot", "global_tas", "veg_c", "detritus_c", "soil_c"]
+
+
+def biome_api_checks(lib, oracle, **kw):
+    E = hector_amd.HectorAmdError
+    c = hector_amd.Core(SCENARIO, 2, lib_path=lib, **kw)
+    c.set_outputs(VARS)
+    beta0 = c.getvar("beta")
+    # test_biome.R:127-140
+    assert np.array_equal(c.getvar("global.beta"), beta0)
+    with pytest.raises(E, match="Biome 'fake' missing from biome list"):
+        c.getvar("fake.beta")
+    with pytest.raises(E, match="Biome 'permafrost' missing from biome list"):
+        c.setvar("permafrost.beta", [0.5])
+    # :142-166 low-level create / delete
+    c.create_biome("testbiome")
+    assert c.biomes() == ["global", "testbiome"]
+    assert np.array_equal(c.getvar("testbiome.beta"), beta0)
+    assert (c.getvar("testbiome.veg_c") == 0).all()
+    with pytest.raises(E, match="already in `biome_list`"):
+        c.create_biome("testbiome")
+    c.delete_biome("testbiome")
+    assert c.biomes() == ["global"]
+    with pytest.raises(E, match="Biome 'testbiome' missing from biome list"):
+        c.getvar("testbiome.beta")
+    with pytest.raises(E):
+        c.delete_biome("global")          # a core keeps at least one biome
+    c.run(Y[1])
+    base = {v: c.fetchvars(v, Y) for v in VARS}
+    # :168-191 rename, then an empty biome changes nothing
+    c.rename_biome("global", "permafrost")
+    assert c.biomes() == ["permafrost"]
+    with pytest.raises(E, match="Biome 'global' missing from biome list"):
+        c.getvar("beta")
+    assert np.array_equal(c.getvar("permafrost.beta"), beta0)
+    with pytest.raises(E, match="already in `biome_list`"):
+        c.create_biome("permafrost")
+    with pytest.raises(E, match="already exists"):
+        c.rename_biome("permafrost", "permafrost")
+    c.create_biome("empty")
+    assert c.biomes() == ["permafrost", "empty"]
+    assert np.array_equal(c.getvar("empty.beta"), beta0)
+    c.run(Y[1])
+    assert (c.status() == 0).all()
+    for v in VARS:
+        got = c.fetchvars(v, Y)
+        assert np.abs(got - base[v]).max() <= 2e-8 * np.abs(base[v]).max(), v
+    # R's create_biome with values, then delete: back to one biome, same run
+    c.delete_biome("empty")
+    hector_amd.create_biome(c, "extra", 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.36, 2.0, 0.35, 0.60, 0.98)
+    assert (c.getvar("extra.q10_rh") == 2.0).all()
+    c.delete_biome("extra")
+    c.rename_biome("permafrost", "global")
+    c.run(Y[1])
+    for v in VARS:
+        assert np.array_equal(c.fetchvars(v, Y), base[v]), v
+    return c
+
+
+def split_of_one_of_several_checks(lib, oracle, **kw):
+    """test_biome.R:193-260 with a core that already has two biomes: split one of them."""
+    c = hector_amd.Core(SCENARIO, 1, lib_path=lib, **kw)
+    hector_amd.split_biome(c, "global", ["a", "b"], fveg_c=[0.7, 0.3])
+    hector_amd.split_biome(c, "b", ["b1", "b2"], fveg_c=[0.5, 0.5], fsoil_c=[0.25, 0.75],
+                           q10_rh=[1.8, 2.4])
+    assert c.biomes() == ["a", "b1", "b2"]
+    x, y = hector_amd.get_biome_inits(c, "a"), hector_amd.get_biome_inits(c, "b1")
+    for k in ("f_nppd", "f_nppv", "f_litterd", "beta", "warmingfactor"):
+        assert np.array_equal(x[k], y[k])
+    g = hector_amd.Core(SCENARIO, 1, lib_path=lib, **kw)
+    veg = g.getvar("veg_c")[0]; soil = g.getvar("soil_c")[0]
+    assert c.getvar("a.veg_c")[0] == pytest.approx(0.7 * veg, rel=1e-15)
+    assert c.getvar("b2.veg_c")[0] == pytest.approx(0.3 * veg * 0.5, rel=1e-15)
+    assert c.getvar("b2.soil_c")[0] == pytest.approx(0.3 * soil * 0.75, rel=1e-15)
+    assert c.getvar("b1.q10_rh")[0] == 1.8 and c.getvar("b2.q10_rh")[0] == 2.4
+    c.set_outputs(VARS + ["a.veg_c", "b1.veg_c", "b2.veg_c"])
+    c.run(Y[1])
+    assert (c.status() == 0).all()
+    # "global.veg_c" of a multi-biome core is the total (simpleNbox.cpp:463-485)
+    tot = c.fetchvars("a.veg_c", Y) + c.fetchvars("b1.veg_c", Y) + c.fetchvars("b2.veg_c", Y)
+    assert np.abs(c.fetchvars("global.veg_c", Y) - tot).max() < 1e-9
+    # the oracle with the same three biomes
+    p = oracle.default_params()
+    d = {k: getattr(p, k)[0] for k in ("veg_c", "detritus_c", "soil_c", "permafrost_c", "npp_flux0")}
+    p.nbiome = 3
+    fr = {"veg_c": [0.7, 0.15, 0.15], "detritus_c": [0.7, 0.15, 0.15],
+          "soil_c": [0.7, 0.3 * 0.25, 0.3 * 0.75], "permafrost_c": [0.7, 0.15, 0.15],
+          "npp_flux0": [0.7, 0.15, 0.15]}
+    for b in range(3):
+        for k in d:
+            getattr(p, k)[b] = c.getvar("%s.%s" % (c.biomes()[b], k))[0]
+            assert getattr(p, k)[b] == pytest.approx(d[k] * fr[k][b], rel=1e-14)
+        for k in ("beta", "q10_rh", "warmingfactor", "f_nppv", "f_nppd", "f_litterd",
+                  "rh_ch4_frac", "pf_mu", "pf_sigma", "fpf_static"):
+            getattr(p, k)[b] = c.getvar("%s.%s" % (c.biomes()[b], k))[0]
+    r, err, _ = oracle.run(p, run_to=Y[1])
+    assert err == 0
+    for v in ("CO2_concentration", "global_tas", "veg_c", "soil_c"):
+        ref = r[v][Y[0] - 1745:Y[1] - 1745 + 1]
+        assert np.abs(c.fetchvars(v, Y)[:, 0] - ref).max() < 2e-8 * np.abs(ref).max(), v
+    # errors of the R function's stopifnot block
+    E = hector_amd.HectorAmdError
+    with pytest.raises(E):
+        hector_amd.split_biome(c, "nope", ["x", "y"])
+    with pytest.raises(E):
+        hector_amd.split_biome(c, "a", ["x", "y"], fveg_c=[0.5, 0.6])
+    with pytest.raises(E):
+        hector_amd.split_biome(c, "a", ["x", "b1"])
+    with pytest.raises(E):
+        hector_amd.split_biome(c, "a", ["x", "y", "z"])   # would make five biomes (limit: four)
+    return c
+
+
+def test_biome_api(emul_lib, oracle):
+    biome_api_checks(emul_lib, oracle, allow_emulation=True)
+
+
+def test_split_one_of_several_biomes_vs_oracle(emul_lib, oracle):
+    split_of_one_of_several_checks(emul_lib, oracle, allow_emulation=True)

@@ -446,6 +446,14 @@ def test_capabilities_and_shared_parameters_on_gpu(hip_lib, tmp_path):
     capability_checks(hip_lib, tmp_path, device=0)
 
 
+def test_biome_api_on_gpu(hip_lib, oracle):
+    """create/delete/rename_biome, an empty biome, split of one of several biomes (test_biome.R
+    :127-300) through the HIP library."""
+    from test_biome_api import biome_api_checks, split_of_one_of_several_checks
+    assert biome_api_checks(hip_lib, oracle, device=0).backend == "hip"
+    split_of_one_of_several_checks(hip_lib, oracle, device=0)
+
+
 def test_carbon_tracking_on_gpu(hip_lib, oracle):
     """Origin maps of every pool (get_tracking_data) from the tracking instantiation of the run
     kernel: vs the oracle for 1 and 4 biomes, reset/resume, and sum-to-one for 300 members."""
