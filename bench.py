@@ -155,13 +155,19 @@ def main():
     nyr = end - start + 1
     stats = torch.zeros((2, nyr, 5), dtype=torch.float64, device=dev)
 
+    # the core queues its kernels on its own HIP stream; the collective runs on torch's
+    core_stream = torch.cuda.ExternalStream(core.stream(), device=dev) if world > 1 else None
+
     def step():
         core.reset(start)
         core.run(end, wait=False)
         core.stats_device("CO2_concentration", start, end, stats[0].data_ptr())
         core.stats_device("global_tas", start, end, stats[1].data_ptr())
         if world > 1:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(core_stream)      # statistics written before they are reduced
             allreduce_stats(stats, dist)
+            core_stream.wait_stream(cur)      # ... and reduced before the next step overwrites them
         return core.last_run_ms()
 
     core.status()  # upload + spinup + alkalinity tuning, outside every timed region

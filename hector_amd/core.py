@@ -211,6 +211,13 @@ class Core:
     def sync(self):
         self._ck(self._lib.hx_sync(self._h))
 
+    def stream(self):
+        """The core's hipStream_t as an integer (for torch.cuda.ExternalStream): every launch of
+        this core -- run, statistics, gathers -- is queued on it, not on torch's current stream."""
+        p = ctypes.c_void_p()
+        self._ck(self._lib.hx_stream(self._h, ctypes.byref(p)))
+        return p.value or 0
+
     def fetchvars(self, var, dates=None, out=None):
         """-> ndarray [n_years, n_members] for dates = (year0, year1) inclusive.  `out`: a
         C-contiguous float64 array of that shape to reuse (a buffer the host has already touched
