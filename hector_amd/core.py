@@ -298,16 +298,43 @@ def shutdown(core):
 
 
 def setvar(core, dates, var, values, unit=None):
-    if dates is not None and not (isinstance(dates, float) and np.isnan(dates)):
+    if not _is_na(dates):
         return core.setvar_dated(var, dates, values, unit)
     return core.setvar(var, values, unit)
 
 
+def _is_na(dates):
+    return dates is None or (isinstance(dates, float) and np.isnan(dates))
+
+
 def fetchvars(core, dates, variables):
-    """-> dict variable -> ndarray [n_years, n_members]"""
+    """fetchvars(core, dates, vars)  R/messages.R:46-88.  dates = (year0, year1) or a list of
+    years: -> dict variable -> ndarray [n_years, n_members]; dates = None / NaN (R's NA), for
+    parameters: -> dict variable -> ndarray [n_members]."""
     if isinstance(variables, str):
         variables = [variables]
+    if _is_na(dates):
+        return {v: core.getvar(v) for v in variables}
     return {v: core.fetchvars(v, dates) for v in variables}
+
+
+GETDATA, SETDATA = "getData", "setData"      # component_data.hpp:409-410
+
+
+def sendmessage(core, msgtype, capability, date=None, value=None, unit=None):
+    """sendmessage(core, msgtype, capability, date, value, unit)  src/rcpp_hector.cpp:262-350,
+    the low-level message bus under setvar/fetchvars.  getData -> list of rows
+    (year or None, variable, values[n_members], units); setData -> the core."""
+    if msgtype == GETDATA:
+        units = core.getunits(capability)
+        if _is_na(date):
+            return [(None, capability, core.getvar(capability), units)]
+        years = [int(y) for y in np.atleast_1d(date)]
+        data = core.fetchvars(capability, (min(years), max(years)))
+        return [(y, capability, data[y - min(years)], units) for y in years]
+    if msgtype == SETDATA:
+        return setvar(core, date, capability, value, unit)
+    raise HectorAmdError("sendmessage: unknown message type %r" % (msgtype,))
 
 
 def get_tracking_data(core, member=0):

@@ -95,3 +95,26 @@ def test_units_and_set_get_of_every_emission(emul_lib):
     assert c.status()[0] == 0
     with pytest.raises(hector_amd.HectorAmdError):
         c.setvar_dated(cap.FFI_EMISSIONS(), [1800], [1.0], "boogedyboo")
+
+
+def test_message_bus_and_na_dates(emul_lib):
+    """sendmessage(core, GETDATA/SETDATA, ...) (src/rcpp_hector.cpp:262-350) and fetchvars with
+    dates = NA for parameters (R/messages.R:46-88)."""
+    import hector_amd as h
+    c = h.Core(SCENARIO, 2, lib_path=emul_lib, allow_emulation=True)
+    p = h.fetchvars(c, float("nan"), ["beta", "q10_rh"])
+    assert np.array_equal(p["beta"], [0.65, 0.65]) and np.array_equal(p["q10_rh"], [1.2, 1.2])
+    assert h.fetchvars(c, None, "S")["S"].shape == (2,)
+    (year, var, val, unit), = h.sendmessage(c, h.GETDATA, "S")
+    assert year is None and var == "S" and unit == "degC" and np.array_equal(val, [3.0, 3.0])
+    h.sendmessage(c, h.SETDATA, "S", None, [2.5, 3.5], "degC")
+    assert np.array_equal(c.getvar("S"), [2.5, 3.5])
+    with pytest.raises(h.HectorAmdError, match="do not match expected"):
+        h.sendmessage(c, h.SETDATA, "S", None, [2.5, 3.5], "K")
+    h.sendmessage(c, h.SETDATA, "ffi_emissions", [1760, 1761], [0.1, 0.1], "Pg C/yr")
+    c.run(1770)
+    rows = h.sendmessage(c, h.GETDATA, "global_tas", [1765, 1770])
+    assert [r[0] for r in rows] == [1765, 1770] and rows[0][3] == "degC"
+    assert np.array_equal(rows[1][2], c.fetchvars("global_tas", (1770, 1770))[0])
+    with pytest.raises(h.HectorAmdError):
+        h.sendmessage(c, "deepOceanCarbonDump", "x")
