@@ -96,12 +96,20 @@ __device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
     fp = fp * h + 4.0 * p4; fp = fp * h + 3.0 * p3; fp = fp * h + 2.0 * p2;
     fp = fp * h + p1;
     if (f == 0.0) { done = true; break; }
+    // bracket of the largest root by the sign of f (sound from any start), bisect when Newton
+    // leaves it -- except at convergence: there the step is a few ulps (or none: hn == h, which
+    // is a bound by now) and its direction is the rounding noise of f; newton_raphson_iterate
+    // accepts such a step and stops, so does this.
     if (f > 0) lo = h; else hi = h;
     double delta = f / fp;
     double hn = h - delta;
-    if (!(hn > lo && hn < hi)) {  // left the bracket (or fp == 0): bisect
-      hn = 0.5 * (lo + hi);
-      delta = h - hn;
+    if (!(hn > lo && hn < hi)) {
+      if (fabs(delta) <= fabs(h) * 0x1p-48) {
+        hn = h;
+      } else {  // left the bracket (or fp == 0): bisect
+        hn = 0.5 * (lo + hi);
+        delta = h - hn;
+      }
     }
     done = !(fabs(hn * factor) < fabs(delta));
     h = hn;
@@ -299,9 +307,13 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
           if (f > 0) lo[b] = x; else hi[b] = x;
           double delta = hx_div1(f, fp);
           double hn = x - delta;
-          if (!(hn > lo[b] && hn < hi[b])) {  // left the bracket (or fp == 0): bisect
-            hn = 0.5 * (lo[b] + hi[b]);
-            delta = x - hn;
+          if (!(hn > lo[b] && hn < hi[b])) {
+            if (fabs(delta) <= fabs(x) * 0x1p-48) {  // converged, see chem_solve
+              hn = x;
+            } else {  // left the bracket (or fp == 0): bisect
+              hn = 0.5 * (lo[b] + hi[b]);
+              delta = x - hn;
+            }
           }
           done[b] = !(fabs(hn * factor) < fabs(delta));
           h[b] = hn;

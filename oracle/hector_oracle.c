@@ -2027,6 +2027,13 @@ static void slr_run(member_t *m, int year, double *out) {
 }
 
 /* Core::run core.cpp:483-504, component order SURVEY 3c */
+/* Conditioning probe of the TEST SUITE (never set by anything else): with rel != 0 every pool is
+ * multiplied by 1 + rel * xi (xi pseudo-random in [-1, 1)) at the end of every model year -- the
+ * size of rounding differences between two faithful implementations.  How far the trajectory
+ * moves tells how strongly this member amplifies such differences.  Per thread. */
+static __thread double g_rounding_noise = 0.0;
+static __thread unsigned long long noise_state = 0x9E3779B97F4A7C15ULL;
+
 static void member_main(member_t *m, int run_to, double *out) {
   const hxo_scenario *s = m->sc;
   const int ns = s->ns;
@@ -2094,6 +2101,20 @@ static void member_main(member_t *m, int run_to, double *out) {
         (m->pa->lo_warming_ratio != 0) ? m->sst_now * d_bsi : d_bsi * m->temp_sst[iy];
     for (int k = 0; k < 11; k++) out[(HXO_RF_H2O + k) * ns + iy] = m->rf_item_v[k];
     slr_run(m, year, out);
+    if (g_rounding_noise != 0.0) { /* conditioning probe, see hxo_set_rounding_noise */
+      double *v[2 + 4 + 3 * HXO_MAXB];
+      int nv = 0;
+      v[nv++] = &m->atmos_c;
+      for (int b = 0; b < 4; b++) v[nv++] = &m->carbon[b];
+      for (int b = 0; b < m->B; b++) {
+        v[nv++] = &m->veg_c[b]; v[nv++] = &m->detritus_c[b]; v[nv++] = &m->soil_c[b];
+      }
+      for (int k = 0; k < nv; k++) {
+        noise_state = noise_state * 6364136223846793005ULL + 1442695040888963407ULL;
+        const double xi = (double)((noise_state >> 33) & 0xFFFFF) / 524288.0 - 1.0; /* [-1, 1) */
+        *v[k] *= 1.0 + g_rounding_noise * xi;
+      }
+    }
     if (m->trk_on && m->trk_out_f) { /* CSVFluxPoolVisitor: pools and their source fractions */
       const int TP = m->TP;
       for (int pl = 0; pl < TP; pl++) {
@@ -2103,6 +2124,11 @@ static void member_main(member_t *m, int run_to, double *out) {
       }
     }
   }
+}
+
+void hxo_set_rounding_noise(double rel) {
+  g_rounding_noise = rel;
+  noise_state = 0x9E3779B97F4A7C15ULL;
 }
 
 int hxo_run_member(const hxo_scenario *s, const hxo_params *p, int run_to,

@@ -80,6 +80,11 @@ class Oracle:
         self.lib.hxo_params_default(self.sc, ctypes.byref(p))
         return p
 
+    def set_rounding_noise(self, rel):
+        """see hxo_set_rounding_noise (hector_oracle.h)"""
+        self.lib.hxo_set_rounding_noise.argtypes = [ctypes.c_double]
+        self.lib.hxo_set_rounding_noise(float(rel))
+
     def split_equal(self, p, n):
         self.lib.hxo_params_split_equal(ctypes.byref(p), n)
         return p

@@ -71,7 +71,10 @@ def test_diagnostics_do_not_change_the_run(emul_lib):
     a.set_outputs(["CO2_concentration", "global_tas"]); a.run(2100)
     b = hector_amd.Core(SCENARIO, 2, lib_path=emul_lib, allow_emulation=True)
     b.set_outputs(KERNEL_VARS + DERIVED_VARS + ["CO2_concentration", "global_tas"]); b.run(2100)
+    # two instantiations of the run kernel (in the extended one the thawed-permafrost pool is a
+    # Runge-Kutta variable instead of an exact advance): the same run to the last few ulps
     for v in ("CO2_concentration", "global_tas"):
-        assert np.array_equal(a.fetchvars(v, (Y0, 2100)), b.fetchvars(v, (Y0, 2100)))
+        x, y = a.fetchvars(v, (Y0, 2100)), b.fetchvars(v, (Y0, 2100))
+        assert np.abs(x - y).max() <= 1e-12 * np.abs(x).max()
     with pytest.raises(hector_amd.HectorAmdError):
         a.fetchvars("HL_CO3", (2000, 2001))      # needs outputs that were not recorded

@@ -22,10 +22,48 @@ ORACLE_FIELD = {"S": "S", "diff": "diff", "aero_scalar": "aero_scalar", "vol_sca
 SCENARIOS = ["ssp119", "ssp245", "ssp370", "ssp534-over", "ssp585", "picontrol"]
 
 
+# Tolerances.  The per-variable tolerances below are what the kernels hold against the oracle for
+# a member whose trajectory is well conditioned (the north star asks for 1e-6).  Some random
+# members are not: with one ocean stash a year (explicit Euler, oceanbox.cpp:240-303) and extreme
+# exchange coefficients the high-latitude box amplifies any rounding difference ~1.09x a year for
+# decades -- in the reference's own arithmetic just as well.  For a member that misses its
+# tolerance the oracle is therefore run again with rounding-sized noise injected (every pool
+# times 1 +- 1e-13 once a year, hxo_set_rounding_noise): the member passes if the kernel is
+# within 50x of what that does to the oracle itself, and never beyond the north star's 1e-6.
+HARD_TOL = 1e-6
+NOISE = 1e-13
+
+
+def self_sensitivity(o, p, names):
+    base, err, _ = o.run(p)
+    o.set_rounding_noise(NOISE)
+    try:
+        pert, err2, _ = o.run(p)
+    finally:
+        o.set_rounding_noise(0.0)
+    out = {}
+    for v in names:
+        y0 = 1 if v == "NBP" else 0
+        out[v] = np.abs(pert[v][y0:] - base[v][y0:]).max() / max(1.0, np.abs(base[v]).max())
+    return out
+
+
+def check_member(o, p, d_by_var, tol_by_var, where, ill):
+    """d_by_var: {oracle variable: relative deviation of the kernel}."""
+    bad = [v for v, d in d_by_var.items() if not d < tol_by_var[v]]
+    if not bad:
+        return
+    sens = self_sensitivity(o, p, bad)
+    for v in bad:
+        allowed = min(HARD_TOL, max(tol_by_var[v], 50.0 * sens[v]))
+        assert d_by_var[v] < allowed, (where, v, d_by_var[v], "oracle self-sensitivity", sens[v])
+    ill.append((where, {v: (d_by_var[v], sens[v]) for v in bad}))
+
+
 def sweep(lib, n, seed, check_every=1, **kw):
     import oracle_binding
     rng = np.random.default_rng(seed)
-    worst = {}
+    worst, ill = {}, []
     for name in SCENARIOS:
         path = os.path.join(ROOT, "hector_amd", "data", name + ".hxs")
         vals = {k: rng.uniform(lo, hi, n) for k, (lo, hi, _) in RANGES.items()}
@@ -46,13 +84,16 @@ def sweep(lib, n, seed, check_every=1, **kw):
             assert (err != 0) == (st[i] != 0), (name, i, err, st[i])
             if err:
                 continue
-            for v, tol in [("CO2_concentration", 2e-8), ("global_tas", 2e-8), ("RF_tot", 2e-8),
-                           ("NBP", 2e-7), ("ocean_c", 2e-8)]:
+            tols = {"CO2_concentration": 2e-8, "global_tas": 2e-8, "RF_tot": 2e-8, "NBP": 2e-7,
+                    "ocean_c": 2e-8}
+            dev = {}
+            for v in tols:
                 y0 = 1 if v == "NBP" else 0      # (no NBP is recorded at startDate)
-                d = np.abs(got[v][y0:, i] - r[v][y0:]).max() / max(1.0, np.abs(r[v]).max())
-                worst[v] = max(worst.get(v, 0.0), d)
-                assert d < tol, (name, i, v, d)
+                dev[v] = np.abs(got[v][y0:, i] - r[v][y0:]).max() / max(1.0, np.abs(r[v]).max())
+                worst[v] = max(worst.get(v, 0.0), dev[v])
+            check_member(o, p, dev, tols, (name, i), ill)
             assert np.array_equal(got["timesteps"][1:, i], r["timesteps"][1:]), (name, i)
+    worst["ill_conditioned_members"] = len(ill)
     return worst
 
 
@@ -63,4 +104,78 @@ def test_random_parameter_sweep(emul_lib):
 @pytest.mark.gpu
 def test_random_parameter_sweep_on_gpu(hip_lib):
     worst = sweep(hip_lib, 96, seed=12, check_every=3, device=0)
+    print("worst relative deviations:", worst)
+
+
+BIOME_KEYS = ["beta", "q10_rh", "warmingfactor", "f_nppv", "f_nppd", "f_litterd", "rh_ch4_frac",
+              "pf_mu", "pf_sigma", "fpf_static"]
+POOLS = ["veg_c", "detritus_c", "soil_c", "permafrost_c", "npp_flux0"]
+
+
+def sweep_biomes(lib, n, seed, scenarios=("ssp245", "ssp585"), check_every=1, **kw):
+    """2, 3 and 4 biomes with random (per-member) pool splits and every per-biome parameter
+    perturbed independently, plus the global ones: member by member against the oracle."""
+    import oracle_binding
+    rng = np.random.default_rng(seed)
+    worst, ill = {}, []
+    for name in scenarios:
+        path = os.path.join(ROOT, "hector_amd", "data", name + ".hxs")
+        o = oracle_binding.Oracle(path)
+        for B in (2, 3, 4):
+            names = ["b%d" % b for b in range(B)]
+            c = hector_amd.Core(path, n, lib_path=lib, **kw)
+            base = {k: c.getvar(k)[0] for k in POOLS}
+            c.split_biome(names)
+            glob = {k: rng.uniform(lo, hi, n) for k, (lo, hi, _) in RANGES.items() if k in ORACLE_FIELD}
+            for k, v in glob.items():
+                c.setvar(k, v, RANGES[k][2])
+            # per-member split of every pool (Dirichlet), independent per pool
+            frac = {k: rng.dirichlet(np.full(B, 3.0), n) for k in POOLS}
+            per = {k: rng.uniform(RANGES[k][0], RANGES[k][1], (n, B)) for k in BIOME_KEYS}
+            for b, nm in enumerate(names):
+                for k in POOLS:
+                    c.setvar("%s.%s" % (nm, k), base[k] * frac[k][:, b])
+                for k in BIOME_KEYS:
+                    c.setvar("%s.%s" % (nm, k), per[k][:, b])
+            outs = ["CO2_concentration", "global_tas", "NBP", "veg_c", "soil_c", "permafrost_c",
+                    "timesteps", names[-1] + ".soil_c"]
+            c.set_outputs(outs); c.run(2300)
+            st = c.status()
+            got = {v: c.fetchvars(v, (1745, 2300)) for v in outs}
+            for i in range(0, n, check_every):
+                p = o.default_params()
+                p.nbiome = B
+                for k, v in glob.items(): setattr(p, ORACLE_FIELD[k], v[i])
+                for b in range(B):
+                    for k in POOLS: getattr(p, k)[b] = base[k] * frac[k][i, b]
+                    for k in BIOME_KEYS: getattr(p, k)[b] = per[k][i, b]
+                r, err, _ = o.run(p)
+                assert (err != 0) == (st[i] != 0), (name, B, i, err, st[i])
+                if err:
+                    continue
+                last = "b%d.soil_c" % (B - 1)   # the oracle's name of the last biome's soil pool
+                tols = {"CO2_concentration": 2e-8, "global_tas": 2e-8, "NBP": 2e-7, "veg_c": 2e-8,
+                        "soil_c": 2e-8, "permafrost_c": 2e-8, last: 2e-8}
+                dev = {}
+                for v in tols:
+                    mine = got[names[-1] + ".soil_c"] if v == last else got[v]
+                    y0 = 1 if v == "NBP" else 0
+                    dev[v] = np.abs(mine[y0:, i] - r[v][y0:]).max() / max(1.0, np.abs(r[v]).max())
+                    key = "biome.soil_c" if v == last else v
+                    worst[key] = max(worst.get(key, 0.0), dev[v])
+                check_member(o, p, dev, tols, (name, B, i), ill)
+                assert np.array_equal(got["timesteps"][1:, i], r["timesteps"][1:]), (name, B, i)
+    worst["ill_conditioned_members"] = len(ill)
+    for w in ill:
+        print("ill-conditioned member", w)
+    return worst
+
+
+def test_random_biome_sweep(emul_lib):
+    sweep_biomes(emul_lib, 3, seed=21, scenarios=("ssp245",), allow_emulation=True)
+
+
+@pytest.mark.gpu
+def test_random_biome_sweep_on_gpu(hip_lib):
+    worst = sweep_biomes(hip_lib, 64, seed=22, check_every=4, device=0)
     print("worst relative deviations:", worst)
