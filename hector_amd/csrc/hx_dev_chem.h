@@ -69,7 +69,8 @@ __device__ __forceinline__ void chem_constants(double Tc, ChemK &k) {
 // exactly one positive root (one sign change: p5,p4 < 0 < p2,p1,p0), so f > 0
 // left of it and f < 0 right of it for h > 0; Newton from the previous [H+]
 // with a sign-maintained bracket reaches the same root the reference's
-// Fujiwara-bound Newton does.  Stop rule = Boost's (|delta| <= |h| 2^-30).
+// Fujiwara-bound Newton does (both to ~1e-16: measured <= 4e-15 against the oracle over random
+// T, DIC, alk).  Stop rule = Boost's (|delta| <= |h| 2^-30, the step is applied first).
 __device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
                                              double inv_vol, double alk,
                                              double &h_io, unsigned &status) {
@@ -122,11 +123,11 @@ __device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
 
 // The carbonate solve exactly as the reference iterates it: Fujiwara bound as the start
 // (find_largest_root, src/ocean_csys.cpp:134-156) and boost::math::tools::
-// newton_raphson_iterate (roots.hpp, Boost >= 1.71) with 31 bits, whose last step may be a
-// bracket-halving one -- its root is only good to ~1e-9 relative, and WHICH 1e-9 depends on the
-// iteration path.  The year-by-year solves do not care (chem_solve converges to the exact root),
-// but the alkalinity tuner compares objective values that differ by less than that, so it gets
-// the reference's own iteration.  Used ~120 times per member, once per run.
+// newton_raphson_iterate (roots.hpp, Boost >= 1.71) with 31 bits, operation by operation and
+// without FMA contraction.  Both this and chem_solve find the root to ~1e-16, but the alkalinity
+// tuner (Brent on |flux - target|, keeping "the last point evaluated") branches on comparisons
+// of objective values that differ in their last bits, so it gets the reference's own iteration
+// and therefore the reference's objective values.  Used ~120 times per member, once per run.
 __device__ __attribute__((noinline)) double chem_solve_ref(const ChemK &k, double carbon,
                                                            double inv_vol, double alk,
                                                            double &h_out, unsigned &status) {

@@ -331,11 +331,10 @@ def unit_vectors_vs_oracle(lib, oracle, device=0):
     assert (out[:, 3] == 0).all()
     for i in range(n):
         o = oracle.csys(Tc[i], carbon[i], alk[i], vol)      # PCO2o, pH, Tr, K0, h, CO3
-        # the reference's root is only defined to 2^-30 relative (newton_raphson_iterate with
-        # 31 bits, ocean_csys.cpp:134-156: its last step can be a bracket-halving one); the
-        # kernel's Newton converges quadratically to the exact root
-        assert abs(out[i, 0] - o[0]) < 3e-9 * o[0]
-        assert abs(out[i, 1] - o[1]) < 1e-9
+        # both root iterations (the reference's from the Fujiwara bound, the kernels' from a
+        # guess) converge quadratically: same [H+] to rounding
+        assert abs(out[i, 0] - o[0]) < 1e-13 * o[0]
+        assert abs(out[i, 1] - o[1]) < 1e-13
         assert abs(out[i, 2] - o[2]) < 1e-13 * o[2]
     for diff in (0.55, 1.16, 2.3, 4.0):
         ker = np.zeros(556)
