@@ -179,3 +179,101 @@ def test_random_biome_sweep(emul_lib):
 def test_random_biome_sweep_on_gpu(hip_lib):
     worst = sweep_biomes(hip_lib, 64, seed=22, check_every=4, device=0)
     print("worst relative deviations:", worst)
+
+
+CONSTRAINTS = {   # capability: (pack section, unit, value(year index k, rng) )
+    "CO2_constrain": ("simpleNbox", "ppmv CO2", lambda k, u: 300.0 + 1.5 * k + 3.0 * u),
+    "NBP_constrain": ("simpleNbox", "Pg C/yr", lambda k, u: 0.3 + 0.01 * k + 0.5 * u),
+    "tas_constrain": ("temperature", "degC", lambda k, u: 0.4 + 0.02 * k + 0.1 * u),
+    "RF_tot_constrain": ("forcing", "W/m2", lambda k, u: 0.5 + 0.03 * k + 0.3 * u),
+    "CH4_constrain": ("CH4", "ppbv CH4", lambda k, u: 900.0 + 8.0 * k + 20.0 * u),
+}
+
+
+def sweep_mixed(lib, n, seed, rounds, tmpdir, check_every=1, **kw):
+    """Everything at once: a random scenario, 1-4 biomes with per-member pool splits, every
+    parameter perturbed, a land-ocean warming ratio for a third of the members and one random
+    constraint over a random window -- kernels vs the oracle reading the edited scenario."""
+    import oracle_binding
+    from conftest import edited_pack
+    rng = np.random.default_rng(seed)
+    worst, ill = {}, []
+    names_all = ["picontrol", "ssp119", "ssp126", "ssp245", "ssp370", "ssp434", "ssp460",
+                 "ssp534-over", "ssp585"]
+    for rd in range(rounds):
+        name = names_all[rng.integers(len(names_all))]
+        path = os.path.join(ROOT, "hector_amd", "data", name + ".hxs")
+        B = int(rng.integers(1, 5))
+        kind = [None] + sorted(CONSTRAINTS)
+        kind = kind[rng.integers(len(kind))]
+        y0 = int(rng.integers(1800, 2000)); y1 = y0 + int(rng.integers(5, 120))
+        years = np.arange(y0, y1 + 1)
+        c = hector_amd.Core(path, n, lib_path=lib, **kw)
+        base = {k: c.getvar(k)[0] for k in POOLS}
+        bn = ["b%d" % b for b in range(B)]
+        if B > 1:
+            c.split_biome(bn)
+        glob = {k: rng.uniform(lo, hi, n) for k, (lo, hi, _) in RANGES.items() if k in ORACLE_FIELD}
+        for k, v in glob.items():
+            c.setvar(k, v, RANGES[k][2])
+        lo_ratio = np.where(rng.uniform(size=n) < 0.33, rng.uniform(1.1, 1.8, n), 0.0)
+        c.setvar("lo_warming_ratio", lo_ratio)
+        frac = {k: rng.dirichlet(np.full(B, 3.0), n) for k in POOLS}
+        per = {k: rng.uniform(RANGES[k][0], RANGES[k][1], (n, B)) for k in BIOME_KEYS}
+        for b in range(B):
+            pre = (bn[b] + ".") if B > 1 else ""
+            for k in POOLS:
+                c.setvar(pre + k, base[k] * frac[k][:, b])
+            for k in BIOME_KEYS:
+                c.setvar(pre + k, per[k][:, b])
+        opath = path
+        if kind:
+            sec, unit, fn = CONSTRAINTS[kind]
+            vals = np.array([fn(k, rng.uniform()) for k in range(years.size)])
+            c.setvar_dated(kind, years, vals, unit)
+            oy, ov = years, vals
+            if kind == "RF_tot_constrain":  # holds for every date up to its last one, flat before
+                oy = np.arange(1745, y1 + 1)     # its first (forcing_component.cpp:498-505); the
+                ov = np.concatenate([np.full(y0 - 1745, vals[0]), vals])  # pack is dense
+            opath = edited_pack(os.path.join(str(tmpdir), "mixed_%d_%d.hxs" % (seed, rd)), sec, kind,
+                                oy, ov, base=path)
+        outs = ["CO2_concentration", "global_tas", "NBP", "land_tas", "timesteps"]
+        c.set_outputs(outs); c.run(2300)
+        st = c.status()
+        got = {v: c.fetchvars(v, (1745, 2300)) for v in outs}
+        o = oracle_binding.Oracle(opath)
+        for i in range(0, n, check_every):
+            p = o.default_params()
+            p.nbiome = B
+            p.lo_warming_ratio = lo_ratio[i]
+            for k, v in glob.items(): setattr(p, ORACLE_FIELD[k], v[i])
+            for b in range(B):
+                for k in POOLS: getattr(p, k)[b] = base[k] * frac[k][i, b]
+                for k in BIOME_KEYS: getattr(p, k)[b] = per[k][i, b]
+            r, err, _ = o.run(p)
+            where = (name, B, kind, y0, y1, i)
+            assert (err != 0) == (st[i] != 0), (where, err, st[i])
+            if err:
+                continue
+            tols = {"CO2_concentration": 2e-8, "global_tas": 2e-8, "NBP": 2e-7, "land_tas": 2e-8}
+            dev = {}
+            for v in tols:
+                y_0 = 1 if v == "NBP" else 0
+                dev[v] = np.abs(got[v][y_0:, i] - r[v][y_0:]).max() / max(1.0, np.abs(r[v]).max())
+                worst[v] = max(worst.get(v, 0.0), dev[v])
+            check_member(o, p, dev, tols, where, ill)
+            assert np.array_equal(got["timesteps"][1:, i], r["timesteps"][1:]), where
+    worst["ill_conditioned_members"] = len(ill)
+    for w in ill:
+        print("ill-conditioned member", w)
+    return worst
+
+
+def test_random_mixed_sweep(emul_lib, tmp_path):
+    sweep_mixed(emul_lib, 3, seed=31, rounds=6, tmpdir=tmp_path, allow_emulation=True)
+
+
+@pytest.mark.gpu
+def test_random_mixed_sweep_on_gpu(hip_lib, tmp_path):
+    worst = sweep_mixed(hip_lib, 48, seed=32, rounds=10, tmpdir=tmp_path, check_every=4, device=0)
+    print("worst relative deviations:", worst)
