@@ -3,6 +3,8 @@
 // reference file:line map).
 #pragma once
 
+#define HX_MAX_STEPS_PER_YEAR 20000
+
 namespace {
 
 // rhs constants that only change at a stash (pools frozen in between,
@@ -443,7 +445,11 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   m.ode_start = t0;
   double t = t0;   // time reached by accepted steps
   int retry = 0;
-  bool alive = true;
+  // A member that has raised an error is not integrated any further: the reference aborts the
+  // run at that point (h_exception), and a state that has left the model's domain (negative
+  // pool, runaway CO2) can drive the step size towards zero -- a lane that never finishes its
+  // year would hang the whole launch.
+  bool alive = m.status == 0;
   while (__any(alive && t < tnew)) {
     const bool seg = alive && t < tnew;
     // fresh integrate_adaptive call: by-value dt, fresh controlled stepper
@@ -528,6 +534,11 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             fails = 0;
             m.nsteps++;
             if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
+            // odeint puts no limit on accepted steps; a launch needs one (a member takes 3-8
+            // steps a year, a stiff one a few hundred)
+            if (m.nsteps > HX_MAX_STEPS_PER_YEAR) {
+              m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false;
+            }
           }
         }
       }
@@ -537,6 +548,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
       retry = 0;
       stash<B, SPIN, CON>(m, t, y, l4, CON ? y[NP - 1] : l5, l7, K, K2, yc, t < tnew);
+      if (m.status != 0) alive = false;
     }
   }
 }

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 #pragma unroll
       for (int b = 0; b < B; ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
                                      op += m.pf[b]; ot += m.thawed[b]; }
-      m.nstash = 0;
+      m.nstash = 0; m.nsteps = 0;
       solve_year<B, true>(m, kc, (double)(step - 1), (double)step, YearCon{});
       double nv = 0, nd = 0, nso = 0, np = 0, nt = 0;
 #pragma unroll

@@ -129,8 +129,9 @@ int hxo_run_member(const hxo_scenario *, const hxo_params *, int run_to,
                    double *out, int *spinup_steps);
 
 /* Test-suite probe: multiply every pool by 1 + rel * xi (xi in [-1, 1), deterministic) at the end
- * of every model year of the runs this thread makes from now on; 0 switches it off.  Used to
- * measure how strongly a member amplifies rounding-level differences (tests/test_random_sweep.py). */
+ * of every model year, and every flux the alkalinity tuner evaluates, in the runs this thread
+ * makes from now on; 0 switches it off.  Used to measure how strongly a member amplifies
+ * rounding-level differences (tests/test_random_sweep.py). */
 void hxo_set_rounding_noise(double rel);
 
 /* The same with carbon tracking from `tracking_date` on (Core::trackingDate; fluxpool source
