@@ -91,6 +91,10 @@ def sweep(lib, n, seed, check_every=1, **kw):
                 if k in ORACLE_FIELD: setattr(p, ORACLE_FIELD[k], vals[k][i])
                 else: getattr(p, k)[0] = vals[k][i]
             r, err, _ = o.run(p)
+            if not err and not np.isfinite(r["CO2_concentration"]).all():
+                err = ROOT_FAILED   # the oracle ran into NaNs without noticing: the kernels flag that
+                assert st[i] != 0, (name, i, "NaN in the oracle, no flag in the kernel")
+                continue
             if err & ROOT_FAILED and not st[i]:
                 # far outside any plausible state (CO2 of thousands of ppm, surface pH > 11) the
                 # reference's root iteration from the polynomial bound can bisect past the root
