@@ -209,7 +209,9 @@ int hx_stream(hx_core *core, void **stream);
 #define HX_ERR_SPINUP 8u   /* did not spin up           core.cpp:394-420 */
 #define HX_ERR_SINGULAR 16u /* DOECLIM matrix singular  temperature_component.cpp:84-86 */
 #define HX_ERR_ROOT 32u    /* carbonate root not found  ocean_csys.cpp:134-156 */
-#define HX_ERR_STEPFAIL 64u /* >500 rejected ODE steps  (odeint failed_step_checker) */
+#define HX_ERR_STEPFAIL 64u /* >500 rejected ODE steps  (odeint failed_step_checker), or more than
+                             * 20 000 accepted ones in a year (step size collapsed) */
+/* A member with a flag is not integrated any further -- the reference throws at that point. */
 
 #ifdef __cplusplus
 }
