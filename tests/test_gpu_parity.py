@@ -446,6 +446,13 @@ def test_capabilities_and_shared_parameters_on_gpu(hip_lib, tmp_path):
     capability_checks(hip_lib, tmp_path, device=0)
 
 
+@pytest.mark.timeout(300)
+def test_runaway_member_is_flagged_and_does_not_hang_on_gpu(hip_lib):
+    """A lane that never finishes its year would hang the launch (and the GPU box)."""
+    from test_host_logic import runaway_member_checks
+    runaway_member_checks(hip_lib, device=0)
+
+
 def test_biome_api_on_gpu(hip_lib, oracle):
     """create/delete/rename_biome, an empty biome, split of one of several biomes (test_biome.R
     :127-300) through the HIP library."""

@@ -104,3 +104,39 @@ def test_example_script_runs(emul_lib, capsys):
     assert (tas2 < tas).all()
     out = capsys.readouterr().out
     assert "2100 warming" in out and "halved fossil emissions" in out
+
+
+RUNAWAY = {"S": 7.4981, "diff": 0.55557, "aero_scalar": 1.6819, "vol_scalar": 0.33619, "C0": 313.54,
+           "tt": 41731000.0, "tu": 47115000.0, "twi": 11610000.0, "tid": 232640000.0,
+           "beta": 0.46336, "q10_rh": 3.5869, "warmingfactor": 2.1026, "f_nppv": 0.29871,
+           "f_nppd": 0.48862, "f_litterd": 0.93955, "rh_ch4_frac": 0.023349, "pf_mu": 0.88199,
+           "pf_sigma": 1.3919, "fpf_static": 0.36564}
+
+
+def runaway_member_checks(lib, **kw):
+    """A member whose carbon cycle runs away (SSP1-1.9 with S = 7.5, Q10 = 3.6, warming factor
+    2.1: a negative pool around 2130, CO2 beyond 1e12 ppm a few years later in an implementation
+    that carries on) must raise its flag and stop -- not drive the step size to zero and hang the
+    launch -- while its neighbours are unaffected."""
+    import os
+    import hector_amd
+    from conftest import ROOT
+    path = os.path.join(ROOT, "hector_amd", "data", "ssp119.hxs")
+    c = hector_amd.Core(path, 3, lib_path=lib, **kw)
+    d = hector_amd.Core(path, 1, lib_path=lib, **kw)
+    for k, v in RUNAWAY.items():
+        base = c.getvar(k)[0]
+        c.setvar(k, [base, v, base])
+    c.set_outputs(["CO2_concentration"]); d.set_outputs(["CO2_concentration"])
+    c.run(2300); d.run(2300)
+    st = c.status()
+    assert st[0] == 0 and st[2] == 0 and st[1] & 4          # HX_ERR_NEGPOOL
+    co2 = c.fetchvars("CO2_concentration", (1745, 2300))
+    assert np.isfinite(co2).all() and co2[:, 1].max() < 5000.0   # frozen at the error, no blow-up
+    assert np.array_equal(co2[:, 0], d.fetchvars("CO2_concentration", (1745, 2300))[:, 0])
+    assert np.array_equal(co2[:, 2], co2[:, 0])
+
+
+@pytest.mark.timeout(120)
+def test_runaway_member_is_flagged_and_does_not_hang(emul_lib):
+    runaway_member_checks(emul_lib, allow_emulation=True)
