@@ -233,6 +233,12 @@ def main():
                 "kernel": "hx_run_kernel<%d>" % args.biomes, "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_member_year": bpmy,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "achieved = algorithmic bytes (SURVEY 8d: state round trip + the yearly "
+                        "re-read of the SST history) / kernel time; it can exceed the HBM peak "
+                        "because the block-causal DOECLIM pass reads the history once per 32 years "
+                        "and the state lives in LDS -- 'traffic' is what the PMC counters saw. "
+                        "What actually bounds the kernel is fp64 issue + latency of one resident "
+                        "wavefront per SIMD (DESIGN.md section 6).",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
