@@ -348,7 +348,8 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   m.atmos = y[0];
   const double sum = ((((((y[0] + y[1]) + y[2]) + y[3]) + c4) + c5) + y[4]) + c7 +
                      m.cum_pf_ch4;
-  if (m.masstot > 0.0 && fabs(sum - m.masstot) > 0.001) m.status |= HX_ERR_MASS;
+  // (written so that a NaN state raises the flag too: the reference would carry it on silently)
+  if (m.masstot > 0.0 && !(fabs(sum - m.masstot) <= 0.001)) m.status |= HX_ERR_MASS;
   m.masstot = sum;
   double ca_residual = 0.0;
   if (SPIN) {  // pin the atmosphere to C0, residual to the deep box :567-603

@@ -1521,7 +1521,8 @@ static void snb_stash(member_t *m, double t, const double c[]) {
   for (int i = 0; i < 8; i++) sum += c[i];
   sum += m->cumulative_pf_ch4;
   const double diff = fabs(sum - m->masstot);
-  if (m->masstot > 0.0 && diff > MB_EPSILON) m->err |= HXO_ERR_MASS;
+  /* !(<=) rather than (>): a NaN state raises the flag as well (the reference would not notice) */
+  if (m->masstot > 0.0 && !(diff <= MB_EPSILON)) m->err |= HXO_ERR_MASS;
   m->masstot = sum;
   const int it = (int)t - m->sc->start;
   if (m->core_in_spinup ||
