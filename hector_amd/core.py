@@ -204,6 +204,12 @@ class Core:
 
     def run(self, runtodate=-1, wait=True):
         self._ck(self._lib.hx_run(self._h, float(runtodate)))
+        # the Rcpp wrapper's check (src/rcpp_hector.cpp:168-175), after the pending auto-reset
+        # like there; Core::run itself -- hx_run -- does nothing for such a date (core.cpp:454-458)
+        if runtodate > 0 and runtodate < self.current_date:
+            raise HectorAmdError("Requested run date %g is prior to the current date of %d. "
+                                 "Run reset() to reset to an earlier date."
+                                 % (runtodate, self.current_date))
         if wait:
             self._ck(self._lib.hx_sync(self._h))
         return self

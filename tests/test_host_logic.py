@@ -140,3 +140,17 @@ def runaway_member_checks(lib, **kw):
 @pytest.mark.timeout(120)
 def test_runaway_member_is_flagged_and_does_not_hang(emul_lib):
     runaway_member_checks(emul_lib, allow_emulation=True)
+
+
+def test_run_to_an_earlier_date_is_an_error_in_the_r_style_api(emul_lib):
+    """rcpp_hector.cpp:168-175 (the C ABI keeps Core::run's silent return, core.cpp:454-458)."""
+    import hector_amd
+    c = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    c.run(1800)
+    with pytest.raises(hector_amd.HectorAmdError, match="prior to the current date of 1800"):
+        c.run(1790)
+    c.run(1800)                      # the current date itself: nothing to do, no error
+    assert c.current_date == 1800
+    c.setvar_dated("ffi_emissions", [1780], [0.5], "Pg C/yr")   # pending auto-reset to 1779
+    c.run(1790)                      # fine: the core goes back first
+    assert c.current_date == 1790
