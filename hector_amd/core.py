@@ -313,15 +313,33 @@ def _is_na(dates):
     return dates is None or (isinstance(dates, float) and np.isnan(dates))
 
 
-def fetchvars(core, dates, variables):
-    """fetchvars(core, dates, vars)  R/messages.R:46-88.  dates = (year0, year1) or a list of
-    years: -> dict variable -> ndarray [n_years, n_members]; dates = None / NaN (R's NA), for
-    parameters: -> dict variable -> ndarray [n_members]."""
+DEFAULT_FETCHVARS = ("CO2_concentration", "RF_tot", "RF_CO2", "global_tas")   # R/hector.R default_fetchvars
+
+
+def fetchvars(core, dates, variables=None):
+    """fetchvars(core, dates, vars)  R/messages.R:46-88.  dates = a tuple (year0, year1) for the
+    whole range or a list of years: -> dict variable -> ndarray [n_dates, n_members]; dates =
+    None / NaN (R's NA), for parameters: -> dict variable -> ndarray [n_members]."""
+    if variables is None:   # getOption("hector.default.fetchvars"), R/messages.R:47-56
+        if _is_na(dates):
+            raise HectorAmdError("The default vars (%s) all require dates" % ", ".join(DEFAULT_FETCHVARS))
+        variables = list(DEFAULT_FETCHVARS)
     if isinstance(variables, str):
         variables = [variables]
     if _is_na(dates):
         return {v: core.getvar(v) for v in variables}
-    return {v: core.fetchvars(v, dates) for v in variables}
+    # dates outside startDate..current date are dropped, none left is an error (:62-72)
+    strt, cur = core.strtdate, core.current_date
+    want = [int(d) for d in np.atleast_1d(dates)]
+    if len(want) == 2 and isinstance(dates, tuple):      # (year0, year1): the whole range
+        want = list(range(min(want), max(want) + 1))
+    valid = [d for d in want if strt <= d <= cur]
+    if not valid:
+        raise HectorAmdError("None of these dates are valid for this core (start=%d, current=%d)"
+                             % (strt, cur))
+    lo, hi = min(valid), max(valid)
+    idx = np.array(valid) - lo
+    return {v: core.fetchvars(v, (lo, hi))[idx] for v in variables}
 
 
 GETDATA, SETDATA = "getData", "setData"      # component_data.hpp:409-410

@@ -118,3 +118,19 @@ def test_message_bus_and_na_dates(emul_lib):
     assert np.array_equal(rows[1][2], c.fetchvars("global_tas", (1770, 1770))[0])
     with pytest.raises(h.HectorAmdError):
         h.sendmessage(c, "deepOceanCarbonDump", "x")
+
+
+def test_r_style_fetchvars_defaults_and_date_filtering(emul_lib):
+    """R/messages.R:46-88: vars = NULL -> the default four, dates outside start..current are
+    dropped, none left is an error."""
+    import hector_amd as h
+    c = h.Core(SCENARIO, 2, lib_path=emul_lib, allow_emulation=True)
+    c.set_outputs(list(h.core.DEFAULT_FETCHVARS)); c.run(1900)
+    r = h.fetchvars(c, [1700, 1800, 1850, 1950])
+    assert sorted(r) == sorted(h.core.DEFAULT_FETCHVARS) and r["global_tas"].shape == (2, 2)
+    assert np.array_equal(r["global_tas"][1], c.fetchvars("global_tas", (1850, 1850))[0])
+    assert h.fetchvars(c, (1890, 1900), "global_tas")["global_tas"].shape == (11, 2)
+    with pytest.raises(h.HectorAmdError, match="None of these dates are valid"):
+        h.fetchvars(c, [1700, 2000])
+    with pytest.raises(h.HectorAmdError, match="all require dates"):
+        h.fetchvars(c, None)
