@@ -313,7 +313,7 @@ def _is_na(dates):
     return dates is None or (isinstance(dates, float) and np.isnan(dates))
 
 
-DEFAULT_FETCHVARS = ("CO2_concentration", "RF_tot", "RF_CO2", "global_tas")   # R/hector.R default_fetchvars
+DEFAULT_FETCHVARS = ("CO2_concentration", "RF_tot", "RF_CO2", "global_tas")   # R/messages.R:4 default_fetchvars
 
 
 def fetchvars(core, dates, variables=None):
