@@ -4,7 +4,8 @@ hector_amd/csrc; this package only binds them."""
 from ._lib import HectorAmdError, DEFAULT_SCENARIO, DEFAULT_LIB  # noqa: F401
 from .core import (Core, newcore, run, reset, shutdown, setvar, fetchvars,  # noqa: F401
                    split_biome, get_tracking_data, create_biome, rename_biome,
-                   get_biome_inits, sendmessage, GETDATA, SETDATA)
+                   get_biome_inits, sendmessage, GETDATA, SETDATA, isactive, startdate,
+                   enddate, getdate, getname, get_biome_list, getunits, getfxn, runscenario)
 from . import capabilities  # noqa: F401
 
 __version__ = "0.1.0"

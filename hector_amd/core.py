@@ -41,12 +41,17 @@ class Core:
     """An N-member ensemble core bound to one GPU."""
 
     def __init__(self, scenario=None, n_members=1, device=0, lib_path=None,
-                 allow_emulation=False):
+                 allow_emulation=False, name=None):
         self._lib = _lib.load(lib_path, allow_emulation)
         self._h = ctypes.c_void_p()
         self._ck(self._lib.hx_newcore((scenario or DEFAULT_SCENARIO).encode(), int(n_members),
                                       int(device), ctypes.byref(self._h)))
         self.n_members = int(n_members)
+        if name is None:   # newcore(..., name =): default here the INI's run_name
+            rn = ctypes.c_char_p()
+            self._ck(self._lib.hx_run_name(self._h, ctypes.byref(rn)))
+            name = rn.value.decode() if rn.value else "Unnamed Hector core"
+        self.name = name
         s, e, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self._ck(self._lib.hx_dates(self._h, ctypes.byref(s), ctypes.byref(e), ctypes.byref(c)))
         self.strtdate, self.enddate = s.value, e.value
@@ -301,6 +306,65 @@ def reset(core, date=0):
 
 def shutdown(core):
     core.shutdown()
+
+
+def isactive(core):
+    """isactive(core)  R/hector.R:122-125: false after shutdown()."""
+    return bool(core._h)
+
+
+def startdate(core):
+    return core.strtdate
+
+
+def enddate(core):
+    return core.enddate
+
+
+def getdate(core):
+    return core.current_date
+
+
+def getname(core):
+    return core.name
+
+
+def get_biome_list(core):
+    return core.biomes()
+
+
+def getunits(vars, core):
+    """getunits(vars)  R/units.R:10-21: unit strings; None (R: NA + a warning) for unknown names.
+    The table lives in the library (hx_var_info), hence the core argument."""
+    out = []
+    for v in ([vars] if isinstance(vars, str) else vars):
+        try:
+            out.append(core.getunits(v))
+        except HectorAmdError:
+            out.append(None)
+    return out[0] if isinstance(vars, str) else out
+
+
+def getfxn(strings):
+    """getfxn(str)  R/fxns.R:11-21: the accessor ('BETA()') that returns a capability string;
+    None for unknown strings."""
+    from . import capabilities
+    rev = {}
+    for fn, (cap, _per_biome) in capabilities._TABLE.items():
+        rev.setdefault(cap, fn + "()")
+    out = [rev.get(x) for x in ([strings] if isinstance(strings, str) else strings)]
+    return out[0] if isinstance(strings, str) else out
+
+
+def runscenario(infile, n_members=1, **kw):
+    """runscenario(infile)  R/hector.R:57-63: run to the end, return the default variables."""
+    core = newcore(infile, n_members, **kw)
+    try:
+        core.set_outputs(list(DEFAULT_FETCHVARS))
+        core.run()
+        return fetchvars(core, (core.strtdate, core.enddate))
+    finally:
+        core.shutdown()
 
 
 def setvar(core, dates, var, values, unit=None):

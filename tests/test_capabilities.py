@@ -134,3 +134,22 @@ def test_r_style_fetchvars_defaults_and_date_filtering(emul_lib):
         h.fetchvars(c, [1700, 2000])
     with pytest.raises(h.HectorAmdError, match="all require dates"):
         h.fetchvars(c, None)
+
+
+def test_remaining_r_level_helpers(emul_lib, golden):
+    """NAMESPACE exports: isactive, startdate, enddate, getdate, getname, get_biome_list,
+    getunits, getfxn, runscenario (R/hector.R:57-160, R/units.R, R/fxns.R)."""
+    import hector_amd as h
+    kw = dict(lib_path=emul_lib, allow_emulation=True)
+    c = h.newcore(SCENARIO, 2, **kw)
+    assert (h.isactive(c), h.startdate(c), h.enddate(c), h.getdate(c)) == (True, 1745, 2300, 1745)
+    assert h.getname(c) == "ssp245" and h.get_biome_list(c) == ["global"]
+    assert h.getname(h.newcore(SCENARIO, 1, name="my run", **kw)) == "my run"
+    assert h.getunits(["beta", "S", "ffi_emissions", "nope"], c) == ["(unitless)", "degC", "Pg C/yr", None]
+    assert h.getunits("S", c) == "degC"
+    assert h.getfxn(["beta", "q10_rh", "zzz"]) == ["BETA()", "Q10_RH()", None]
+    h.shutdown(c)
+    assert not h.isactive(c)
+    r = h.runscenario(SCENARIO, **kw)
+    assert sorted(r) == sorted(h.core.DEFAULT_FETCHVARS) and r["global_tas"].shape == (556, 1)
+    assert abs(r["global_tas"][-1, 0] - golden["global_tas"][-1]) < 2e-8
