@@ -220,7 +220,10 @@ int main(int argc, char **argv) {
             row(y, run, "slr", "slr_no_ice", data["slr_no_ice"][o], "cm", p_def);
           }
         }
-        row(y, run, vi.component.c_str(), vname, data[vname][o], vi.units.c_str(), p_def);
+        // the reference's stream prints final_rh under the name rh_ch4 (csv_outputstream_visitor.cpp:
+        // 151); the file is kept identical, fetchvars("rh_ch4") returns the CH4 respiration itself
+        const bool rh_alias = !std::strcmp(vname, "rh_ch4");
+        row(y, run, vi.component.c_str(), vname, data[rh_alias ? "RH" : vname][o], vi.units.c_str(), p_def);
         if (!std::strcmp(vname, "earth_c"))  // biome rows close the simpleNbox block
           for (auto &bv : biome_vars) {
             const char *u = nullptr;

@@ -117,3 +117,15 @@ def test_cli_writes_tracking_csv(emul_lib, tmp_path):
     assert {r[1] for r in rows if r[2] in ("HL", "LL", "intermediate", "deep")} == {"ocean"}
     # without a tracking date no tracking file (the reference writes an empty one)
     assert not os.path.exists(tmp_path / "tracking_ssp245.0.csv")
+
+
+def test_cli_rh_ch4_row_is_what_the_reference_stream_prints(emul_lib, tmp_path):
+    """csv_outputstream_visitor.cpp:151 writes final_rh under the name rh_ch4: the file does too
+    (fetchvars("rh_ch4") is the CH4 respiration, tested in test_diagnostics)."""
+    r = subprocess.run([EMUL_CLI, SCENARIO, "--run-to", "2050", "--output-dir", str(tmp_path),
+                        "--precision", "15"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = read_stream(tmp_path / "outputstream_ssp245.csv")
+    v = {(x["variable"], x["year"]): float(x["value"]) for x in rows if x["variable"] in ("RH", "rh_ch4")}
+    for y in ("1800", "2000", "2050"):
+        assert v[("rh_ch4", y)] == v[("RH", y)] and v[("RH", y)] > 10.0
