@@ -16,15 +16,28 @@ N = 1 workload: BASELINE.json configs[2] -- 65 536-member perturbed ECS/Q10
 ensemble on one MI355X (the 1 048 576-member / 8-GPU configs[3] is the same
 kernel at 131 072 members per GPU: pass --members 131072).
 
-Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
-  roofline     -- algorithmic HBM bytes per launch (2 680 B per member-year,
-                  SURVEY.md 8d, x members x 555) / mean kernel time by HIP events
-                  on the core's stream, against the 8 TB/s HBM3E peak
-  cpu_baseline -- the CPU oracle (a scalar C port of the reference loop, validated
-                  against the reference's golden trajectory) on a bounded sample of
-                  the same ensemble, all host cores, 555-year loop only
+Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
+  roofline      -- the BINDING bound: executed fp64 flop/s against the 78.6 TFLOP/s fp64
+                   vector peak.  Flops per launch come from the committed SQ-counter profile
+                   of this exact kernel source and configuration (profiles/pmc_index.json,
+                   written by tools/prof/summarize.py: SQ_INSTS_VALU_FLOPS_FP64 x 64 lanes x
+                   lane utilisation); the time is the mean HIP-event duration of the run
+                   kernel on the core's stream, measured here.  With it: valu_active_frac
+                   (same profile), traffic (HBM bytes per launch from the FETCH_SIZE /
+                   WRITE_SIZE passes), hbm_measured_frac = traffic / kernel time / 8 TB/s,
+                   and hbm_yardstick -- the north star's "algorithmic bytes" figure (2 680 B
+                   per member-year, SURVEY.md 8d, x members x 555): a yardstick the kernel
+                   beats by design (block-causal DOECLIM pass, LDS-resident state), not a
+                   ceiling.
+  other_configs -- the other single-GPU BASELINE configurations (1 024 members; 131 072
+                   members = configs[3]'s per-GPU share; 65 536 members x 4 biomes), 5 steps
+                   each, timed the same way after the headline (N = 1 only)
+  cpu_baseline  -- the CPU oracle (a scalar C port of the reference loop, pinned to the
+                   reference's golden trajectory) on a bounded sample of the same ensemble,
+                   all host cores, 555-year loop only
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,19 +47,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_MEMBER_YEAR = {1: 2680.0, 4: 3072.0}  # SURVEY.md 8(d) / BASELINE.md 4
-HBM_PEAK = 8.0e12                               # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VECTOR_PEAK = 78.6e12   # fp64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 YEARS = 555
+KERNEL_SOURCES = ["hx_kernels.hip", "hx_dev_chem.h", "hx_dev_const.h", "hx_dev_member.h",
+                  "hx_dev_solver.h", "hx_dev_track.h", "hx_layout.h", "hx_addrspace.h"]
 
 
-def pmc_traffic(members, biomes):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE +
-    WRITE_SIZE, calibrated; profiles/r01_pmc_traffic.json) for this exact workload, or None:
-    counters cannot be read from inside the timed run."""
+def kernel_source_hash():
+    """sha256 over the device sources: the key of profiles/pmc_index.json, so that counters
+    collected on another version of the kernels are never quoted for this one."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "hector_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(members, biomes):
+    """-> (entry, stale).  entry: the committed counter figures for THIS kernel source and
+    configuration.  If the kernels changed since the last collection: the newest entry of the
+    same configuration, flagged stale, and a loud complaint on stderr; (None, True) if there
+    is none at all (counters cannot be read from inside the timed run)."""
+    cfg = "%dx%d" % (members, biomes)
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return d["traffic_bytes_per_launch"].get("%dx%d" % (members, biomes))
+        index = json.load(open(os.path.join(ROOT, "profiles", "pmc_index.json")))
     except Exception:
-        return None
+        index = {"entries": {}, "order": []}
+    h = kernel_source_hash()
+    if cfg in index["entries"].get(h, {}):
+        return index["entries"][h][cfg], False
+    sys.stderr.write("bench.py: NO PMC PROFILE for kernel source %s, configuration %s in "
+                     "profiles/pmc_index.json (tools/prof/collect.sh + summarize.py): roofline "
+                     "figures that need counters are null or flagged stale\n" % (h, cfg))
+    for hh in reversed(index["order"]):  # newest collection first
+        if cfg in index["entries"].get(hh, {}):
+            return index["entries"][hh][cfg], True
+    return None, True
 
 
 def effective_cores():
@@ -98,6 +134,95 @@ def cpu_baseline(target_seconds=15.0, chunk=32):
     return n * YEARS / dt, dt, n, cores
 
 
+def make_core(n, biomes, offset, device):
+    """The synthetic perturbed-parameter ensemble of SURVEY.md 8(d) for members
+    [offset, offset + n): ECS/Q10 (1 biome) or ECS + per-biome Q10 / warming factor (4)."""
+    import hector_amd
+    from hector_amd import ensemble
+    core = hector_amd.Core(n_members=n, device=device)
+    if biomes == 1:
+        S, q10 = ensemble.ecs_q10(n, offset=offset)
+        core.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    else:
+        S, q10s, wfs = ensemble.biome4(n, offset=offset)
+        names = ["b1", "b2", "b3", "b4"]
+        core.split_biome(names)
+        core.setvar("S", S, "degC")
+        for b, nm in enumerate(names):
+            core.setvar(nm + ".q10_rh", q10s[b]).setvar(nm + ".warmingfactor", wfs[b])
+    return core
+
+
+def roofline_object(members, biomes, kernel_ms):
+    """The roofline object of one configuration from its measured kernel time (this run) and
+    the committed counter profile of the same kernel source (profiles/pmc_index.json)."""
+    entry, stale = pmc_entry(members, biomes)
+    bpmy = BYTES_PER_MEMBER_YEAR[biomes]
+    alg_bytes = bpmy * members * YEARS  # per launch (one GPU)
+    secs = kernel_ms * 1e-3
+    yard = alg_bytes / secs / 1e9
+    r = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VECTOR_PEAK / 1e12,
+         "unit": "TFLOP/s", "frac": None, "traffic": None,
+         "kernel": "hx_run_kernel<%d>" % biomes, "kernel_ms": kernel_ms,
+         "kernel_source_hash": kernel_source_hash()}
+    if entry is not None:
+        flops = entry["fp64_flops_per_launch"]
+        r["achieved"] = flops / secs / 1e12
+        r["frac"] = r["achieved"] / r["peak"]
+        r["fp64_flops_per_launch"] = flops
+        r["valu_active_frac"] = entry["valu_active_frac"]
+        r["traffic"] = entry["traffic_bytes_per_launch"]
+        r["hbm_measured_frac"] = entry["traffic_bytes_per_launch"] / secs / HBM_PEAK
+        r["pmc_profile"] = entry["source"]
+        r["pmc_profile_stale"] = stale
+    r["formula"] = ("achieved = executed fp64 flops per launch (SQ_INSTS_VALU_FLOPS_FP64 x 64 lanes "
+                    "x lane utilisation; 2 per FMA, 1 per add / mul / rcp / sqrt; rocprofv3 --pmc "
+                    "pass of this kernel source, profiles/) / mean HIP-event kernel time of this "
+                    "run; peak = fp64 vector 78.6 TFLOP/s; hbm_measured_frac = PMC traffic "
+                    "(2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s")
+    r["hbm_yardstick"] = {
+        "bound": "hbm", "achieved": yard, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": yard / (HBM_PEAK / 1e9), "algorithmic_bytes_per_member_year": bpmy,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "note": "north-star yardstick (SURVEY 8d: yearly state round trip + yearly re-read of the "
+                "SST history); not a ceiling -- the block-causal DOECLIM pass reads the history "
+                "once per 32 years and the state lives in LDS, so the kernel moves ~7 % of it"}
+    return r
+
+
+def time_config(n, biomes, steps, warmup, device):
+    """One extra configuration, timed like the headline: -> dict for other_configs."""
+    import numpy as np
+    import torch
+    core = make_core(n, biomes, 0, device)
+    start, end = core.strtdate, core.enddate
+    stats = torch.zeros((2, end - start + 1, 5), dtype=torch.float64, device="cuda:%d" % device)
+
+    def step():
+        core.reset(start)
+        core.run(end, wait=False)
+        core.stats_device("CO2_concentration", start, end, stats[0].data_ptr())
+        core.stats_device("global_tas", start, end, stats[1].data_ptr())
+        return core.last_run_ms()
+    core.status()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = [step() for _ in range(steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    bad = int((core.status() != 0).sum())
+    core.shutdown()
+    kernel_ms = float(np.mean(kms))
+    rf = roofline_object(n, biomes, kernel_ms)
+    return {"members": n, "biomes": biomes, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "kernel_ms": kernel_ms, "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
+            "members_with_model_errors": bad,
+            "fp64_valu_frac": rf["frac"], "hbm_yardstick_frac": rf["hbm_yardstick"]["frac"],
+            "pmc_profile_stale": rf.get("pmc_profile_stale")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +231,7 @@ def main():
     ap.add_argument("--members", type=int, default=65536, help="members per GPU")
     ap.add_argument("--biomes", type=int, default=1, choices=[1, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target wall time of the bounded CPU-baseline sample")
     ap.add_argument("--dist-backend", default="nccl",
@@ -116,8 +242,6 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    import hector_amd
-    from hector_amd import ensemble
     from hector_amd.distributed import allreduce_stats, finalize
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,17 +264,7 @@ def main():
 
     n = args.members
     offset = rank * n  # weak scaling: contiguous member blocks, SURVEY.md 8(e)
-    core = hector_amd.Core(n_members=n, device=local_rank)
-    if args.biomes == 1:
-        S, q10 = ensemble.ecs_q10(n, offset=offset)
-        core.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
-    else:
-        S, q10s, wfs = ensemble.biome4(n, offset=offset)
-        names = ["b1", "b2", "b3", "b4"]
-        core.split_biome(names)
-        core.setvar("S", S, "degC")
-        for b, nm in enumerate(names):
-            core.setvar(nm + ".q10_rh", q10s[b]).setvar(nm + ".warmingfactor", wfs[b])
+    core = make_core(n, args.biomes, offset, local_rank)
     start, end = core.strtdate, core.enddate
     nyr = end - start + 1
     stats = torch.zeros((2, nyr, 5), dtype=torch.float64, device=dev)
@@ -193,16 +307,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kernel_ms = float(km.item())
+    kernel_ms = float(km.item())   # slowest rank's mean kernel time
     bad = int((core.status() != 0).sum())
+    stats_host = stats.cpu().numpy()
+    core.shutdown()
 
     if rank == 0:
         total_members = n * world
         value = total_members * YEARS * args.steps / elapsed
-        bpmy = BYTES_PER_MEMBER_YEAR[args.biomes]
-        alg_bytes = bpmy * n * YEARS  # per launch (one GPU)
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        mean, std, mn, mx = finalize(stats.cpu().numpy())
+        mean, std, mn, mx = finalize(stats_host)
         out = {
             "metric": "ensemble-member simulated years/sec",
             "value": value,
@@ -223,24 +336,25 @@ def main():
                             (n, "ECS/Q10" if args.biomes == 1 else "4-biome ECS/Q10/warmingfactor",
                              2 if args.biomes == 1 else 4),
                 "members_per_gpu": n, "global_members": total_members, "years_per_member": YEARS,
-                "biomes": args.biomes, "parallelism": "member-sharded x%d, stats all-reduce" % world,
+                "biomes": args.biomes,
+                "parallelism": "member-sharded x%d, one packed stats all-reduce" % world,
+                "collective_backend": ("%s (RCCL)" % args.dist_backend if args.dist_backend == "nccl"
+                                       else args.dist_backend) if world > 1 else None,
+                "collective_world_size": world,
                 "spinup_ms_excluded": spin_ms, "members_with_model_errors": bad,
+                "members_in_statistics": int(stats_host[0, -1, 0]),
                 "co2_2300_mean_ppm": float(mean[0, -1]), "tgav_2300_mean_K": float(mean[1, -1]),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(n, args.biomes),
-                "kernel": "hx_run_kernel<%d>" % args.biomes, "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_member_year": bpmy,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "achieved = algorithmic bytes (SURVEY 8d: state round trip + the yearly "
-                        "re-read of the SST history) / kernel time; it can exceed the HBM peak "
-                        "because the block-causal DOECLIM pass reads the history once per 32 years "
-                        "and the state lives in LDS -- 'traffic' is what the PMC counters saw. "
-                        "What actually bounds the kernel is fp64 issue + latency of one resident "
-                        "wavefront per SIMD (DESIGN.md section 6).",
-            },
+            # per-rank maximum of the mean kernel time when N > 1
+            "roofline": roofline_object(n, args.biomes, kernel_ms),
         }
+        if world == 1 and not args.no_other_configs:
+            others = []
+            for (m2, b2) in ((1024, 1), (131072, 1), (65536, 4)):
+                if (m2, b2) == (n, args.biomes):
+                    continue
+                others.append(time_config(m2, b2, 5, 1, local_rank))
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             v, dt, ns, cores = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = {
@@ -248,9 +362,14 @@ def main():
                 "sample": "%d members (the first ones of the same seeded ECS/Q10 ensemble) x 555 years, "
                           "oracle/hector_oracle.c (scalar C restatement of the reference loop, "
                           "spinup shared and excluded), %d threads, %.1f s wall" % (ns, cores, dt),
+                "provenance": "oracle pinned to the reference's golden trajectory "
+                              "tests/testthat/compdata/hector_comp.csv (<= 1e-13 rel CO2, 10 variables x "
+                              "556 years; tests/test_oracle_golden.py); not the reference binary (its Boost "
+                              "dependency is absent from the image).  The reference's own C++ loop measured "
+                              "by the survey with a Boost shim: 600-1 030 member-years/s/core (BASELINE.md "
+                              "2), i.e. the oracle is ~100-200x the reference per core",
             }
         print(json.dumps(out))
-    core.shutdown()
     if world > 1:
         dist.destroy_process_group()
 

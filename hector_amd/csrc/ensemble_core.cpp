@@ -16,6 +16,7 @@ int hx_doeclim_block_years();
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
 hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st);
+hipError_t hx_launch_or_flags(unsigned *status, const double *flag_row, int npad, hipStream_t st);
 hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st);
 hipError_t hx_launch_slr(const double *tgav, int npad, int start_year, int iy_to, double *out,
                          size_t var_stride, hipStream_t st);
@@ -414,7 +415,8 @@ void EnsembleCore::free_device() {
   fr(d_track_); fr(d_track_out_f_); fr(d_track_out_v_);
   d_track_ = d_track_out_f_ = d_track_out_v_ = nullptr;
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
-  d_hist_ = nullptr;
+  fr(d_hist_status_);
+  d_hist_ = nullptr; d_hist_status_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
   fr(d_diag_); fr(d_slr_); d_diag_ = d_slr_ = nullptr; diag_cap_ = 0; slr_valid_to_ = -1;
   d_derived_ = nullptr; d_dpart_ = nullptr; d_gather_ = nullptr; d_lane_of_member_ = nullptr;
@@ -448,8 +450,10 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
   check(hipMalloc(&d_derived_, sizeof(double) * np * HX_NDERIVED(B_)), "hipMalloc derived");
   check(hipMalloc(&d_lane_of_member_, sizeof(int) * np), "hipMalloc lane map");
-  if (history_)
+  if (history_) {
     check(hipMalloc(&d_hist_, sizeof(double) * ns * np * HX_NSTATE(B_)), "hipMalloc state history");
+    check(hipMalloc(&d_hist_status_, sizeof(unsigned) * ns * np), "hipMalloc status history");
+  }
   hist_valid_to_ = 0;
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
@@ -472,7 +476,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.dpart = d_dpart_;
   b.dpart2 = d_dpart_ ? d_dpart_ + (size_t)npad_ * hx_doeclim_block_years() : nullptr;
   for (int v = 0; v < HXO_NVAR; ++v) b.out[v] = d_out_[v];
-  b.hist = d_hist_;
+  b.hist = d_hist_; b.hist_status = d_hist_status_;
   for (int k = 0; k < HXM_N; ++k) b.mseries[k] = d_mseries_[k];
   b.uparams = d_uparams_;
   b.track = d_track_; b.track_out_f = d_track_out_f_; b.track_out_v = d_track_out_v_;
@@ -688,6 +692,12 @@ void EnsembleCore::split_biome_of(const std::string &old_biome,
     }
     nn.push_back(names[(size_t)a]);
   }
+  {
+    std::vector<int> old_of_new;
+    for (int b = 0; b < B_; ++b) if (b != ob) old_of_new.push_back(b);
+    for (int a = 0; a < nb; ++a) old_of_new.push_back(-1);
+    remap_biome_outputs(old_of_new);
+  }
   params_.swap(np);
   row_uniform_.swap(nu);
   B_ = nB;
@@ -696,6 +706,17 @@ void EnsembleCore::split_biome_of(const std::string &old_biome,
   params_dirty_ = true;
   need_spinup_ = true;
   last_iy_ = 0;
+}
+
+// "<biome>.<variable>" outputs are enabled by biome index: keep them with their biome when the
+// list is renumbered (old_of_new[b] = previous index of new biome b, -1 = a new biome)
+void EnsembleCore::remap_biome_outputs(const std::vector<int> &old_of_new) {
+  bool was[HXOB_N][HX_MAXB];
+  for (int k = 0; k < HXOB_N; ++k)
+    for (int b = 0; b < HX_MAXB; ++b) { was[k][b] = out_enabled_[HXO_B(k, b)]; out_enabled_[HXO_B(k, b)] = false; }
+  for (size_t b = 0; b < old_of_new.size() && b < (size_t)HX_MAXB; ++b)
+    if (old_of_new[b] >= 0)
+      for (int k = 0; k < HXOB_N; ++k) out_enabled_[HXO_B(k, (int)b)] = was[k][old_of_new[b]];
 }
 
 int EnsembleCore::biome_index(const std::string &biome) const {
@@ -734,6 +755,11 @@ void EnsembleCore::delete_biome(const std::string &biome) {
   params_.erase(params_.begin() + first, params_.begin() + first + HXPB_N);
   row_uniform_.erase(row_uniform_.begin() + first, row_uniform_.begin() + first + HXPB_N);
   biome_names_.erase(biome_names_.begin() + b);
+  {
+    std::vector<int> old_of_new;
+    for (int k = 0; k < B_; ++k) if (k != b) old_of_new.push_back(k);
+    remap_biome_outputs(old_of_new);
+  }
   --B_;
   layout_dirty_ = params_dirty_ = need_spinup_ = true;
   last_iy_ = 0;
@@ -880,6 +906,17 @@ void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
     for (auto &sec : sections)
       if (!sec.empty()) scen_.set_series_value(sec, capability, years[i], values[i]);
     miny = std::min(miny, years[i]);
+  }
+  // once a variable has per-member series (setvar_dated_members) the kernels and fetchvars read
+  // those: a value "for every member" goes into every member's row as well
+  for (int k = 0; k < HXM_N; ++k) {
+    static const char *const names[HXM_N] = {"ffi_emissions", "daccs_uptake", "luc_emissions",
+                                             "luc_uptake", "CH4_emissions"};
+    if (capability != names[k] || member_series_[k].empty()) continue;
+    for (int i = 0; i < n; ++i)
+      std::fill(member_series_[k].begin() + (size_t)(years[i] - scen_.start) * n_,
+                member_series_[k].begin() + (size_t)(years[i] - scen_.start + 1) * n_, values[i]);
+    mseries_dirty_ = true;
   }
   shared_dirty_ = true;
   // R/messages.R:125-133: reset_date = min(date) - 1
@@ -1092,6 +1129,8 @@ void EnsembleCore::prepare() {
     for (int v = 0; v < HXO_NVAR; ++v)
       if (d_out_[v]) check(hx_launch_broadcast(d_out_[v], 1, npad_, stream_), "broadcast out");
   }
+  check(hx_launch_or_flags(d_status_, d_derived_ + (size_t)HXD_FLAG * npad_, npad_, stream_),
+        "derive flags");
   // snapshot of the post-spinup state for reset(startDate)
   const size_t np = (size_t)npad_;
   check(hipMemcpyAsync(d_state_ + np * HX_NSTATE(B_), d_state_, sizeof(double) * np * HX_NSTATE(B_),
@@ -1137,6 +1176,10 @@ void EnsembleCore::reset(double date) {
                                "running; only reset(0) and reset(startDate) work without it)");
     check(hipMemcpyAsync(d_state_, d_hist_ + (size_t)iy * rows * np, sizeof(double) * np * rows,
                          hipMemcpyDeviceToDevice, stream_), "restore state from history");
+    // a member that failed after `date` is healthy again at `date` (the reference's reset()+run()
+    // recovers once the inputs are fixed)
+    check(hipMemcpyAsync(d_status_, d_hist_status_ + (size_t)iy * np, sizeof(unsigned) * np,
+                         hipMemcpyDeviceToDevice, stream_), "restore status from history");
   }
   last_iy_ = iy;
   if (dirty_from_iy_ >= iy) dirty_from_iy_ = -1;

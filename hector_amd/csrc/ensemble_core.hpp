@@ -159,6 +159,8 @@ class EnsembleCore {
     return (tracking_year_ > scen_.start && tracking_year_ <= scen_.end) ? tracking_year_ - scen_.start : -1;
   }
   double *d_derived_ = nullptr, *d_dpart_ = nullptr, *d_gather_ = nullptr, *d_hist_ = nullptr;
+  unsigned *d_hist_status_ = nullptr;  // [ns][npad] status bits of every year (with d_hist_)
+  void remap_biome_outputs(const std::vector<int> &old_of_new);
   bool history_ = false, shared_dirty_ = false;
   int hist_valid_to_ = 0;   // history slabs 1..hist_valid_to_ are valid
   int dirty_from_iy_ = -1;  // pending auto-reset target (R wrapper's reset_date)

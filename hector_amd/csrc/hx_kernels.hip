@@ -216,7 +216,10 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   m.cum_luc_va = 0; m.cum_pf_ch4 = 0; m.masstot = 0;
   m.max_ts = 1.0; m.ts_timeout = 0; m.lastflux_ann = 0; m.sdt = kc.dt0;
   m.alkH = 0; m.alkL = 0; m.hH = 1e-8; m.hL = 1e-8;
-  m.status = (unsigned)ldd(buf, HXD_FLAG, mem);
+  // (the bits found while deriving the member's constants -- a singular DOECLIM system -- depend
+  // on S and diff, which the spinup never sees: they are OR'ed in per member after the spinup,
+  // hx_or_flags_kernel, so that a shared spinup neither loses nor spreads them)
+  m.status = 0;
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     const int r = HXP_NGLOBAL + b * HXPB_N;
@@ -797,6 +800,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(B) * buf.npad;
         store_state<B>(buf, mem, m, slab);
         store_park_state<B>(buf, mem, m, slab);
+        HX_GU(buf.hist_status)[(size_t)iy * buf.npad + mem] = m.status;
       }
     }
   }
@@ -817,6 +821,12 @@ __global__ void hx_broadcast_u32_kernel(unsigned *v, int npad) {
   const int mem = blockIdx.x * blockDim.x + threadIdx.x;
   if (mem >= npad || mem == 0) return;
   v[mem] = v[0];
+}
+// status |= the member's own derive-time flags (HXD_FLAG row), after the spinup
+__global__ void hx_or_flags_kernel(unsigned *status, const double *flag_row, int npad) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mem >= npad) return;
+  status[mem] |= (unsigned)flag_row[mem];
 }
 
 // ===========================================================================
@@ -1175,6 +1185,11 @@ hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t s
 }
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st) {
   hipLaunchKernelGGL(hx_broadcast_u32_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, v, npad);
+  return hipGetLastError();
+}
+hipError_t hx_launch_or_flags(unsigned *status, const double *flag_row, int npad, hipStream_t st) {
+  hipLaunchKernelGGL(hx_or_flags_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, status,
+                     flag_row, npad);
   return hipGetLastError();
 }
 hipError_t hx_launch_doeclim_kernel(const double *diff_row, double *ker, int ns, int count,

@@ -149,6 +149,7 @@ struct HxBuffers {
   const double *dpart2;  // same for the heat-flux diagnostic
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
+  unsigned *hist_status; // ... and the members' status bits of every year [ns][npad]
   int n, npad, ker_per_member;
   const double *mseries[HXM_N];  // per-member emissions (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are

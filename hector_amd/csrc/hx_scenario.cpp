@@ -266,6 +266,7 @@ Scenario Scenario::load_pack(const std::string &path) {
   s.source = path;
   std::string line;
   bool magic = false;
+  std::map<std::string, int> first_year;
   while (std::getline(f, line)) {
     std::istringstream is(line);
     std::string kind, sec, key;
@@ -277,6 +278,8 @@ Scenario Scenario::load_pack(const std::string &path) {
     } else if (kind == "series") {
       int y0, n;
       if (!(is >> sec >> key >> y0 >> n)) continue;
+      if (n <= 0) throw std::runtime_error("series " + sec + "." + key + ": bad length");
+      first_year[sec + "." + key] = y0;
       std::vector<double> v((size_t)n);
       std::string tok;
       for (int i = 0; i < n; ++i) {
@@ -287,6 +290,15 @@ Scenario Scenario::load_pack(const std::string &path) {
     }
   }
   if (!magic) throw std::runtime_error(path + " is not a scenario pack");
+  // a pack's series are dense over startDate..endDate: everything downstream indexes them by
+  // year - startDate without further checks
+  {
+    const int y0 = (int)s.scalar("core", "startDate"), y1 = (int)s.scalar("core", "endDate");
+    for (auto &kv : s.series_)
+      if (first_year[kv.first] != y0 || (int)kv.second.size() != y1 - y0 + 1)
+        throw std::runtime_error("series " + kv.first + " of " + path + " does not cover " +
+                                 std::to_string(y0) + ".." + std::to_string(y1));
+  }
   s.finish();
   return s;
 }

@@ -2202,3 +2202,57 @@ int hxo_run_ensemble_ecs_q10(const hxo_scenario *s, const hxo_params *base,
   free(out); free(buf); free(buf0);
   return err;
 }
+
+/* see hector_oracle.h */
+static int same_spinup_params(const hxo_params *a, const hxo_params *b) {
+  if (a->nbiome != b->nbiome || a->C0 != b->C0 || a->tt != b->tt || a->tu != b->tu ||
+      a->twi != b->twi || a->tid != b->tid || a->preind_surface_c != b->preind_surface_c ||
+      a->preind_interdeep_c != b->preind_interdeep_c)
+    return 0;
+  for (int k = 0; k < a->nbiome; k++)
+    if (a->npp_flux0[k] != b->npp_flux0[k] || a->veg_c[k] != b->veg_c[k] ||
+        a->detritus_c[k] != b->detritus_c[k] || a->soil_c[k] != b->soil_c[k] ||
+        a->permafrost_c[k] != b->permafrost_c[k] || a->f_nppv[k] != b->f_nppv[k] ||
+        a->f_nppd[k] != b->f_nppd[k] || a->f_litterd[k] != b->f_litterd[k])
+      return 0;
+  return 1;
+}
+
+int hxo_run_ensemble(const hxo_scenario *s, const hxo_params *params, int n, int run_to,
+                     double *co2, double *tgav, unsigned char *timesteps, int *errs) {
+  int err = 0;
+  const int ns = s->ns;
+  double *out = (double *)malloc(sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
+  double *buf0 = (double *)malloc(sizeof(double) * (size_t)ns * 8);
+  double *buf = (double *)malloc(sizeof(double) * (size_t)ns * 8);
+  member_t M0;
+  member_prepare(&M0, s, &params[0], buf0);
+  (void)member_spinup(&M0);
+  for (int i = 0; i < n; i++) {
+    member_t M;
+    if (same_spinup_params(&params[0], &params[i])) {
+      M = M0;
+      memcpy(buf, buf0, sizeof(double) * (size_t)ns * 8);
+      M.pa = &params[i];
+      M.Ker = buf; M.forcing = buf + ns; M.temp = buf + 2 * ns;
+      M.temp_landair = buf + 3 * ns; M.temp_sst = buf + 4 * ns;
+      M.heatflux_mixed = buf + 5 * ns; M.heatflux_interior = buf + 6 * ns;
+      M.Tland_record = buf + 7 * ns;
+      doeclim_prepare(&M); /* A, IB, time scales, Ker depend on S, diff, qco2 */
+    } else {
+      member_prepare(&M, s, &params[i], buf);
+      (void)member_spinup(&M);
+    }
+    memset(out, 0, sizeof(double) * (size_t)HXO_NVAR * (size_t)ns);
+    member_main(&M, run_to, out);
+    err |= M.err;
+    if (errs) errs[i] = M.err;
+    if (co2) memcpy(co2 + (size_t)i * ns, out + HXO_CO2 * ns, sizeof(double) * ns);
+    if (tgav) memcpy(tgav + (size_t)i * ns, out + HXO_TGAV * ns, sizeof(double) * ns);
+    if (timesteps)
+      for (int y = 0; y < ns; y++)
+        timesteps[(size_t)i * ns + y] = (unsigned char)out[(size_t)HXO_NSTASH * ns + y];
+  }
+  free(out); free(buf); free(buf0);
+  return err;
+}

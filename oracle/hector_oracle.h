@@ -151,6 +151,15 @@ int hxo_run_ensemble_ecs_q10(const hxo_scenario *, const hxo_params *base,
                              int n, const double *S, const double *q10,
                              int run_to, double *co2, double *tgav);
 
+/* Run members [0,n), each with its own parameter set.  Members whose spinup-relevant
+ * parameters (C0, ocean transports and preindustrial carbon, npp_flux0, initial pools, the
+ * NPP / litter fractions) equal those of member 0 start from member 0's spun-up state -- the
+ * sharing hxo_run_ensemble_ecs_q10 uses (bit-identical to a spinup of their own); the others
+ * spin up themselves.  co2 / tgav [n*ns], timesteps [n*ns] (stashes per year), errs [n] may
+ * each be NULL.  Returns the OR of the error masks. */
+int hxo_run_ensemble(const hxo_scenario *, const hxo_params *params, int n, int run_to,
+                     double *co2, double *tgav, unsigned char *timesteps, int *errs);
+
 /* unit vectors for tests */
 /* carbonate chemistry: T (degC), carbon (PgC), alk (mol/kg), box volume (m3)
  * -> out[0]=PCO2o, out[1]=pH, out[2]=Tr, out[3]=K0, out[4]=h, out[5]=CO3 */

@@ -132,6 +132,22 @@ class Oracle:
                                                 co2.ctypes.data, tg.ctypes.data)
         return co2, tg, err
 
+    def run_ensemble(self, params, run_to=None, timesteps=True):
+        """params: list of Params (one per member) -> co2[n, ns], tgav[n, ns],
+        timesteps[n, ns] (uint8, stashes per year) or None, errs[n]; see hector_oracle.h"""
+        n = len(params)
+        arr = (Params * n)(*params)
+        co2 = np.zeros((n, self.ns)); tg = np.zeros((n, self.ns))
+        ts = np.zeros((n, self.ns), dtype=np.uint8) if timesteps else None
+        errs = np.zeros(n, dtype=np.int32)
+        fn = self.lib.hxo_run_ensemble
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        fn(self.sc, ctypes.cast(arr, ctypes.c_void_p), n, run_to or self.end, co2.ctypes.data,
+           tg.ctypes.data, ts.ctypes.data if timesteps else None, errs.ctypes.data)
+        return co2, tg, ts, errs
+
     def csys(self, Tc, carbon, alk, volume):
         out = np.zeros(6)
         self.lib.hxo_csys(Tc, carbon, alk, volume, out.ctypes.data)

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>_<members>x<biomes>/ (tools/prof/collect.sh) -> profiles/:
+   profiles/<tag>_pmc_<members>x<biomes>.json       counters of the 555-year dispatch + derived figures
+   profiles/<tag>_kernel_stats_<members>x<biomes>.csv   rocprofv3 --kernel-trace --stats summary
+   profiles/pmc_index.json                          what bench.py looks up: kernel-source hash ->
+                                                    configuration -> traffic, flops, VALU-active share
+
+    python tools/prof/summarize.py r02 65536x1 65536x4 1024x1
+
+HBM traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB as reported): gfx950's FETCH_SIZE counts half of
+coalesced reads; the factor is re-measured in every collection on hx_stats_kernel, which reads
+one [556][npad] fp64 array exactly once (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+Executed fp64 flops = SQ_INSTS_VALU_FLOPS_FP64 (per wave-instruction: 2 per FMA, 1 per
+add / mul / transcendental) x 64 lanes x lane utilisation (SQ_THREAD_CYCLES_VALU /
+(64 SQ_ACTIVE_INST_VALU))."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+YEARS = 555
+
+
+def counters(d, kernel="hx_run_kernel"):
+    """counter -> value of the largest dispatch of `kernel` (summed over its XCD rows)."""
+    acc = {}
+    path = os.path.join(d, "p_counter_collection.csv")
+    if not os.path.exists(path):
+        return {}
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"]:
+            k = (r["Dispatch_Id"], r["Counter_Name"])
+            acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+    best = {}
+    for (_, cn), v in acc.items():
+        best[cn] = max(best.get(cn, 0.0), v)
+    return best
+
+
+def main():
+    tag = sys.argv[1]
+    index_path = os.path.join(P, "pmc_index.json")
+    index = json.load(open(index_path)) if os.path.exists(index_path) else {"entries": {}, "order": []}
+    h = kernel_source_hash()
+    if h in index["order"]:
+        index["order"].remove(h)
+    index["order"].append(h)  # order of collection, newest last
+    for cfg in sys.argv[2:]:
+        members, biomes = (int(x) for x in cfg.split("x"))
+        d = os.path.join(G, "%s_%s" % (tag, cfg))
+        c = {}
+        for sub in ("fetch", "write", "sq_a", "sq_b", "sq_c"):
+            c.update(counters(os.path.join(d, sub)))
+        cal = counters(os.path.join(d, "fetch"), "hx_stats_kernel").get("FETCH_SIZE")
+        npad = (members + 63) // 64 * 64
+        known_kib = 556 * npad * 8 / 1024.0
+        factor = known_kib / cal if cal else None
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        waves = c["SQ_WAVES"]
+        lane_util = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+        flops = c["SQ_INSTS_VALU_FLOPS_FP64"] * 64.0 * lane_util
+        bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
+        der = {
+            "VALU_insts_per_wave_year": c["SQ_INSTS_VALU"] / waves / YEARS,
+            "SALU_insts_per_wave_year": c["SQ_INSTS_SALU"] / waves / YEARS,
+            "fp64_FMA_per_wave_year": c["SQ_INSTS_VALU_FMA_F64"] / waves / YEARS,
+            "fp64_ADD_per_wave_year": c["SQ_INSTS_VALU_ADD_F64"] / waves / YEARS,
+            "fp64_MUL_per_wave_year": c["SQ_INSTS_VALU_MUL_F64"] / waves / YEARS,
+            "fp64_TRANS_per_wave_year": c["SQ_INSTS_VALU_TRANS_F64"] / waves / YEARS,
+            "branches_per_wave_year": c["SQ_INSTS_BRANCH"] / waves / YEARS,
+            "VMEM_reads_per_wave_year": c["SQ_INSTS_VMEM_RD"] / waves / YEARS,
+            "LDS_insts_per_wave_year": c["SQ_INSTS_LDS"] / waves / YEARS,
+            "lane_utilisation": lane_util,
+            "valu_active_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+            "any_active_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+            "wait_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+            "mean_wave_cycles_per_year": 4 * c["SQ_WAVE_CYCLES"] / waves / YEARS,
+            "executed_fp64_flops_per_launch": flops,
+            "executed_fp64_flops_per_member_year": flops / (members * YEARS),
+            "hbm_traffic_bytes_per_launch": traffic,
+            "fetch_size_correction_measured": factor,
+        }
+        json.dump({"kernel": "hx_run_kernel<%d,...>" % biomes, "kernel_source_hash": h,
+                   "workload": "%d members x 555 years, %d biome(s), one launch" % (members, biomes),
+                   "counters_of_the_555_year_dispatch": c, "derived": der,
+                   "bench_line_same_build": bench,
+                   "note": "SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count units of 4 clocks; "
+                           "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB, factor 2 re-measured on "
+                           "hx_stats_kernel in the same pass (fetch_size_correction_measured)"},
+                  open(os.path.join(P, "%s_pmc_%s.json" % (tag, cfg)), "w"), indent=1)
+        st = os.path.join(d, "stats", "s_kernel_stats.csv")
+        if os.path.exists(st):
+            shutil.copy(st, os.path.join(P, "%s_kernel_stats_%s.csv" % (tag, cfg)))
+        index["entries"].setdefault(h, {})[cfg] = {
+            "traffic_bytes_per_launch": traffic,
+            "fp64_flops_per_launch": flops,
+            "valu_active_frac": der["valu_active_frac"],
+            "lane_utilisation": lane_util,
+            "source": "profiles/%s_pmc_%s.json" % (tag, cfg),
+        }
+        print(cfg, json.dumps(der, indent=1))
+    json.dump(index, open(index_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
