@@ -51,7 +51,8 @@ HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK = 78.6e12   # fp64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 YEARS = 555
 KERNEL_SOURCES = ["hx_kernels.hip", "hx_dev_chem.h", "hx_dev_const.h", "hx_dev_member.h",
-                  "hx_dev_solver.h", "hx_dev_track.h", "hx_layout.h", "hx_addrspace.h"]
+                  "hx_dev_solver.h", "hx_dev_track.h", "hx_dev_math.h", "hx_dev_clock.h",
+                  "hx_layout.h", "hx_addrspace.h"]
 
 
 def kernel_source_hash():

@@ -488,7 +488,9 @@ HxBuffers EnsembleCore::buffers() const {
     for (int k : {HXPB_BETA, HXPB_PF_MU, HXPB_PF_SIGMA})
       if (!row_uniform_[r + k]) b.uni_bio = 0;
   }
-  b.stash_diag = b.biome_diag = 0;
+  b.stash_diag = b.biome_diag = b.out_rare = 0;
+  for (int v = 0; v < HXO_NVAR; ++v)
+    if (d_out_[v] && v != HXO_SST && v != HXO_TLAND && v != HXO_CO2 && v != HXO_TGAV) b.out_rare = 1;
   for (int v = HXO_NPP; v <= HXO_CA_RESIDUAL; ++v) if (d_out_[v]) b.stash_diag = 1;
   for (int v = HXO_BIOME0; v < HXO_NVAR; ++v) if (d_out_[v]) b.biome_diag = 1;
   for (int bb = 0; bb < HX_MAXB; ++bb)

@@ -16,3 +16,5 @@ typedef const double HX_CONSTANT *hx_ccd;
 #define HX_GU(p) ((hx_gu)(p))
 // hardware reciprocal seed (v_rcp_f64: ~4.6e-8 relative, measured), refined in hx_recip()
 #define HX_RCP(x) __builtin_amdgcn_rcp(x)
+// hardware reciprocal-square-root seed (v_rsq_f64), refined in hx_sqrt()
+#define HX_RSQ(x) __builtin_amdgcn_rsq(x)

@@ -264,6 +264,51 @@ __device__ __forceinline__ void chem_constants2(double TcH, double TcL, ChemK &k
   }
 }
 
+// The run kernel's version of chem_constants2, split around the year's batch of exponentials
+// (hx_dev_math.h): chem_exponents() gives the arguments of the six exponentials of one box --
+// K0, Kw, Kh, K1, K2, Kb, same formulas as above, 10^-pK as exp(-pK ln 10) -- and
+// chem_from_exponentials() builds the box's constants from their values.  (The alkalinity tuner
+// keeps chem_constants2: it runs once, and Brent's branch decisions see the last bits.)
+__device__ __forceinline__ void chem_exponents(double Tc, double lnTk, double *a) {
+  const double S = O_S;
+  const double sqrtS = 5.873670062235365;      // sqrt(34.5)
+  const double S15 = 202.64161714712009;       // 34.5^1.5
+  const double LN10 = 2.302585092994045684;
+  const double Tk = Tc + 273.15;
+  const double rTk = hx_recip(Tk);
+  const double T100 = Tk * 0.01;
+  const double lnTk100 = lnTk - 4.605170185988092;  // ln(Tk/100)
+  a[0] = (-58.0931 + 9050.69 * rTk + 22.2940 * lnTk100) +
+         S * (0.027766 - 0.025888 * T100 + 0.0050578 * (T100 * T100));
+  a[1] = (-13847.26 * rTk + 148.96502 - 23.6521 * lnTk) +
+         ((118.67 * rTk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S);
+  a[2] = (9345.17 * rTk - 60.2409 + 23.3585 * lnTk100) +
+         S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk);
+  const double pK1 = 3633.86 * rTk - 61.2172 + 9.6777 * lnTk - 0.011555 * S + 0.0001152 * S * S;
+  a[3] = -pK1 * LN10;
+  const double pK2 = 471.78 * rTk + 25.9290 - 3.16967 * lnTk - 0.01781 * S + 0.0001122 * S * S;
+  a[4] = -pK2 * LN10;
+  const double tmp1 = (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 - 0.0996 * S * S) * rTk;
+  const double tmp2 = +148.0248 + 137.1942 * sqrtS + 1.62142 * S;
+  const double tmp3 = +(-24.4344 - 25.085 * sqrtS - 0.2474 * S) * lnTk + 0.053105 * sqrtS * Tk;
+  a[5] = tmp1 + tmp2 + tmp3;
+}
+__device__ __forceinline__ void chem_from_exponentials(double Tc, const double *e, double As,
+                                                       ChemK &k) {
+  const double Sc = 2073.1 - (125.62 * Tc) + (3.6276 * Tc * Tc) - (0.043219 * Tc * Tc * Tc);
+  k.Kw = e[1]; k.Kh = e[2]; k.K1 = e[3]; k.K2 = e[4]; k.Kb = e[5];
+  k.Tr = (0.585 * e[0] * rsqrt(Sc) * O_U * O_U);
+  k.g = k.Tr * As * (12.0 / 1e15);
+}
+
+// The yearly / per-stash solve of both boxes.  From a warm start (the previous [H+], a fraction
+// of a percent away) the safeguards of the bracketed iteration never engage: the iterates approach the
+// root from its right, where the quintic is concave, and stay inside the bracket -- so this is
+// the plain Newton iteration with the same stop rule (Boost's: |delta| <= |h| 2^-30, the step
+// applied first), i.e. the same iterates, without the bracket bookkeeping that made up half of
+// the loop body (the two solves are ~17 % of a model year).  A lane whose iteration does not
+// settle in 8 steps on a positive finite root (a cold or pathological start) redoes the solve
+// from its original start with the safeguarded iteration (the cold branch below).
 __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, double cH,
                                             double cL, double alkH, double alkL, double &hH,
                                             double &hL, double &pco2H, double &pco2L,
@@ -273,8 +318,6 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
   const double carbon[2] = {cH, cL}, alk[2] = {alkH, alkL};
   const double inv_vol[2] = {1.0 / O_vHL, 1.0 / O_vLL};
   double dic[2], p4[2], p3[2], p2[2], p1[2], p0[2], h[2] = {hH, hL};
-  double lo[2] = {0.0, 0.0}, hi[2] = {1.0, 1.0};
-  bool done[2] = {false, false};
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const double K1 = k[b]->K1, K2 = k[b]->K2, Kb = k[b]->Kb, Kw = k[b]->Kw;
@@ -291,7 +334,9 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
   const double factor = 0x1p-30;
   const double q4[2] = {4.0 * p4[0], 4.0 * p4[1]}, q3[2] = {3.0 * p3[0], 3.0 * p3[1]},
                q2[2] = {2.0 * p2[0], 2.0 * p2[1]};
-  for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
+  bool conv[2] = {false, false};
+  for (int it = 0; it < 8 && !(conv[0] && conv[1]); ++it) {
+    HX_COUNT(0, 18);  // (profiling build) Newton iterations
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const double x = h[b];
@@ -301,28 +346,56 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
       double fp = -5.0;
       fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
       fp = fp * x + p1[b];
-      if (!done[b]) {
-        if (f == 0.0) {
-          done[b] = true;
-        } else {
-          if (f > 0) lo[b] = x; else hi[b] = x;
-          double delta = hx_div1(f, fp);
-          double hn = x - delta;
-          if (!(hn > lo[b] && hn < hi[b])) {
-            if (fabs(delta) <= fabs(x) * 0x1p-48) {  // converged, see chem_solve
-              hn = x;
-            } else {  // left the bracket (or fp == 0): bisect
-              hn = 0.5 * (lo[b] + hi[b]);
-              delta = x - hn;
-            }
-          }
-          done[b] = !(fabs(hn * factor) < fabs(delta));
-          h[b] = hn;
-        }
-      }
+      const double delta = hx_div1(f, fp);
+      const double hn = x - delta;
+      const bool c = !(fabs(hn * factor) < fabs(delta));
+      h[b] = conv[b] ? h[b] : hn;
+      conv[b] = conv[b] || c;
     }
   }
-  if (!(done[0] && done[1])) status |= HX_ERR_ROOT;
+  const bool ok = conv[0] && conv[1] && h[0] > 0.0 && h[1] > 0.0 && h[0] < 1.0 && h[1] < 1.0;
+  if (__any(!ok)) {
+    HX_COUNT(0, 19);  // (profiling build) safeguarded restarts
+    if (!ok) {
+      // safeguarded restart from the original [H+]: Newton inside a sign-maintained bracket of
+      // the largest root, bisection when a step leaves it (see chem_solve); sound from any start
+      h[0] = hH; h[1] = hL;
+      double lo[2] = {0.0, 0.0}, hi[2] = {1.0, 1.0};
+      bool done[2] = {false, false};
+      for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const double x = h[b];
+          double f = -1.0;
+          f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
+          f = f * x + p0[b];
+          double fp = -5.0;
+          fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
+          fp = fp * x + p1[b];
+          if (!done[b]) {
+            if (f == 0.0) {
+              done[b] = true;
+            } else {
+              if (f > 0) lo[b] = x; else hi[b] = x;
+              double delta = hx_div1(f, fp);
+              double hn = x - delta;
+              if (!(hn > lo[b] && hn < hi[b])) {
+                if (fabs(delta) <= fabs(x) * 0x1p-48) {  // converged, see chem_solve
+                  hn = x;
+                } else {  // left the bracket (or fp == 0): bisect
+                  hn = 0.5 * (lo[b] + hi[b]);
+                  delta = x - hn;
+                }
+              }
+              done[b] = !(fabs(hn * factor) < fabs(delta));
+              h[b] = hn;
+            }
+          }
+        }
+      }
+      if (!(done[0] && done[1])) status |= HX_ERR_ROOT;
+    }
+  }
   hH = h[0]; hL = h[1];
   double pc[2];
 #pragma unroll

@@ -201,6 +201,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     aH = ((co2 - m.pco2H) * m.kH.g) * yf;
     aL = ((co2 - m.pco2L) * m.kL.g) * yf;
   }
+  HX_STAMP(m, 7);   // stash: constants from the park + carbonate solve
   // box-to-box transports, oceanbox.cpp:244-257 (order: HL, LL, IO, DO)
   const double lHD = m.cHL * kHD * yf;
   const double lLH = m.cLL * kLH * yf, lLI = m.cLL * kLI * yf;
@@ -378,7 +379,9 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     }
   }
   m.ode_start = t;
+  HX_STAMP(m, 8);   // stash: ocean boxes + land pools
   if (more) prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);  // constants of the next segment
+  HX_STAMP(m, 9);   // stash: next segment's interval constants
 }
 
 // exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
@@ -431,6 +434,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     load_landk<B>(m, lk);
     prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);
   }
+  HX_STAMP(m, 5);   // interval constants of the year's first segment
   // getCValues  simpleNbox-runtime.cpp:247-258
   double y[NP], l4, l5, l7;
   auto load_pools = [&]() {
@@ -461,6 +465,8 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     int fails = 0;
     bool stepping = seg;
     while (__any(stepping)) {
+      HX_STAMP(m, 10);
+      HX_COUNT(m, 16);  // step-loop iterations
       if (stepping) {
         if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
         if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
@@ -543,7 +549,10 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           }
         }
       }
+      HX_STAMP(m, 6);   // dopri5 attempts (+ retries)
     }
+    HX_STAMP(m, 10);
+    HX_COUNT(m, 17);    // segments
     if (seg && alive) {
       // the solver keeps integrating its own c[] afterwards (no getCValues,
       // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move

@@ -40,6 +40,8 @@
 #define HX_KPAD 32  // zero entries in front of / behind the Ker table
 
 #include "hx_dev_const.h"
+#include "hx_dev_clock.h"
+#include "hx_dev_math.h"
 #include "hx_dev_chem.h"
 #include "hx_dev_member.h"
 #include "hx_dev_solver.h"
@@ -331,6 +333,10 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   __shared__ double s_park[hx_npark<B>()][64];
   Member<B> m;
   bind_member<B>(args->buf, mem, m, s_park, lane);
+#ifdef HX_PHASE_CLOCK
+  for (int k = 0; k < HX_NCLK; ++k) hx_s_clk[k] = 0;
+  hx_s_clk[HX_NCLK] = (long long)__builtin_readcyclecounter();
+#endif
   load_state<B>(args->buf, mem, m);
   {  // year-level state -> park
     const HxBuffers &buf = args->buf;
@@ -340,8 +346,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     PKM(m, PK_TL_M2) = lds_(buf, HXS_TL_M2, mem); PKM(m, PK_F_PREV) = lds_(buf, HXS_F_PREV, mem);
     PKM(m, PK_BASE_TOT) = lds_(buf, HXS_BASE_TOT, mem);
     PKM(m, PK_BASE_CO2) = lds_(buf, HXS_BASE_CO2, mem);
-    PKM(m, PK_LN_CH4) = log(lds_(buf, HXS_CH4, mem));
-    PKM(m, PK_LN_CO2R) = log(hx_div(m.atmos * PGC2PPM, m.C0));
+    PKM(m, PK_LN_CH4) = hx_log(lds_(buf, HXS_CH4, mem));
+    PKM(m, PK_LN_CO2R) = hx_log(hx_div(m.atmos * PGC2PPM, m.C0));
 #pragma unroll
     for (int b = 0; b < B; ++b)
       PKM(m, PK_FFROZEN0 + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
+    HX_STAMP(m, 0);   // (kernel entry / loop overhead)
     if constexpr (CON) m.iy = iy;
     double ch4, o3;
     // ======================= phase A ========================================
@@ -457,7 +464,38 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if (prev_ch4 != kc.M0)
         toh = ((kc.CCH4 * (PKM(m, PK_LN_CH4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
               sh[HXSH_OH_D];
-      const double tau_oh = kc.TOH0 * exp(-toh);
+      // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
+      // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
+      if (iy >= 3) {
+        twin += tl_m2;  // Tland of year iy-3 enters
+        if (iold >= 1) twin -= tl_old;
+        PKM(m, PK_TWIN) = twin;
+      }
+      // ---- the year's logarithms and exponentials, in two batches (hx_dev_math.h): every
+      // argument is known here -- both boxes' temperatures (SST of last year), the OH lifetime
+      // exponent, the biomes' temperatures
+      const double TcH = sst + 18 + (-16.4), TcL = sst + 18 + 2.9;
+      double Tb[B];
+      double lg[2 + B];
+      lg[0] = TcH + 273.15; lg[1] = TcL + 273.15;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        Tb[b] = tland * p_wf[b];
+        lg[2 + b] = (Tb[b] > 0) ? Tb[b] : 1.0;  // ln(Tb) of the permafrost curve, if Tb > 0
+      }
+      hx_log_batch<2 + B>(lg);
+      double ex[13 + 2 * B];
+      chem_exponents(TcH, lg[0], &ex[0]);
+      chem_exponents(TcL, lg[1], &ex[6]);
+      ex[12] = -toh;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const double Trm = (iy > 1) ? (twin * p_wf[b]) * 0.005 : 0.0;
+        ex[13 + 2 * b] = p_lnq10[b] * (Tb[b] * 0.1);
+        ex[14 + 2 * b] = p_lnq10[b] * (Trm * 0.1);
+      }
+      hx_exp_chunks<13 + 2 * B>(ex);
+      const double tau_oh = kc.TOH0 * ex[12];
       if constexpr (CON) {
       if (buf.out[HXO_TAU_OH]) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
       if (buf.stash_diag) {  // sums over the year's stashes start at zero (oceanbox::new_year)
@@ -486,16 +524,20 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         }
       }
       PKM(m, PK_CH4) = ch4;
-      const double ln_ch4 = log(ch4);
+      const double ln_ch4 = hx_log(ch4);
       PKM(m, PK_LN_CH4) = ln_ch4;
       o3 = ((5 * ln_ch4 + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
       // ---- ocean: new year ----
-      chem_constants2(sst + 18 + (-16.4), sst + 18 + 2.9, m.kH, m.kL);
+      HX_STAMP(m, 1);   // park reads, the year's log / exp batches, OH / CH4 / O3
+      chem_from_exponentials(TcH, &ex[0], O_AsHL, m.kH);
+      chem_from_exponentials(TcL, &ex[6], O_AsLL, m.kL);
+      HX_STAMP(m, 2);   // T-only equilibrium constants of both boxes (from the exponentials)
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
       // (the alkalinities were tuned once, right after the spinup: hx_alk_kernel)
       chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
                   m.status);
       m.chem_fresh = true;
+      HX_STAMP(m, 3);   // year-start carbonate solve
       // ---- slowparameval (t = year-1) ----
       m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
       m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
@@ -508,35 +550,27 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
       const double lnc = PKM(m, PK_LN_CO2R);  // = log((atmos C * PGC2PPM) / C0), from last year's phase C
-      // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
-      // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
-      if (iy >= 3) {
-        twin += tl_m2;  // Tland of year iy-3 enters
-        if (iold >= 1) twin -= tl_old;
-        PKM(m, PK_TWIN) = twin;
-      }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         m.co2fert[b] = 1 + p_beta[b] * lnc;
-        const double Tb = tland * p_wf[b];
-        m.tempfertd[b] = exp(p_lnq10[b] * (Tb * 0.1));
+        m.tempfertd[b] = ex[13 + 2 * b];  // exp(ln q10 * Tb / 10)
         m.f_new_thaw[b] = 0.0;
         if (m.pf[b] != 0.0) {
           double ff = 1.0;
-          if (Tb > 0) {
-            const double d = hx_div(log(Tb) - p_mu[b], p_sigma[b] * 1.4142135623730951);
+          if (Tb[b] > 0) {
+            const double d = hx_div(lg[2 + b] - p_mu[b], p_sigma[b] * 1.4142135623730951);
             ff = 1 - erfc(-d) / 2;
           }
           m.f_new_thaw[b] = s_ffrozen[b] - ff;
           PKM(m, PK_FFROZEN0 + b) = ff;
         }
-        const double Trm = (iy > 1) ? (twin * p_wf[b]) * 0.005 : 0.0;
-        const double tfs = exp(p_lnq10[b] * (Trm * 0.1));
+        const double tfs = ex[14 + 2 * b];  // exp(ln q10 * Trm / 10), Trm = 200-year mean
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
         m.tempferts[b] = fmax(tfs, last);  // sticky :1054-1059
       }
     }
     HX_FENCE();
+    HX_STAMP(m, 4);     // slow parameters
     // ======================= phase B: carbon-cycle solver ====================
     {
       const double year = (double)(args->kc.start_year + iy);
@@ -552,6 +586,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       solve_year<B, false, CON>(m, args->kc, year - 1.0, year, yc);
     }
     HX_FENCE();
+    HX_STAMP(m, 10);    // rest of the solver (loop control, lanes idling through others' segments)
     // ======================= phase C ========================================
     {
       const HxBuffers &buf = args->buf;
@@ -564,6 +599,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                     const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
         HX_FENCE();
+        HX_STAMP(m, 11);  // DOECLIM history pass (once per HX_DBLK years)
       }
       // every HBM value this phase needs, issued back to back
       const double tland = PKM(m, PK_TLAND), sst = PKM(m, PK_SST);
@@ -583,14 +619,14 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
       // ---- forcing ----
       const double co2c = m.atmos * PGC2PPM;
-      const double ln_co2r = log(hx_div(co2c, m.C0));
+      const double ln_co2r = hx_log(hx_div(co2c, m.C0));
       PKM(m, PK_LN_CO2R) = ln_co2r;
       double rf_tot = 0, rf_co2 = 0;
       if (iy >= kc.baseyear_idx) {
         const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
         const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
         const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
-        const double sqN = sh[HXSH_SQRT_N2O], sqM = sqrt(ch4), sqC = sqrt(co2c);
+        const double sqN = sh[HXSH_SQRT_N2O], sqM = hx_sqrt(ch4), sqC = hx_sqrt(co2c);
         const double C_alpha_max = m.C0 - (b1 / (2 * a1));
         double alpha_prime;
         if (co2c > C_alpha_max) alpha_prime = d1 - ((b1 * b1) / (4 * a1));
@@ -623,6 +659,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           rf_co2 = fco2 - base_co2;
         }
       }
+      HX_STAMP(m, 12);    // phase C loads + forcing
       // ---- DOECLIM: history before the block (doeclim_pass_dev) + in-block terms ----
       double tl_new, sst_new, heatflux = 0, tgav, flux_mixed = 0, flux_interior = 0;
       {
@@ -696,6 +733,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           sst_rep = toa / D_bsi;
         }
       }
+      HX_STAMP(m, 13);    // DOECLIM in-block sum + year step
       PKM(m, PK_F_PREV) = rf_tot;
       PKM(m, PK_TL_M2) = tl_m1;  // Tland of years iy-2, iy-1
       PKM(m, PK_TL_M1) = tl_seen;  // for the next year
@@ -708,6 +746,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if constexpr (CON) { if (buf.out[HXO_SST_LO]) sto_(buf, HXO_SST_LO, o, sst_rep); }
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
+      if (buf.out_rare) {  // (one test instead of ~25 pointer loads and branches a year)
       if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);
       if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);
       if (buf.out[HXO_OCEAN_C]) sto_(buf, HXO_OCEAN_C, o, m.cDO + m.cIO + m.cLL + m.cHL);
@@ -773,6 +812,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);
       }
       }
+      }  // out_rare
       if constexpr (CON == 2) {  // CSVFluxPoolVisitor: pools and their origins, once a year
         if (buf.track_out_f && kc.trk_iy >= 0 && iy >= kc.trk_iy) {
           constexpr int TP = hx_tp<B>();
@@ -796,6 +836,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           ov[(size_t)tkp_ocean<B>(2) * np] = m.cIO; ov[(size_t)tkp_ocean<B>(3) * np] = m.cDO;
         }
       }
+      HX_STAMP(m, 14);    // outputs
       if (buf.hist) {  // Core::reset(date) needs every component's state of every year
         double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(B) * buf.npad;
         store_state<B>(buf, mem, m, slab);
@@ -807,6 +848,11 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   HX_FENCE();
   store_state<B>(args->buf, mem, m);
   store_park_state<B>(args->buf, mem, m);
+#ifdef HX_PHASE_CLOCK
+  if (args->buf.out[HXO_TGAV])
+    for (int k = 0; k < HX_NCLK; ++k)
+      HX_GD(args->buf.out[HXO_TGAV])[(size_t)k * args->buf.npad + mem] = (double)hx_s_clk[k];
+#endif
 }
 
 // ===========================================================================
@@ -1108,8 +1154,10 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
   const int blocks = (nmem_launch + 63) / 64;
   switch (B) {
     case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#ifndef HX_MINIMAL_BUILD
     case 2: hipLaunchKernelGGL(hx_spinup_kernel<2>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
     case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     default: return hipErrorInvalidValue;
   }
@@ -1127,6 +1175,11 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
                          int iy_from, int iy_to, hipStream_t st) {
   const int blocks = npad / 64;
   const size_t lds = 0;
+#ifdef HX_MINIMAL_BUILD  // experiment builds (tools/prof): the plain kernel only
+  (void)hf; (void)kpm; (void)con;
+  hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  return;
+#endif
   if (con == 2 && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (con == 2)
@@ -1148,8 +1201,10 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
                          int iy_from, int iy_to, hipStream_t st) {
   switch (B) {
     case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+#ifndef HX_MINIMAL_BUILD
     case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+#endif
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     default: return hipErrorInvalidValue;
   }

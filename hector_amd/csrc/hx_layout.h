@@ -158,6 +158,8 @@ struct HxBuffers {
   double *track;         // [hx_trk_rows(B)][npad]
   double *track_out_f;   // [ns - trk_iy][TP*TP][npad] fractions from the tracking date on
   double *track_out_v;   // [ns - trk_iy][TP][npad] pool values
+  int out_rare;            // some output besides sst, land_tas, CO2_concentration, global_tas is
+                           // recorded: the year's output block tests the others only then
   int biome_diag;          // some "<biome>.<variable>" output is recorded
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
 };
