@@ -10,8 +10,17 @@ namespace {
 // rhs constants that only change at a stash (pools frozen in between,
 // src/simpleNbox-runtime.cpp:809-840)
 struct Interval {
-  double P, npp, rh, v1, d2, s3, k4, k5, k7;
-  double totC, surf, inv_surf;
+  double Pn;              // (P - npp) + rh: everything in d(atmos)/dt but the air-sea flux
+  double v1, d2, s3, k4, k5, k7;
+  double totC;
+  // air-sea flux of the interval as a function of the solver's c[] (calc_annual_surface_flux for
+  // both boxes, ocean_component.cpp:606-616, ocean_csys.cpp:375-396):
+  //   ao = (co2 - pH scale) gH + (co2 - pL scale) gL,  co2 = c0 / 2.13,
+  //   scale = (surf + (c4 - totC)) / surf = 1 + (c4 - totC) / surf
+  //      = c0 aoA - (pG + (c4 - totC) aoB),  aoA = (gH + gL) / 2.13,  pG = pH gH + pL gL,
+  //        aoB = pG / surf
+  // three operations per evaluation instead of seven; c4 - totC stays an exact small difference
+  double aoA, aoB, pG;
 };
 
 template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, const LandK<B> &k, int b) {
@@ -47,9 +56,7 @@ struct Flows {
 
 template <int B>
 __device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F, Interval &K) {
-  K.npp = F.npp;
-  K.rh = F.rh;
-  K.P = ((m.ffi - m.daccs) + m.luc_e) - m.luc_u;
+  K.Pn = ((((m.ffi - m.daccs) + m.luc_e) - m.luc_u) - F.npp) + F.rh;
   K.v1 = F.fav - F.litter;
   K.d2 = ((F.fad + F.lfvd) - F.detsoil) - F.fda;
   K.s3 = ((F.fas + F.lfvs) + F.detsoil) - F.fsa;
@@ -57,8 +64,9 @@ __device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F
   K.k5 = ((F.thaw - F.refr) - F.tpm) - F.tpc;
   K.k7 = -m.ffi + m.daccs;
   K.totC = m.cDO + m.cIO + m.cLL + m.cHL;  // ocean_component.cpp:325-328
-  K.surf = m.cLL + m.cHL;
-  K.inv_surf = hx_recip(K.surf);
+  K.pG = m.pco2H * m.kH.g + m.pco2L * m.kL.g;
+  K.aoA = PGC2PPM * (m.kH.g + m.kL.g);
+  K.aoB = K.pG * hx_recip(m.cLL + m.cHL);
 }
 
 // NBP constraint inside calcderivs: NPP and RH moved by +-diff/2, their parts scaled
@@ -156,11 +164,9 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, cons
   if (SPIN) {
     ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
   } else {
-    const double scale = (K.surf + (y[4] - K.totC)) * K.inv_surf;
-    const double co2 = y[0] * PGC2PPM;
-    ao = (co2 - m.pco2H * scale) * m.kH.g + (co2 - m.pco2L * scale) * m.kL.g;
+    ao = fma(y[0], K.aoA, -fma(y[4] - K.totC, K.aoB, K.pG));
   }
-  d[0] = ((K.P - ao) - K.npp) + K.rh;
+  d[0] = K.Pn - ao;
   d[1] = (K.v1 - r * y[1]) + m.luc_u;
   d[2] = K.d2 - r * y[2];
   d[3] = K.s3 - r * y[3];
