@@ -188,6 +188,97 @@ __device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_his
   }
 }
 
+#if HX_HAS_MFMA
+// The same history pass on the fp64 matrix pipe, for ensembles that share the diffusivity (one
+// Ker table).  part[j][m] = sum_{i < blk0} Ker[kb + i - j] T[i][m] is a (32 x H) Toeplitz matrix
+// times the (H x 64) history of the wavefront's members: the one dense contraction of the model.
+// v_mfma_f64_16x16x4_f64 takes a 16 x 4 slice of the Toeplitz matrix (A: lane l holds
+// A[l & 15][l >> 4] = Ker[kb + (i0 + (l >> 4)) - (j0 + (l & 15))]) and the 4 x 16 slice of the
+// history of 16 members (B: lane l holds T[i0 + (l >> 4)][16 g + (l & 15)]) and accumulates the
+// 16 x 16 tile D[(l >> 4) + 4 r][l & 15], r < 4, in ascending history order like the scalar loop.
+// Per four history years: 6 loads and 8 MFMAs (two halves of the block x four member groups)
+// instead of 128 v_fma_f64 -- with one wavefront per SIMD the 128 issue slots were the cost.
+// The history is read once per block instead of twice.
+// (Inlined: as a real call like doeclim_pass_dev it is as fast, but hx_run_kernel<2,0,0,0> built
+// with ROCm 7.2's compiler then faults on the device -- one instantiation of 32, found by the
+// test suite; nothing in the source distinguishes it.)
+template <bool HF>
+__device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
+                                                            const double *ker, double *part,
+                                                            double *part2, int ns, int npad,
+                                                            int blk0, int mem) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int lane = mem & 63, q = lane >> 4, c = lane & 15;
+  const size_t np = (size_t)npad;
+  hx_gcd hist = HX_GCD(sst_hist) + (mem - lane) + c;  // member 16 g + c of this wavefront
+  hx_gcd kg = HX_GCD(ker) + (ns - blk0 - 1 + HX_KPAD) - c + q;  // Ker[kb + (i0 + q) - c] at [i0]
+  d4 acc[2][4], acc2[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[h][g] = d4{0, 0, 0, 0}; acc2[h][g] = d4{0, 0, 0, 0}; }
+  double a0, a1, e0 = 0, e1 = 0, b[4];
+  auto load = [&](int i0, double &A0, double &A1, double &E0, double &E1, double (&Bv)[4]) {
+    const int i = i0 + q;
+    A0 = kg[i0];
+    A1 = kg[i0 - 16];
+    if (HF) { E0 = kg[i0 + 1]; E1 = kg[i0 - 15]; }
+    // rows >= blk0 must not contribute (they may hold values of an earlier run): read row 0
+    // instead, the SST anomaly of startDate, which is 0 for every member -- the operands of the
+    // MFMAs then come straight from loads, no VALU select in between
+    const size_t row = (size_t)(i < blk0 ? i : 0) * np;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Bv[g] = hist[row + 16 * g];
+  };
+  // two register sets in turn: the loads of the next four history years are in flight while the
+  // MFMAs of the current ones execute (a set past the end loads clamped rows and is masked to 0)
+  double c0, c1, f0 = 0, f1 = 0, d[4];
+  auto mma = [&](double A0, double A1, double E0, double E1, const double (&Bv)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[g], acc[0][g], 0, 0, 0);
+      acc[1][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv[g], acc[1][g], 0, 0, 0);
+      if (HF) {
+        acc2[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(E0, Bv[g], acc2[0][g], 0, 0, 0);
+        acc2[1][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(E1, Bv[g], acc2[1][g], 0, 0, 0);
+      }
+    }
+  };
+  // (the empty asm statements pin the accumulators to the AGPR half of the register file across
+  // the loop's back edge; left alone the compiler carries them in VGPRs and copies all 64 (128)
+  // registers into and out of AGPRs around every group of MFMAs)
+  auto pin = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        asm volatile("" : "+a"(acc[h][g]));
+        if (HF) asm volatile("" : "+a"(acc2[h][g]));
+      }
+  };
+  load(0, a0, a1, e0, e1, b);
+  pin();
+  for (int i0 = 0; i0 < blk0; i0 += 8) {
+    load(i0 + 4, c0, c1, f0, f1, d);
+    mma(a0, a1, e0, e1, b);
+    load(i0 + 8, a0, a1, e0, e1, b);
+    mma(c0, c1, f0, f1, d);
+    pin();
+  }
+  hx_gd po = HX_GD(part) + (mem - lane) + c, po2 = HX_GD(part2) + (mem - lane) + c;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t o = (size_t)(16 * h + q + 4 * r) * np + 16 * g;
+        po[o] = acc[h][g][r];
+        if (HF) po2[o] = acc2[h][g][r];
+      }
+}
+#endif
+
 // ===========================================================================
 // Spinup: Core::run_spinup (src/core.cpp:394-420) + CarbonCycleSolver::
 // run_spinup (src/carbon-cycle-solver.cpp:313-370).  Pseudo-years 0,1,2...
@@ -596,6 +687,12 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
         // new DOECLIM block: this lane's partial sums over its SST history
         blk0 = iy;
+#if HX_HAS_MFMA
+        if constexpr (!KERPM)
+          doeclim_pass_mfma<HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+                                const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
+        else
+#endif
         doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                     const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
         HX_FENCE();

@@ -12,3 +12,4 @@ typedef const double *hx_ccd;
 #define HX_GU(p) ((hx_gu)(p))
 #define HX_RCP(x) (1.0 / (x))
 #define HX_RSQ(x) (1.0 / sqrt(x))
+#define HX_HAS_MFMA 0
