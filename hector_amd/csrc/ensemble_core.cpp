@@ -875,6 +875,32 @@ const DatedDef kDated[] = {
 };
 }  // namespace
 
+namespace {
+struct MemberSeriesDef { const char *name; int k; const char *section; const char *units; int lag; };
+// lag: the shared table holds the value of date year-1 for what slowparameval reads
+const MemberSeriesDef kMemberSeries[] = {
+    {"ffi_emissions", HXM_FFI, "simpleNbox", "Pg C/yr", 1},
+    {"daccs_uptake", HXM_DACCS, "simpleNbox", "Pg C/yr", 1},
+    {"luc_emissions", HXM_LUC_E, "simpleNbox", "Pg C/yr", 1},
+    {"luc_uptake", HXM_LUC_U, "simpleNbox", "Pg C/yr", 1},
+    {"CH4_emissions", HXM_CH4_EM, "CH4", "Tg CH4", 0},
+    // constraints that differ between members (NaN = no constraint for that member and year)
+    {"CO2_constrain", HXM_CO2_CON, "simpleNbox", "ppmv CO2", 0},
+    {"NBP_constrain", HXM_NBP_CON, "simpleNbox", "Pg C/yr", 0},
+    {"tas_constrain", HXM_TAS_CON, "temperature", "degC", 0},
+    {"RF_tot_constrain", HXM_FTOT_CON, "forcing", "W/m2", 0},
+    {"CH4_constrain", HXM_CH4_CON, "CH4", "ppbv CH4", 0},
+};
+bool is_constraint_series(int k) { return k >= HXM_CO2_CON && k <= HXM_CH4_CON; }
+int constraint_bit(int k) {
+  switch (k) {
+    case HXM_CO2_CON: return HXC_CO2; case HXM_NBP_CON: return HXC_NBP;
+    case HXM_TAS_CON: return HXC_TAS; case HXM_FTOT_CON: return HXC_FTOT;
+    case HXM_CH4_CON: return HXC_CH4; default: return 0;
+  }
+}
+}  // namespace
+
 void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
                                 const double *values, int n, const char *units) {
   std::string sections[2];
@@ -911,10 +937,9 @@ void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
   }
   // once a variable has per-member series (setvar_dated_members) the kernels and fetchvars read
   // those: a value "for every member" goes into every member's row as well
-  for (int k = 0; k < HXM_N; ++k) {
-    static const char *const names[HXM_N] = {"ffi_emissions", "daccs_uptake", "luc_emissions",
-                                             "luc_uptake", "CH4_emissions"};
-    if (capability != names[k] || member_series_[k].empty()) continue;
+  for (const MemberSeriesDef &d : kMemberSeries) {
+    const int k = d.k;
+    if (capability != d.name || member_series_[k].empty()) continue;
     for (int i = 0; i < n; ++i)
       std::fill(member_series_[k].begin() + (size_t)(years[i] - scen_.start) * n_,
                 member_series_[k].begin() + (size_t)(years[i] - scen_.start + 1) * n_, values[i]);
@@ -926,17 +951,6 @@ void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
   if (target < last_iy_) dirty_from_iy_ = (dirty_from_iy_ < 0) ? target : std::min(dirty_from_iy_, target);
 }
 
-namespace {
-struct MemberSeriesDef { const char *name; int k; const char *section; const char *units; int lag; };
-// lag: the shared table holds the value of date year-1 for what slowparameval reads
-const MemberSeriesDef kMemberSeries[] = {
-    {"ffi_emissions", HXM_FFI, "simpleNbox", "Pg C/yr", 1},
-    {"daccs_uptake", HXM_DACCS, "simpleNbox", "Pg C/yr", 1},
-    {"luc_emissions", HXM_LUC_E, "simpleNbox", "Pg C/yr", 1},
-    {"luc_uptake", HXM_LUC_U, "simpleNbox", "Pg C/yr", 1},
-    {"CH4_emissions", HXM_CH4_EM, "CH4", "Tg CH4", 0},
-};
-}  // namespace
 
 void EnsembleCore::setvar_dated_members(const std::string &capability, const int *years,
                                         const double *values, int nyears, const char *units) {
@@ -945,7 +959,8 @@ void EnsembleCore::setvar_dated_members(const std::string &capability, const int
   if (!d)
     throw std::runtime_error("per-member dated input not supported for " + capability +
                              " (ffi_emissions, luc_emissions, daccs_uptake, luc_uptake, "
-                             "CH4_emissions are)");
+                             "CH4_emissions, CO2_constrain, NBP_constrain, tas_constrain, "
+                             "RF_tot_constrain, CH4_constrain are)");
   if (units && units[0] && std::string(units) != d->units)
     throw std::runtime_error("Units: " + std::string(units) + " do not match expected: " +
                              d->units + " for " + capability);
@@ -953,9 +968,10 @@ void EnsembleCore::setvar_dated_members(const std::string &capability, const int
   std::vector<double> &ms = member_series_[d->k];
   if (ms.empty()) {  // start from the scenario's series, the same for every member
     ms.resize((size_t)ns * n_);
-    const std::vector<double> base = scen_.has_series(d->section, capability)
-                                         ? scen_.series(d->section, capability)
-                                         : std::vector<double>((size_t)ns, 0.0);
+    const std::vector<double> base =
+        scen_.has_series(d->section, capability)
+            ? scen_.series(d->section, capability)
+            : std::vector<double>((size_t)ns, is_constraint_series(d->k) ? std::nan("") : 0.0);
     for (int iy = 0; iy < ns; ++iy)
       std::fill(ms.begin() + (size_t)iy * n_, ms.begin() + (size_t)(iy + 1) * n_, base[(size_t)iy]);
   }
@@ -963,6 +979,10 @@ void EnsembleCore::setvar_dated_members(const std::string &capability, const int
   for (int i = 0; i < nyears; ++i) {
     if (years[i] < scen_.start || years[i] > scen_.end)
       throw std::runtime_error("date outside startDate..endDate");
+    // a CH4 constraint at startDate replaces the preindustrial concentration of the whole core
+    // (ch4_component.cpp:137-147): that one cannot differ between members
+    if (d->k == HXM_CH4_CON && years[i] == scen_.start)
+      throw std::runtime_error("CH4_constrain at startDate: one value for the whole core (setvar_dated)");
     std::copy(values + (size_t)i * n_, values + (size_t)(i + 1) * n_,
               ms.begin() + (size_t)(years[i] - scen_.start) * n_);
     miny = std::min(miny, years[i]);
@@ -987,12 +1007,21 @@ void EnsembleCore::upload_member_series() {
                          hipMemcpyHostToDevice, stream_), "upload member series");
     check(hipStreamSynchronize(stream_), "sync member series");
   }
+  upload_args();
+  mseries_dirty_ = false;
+}
+
+// the kernels' argument block: buffers + scenario scalars; the constraint mask also carries the
+// constraints that only some members hold
+void EnsembleCore::upload_args() {
   HxArgs a;
   a.buf = buffers();
   a.kc = kc_;
+  for (int k = 0; k < HXM_N; ++k)
+    if (!member_series_[k].empty()) a.kc.con_mask |= constraint_bit(k);
+  member_con_mask_ = a.kc.con_mask & ~kc_.con_mask;
   check(hipMemcpyAsync(d_args_, &a, sizeof a, hipMemcpyHostToDevice, stream_), "upload args");
   check(hipStreamSynchronize(stream_), "sync args");
-  mseries_dirty_ = false;
 }
 
 void EnsembleCore::lane_of_member(int *out) {
@@ -1083,11 +1112,7 @@ void EnsembleCore::upload_params() {
     for (double v : params_[HXP_LO_RATIO]) if (v != 0.0) lo_any = true;
     kc_.con_mask = (kc_.con_mask & ~HXC_LO) | (lo_any ? HXC_LO : 0);
     kc_.trk_iy = trk_iy();
-    HxArgs a;
-    a.buf = buffers();
-    a.kc = kc_;
-    check(hipMemcpyAsync(d_args_, &a, sizeof a, hipMemcpyHostToDevice, stream_), "upload args");
-    check(hipStreamSynchronize(stream_), "sync args");
+    upload_args();
   }
   params_dirty_ = false;
 }
@@ -1205,12 +1230,13 @@ void EnsembleCore::run(double runtodate) {
   // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
   // history pass every HX_DBLK years), so there is no global barrier to wait at
   const bool hf = d_out_[HXO_HEATFLUX] || d_out_[HXO_FLUX_MIXED] || d_out_[HXO_FLUX_INTERIOR];
-  bool ext = kc_.con_mask != 0;  // extended kernel: constraints or the extra diagnostics
+  const int con_mask = kc_.con_mask | member_con_mask_;
+  bool ext = con_mask != 0;  // extended kernel: constraints or the extra diagnostics
   for (int v = HXO_NPP; v < HXO_NVAR; ++v) if (d_out_[v]) ext = true;
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) ext = true;
   int con = ext ? 1 : 0;
   if (d_track_) {
-    if (kc_.con_mask & (HXC_CO2 | HXC_NBP))
+    if (con_mask & (HXC_CO2 | HXC_NBP))
       throw std::runtime_error("carbon tracking together with a CO2 or NBP constraint is not "
                                "supported (the constraint residual is an untracked source)");
     con = 2;

@@ -136,9 +136,11 @@ class EnsembleCore {
   int last_iy_ = 0;
   HxConst kc_{};
   std::vector<double> member_series_[HXM_N];  // host [ns][n_], member order; empty = shared
-  double *d_mseries_[HXM_N] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *d_mseries_[HXM_N] = {};
   bool mseries_dirty_ = false;
   void upload_member_series();
+  void upload_args();
+  int member_con_mask_ = 0;  // HXC_* bits that only per-member constraint series contribute
   void init_from_scenario();
   std::vector<std::string> halo_names_;
   std::vector<std::vector<double>> halo_conc_;  // [gas][ns] halocarbon concentrations, pptv

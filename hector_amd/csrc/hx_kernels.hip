@@ -610,7 +610,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       if constexpr (CON) {  // ch4_component.cpp:156-157
         if (kc.con_mask & HXC_CH4) {
-          const double c = sh[HXSH_CH4_CON];
+          double c = sh[HXSH_CH4_CON];
+          if (buf.mseries[HXM_CH4_CON]) c = HX_GCD(buf.mseries[HXM_CH4_CON])[(size_t)iy * buf.npad + mem];
           if (!isnan(c)) ch4 = c;
         }
       }
@@ -672,6 +673,15 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         yc.co2 = sh[HXSH_CO2_CON];
         yc.nbp_hi = sh[HXSH_NBP_CON];
         yc.nbp_lo = (sh - HXSH_STRIDE)[HXSH_NBP_CON];
+        {  // constraints that differ between members
+          const HxBuffers &buf = args->buf;
+          const size_t o = (size_t)iy * buf.npad + mem;
+          if (buf.mseries[HXM_CO2_CON]) yc.co2 = HX_GCD(buf.mseries[HXM_CO2_CON])[o];
+          if (buf.mseries[HXM_NBP_CON]) {
+            yc.nbp_hi = HX_GCD(buf.mseries[HXM_NBP_CON])[o];
+            yc.nbp_lo = HX_GCD(buf.mseries[HXM_NBP_CON])[o - buf.npad];
+          }
+        }
         yc.t_half = year - 0.5;
       }
       solve_year<B, false, CON>(m, args->kc, year - 1.0, year, yc);
@@ -743,7 +753,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
                       p_vol * sh[HXSH_RF_VOL];
         if constexpr (CON) {  // forcing_component.cpp:498-505
           if (kc.con_mask & HXC_FTOT) {
-            const double c = sh[HXSH_FTOT_CON];
+            double c = sh[HXSH_FTOT_CON];
+            if (buf.mseries[HXM_FTOT_CON]) c = HX_GCD(buf.mseries[HXM_FTOT_CON])[(size_t)iy * buf.npad + mem];
             if (!isnan(c)) ftot = c;
           }
         }
@@ -800,7 +811,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
         if constexpr (CON) {  // user-supplied temperature :510-525
           if (kc.con_mask & HXC_TAS) {
-            const double c = sh[HXSH_TAS_CON];
+            double c = sh[HXSH_TAS_CON];
+            if (buf.mseries[HXM_TAS_CON]) c = HX_GCD(buf.mseries[HXM_TAS_CON])[(size_t)iy * buf.npad + mem];
             if (!isnan(c)) {
               tgav = c;
               tl_new = (tgav - (1.0 - D_flnd) * D_bsi * sst_new) / D_flnd;

@@ -105,7 +105,16 @@ enum HxSharedCol {
 };
 
 // ---- optional per-member input series [ns][npad], overriding the shared column ----------
-enum HxMemberSeries { HXM_FFI = 0, HXM_DACCS, HXM_LUC_E, HXM_LUC_U, HXM_CH4_EM, HXM_N };
+enum HxMemberSeries {
+  HXM_FFI = 0, HXM_DACCS, HXM_LUC_E, HXM_LUC_U, HXM_CH4_EM,
+  // a constraint series per member (NaN = none for that member and year); the HXC_* bit of
+  // HxConst::con_mask is set when the scenario OR some member holds such a constraint
+  HXM_CO2_CON, HXM_NBP_CON, HXM_TAS_CON, HXM_FTOT_CON, HXM_CH4_CON,
+  // computed on the device (hx_gas_kernel) when N2O / halocarbon parameters differ between
+  // members: sqrt(N2O) and the sum of halocarbon + albedo + misc forcings of every year
+  HXM_SQRT_N2O, HXM_RF_OTHER,
+  HXM_N
+};
 
 // ---- status bits (per member) ---------------------------------------------
 #define HX_ERR_MASS 1u       // mass balance > 1e-3 PgC   simpleNbox-runtime.cpp:553-563
@@ -151,7 +160,7 @@ struct HxBuffers {
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   unsigned *hist_status; // ... and the members' status bits of every year [ns][npad]
   int n, npad, ker_per_member;
-  const double *mseries[HXM_N];  // per-member emissions (row iy as in the shared table) or nullptr
+  const double *mseries[HXM_N];  // per-member series (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
   int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)
   // carbon tracking (CON == 2 kernels): per-member origin matrix and its yearly record
