@@ -17,6 +17,8 @@ hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t s
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
 hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st);
 hipError_t hx_launch_or_flags(unsigned *status, const double *flag_row, int npad, hipStream_t st);
+hipError_t hx_launch_gas(const double *par, const double *ser, const double *h0, int nh, int ns,
+                         int npad, double *n2o_out, double *rf_other_out, hipStream_t st);
 hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st);
 hipError_t hx_launch_slr(const double *tgav, int npad, int start_year, int iy_to, double *out,
                          size_t var_stride, hipStream_t st);
@@ -416,6 +418,7 @@ void EnsembleCore::free_device() {
   d_track_ = d_track_out_f_ = d_track_out_v_ = nullptr;
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   fr(d_hist_status_);
+  fr(d_gas_par_); fr(d_gas_ser_); d_gas_par_ = d_gas_ser_ = nullptr;
   d_hist_ = nullptr; d_hist_status_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
   fr(d_diag_); fr(d_slr_); d_diag_ = d_slr_ = nullptr; diag_cap_ = 0; slr_valid_to_ = -1;
@@ -539,19 +542,38 @@ const SharedParamDef kSharedParams[] = {
     {"delta_n2o", "forcing", "(unitless)"}, {"rho_bc", "forcing", "W/m2/Tg"},
     {"rho_oc", "forcing", "W/m2/Tg"}, {"rho_so2", "forcing", "W/m2/Gg"},
     {"rho_nh3", "forcing", "W/m2/Tg"},
+    // N2O lifetime and conversion (component_data.hpp:274-275; INI keys of [N2O])
+    {"TN2O0", "N2O", "Years"}, {"UC_N2O", "N2O", "Tg/ppbv"},
 };
 }  // namespace
 
-// -> section of a shared scalar parameter ("" if `capability` is not one); *units gets its unit
+// -> section of a shared scalar parameter ("" if `capability` is not one); *units gets its unit,
+// *key the INI key it is stored under ("tau_<gas>" is the key "tau" of [<gas>_halocarbon])
 static std::string shared_param_section(const Scenario &scen, const std::string &capability,
-                                        std::string *units) {
+                                        std::string *units, std::string *key = nullptr) {
+  if (key) *key = capability;
   for (const SharedParamDef &d : kSharedParams)
     if (capability == d.name) { if (units) *units = d.units; return d.section; }
   for (const Halocarbon &h : scen.halocarbons) {
     if (capability == "rho_" + h.name) { if (units) *units = "W/m2/pptv"; return h.name + "_halocarbon"; }
     if (capability == "delta_" + h.name) { if (units) *units = "(unitless)"; return h.name + "_halocarbon"; }
+    if (capability == "tau_" + h.name) {
+      if (units) *units = "Years";
+      if (key) *key = "tau";
+      return h.name + "_halocarbon";
+    }
   }
   return "";
+}
+
+// The parameters of the N2O and halocarbon components that may differ between members: their
+// recurrences then run per member on the device (hx_gas_kernel) instead of once on the host.
+static bool gas_member_capable(const Scenario &scen, const std::string &capability) {
+  if (capability == "N0" || capability == "TN2O0" || capability == "UC_N2O") return true;
+  for (const Halocarbon &h : scen.halocarbons)
+    if (capability == "rho_" + h.name || capability == "delta_" + h.name || capability == "tau_" + h.name)
+      return true;
+  return false;
 }
 
 void EnsembleCore::setvar(const std::string &capability, const double *values, int nvalues,
@@ -561,17 +583,25 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
     return;
   }
   {
-    std::string expect;
-    const std::string sec = shared_param_section(scen_, capability, &expect);
+    std::string expect, key;
+    const std::string sec = shared_param_section(scen_, capability, &expect, &key);
     if (!sec.empty()) {
       if (units && units[0] && expect != units)
         throw std::runtime_error("Units: " + std::string(units) + " do not match expected: " +
                                  expect + " for " + capability);
-      for (int i = 1; i < nvalues; ++i)
-        if (values[i] != values[0])
+      bool uniform = true;
+      for (int i = 1; i < nvalues; ++i) if (values[i] != values[0]) uniform = false;
+      if (!uniform) {
+        if (nvalues != n_) throw std::runtime_error("setvar: need 1 or n_members values");
+        if (!gas_member_capable(scen_, capability))
           throw std::runtime_error(capability + " belongs to a member-independent component: one "
                                    "value for the whole core");
-      scen_.set_scalar(sec, capability, values[0]);
+        gas_member_[capability].assign(values, values + n_);
+      } else {
+        gas_member_.erase(capability);
+      }
+      scen_.set_scalar(sec, key, values[0]);  // (member 0's value where members differ)
+      gas_dirty_ = true;
       shared_dirty_ = true;
       last_iy_ = 0;
       need_spinup_ = true;
@@ -611,9 +641,12 @@ void EnsembleCore::getvar(const std::string &capability, double *out) const {
     return;
   }
   {
-    const std::string sec = shared_param_section(scen_, capability, nullptr);
+    std::string key;
+    const std::string sec = shared_param_section(scen_, capability, nullptr, &key);
     if (!sec.empty()) {
-      std::fill(out, out + n_, scen_.scalar(sec, capability));
+      auto it = gas_member_.find(capability);
+      if (it != gas_member_.end()) std::copy(it->second.begin(), it->second.end(), out);
+      else std::fill(out, out + n_, scen_.scalar(sec, key));
       return;
     }
   }
@@ -813,6 +846,7 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
       for (const char *dep : d->deps) if (dep) want[out_index(dep)] = true;
       continue;
     }
+    if (c == "N2O_concentration") continue;  // the N2O component's own series (shared or per member)
     if (host_output(c)) continue;  // answered from the scenario / the shared gas cycles
     if (c == "pH" || c == "PCO2" || c == "DIC" || c == "CO3" || c == "ML_ocean_c") {
       const std::string base = c == "ML_ocean_c" ? "ocean_c" : c;
@@ -1024,6 +1058,97 @@ void EnsembleCore::upload_args() {
   check(hipStreamSynchronize(stream_), "sync args");
 }
 
+// N2O and halocarbon recurrences per member on the device (hx_gas_kernel): parameter rows in
+// lane order, the member-independent series the recurrences read, and the two result series
+// the extended run kernel picks up instead of the per-year table's columns.
+void EnsembleCore::run_gas_kernel() {
+  gas_dirty_ = false;
+  auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  if (gas_member_.empty()) {  // back to the host's shared series
+    if (d_mseries_[HXM_N2O]) {
+      sync();
+      fr(d_mseries_[HXM_N2O]); fr(d_mseries_[HXM_RF_OTHER]);
+      d_mseries_[HXM_N2O] = d_mseries_[HXM_RF_OTHER] = nullptr;
+      upload_args();
+    }
+    return;
+  }
+  const Scenario &s = scen_;
+  const size_t np = (size_t)npad_, ns = (size_t)s.ns();
+  const size_t nh = s.halocarbons.size();
+  std::vector<size_t> horder(nh);  // forcings are summed in std::map key order ("RF_<gas>")
+  for (size_t h = 0; h < nh; ++h) horder[h] = h;
+  std::sort(horder.begin(), horder.end(), [&](size_t a, size_t b) {
+    return s.halocarbons[a].name < s.halocarbons[b].name;
+  });
+  auto member_value = [&](const std::string &cap, double dflt, size_t lane) {
+    auto it = gas_member_.find(cap);
+    if (it == gas_member_.end()) return dflt;
+    return it->second[(size_t)std::min(member_of_lane_[lane], n_ - 1)];
+  };
+  std::vector<double> par((3 + 3 * nh) * np), ser((4 + 2 * nh) * ns), h0(nh);
+  for (size_t l = 0; l < np; ++l) {
+    par[l] = member_value("N0", s.scalar("N2O", "N0"), l);
+    par[np + l] = member_value("TN2O0", s.scalar("N2O", "TN2O0"), l);
+    par[2 * np + l] = member_value("UC_N2O", s.scalar("N2O", "UC_N2O"), l);
+    for (size_t k = 0; k < nh; ++k) {
+      const Halocarbon &H = s.halocarbons[horder[k]];
+      par[(3 + 3 * k) * np + l] = member_value("tau_" + H.name, H.tau, l);
+      par[(4 + 3 * k) * np + l] = member_value("rho_" + H.name, H.rho, l);
+      par[(5 + 3 * k) * np + l] = member_value("delta_" + H.name, H.delta, l);
+    }
+  }
+  const auto &n2o_em = s.series("N2O", "N2O_emissions");
+  const auto &n2o_nat = s.series("N2O", "N2O_natural_emissions");
+  const std::vector<double> nanv(ns, std::nan(""));
+  auto con = [&](const std::string &sec, const std::string &key) -> const std::vector<double> & {
+    return s.has_series(sec, key) ? s.series(sec, key) : nanv;
+  };
+  const auto &n2o_con = con("N2O", "N2O_constrain");
+  const auto albedo = s.has_series("simpleNbox", "RF_albedo") ? s.series("simpleNbox", "RF_albedo")
+                                                                : std::vector<double>(ns, -0.2);
+  const auto misc = s.has_series("forcing", "RF_misc") ? s.series("forcing", "RF_misc")
+                                                        : std::vector<double>(ns, 0.0);
+  for (size_t iy = 0; iy < ns; ++iy) {
+    ser[iy] = n2o_em[iy] + n2o_nat[iy];
+    ser[ns + iy] = n2o_con[iy];
+    ser[2 * ns + iy] = albedo[iy];
+    ser[3 * ns + iy] = misc[iy];
+  }
+  for (size_t k = 0; k < nh; ++k) {
+    const Halocarbon &H = s.halocarbons[horder[k]];
+    const auto &hc = con(H.name + "_halocarbon", H.name + "_constrain");
+    h0[k] = H.H0;
+    for (size_t iy = 0; iy < ns; ++iy) {
+      const double emissMol = H.emissions[iy] / H.molarMass * 1.0;  // halocarbon_component.cpp:194-199
+      ser[(4 + 2 * k) * ns + iy] = emissMol / (0.1 * 1.8);
+      ser[(5 + 2 * k) * ns + iy] = hc[iy];
+    }
+  }
+  sync();
+  fr(d_gas_par_); fr(d_gas_ser_);
+  d_gas_par_ = d_gas_ser_ = nullptr;
+  double *d_h0 = nullptr;
+  check(hipMalloc(&d_gas_par_, sizeof(double) * par.size()), "hipMalloc gas parameters");
+  check(hipMalloc(&d_gas_ser_, sizeof(double) * (ser.size() + nh)), "hipMalloc gas series");
+  d_h0 = d_gas_ser_ + ser.size();
+  if (!d_mseries_[HXM_N2O]) {
+    check(hipMalloc(&d_mseries_[HXM_N2O], sizeof(double) * ns * np), "hipMalloc N2O series");
+    check(hipMalloc(&d_mseries_[HXM_RF_OTHER], sizeof(double) * ns * np), "hipMalloc RF series");
+  }
+  check(hipMemcpyAsync(d_gas_par_, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice,
+                       stream_), "upload gas parameters");
+  check(hipMemcpyAsync(d_gas_ser_, ser.data(), sizeof(double) * ser.size(), hipMemcpyHostToDevice,
+                       stream_), "upload gas series");
+  check(hipMemcpyAsync(d_h0, h0.data(), sizeof(double) * nh, hipMemcpyHostToDevice, stream_),
+        "upload gas preindustrial values");
+  check(hx_launch_gas(d_gas_par_, d_gas_ser_, d_h0, (int)nh, (int)ns, npad_,
+                      const_cast<double *>(d_mseries_[HXM_N2O]),
+                      const_cast<double *>(d_mseries_[HXM_RF_OTHER]), stream_), "gas kernel");
+  check(hipStreamSynchronize(stream_), "gas kernel sync");
+  upload_args();
+}
+
 void EnsembleCore::lane_of_member(int *out) {
   prepare();
   std::memcpy(out, lane_of_member_.data(), sizeof(int) * (size_t)n_);
@@ -1131,7 +1256,9 @@ void EnsembleCore::prepare() {
   if (params_dirty_) {
     upload_params();
     for (int k = 0; k < HXM_N; ++k) if (!member_series_[k].empty()) mseries_dirty_ = true;  // lanes may have moved
+    gas_dirty_ = true;
   }
+  if (gas_dirty_ || (!gas_member_.empty() && !d_mseries_[HXM_N2O])) run_gas_kernel();
   if (mseries_dirty_) upload_member_series();
   if (!need_spinup_) return;
   // Spinup is independent of every parameter that is not in the spinup set
@@ -1295,10 +1422,61 @@ bool EnsembleCore::fetch_host(const std::string &capability_in, int year0, int y
     return capability.size() > suf.size() &&
            capability.compare(capability.size() - suf.size(), suf.size(), suf) == 0;
   };
+  if (capability == "N2O_concentration" && !gas_member_.empty() &&
+      (gas_member_.count("N0") || gas_member_.count("TN2O0") || gas_member_.count("UC_N2O")))
+    return false;  // differs between members: answered from the device series (fetchvars)
   if (ser.empty() && capability == "N2O_concentration") {
     ser.resize((size_t)ns);
     for (int iy = 0; iy < ns; ++iy) ser[(size_t)iy] = shared_[(size_t)iy * HXSH_STRIDE + HXSH_N2O];
     computed = true;
+  }
+  if (ser.empty() && (ends(csuf) || capability.compare(0, 3, "RF_") == 0)) {
+    // a gas whose lifetime / efficiency differs between members: its recurrence per member, here
+    // on the host for the one gas asked for (halocarbon_component.cpp:181-229)
+    for (size_t h = 0; h < scen_.halocarbons.size(); ++h) {
+      const Halocarbon &H = scen_.halocarbons[h];
+      const bool conc = capability == H.name + csuf, rf = capability == "RF_" + H.name;
+      if (!(conc || rf)) continue;
+      if (!(gas_member_.count("tau_" + H.name) || (rf && (gas_member_.count("rho_" + H.name) ||
+                                                           gas_member_.count("delta_" + H.name)))))
+        break;
+      if (!out_host) return true;
+      if (shared_dirty_ || need_spinup_ || gas_dirty_)
+        throw std::runtime_error("fetchvars: run the core after changing inputs");
+      if (year0 < scen_.start || year1 > last_date() || year1 < year0)
+        throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
+      auto val = [&](const std::string &cap, double dflt, int i) {
+        auto it = gas_member_.find(cap);
+        return it == gas_member_.end() ? dflt : it->second[(size_t)i];
+      };
+      const std::string ckey = H.name + "_halocarbon." + H.name + "_constrain";
+      const std::vector<double> *hc = scen_.has_series(H.name + "_halocarbon", H.name + "_constrain")
+                                          ? &scen_.series(H.name + "_halocarbon", H.name + "_constrain") : nullptr;
+      const int base = kc_.baseyear_idx;
+      std::vector<double> v((size_t)ns);
+      for (int i = 0; i < n_; ++i) {
+        const double tau = val("tau_" + H.name, H.tau, i), rho = val("rho_" + H.name, H.rho, i),
+                     delta = val("delta_" + H.name, H.delta, i);
+        const double expfac = std::exp(-(1 / tau));
+        double c = H.H0;
+        for (int iy = 0; iy < ns; ++iy) {
+          if (iy >= 1) {
+            const double dconc = (H.emissions[(size_t)iy] / H.molarMass * 1.0) / (0.1 * 1.8);
+            c = c * expfac + dconc * tau * (1.0 - expfac);
+            if (hc && !std::isnan((*hc)[(size_t)iy])) c = (*hc)[(size_t)iy];
+          }
+          const double rf_un = rho * c;
+          v[(size_t)iy] = conc ? c : (iy >= 1 ? rf_un + delta * rf_un : 0.0);
+        }
+        for (int y = year0; y <= year1; ++y) {
+          const int iy = y - scen_.start;
+          double x = v[(size_t)iy];
+          if (rf) x = (iy >= base) ? x - v[(size_t)base] : 0.0;
+          out_host[(size_t)(y - year0) * n_ + i] = x;
+        }
+      }
+      return true;
+    }
   }
   if (ser.empty() && (ends(csuf) || ends(esuf) || capability.compare(0, 3, "RF_") == 0)) {
     for (size_t h = 0; h < scen_.halocarbons.size(); ++h) {
@@ -1523,6 +1701,7 @@ void EnsembleCore::compute_derived(const std::string &capability, int iy0, int n
   HxDiagArgs a{};
   a.npad = npad_; a.iy0 = iy0; a.ny = ny; a.base_idx = kc_.baseyear_idx;
   a.shared = d_shared_;
+  a.n2o_members = d_mseries_[HXM_N2O];
   a.lo_ratio = d_params_ + (size_t)HXP_LO_RATIO * np;
   a.sqrtN0 = kc_.sqrtN0; a.sqrtM0 = kc_.sqrtM0; a.M0f = kc_.M0f;
   a.delta_n2o = kc_.delta_n2o; a.delta_ch4 = kc_.delta_ch4;
@@ -1568,9 +1747,10 @@ void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1
         return;
       }
   }
+  const bool n2o_members = capability == "N2O_concentration" && d_mseries_[HXM_N2O];
   const DerivedDef *dd = derived_of(capability);
-  const int v = dd ? -1 : out_index(capability);
-  if (!dd && !d_out_[v])
+  const int v = (dd || n2o_members) ? -1 : out_index(capability);
+  if (!dd && !n2o_members && !d_out_[v])
     throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");
   if (year0 < scen_.start || year1 > last_date() || year1 < year0)
     throw std::runtime_error("fetchvars: dates must lie between startDate and the current date");
@@ -1594,6 +1774,8 @@ void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1
     }
     compute_derived(capability, iy0, ny);
     src = d_diag_;
+  } else if (n2o_members) {
+    src = d_mseries_[HXM_N2O] + (size_t)iy0 * npad_;
   } else {
     src = d_out_[v] + (size_t)iy0 * npad_;
   }

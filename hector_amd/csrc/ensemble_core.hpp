@@ -140,6 +140,11 @@ class EnsembleCore {
   bool mseries_dirty_ = false;
   void upload_member_series();
   void upload_args();
+  // N2O / halocarbon parameters that differ between members: capability -> [n_] (member order)
+  std::map<std::string, std::vector<double>> gas_member_;
+  double *d_gas_par_ = nullptr, *d_gas_ser_ = nullptr;
+  void run_gas_kernel();  // fills the per-member N2O and halocarbon-forcing series
+  bool gas_dirty_ = false;
   int member_con_mask_ = 0;  // HXC_* bits that only per-member constraint series contribute
   void init_from_scenario();
   std::vector<std::string> halo_names_;

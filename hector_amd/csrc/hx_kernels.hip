@@ -124,11 +124,12 @@ __global__ __launch_bounds__(256) void hx_derive_kernel(const double *params, do
 
 // The DOECLIM history pass (in-kernel device call; see DESIGN.md section 4 for
 // the algorithm): one lane = one member, all HX_DBLK block years, two sweeps of 16
-// accumulators.  Deliberately NOT inlined: as a real call it gets its own register
-// allocation (16 loads in flight need landing registers the year loop does not have),
-// and the caller's live registers are saved around it once per HX_DBLK years.
+// accumulators.  (Round 1 kept it out of line for its own register allocation; with ROCm 7.2's
+// compiler a real call inside this kernel turned out fragile -- two of the 32 instantiations
+// faulted on the device after unrelated edits, see doeclim_pass_mfma -- so it is inlined.  It
+// now serves only ensembles whose members differ in diffusivity.)
 template <bool KERPM, bool HF>
-__device__ __attribute__((noinline)) void doeclim_pass_dev(const double *sst_hist,
+__device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
                                                            const double *ker, double *part,
                                                            double *part2, int ns, int npad,
                                                            int blk0, int mem) {
@@ -733,7 +734,15 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
         const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
         const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
-        const double sqN = sh[HXSH_SQRT_N2O], sqM = hx_sqrt(ch4), sqC = hx_sqrt(co2c);
+        double sqN = sh[HXSH_SQRT_N2O], sqN0 = kc.sqrtN0, rf_other = sh[HXSH_RF_OTHER];
+        if constexpr (CON) {  // N2O / halocarbon parameters that differ between members
+          if (buf.mseries[HXM_N2O]) {
+            sqN = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[(size_t)iy * buf.npad + mem]);
+            sqN0 = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[mem]);
+            rf_other = HX_GCD(buf.mseries[HXM_RF_OTHER])[(size_t)iy * buf.npad + mem];
+          }
+        }
+        const double sqM = hx_sqrt(ch4), sqC = hx_sqrt(co2c);
         const double C_alpha_max = m.C0 - (b1 / (2 * a1));
         double alpha_prime;
         if (co2c > C_alpha_max) alpha_prime = d1 - ((b1 * b1) / (4 * a1));
@@ -742,13 +751,13 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         else alpha_prime = d1;
         const double sarf_co2 = (alpha_prime + c1 * sqN) * ln_co2r;
         const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
-        const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - kc.sqrtN0);
+        const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - sqN0);
         const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
         const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
         const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
         const double fh2o = 0.0485 * ((ch4 - kc.M0f) * kc.inv_h2o_span);
         const double fo3 = 0.042 * o3;
-        double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + sh[HXSH_RF_OTHER]) +
+        double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
                        p_aero * sh[HXSH_RF_AERO]) +
                       p_vol * sh[HXSH_RF_VOL];
         if constexpr (CON) {  // forcing_component.cpp:498-505
@@ -985,6 +994,55 @@ __global__ void hx_or_flags_kernel(unsigned *status, const double *flag_row, int
 }
 
 // ===========================================================================
+// N2OComponent::run (src/n2o_component.cpp:152-191) and HalocarbonComponent::run
+// (src/halocarbon_component.cpp:181-229) per member, for ensembles whose N2O or halocarbon
+// parameters differ between members (otherwise the host runs them once while it builds the
+// per-year table).  Neither depends on the carbon-climate state, so they run ahead of the year
+// loop, one member per thread: N2O[t] and the year's halocarbon + albedo + misc forcing.
+//   par [3 + 3 nh][npad]: N0, TN2O0, UC_N2O, then tau, rho, delta of each gas
+//   ser [4 + 2 nh][ns]:   N2O emissions (anthropogenic + natural), N2O constraint (NaN = none),
+//                         RF_albedo, RF_misc, then per gas the year's concentration increment
+//                         per unit lifetime (emissions / molar mass / 0.18) and its constraint
+//   h0 [nh]: preindustrial concentrations.  Gases in the order their forcings are summed.
+// ===========================================================================
+__global__ __launch_bounds__(64) void hx_gas_kernel(const double *par, const double *ser,
+                                                    const double *h0, int nh, int ns, int npad,
+                                                    double *n2o_out, double *rf_other_out) {
+  const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mem >= npad) return;
+  const size_t np = (size_t)npad;
+  const double N0 = par[mem], TN2O0 = par[np + mem], UC = par[2 * np + mem];
+  const double *em = ser, *ncon = ser + ns, *alb = ser + 2 * (size_t)ns, *misc = ser + 3 * (size_t)ns;
+  constexpr int MAXH = 40;
+  double conc[MAXH], expfac[MAXH];
+  for (int h = 0; h < nh && h < MAXH; ++h) {
+    conc[h] = h0[h];
+    expfac[h] = exp(-(1 / par[(size_t)(3 + 3 * h) * np + mem]));
+  }
+  const double N0f = isnan(ncon[0]) ? N0 : ncon[0];  // n2o_component.cpp:137-145
+  double n2o = N0f;
+  n2o_out[mem] = n2o;
+  rf_other_out[mem] = (0.0 + alb[0]) + misc[0];
+  for (int iy = 1; iy < ns; ++iy) {
+    const double tau_n = TN2O0 * pow(n2o / N0f, -0.05);
+    n2o = n2o + (em[iy] / UC - n2o / tau_n);
+    if (!isnan(ncon[iy])) n2o = ncon[iy];
+    double rf_h = 0.0;
+    for (int h = 0; h < nh && h < MAXH; ++h) {
+      const double tau = par[(size_t)(3 + 3 * h) * np + mem], rho = par[(size_t)(4 + 3 * h) * np + mem],
+                   delta = par[(size_t)(5 + 3 * h) * np + mem];
+      const double dconc = ser[(size_t)(4 + 2 * h) * ns + iy], hc = ser[(size_t)(5 + 2 * h) * ns + iy];
+      conc[h] = conc[h] * expfac[h] + dconc * tau * (1.0 - expfac[h]);
+      if (!isnan(hc)) conc[h] = hc;
+      const double rf_un = rho * conc[h];
+      rf_h = rf_h + (rf_un + delta * rf_un);
+    }
+    n2o_out[(size_t)iy * np + mem] = n2o;
+    rf_other_out[(size_t)iy * np + mem] = (rf_h + alb[iy]) + misc[iy];
+  }
+}
+
+// ===========================================================================
 // Output gather: members are assigned to lanes in a behaviour-sorted order (see
 // EnsembleCore::upload_params); results go back to the caller in member order.
 // dst[y][member] = src[y][lane_of_member[member]]
@@ -1135,7 +1193,8 @@ __device__ __forceinline__ double diag_rf(int kind, const HxDiagArgs &a, int iy,
   const size_t o = (size_t)iy * a.npad + mem;
   const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
   const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
-  const double sqN = sh[HXSH_SQRT_N2O];
+  double sqN = sh[HXSH_SQRT_N2O], sqN0 = a.sqrtN0;
+  if (a.n2o_members) { sqN = sqrt(a.n2o_members[o]); sqN0 = sqrt(a.n2o_members[mem]); }
   if (kind == HXG_RF_O3) return 0.042 * a.o3[o];
   const double ch4 = a.ch4[o], sqM = sqrt(ch4);
   if (kind == HXG_RF_H2O) return 0.0485 * ((ch4 - a.M0f) / (1831 - a.M0f));
@@ -1144,7 +1203,7 @@ __device__ __forceinline__ double diag_rf(int kind, const HxDiagArgs &a, int iy,
     return (a.delta_ch4 * sarf) + sarf;
   }
   const double sqC = sqrt(a.co2[o]);
-  const double sarf = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - a.sqrtN0);
+  const double sarf = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - sqN0);
   return (a.delta_n2o * sarf) + sarf;
 }
 
@@ -1349,6 +1408,13 @@ hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t s
 }
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st) {
   hipLaunchKernelGGL(hx_broadcast_u32_kernel, dim3((npad + 255) / 256), dim3(256), 0, st, v, npad);
+  return hipGetLastError();
+}
+hipError_t hx_launch_gas(const double *par, const double *ser, const double *h0, int nh, int ns,
+                         int npad, double *n2o_out, double *rf_other_out, hipStream_t st) {
+  if (nh > 40) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hx_gas_kernel, dim3((npad + 63) / 64), dim3(64), 0, st, par, ser, h0, nh, ns,
+                     npad, n2o_out, rf_other_out);
   return hipGetLastError();
 }
 hipError_t hx_launch_or_flags(unsigned *status, const double *flag_row, int npad, hipStream_t st) {

@@ -111,8 +111,9 @@ enum HxMemberSeries {
   // HxConst::con_mask is set when the scenario OR some member holds such a constraint
   HXM_CO2_CON, HXM_NBP_CON, HXM_TAS_CON, HXM_FTOT_CON, HXM_CH4_CON,
   // computed on the device (hx_gas_kernel) when N2O / halocarbon parameters differ between
-  // members: sqrt(N2O) and the sum of halocarbon + albedo + misc forcings of every year
-  HXM_SQRT_N2O, HXM_RF_OTHER,
+  // members: the N2O concentration and the sum of halocarbon + albedo + misc forcings of every
+  // year (row 0 of the N2O series is the member's preindustrial value)
+  HXM_N2O, HXM_RF_OTHER,
   HXM_N
 };
 
@@ -184,6 +185,7 @@ struct HxDiagArgs {
   const double *co2, *ch4, *o3, *tgav;
   const double *lo_ratio;                  // parameter row (ocean_tas)
   const double *shared;                    // per-year table
+  const double *n2o_members;               // per-member N2O series [ns][npad] or null (RF_N2O)
   double deltaT, inv_vol;                  // of the box
   double sqrtN0, sqrtM0, M0f, delta_n2o, delta_ch4;
   int base_idx, npad, iy0, ny;

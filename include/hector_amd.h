@@ -52,8 +52,12 @@ int hx_shutdown(hx_core *core);
  * nvalues is 1 (every member) or n_members.  units: NULL/"" = unchecked, else it
  * must match the reference's unit string (e.g. "degC" for S).  Like the R
  * wrapper this invalidates results from date 0 (the next run respins if needed).
- * Parameters of the member-independent components (delta_co2, rho_bc, rho_<gas>, M0, N0,
- * Tsoil, Tstrat ...) take one value for the whole core. */
+ * Parameters of the member-independent components (delta_co2, rho_bc, M0, Tsoil, Tstrat ...)
+ * take one value for the whole core -- except those of the N2O and halocarbon components
+ * (N0, TN2O0, UC_N2O: src/n2o_component.cpp:95-130; tau_<gas> = the INI key "tau" of
+ * [<gas>_halocarbon], rho_<gas>, delta_<gas>: src/halocarbon_component.cpp:118-150), which the
+ * reference perturbs per run: with one value per member their recurrences run per member on
+ * the device ahead of the year loop (16 B per member-year of HBM). */
 int hx_setvar(hx_core *core, const char *capability, const double *values, int nvalues,
               const char *units);
 /* setvar(core, dates, var, values, unit) for a scenario INPUT series (emissions, SV,
@@ -67,8 +71,10 @@ int hx_setvar_dated(hx_core *core, const char *capability, const int *years, con
 /* The same with a different value for every member -- the reference's "re-run a period with new
  * emissions per run" pattern (vignettes/ex_hector_apply.Rmd; one reset/setvar/run per run
  * there), for all members in one run: values[i * n_members + member] is the value of
- * years[i].  ffi_emissions, luc_emissions, daccs_uptake, luc_uptake, CH4_emissions
- * (8 B per member-year of HBM each, once used). */
+ * years[i].  ffi_emissions, luc_emissions, daccs_uptake, luc_uptake, CH4_emissions, and the
+ * constraints CO2_constrain, NBP_constrain, tas_constrain, RF_tot_constrain, CH4_constrain
+ * (NaN = no constraint for that member and year; a CH4 constraint at startDate is core-wide)
+ * -- 8 B per member-year of HBM each, once used. */
 int hx_setvar_dated_members(hx_core *core, const char *capability, const int *years,
                             const double *values, int nyears, const char *units);
 /* Keep every year's component state in HBM so hx_reset can return to any computed date --
