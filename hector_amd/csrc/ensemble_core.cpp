@@ -209,8 +209,8 @@ void EnsembleCore::init_from_scenario() {
       if (std::find(biomes.begin(), biomes.end(), b) == biomes.end()) biomes.push_back(b);
     }
     if (!biomes.empty()) {
-      if ((int)biomes.size() > HX_MAXB)
-        throw std::runtime_error("at most " + std::to_string(HX_MAXB) + " biomes are supported");
+      if ((int)biomes.size() > HX_BDYN)
+        throw std::runtime_error("at most " + std::to_string(HX_BDYN) + " biomes are supported");
       B_ = (int)biomes.size();
       biome_names_ = biomes;
       const std::vector<std::vector<double>> global = params_;
@@ -496,9 +496,10 @@ HxBuffers EnsembleCore::buffers() const {
     if (d_out_[v] && v != HXO_SST && v != HXO_TLAND && v != HXO_CO2 && v != HXO_TGAV) b.out_rare = 1;
   for (int v = HXO_NPP; v <= HXO_CA_RESIDUAL; ++v) if (d_out_[v]) b.stash_diag = 1;
   for (int v = HXO_BIOME0; v < HXO_NVAR; ++v) if (d_out_[v]) b.biome_diag = 1;
-  for (int bb = 0; bb < HX_MAXB; ++bb)
+  for (int bb = 0; bb < HX_BDYN; ++bb)
     if (d_out_[HXO_B(HXOB_NPP, bb)] || d_out_[HXO_B(HXOB_RH, bb)]) b.stash_diag = 1;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
+  b.nbiome = B_;
   return b;
 }
 
@@ -672,8 +673,8 @@ void EnsembleCore::split_biome_of(const std::string &old_biome,
                                   const double *fnpp) {
   const int nb = (int)names.size(), ob = biome_index(old_biome);
   if (ob < 0) throw std::runtime_error("Biome '" + old_biome + "' missing from biome list.");
-  if (nb < 1 || B_ - 1 + nb > HX_MAXB)
-    throw std::runtime_error("split_biome: at most " + std::to_string(HX_MAXB) + " biomes supported");
+  if (nb < 1 || B_ - 1 + nb > HX_BDYN)
+    throw std::runtime_error("split_biome: at most " + std::to_string(HX_BDYN) + " biomes supported");
   for (int a = 0; a < nb; ++a) {
     if (names[(size_t)a].empty() || names[(size_t)a].find('.') != std::string::npos)
       throw std::runtime_error("split_biome: bad biome name '" + names[(size_t)a] + "'");
@@ -746,10 +747,10 @@ void EnsembleCore::split_biome_of(const std::string &old_biome,
 // "<biome>.<variable>" outputs are enabled by biome index: keep them with their biome when the
 // list is renumbered (old_of_new[b] = previous index of new biome b, -1 = a new biome)
 void EnsembleCore::remap_biome_outputs(const std::vector<int> &old_of_new) {
-  bool was[HXOB_N][HX_MAXB];
+  bool was[HXOB_N][HX_BDYN];
   for (int k = 0; k < HXOB_N; ++k)
-    for (int b = 0; b < HX_MAXB; ++b) { was[k][b] = out_enabled_[HXO_B(k, b)]; out_enabled_[HXO_B(k, b)] = false; }
-  for (size_t b = 0; b < old_of_new.size() && b < (size_t)HX_MAXB; ++b)
+    for (int b = 0; b < HX_BDYN; ++b) { was[k][b] = out_enabled_[HXO_B(k, b)]; out_enabled_[HXO_B(k, b)] = false; }
+  for (size_t b = 0; b < old_of_new.size() && b < (size_t)HX_BDYN; ++b)
     if (old_of_new[b] >= 0)
       for (int k = 0; k < HXOB_N; ++k) out_enabled_[HXO_B(k, (int)b)] = was[k][old_of_new[b]];
 }
@@ -766,8 +767,8 @@ void EnsembleCore::create_biome(const std::string &biome) {
     throw std::runtime_error("Biome '" + biome + "' is already in `biome_list`.");
   if (biome.empty() || biome.find('.') != std::string::npos)
     throw std::runtime_error("create_biome: bad biome name '" + biome + "'");
-  if (B_ >= HX_MAXB)
-    throw std::runtime_error("create_biome: at most " + std::to_string(HX_MAXB) + " biomes supported");
+  if (B_ >= HX_BDYN)
+    throw std::runtime_error("create_biome: at most " + std::to_string(HX_BDYN) + " biomes supported");
   const int last = HXP_NGLOBAL + (B_ - 1) * HXPB_N;
   for (int k = 0; k < HXPB_N; ++k) {
     const bool pool = k == HXPB_VEG0 || k == HXPB_DET0 || k == HXPB_SOIL0 || k == HXPB_PF0 ||
@@ -1363,6 +1364,9 @@ void EnsembleCore::run(double runtodate) {
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) ext = true;
   int con = ext ? 1 : 0;
   if (d_track_) {
+    if (B_ > HX_MAXB)
+      throw std::runtime_error("carbon tracking is available for up to " + std::to_string(HX_MAXB) +
+                               " biomes (the looped kernels for more biomes carry no origin maps)");
     if (con_mask & (HXC_CO2 | HXC_NBP))
       throw std::runtime_error("carbon tracking together with a CO2 or NBP constraint is not "
                                "supported (the constraint residual is an untracked source)");

@@ -52,7 +52,8 @@ class EnsembleCore {
                       const double *fveg, const double *fdet, const double *fsoil,
                       const double *fpf, const double *fnpp);
   // create_biome_impl / delete_biome_impl / rename_biome (src/rcpp_hector.cpp; SimpleNbox::
-  // createBiome, deleteBiome, renameBiome): at most HX_MAXB biomes
+  // createBiome, deleteBiome, renameBiome): at most HX_BDYN biomes (1..HX_MAXB run unrolled
+  // kernels, more the looped ones)
   void create_biome(const std::string &biome);
   void delete_biome(const std::string &biome);
   void rename_biome(const std::string &oldname, const std::string &newname);

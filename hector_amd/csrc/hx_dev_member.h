@@ -32,10 +32,15 @@ enum HxParkB1 { PKB_NPP0 = 0, PKB_F_NPPV, PKB_F_NPPD, PKB_F_LITTERD, PKB_RH_CH4_
                 PKB_FPF_STATIC, PKB_BETA, PKB_WF, PKB_LNQ10, PKB_MU, PKB_SIGMA, PKB_N };
 // multi-biome kernels park the nine per-biome arrays of Member instead (see BiomeArr)
 constexpr int HX_NBIOME_ARR = 9;
+// Template tag of the LOOPED kernels: the biome count is the core's (HxBuffers::nbiome, up to
+// HX_BDYN), every per-biome loop runs to it, the per-biome arrays are sized for HX_BDYN.  The
+// reference creates any number of biomes (simpleNbox.cpp:864-1124); 1-4 have unrolled kernels.
+constexpr int HX_DYN = 0;
+template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : B; }
 template <int B> constexpr int hx_npark() {
-  return PK_FFROZEN0 + B + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * B);
+  return PK_FFROZEN0 + hx_bmax<B>() + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * hx_bmax<B>());
 }
-template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + B; }
+template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + hx_bmax<B>(); }
 
 // Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
 // registers, 36 doubles for B = 4 on top of the solver's working set overflow 256 VGPRs +
@@ -85,7 +90,12 @@ struct Member {
   const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
   int iy;                 // year index being integrated
   int trk_iy;             // first tracked year index (tracking kernels)
+  int nb;                 // biome count (looped kernels)
 };
+// trip count of the per-biome loops
+template <int B> __device__ __forceinline__ int nbio(const Member<B> &m) {
+  if constexpr (B == HX_DYN) return m.nb; else return B;
+}
 #define PKM(m, slot) ((m).pk[(slot)][(m).lane])
 
 // biome constants of the land model, fetched where they are used
@@ -93,37 +103,58 @@ template <int B>
 struct LandK {
   double npp0[B], f_nppv[B], f_nppd[B], f_litterd[B], rh_ch4_frac[B], fpf_static[B];
 };
+// looped kernels: a column of the parameter table read where it is used (scalar load from the
+// uniform table when every member shares the biome constants, else the member's row)
+struct ParamCol {
+  hx_ccd upar;
+  hx_gcd par;
+  int npad, col;
+  __device__ __forceinline__ double operator[](int b) const {
+    const int row = HXP_NGLOBAL + b * HXPB_N + col;
+    return upar ? upar[row] : par[(size_t)row * npad];
+  }
+};
+template <>
+struct LandK<HX_DYN> {
+  ParamCol npp0, f_nppv, f_nppd, f_litterd, rh_ch4_frac, fpf_static;
+};
 template <int B>
 __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
   HX_FENCE();
-  if constexpr (B == 1) {
+  if constexpr (B == HX_DYN) {
+    const ParamCol c{m.upar, m.par, m.npad, 0};
+    k.npp0 = c; k.npp0.col = HXPB_NPP0; k.f_nppv = c; k.f_nppv.col = HXPB_F_NPPV;
+    k.f_nppd = c; k.f_nppd.col = HXPB_F_NPPD; k.f_litterd = c; k.f_litterd.col = HXPB_F_LITTERD;
+    k.rh_ch4_frac = c; k.rh_ch4_frac.col = HXPB_RH_CH4_FRAC;
+    k.fpf_static = c; k.fpf_static.col = HXPB_FPF_STATIC;
+  } else if constexpr (B == 1) {
     constexpr int o = hx_pkb1<B>();
     k.npp0[0] = PKM(m, o + PKB_NPP0); k.f_nppv[0] = PKM(m, o + PKB_F_NPPV);
     k.f_nppd[0] = PKM(m, o + PKB_F_NPPD); k.f_litterd[0] = PKM(m, o + PKB_F_LITTERD);
     k.rh_ch4_frac[0] = PKM(m, o + PKB_RH_CH4_FRAC); k.fpf_static[0] = PKM(m, o + PKB_FPF_STATIC);
-    return;
-  }
-  if (m.upar) {
-    // every member has the same biome constants (the usual case: ensembles perturb Q10, beta,
-    // warming factors): wave-uniform scalar loads instead of 6 B vector loads from HBM
+  } else {
+    if (m.upar) {
+      // every member has the same biome constants (the usual case: ensembles perturb Q10, beta,
+      // warming factors): wave-uniform scalar loads instead of 6 B vector loads from HBM
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        hx_ccd r = m.upar + (HXP_NGLOBAL + b * HXPB_N);
+        k.npp0[b] = r[HXPB_NPP0]; k.f_nppv[b] = r[HXPB_F_NPPV]; k.f_nppd[b] = r[HXPB_F_NPPD];
+        k.f_litterd[b] = r[HXPB_F_LITTERD]; k.rh_ch4_frac[b] = r[HXPB_RH_CH4_FRAC];
+        k.fpf_static[b] = r[HXPB_FPF_STATIC];
+      }
+      return;
+    }
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      hx_ccd r = m.upar + (HXP_NGLOBAL + b * HXPB_N);
-      k.npp0[b] = r[HXPB_NPP0]; k.f_nppv[b] = r[HXPB_F_NPPV]; k.f_nppd[b] = r[HXPB_F_NPPD];
-      k.f_litterd[b] = r[HXPB_F_LITTERD]; k.rh_ch4_frac[b] = r[HXPB_RH_CH4_FRAC];
-      k.fpf_static[b] = r[HXPB_FPF_STATIC];
+      hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
+      k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
+      k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
+      k.f_nppd[b] = r[(size_t)HXPB_F_NPPD * m.npad];
+      k.f_litterd[b] = r[(size_t)HXPB_F_LITTERD * m.npad];
+      k.rh_ch4_frac[b] = r[(size_t)HXPB_RH_CH4_FRAC * m.npad];
+      k.fpf_static[b] = r[(size_t)HXPB_FPF_STATIC * m.npad];
     }
-    return;
-  }
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
-    k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
-    k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
-    k.f_nppd[b] = r[(size_t)HXPB_F_NPPD * m.npad];
-    k.f_litterd[b] = r[(size_t)HXPB_F_LITTERD * m.npad];
-    k.rh_ch4_frac[b] = r[(size_t)HXPB_RH_CH4_FRAC * m.npad];
-    k.fpf_static[b] = r[(size_t)HXPB_FPF_STATIC * m.npad];
   }
 }
 
@@ -152,13 +183,17 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   m.npad = buf.npad;
   m.pk = park;
   m.lane = lane;
-  m.upar = (B > 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
-  if constexpr (B > 1) {
+  m.upar = (B != 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
+  m.nb = buf.nbiome;
+  if constexpr (B != 1) {
     constexpr int o = hx_pkb1<B>();
     ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
                                    &m.co2fert, &m.tempfertd, &m.f_new_thaw};
 #pragma unroll
-    for (int k = 0; k < HX_NBIOME_ARR; ++k) { arr[k]->base = park + o + k * B; arr[k]->lane = lane; }
+    for (int k = 0; k < HX_NBIOME_ARR; ++k) {
+      arr[k]->base = park + o + k * hx_bmax<B>();
+      arr[k]->lane = lane;
+    }
   }
   m.C0 = ldp(buf, HXP_C0, mem);
   // constants -> park
@@ -201,7 +236,7 @@ __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member
   m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem);
   m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < nbio<B>(m); ++b) {
     const int r = HXS_NGLOBAL + b * HXSB_N;
     m.veg[b] = lds_(buf, r + HXSB_VEG, mem); m.det[b] = lds_(buf, r + HXSB_DET, mem);
     m.soil[b] = lds_(buf, r + HXSB_SOIL, mem); m.pf[b] = lds_(buf, r + HXSB_PF, mem);
@@ -230,7 +265,7 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf_, int mem,
   sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
   sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < nbio<B>(m); ++b) {
     const int r = HXS_NGLOBAL + b * HXSB_N;
     sts_(buf, r + HXSB_VEG, mem, m.veg[b]); sts_(buf, r + HXSB_DET, mem, m.det[b]);
     sts_(buf, r + HXSB_SOIL, mem, m.soil[b]); sts_(buf, r + HXSB_PF, mem, m.pf[b]);
@@ -254,7 +289,7 @@ __device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
   sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
   if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
 #pragma unroll
-  for (int b = 0; b < B; ++b)
+  for (int b = 0; b < nbio<B>(m); ++b)
     sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
 }
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B>
   double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
   double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < nbio<B>(m); ++b) {
     const double n = m_npp(m, lk, b);
     npp_c += n;
     fav += n * lk.f_nppv[b];
@@ -245,7 +245,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
     }
   }
-  [[maybe_unused]] TrkStashIn<B> tk;
+  [[maybe_unused]] TrkStashIn<(B == HX_DYN ? 1 : B)> tk;  // (no tracking in the looped kernels)
   if constexpr (CON == 2 && !SPIN) {
     tk.yf = yf;
     tk.pre[0] = m.cHL; tk.pre[1] = m.cLL; tk.pre[2] = m.cIO; tk.pre[3] = m.cDO;
@@ -267,13 +267,14 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
 
   // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
   double npp_t = 0, rh_t = 0, pf_t = 0;
+  const int NB = nbio<B>(m);
 #pragma unroll
-  for (int b = 0; b < B; ++b) npp_t += m_npp(m, lk, b);
+  for (int b = 0; b < NB; ++b) npp_t += m_npp(m, lk, b);
 #pragma unroll
-  for (int b = 0; b < B; ++b)
+  for (int b = 0; b < NB; ++b)
     rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
 #pragma unroll
-  for (int b = 0; b < B; ++b) pf_t += m.pf[b];
+  for (int b = 0; b < NB; ++b) pf_t += m.pf[b];
   double alf = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
   const double npp_rh = npp_t + rh_t;
   double tpf = c5;
@@ -311,7 +312,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   const double inv_nr = hx_recip(npp_rh);
   const double inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < NB; ++b) {
     const double wt = (B == 1) ? 1.0
         : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
     const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
@@ -446,8 +447,8 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   auto load_pools = [&]() {
     double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll
-    for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
-                                   p += m.pf[b]; th += m.thawed[b]; }
+    for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+                                            p += m.pf[b]; th += m.thawed[b]; }
     y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;
     l4 = p; l5 = th; l7 = m.earth;
     if constexpr (CON) y[5] = th;

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   // hx_or_flags_kernel, so that a shared spinup neither loses nor spreads them)
   m.status = 0;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < nbio<B>(m); ++b) {
     const int r = HXP_NGLOBAL + b * HXPB_N;
     m.veg[b] = ldp(buf, r + HXPB_VEG0, mem); m.det[b] = ldp(buf, r + HXPB_DET0, mem);
     m.soil[b] = ldp(buf, r + HXPB_SOIL0, mem); m.pf[b] = ldp(buf, r + HXPB_PF0, mem);
@@ -335,13 +335,13 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
       const double o0 = m.atmos, oO = m.cDO + m.cIO + m.cLL + m.cHL, oE = m.earth;
       double ov = 0, od = 0, os = 0, op = 0, ot = 0;
 #pragma unroll
-      for (int b = 0; b < B; ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
+      for (int b = 0; b < nbio<B>(m); ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
                                      op += m.pf[b]; ot += m.thawed[b]; }
       m.nstash = 0; m.nsteps = 0;
       solve_year<B, true>(m, kc, (double)(step - 1), (double)step, YearCon{});
       double nv = 0, nd = 0, nso = 0, np = 0, nt = 0;
 #pragma unroll
-      for (int b = 0; b < B; ++b) { nv += m.veg[b]; nd += m.det[b]; nso += m.soil[b];
+      for (int b = 0; b < nbio<B>(m); ++b) { nv += m.veg[b]; nd += m.det[b]; nso += m.soil[b];
                                      np += m.pf[b]; nt += m.thawed[b]; }
       double mx = fabs(m.atmos - o0);
       mx = fmax(mx, fabs(nv - ov)); mx = fmax(mx, fabs(nd - od));
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   // SimpleNbox::run, first call: end_of_spinup_vegc  runtime.cpp:209-213
   double v1 = 0;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < nbio<B>(m); ++b) {
     v1 += m.veg[b];
     sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, 1.0);
   }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   {
     double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll
-    for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+    for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                    p += m.pf[b]; th += m.thawed[b]; }
     put(HXO_PERMAFROST_C, p); put(HXO_VEG_C, v); put(HXO_DET_C, d);
     put(HXO_SOIL_C, s); put(HXO_THAWED_C, th);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   put(HXO_C_HL, m.cHL); put(HXO_C_LL, m.cLL); put(HXO_C_IO, m.cIO); put(HXO_C_DO, m.cDO);
   put(HXO_F_FROZEN, 1.0); put(HXO_TAU_OH, kc.TOH0);
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < nbio<B>(m); ++b) {
     put(HXO_B(HXOB_VEG, b), m.veg[b]); put(HXO_B(HXOB_DET, b), m.det[b]);
     put(HXO_B(HXOB_SOIL, b), m.soil[b]); put(HXO_B(HXOB_PF, b), m.pf[b]);
     put(HXO_B(HXOB_THAWED, b), m.thawed[b]); put(HXO_B(HXOB_F_FROZEN, b), 1.0);
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     PKM(m, PK_LN_CH4) = hx_log(lds_(buf, HXS_CH4, mem));
     PKM(m, PK_LN_CO2R) = hx_log(hx_div(m.atmos * PGC2PPM, m.C0));
 #pragma unroll
-    for (int b = 0; b < B; ++b)
+    for (int b = 0; b < nbio<B>(m); ++b)
       PKM(m, PK_FFROZEN0 + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
   }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
@@ -513,8 +513,11 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       const int iold = iy - 203;
       const double tl_old =
           HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * buf.npad + mem];
-      double p_beta[B], p_wf[B], p_lnq10[B], p_mu[B], p_sigma[B], s_ffrozen[B];
+      constexpr int SB = (B == HX_DYN) ? 1 : B;  // (the looped kernels read these where they use them)
+      double p_beta[SB], p_wf[SB], p_lnq10[SB], p_mu[SB], p_sigma[SB], s_ffrozen[SB];
       LandK<B> lk;
+      if constexpr (B == HX_DYN) load_landk<B>(m, lk);
+      if constexpr (B != HX_DYN) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         s_ffrozen[b] = PKM(m, PK_FFROZEN0 + b);
@@ -546,11 +549,12 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           }
         }
       }
+      }
       // ---- OH, CH4, O3 ----
       double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
       if (iy > 1) {
 #pragma unroll
-        for (int b = 0; b < B; ++b) rh_ch4 += m_rh_tp_ch4(m, lk, b);
+        for (int b = 0; b < nbio<B>(m); ++b) rh_ch4 += m_rh_tp_ch4(m, lk, b);
       }
       double toh = 0.0;
       if (prev_ch4 != kc.M0)
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       // argument is known here -- both boxes' temperatures (SST of last year), the OH lifetime
       // exponent, the biomes' temperatures
       const double TcH = sst + 18 + (-16.4), TcL = sst + 18 + 2.9;
-      double Tb[B];
+      double Tb[SB];
       double lg[2 + B];
       lg[0] = TcH + 273.15; lg[1] = TcL + 273.15;
 #pragma unroll
@@ -643,6 +647,31 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
       const double lnc = PKM(m, PK_LN_CO2R);  // = log((atmos C * PGC2PPM) / C0), from last year's phase C
+      if constexpr (B == HX_DYN) {
+        // looped kernels: the same per biome, one at a time, parameters read where they are used
+        for (int b = 0; b < m.nb; ++b) {
+          const int pr = HXP_NGLOBAL + b * HXPB_N;
+          const double wf = ldp(buf, pr + HXPB_WF, mem), lnq10 = ldd(buf, HXD_NGLOBAL + b, mem);
+          m.co2fert[b] = 1 + ldp(buf, pr + HXPB_BETA, mem) * lnc;
+          const double Tbb = tland * wf;
+          m.tempfertd[b] = hx_exp(lnq10 * (Tbb * 0.1));
+          m.f_new_thaw[b] = 0.0;
+          if (m.pf[b] != 0.0) {
+            double ff = 1.0;
+            if (Tbb > 0) {
+              const double d = hx_div(hx_log(Tbb) - ldp(buf, pr + HXPB_PF_MU, mem),
+                                      ldp(buf, pr + HXPB_PF_SIGMA, mem) * 1.4142135623730951);
+              ff = 1 - erfc(-d) / 2;
+            }
+            m.f_new_thaw[b] = PKM(m, PK_FFROZEN0 + b) - ff;
+            PKM(m, PK_FFROZEN0 + b) = ff;
+          }
+          const double Trm = (iy > 1) ? (twin * wf) * 0.005 : 0.0;
+          const double tfs = hx_exp(lnq10 * (Trm * 0.1));
+          const double last = (iy > 1) ? m.tempferts[b] : 0.0;
+          m.tempferts[b] = fmax(tfs, last);
+        }
+      }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         m.co2fert[b] = 1 + p_beta[b] * lnc;
@@ -883,7 +912,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           buf.out[HXO_SOIL_C] || buf.out[HXO_THAWED_C]) {
         double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll
-        for (int b = 0; b < B; ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
+        for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                        p += m.pf[b]; th += m.thawed[b]; }
         if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, p);
         if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, v);
@@ -905,7 +934,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         LandK<B> lkb;
         load_landk<B>(m, lkb);
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
+        for (int b = 0; b < nbio<B>(m); ++b) {
           auto putb = [&](int k, double v) { if (buf.out[HXO_B(k, b)]) sto_(buf, HXO_B(k, b), o, v); };
           putb(HXOB_VEG, m.veg[b]); putb(HXOB_DET, m.det[b]); putb(HXOB_SOIL, m.soil[b]);
           putb(HXOB_PF, m.pf[b]); putb(HXOB_THAWED, m.thawed[b]);
@@ -921,10 +950,10 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         load_landk<B>(m, lk);
         double rch4 = 0, ptot = 0, ff = 0;
 #pragma unroll
-        for (int b = 0; b < B; ++b) { rch4 += m_rh_tp_ch4(m, lk, b); ptot += m.pf[b]; }
+        for (int b = 0; b < nbio<B>(m); ++b) { rch4 += m_rh_tp_ch4(m, lk, b); ptot += m.pf[b]; }
         if (ptot > 0.0) {
 #pragma unroll
-          for (int b = 0; b < B; ++b) ff += (m.pf[b] / ptot) * PKM(m, PK_FFROZEN0 + b);
+          for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * PKM(m, PK_FFROZEN0 + b);
         } else ff = 1.0;
         if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rch4);
         if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);
@@ -956,7 +985,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       HX_STAMP(m, 14);    // outputs
       if (buf.hist) {  // Core::reset(date) needs every component's state of every year
-        double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(B) * buf.npad;
+        double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(nbio<B>(m)) * buf.npad;
         store_state<B>(buf, mem, m, slab);
         store_park_state<B>(buf, mem, m, slab);
         HX_GU(buf.hist_status)[(size_t)iy * buf.npad + mem] = m.status;
@@ -1327,7 +1356,9 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
     case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
 #endif
     case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
-    default: return hipErrorInvalidValue;
+    default:
+      if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(hx_spinup_kernel<HX_DYN>, dim3(blocks), dim3(64), 0, st, d_args, d_steps);
   }
   return hipGetLastError();
 }
@@ -1343,16 +1374,25 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
                          int iy_from, int iy_to, hipStream_t st) {
   const int blocks = npad / 64;
   const size_t lds = 0;
+  if constexpr (B == HX_DYN) {  // the looped kernels: no carbon tracking
+    if (con == 2) return;
+  }
 #ifdef HX_MINIMAL_BUILD  // experiment builds (tools/prof): the plain kernel only
   (void)hf; (void)kpm; (void)con;
   hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   return;
 #endif
-  if (con == 2 && kpm)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
-  else if (con == 2)
-    hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
-  else if (con && kpm)
+  if constexpr (B != HX_DYN) {
+    if (con == 2 && kpm) {
+      hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
+    if (con == 2) {
+      hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
+  }
+  if (con && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (con)
     hipLaunchKernelGGL((hx_run_kernel<B, true, false, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
@@ -1374,7 +1414,9 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
     case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
 #endif
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
-    default: return hipErrorInvalidValue;
+    default:
+      if (B < 1 || B > HX_BDYN || con == 2) return hipErrorInvalidValue;
+      launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st);
   }
   return hipGetLastError();
 }

@@ -6,7 +6,9 @@
 #pragma once
 #include <stdint.h>
 
-#define HX_MAXB 4          // biomes supported by the kernels (template B = 1..4)
+#define HX_MAXB 4          // biome counts with a templated (fully unrolled) kernel: B = 1..4
+#define HX_BDYN 16         // more biomes, up to this many, run the looped kernels (template tag 0):
+                           // per-biome arrays in the LDS park, loops over the core's biome count
 #define HX_WAVE 64
 
 // ---- per-member parameter rows (read-only during a run) -------------------
@@ -79,14 +81,14 @@ enum HxOutVar {
   HXO_CA_RESIDUAL,
   HXO_RH_CH4, HXO_F_FROZEN, HXO_GMST, HXO_FLUX_MIXED, HXO_FLUX_INTERIOR,
   HXO_C_HL, HXO_C_LL, HXO_C_IO, HXO_C_DO, HXO_PCO2_HL, HXO_PCO2_LL, HXO_TAU_OH,
-  // per-biome "<biome>.veg_c" ...: index HXO_BIOME0 + k * HX_MAXB + biome, k = HxBiomeOut
+  // per-biome "<biome>.veg_c" ...: index HXO_BIOME0 + k * HX_BDYN + biome, k = HxBiomeOut
   HXO_BIOME0,
-  HXO_NVAR = HXO_BIOME0 + 11 * HX_MAXB
+  HXO_NVAR = HXO_BIOME0 + 11 * HX_BDYN
 };
 
 enum HxBiomeOut { HXOB_VEG = 0, HXOB_DET, HXOB_SOIL, HXOB_PF, HXOB_THAWED, HXOB_NPP, HXOB_RH,
                    HXOB_RH_CH4, HXOB_F_FROZEN, HXOB_TEMPFERTD, HXOB_TEMPFERTS, HXOB_N };
-#define HXO_B(k, b) (HXO_BIOME0 + (k) * HX_MAXB + (b))
+#define HXO_B(k, b) (HXO_BIOME0 + (k) * HX_BDYN + (b))
 
 // ---- shared per-year scenario table: row iy = year - startDate ------------
 enum HxSharedCol {
@@ -161,6 +163,7 @@ struct HxBuffers {
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   unsigned *hist_status; // ... and the members' status bits of every year [ns][npad]
   int n, npad, ker_per_member;
+  int nbiome;              // the core's biome count (the looped kernels' trip count)
   const double *mseries[HXM_N];  // per-member series (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
   int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)

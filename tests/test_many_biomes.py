@@ -1,0 +1,102 @@
+"""More than four biomes: the reference creates any number of biomes
+(src/simpleNbox.cpp:864-1124, biome_list.push_back at :928; tests/testthat/test_biome.R:127-300);
+1-4 run fully unrolled kernels, 5-16 the looped kernels (template tag HX_DYN: per-biome arrays
+in the LDS park, loops to the core's biome count).  Heterogeneous splits into 5, 8, 11 and 16
+biomes -- unequal pool fractions, per-biome Q10 / warming factor / beta, per member -- against
+the oracle; the identical-split property; per-biome outputs; create / delete keep working."""
+import numpy as np
+import pytest
+
+import hector_amd
+from hector_amd import ensemble
+from conftest import SCENARIO
+
+Y0 = 1745
+
+
+def many_biome_checks(lib, oracle, counts=(5, 8, 16), n=6, run_to=2300, **kw):
+    for nb in counts:
+        names = ["b%02d" % i for i in range(nb)]
+        r = np.random.default_rng(100 + nb)
+        fr = r.random(nb) + 0.3; fr /= fr.sum()
+        fs = r.random(nb) + 0.3; fs /= fs.sum()
+        c = hector_amd.Core(SCENARIO, n, lib_path=lib, **kw)
+        hector_amd.split_biome(c, "global", names, fveg_c=fr, fdetritus_c=fr, fsoil_c=fs,
+                               fpermafrost_c=fs, fnpp_flux0=fr)
+        assert c.biomes() == names
+        S = 2.0 + 3.0 * ensemble.uniform01(np.arange(n), 70, seed=nb)
+        q10 = {b: 1.2 + 1.6 * ensemble.uniform01(np.arange(n), 71 + i, seed=nb) for i, b in enumerate(names)}
+        wf = {b: 0.8 + 1.4 * r.random() for b in names}
+        beta = {b: 0.3 + 0.5 * r.random() for b in names}
+        c.setvar("S", S, "degC")
+        for b in names:
+            c.setvar(b + ".q10_rh", q10[b]).setvar(b + ".warmingfactor", wf[b]).setvar(b + ".beta", beta[b])
+        last = names[-1]
+        c.set_outputs(["CO2_concentration", "global_tas", "veg_c", "soil_c", "permafrost_c", "timesteps",
+                       last + ".veg_c", names[0] + ".soil_c", last + ".NPP"])
+        c.run(run_to)
+        assert (c.status() == 0).all(), nb
+        got = {v: c.fetchvars(v, (Y0, run_to)) for v in ("CO2_concentration", "global_tas", "veg_c", "soil_c",
+                                                        "permafrost_c", last + ".veg_c", names[0] + ".soil_c",
+                                                        last + ".NPP")}
+        ts = c.fetchvars("timesteps", (Y0 + 1, run_to))
+        nk = run_to - Y0 + 1
+        for i in range(n):
+            p = oracle.default_params()
+            d = {k: getattr(p, k)[0] for k in ("veg_c", "detritus_c", "soil_c", "permafrost_c", "npp_flux0")}
+            p.nbiome = nb
+            p.S = S[i]
+            for j, b in enumerate(names):
+                for k in ("f_nppv", "f_nppd", "f_litterd", "rh_ch4_frac", "pf_mu", "pf_sigma", "fpf_static"):
+                    getattr(p, k)[j] = getattr(p, k)[0]
+                p.veg_c[j] = d["veg_c"] * fr[j]; p.detritus_c[j] = d["detritus_c"] * fr[j]
+                p.soil_c[j] = d["soil_c"] * fs[j]; p.permafrost_c[j] = d["permafrost_c"] * fs[j]
+                p.npp_flux0[j] = d["npp_flux0"] * fr[j]
+                p.q10_rh[j] = q10[b][i]; p.warmingfactor[j] = wf[b]; p.beta[j] = beta[b]
+            ref, err, _ = oracle.run(p, run_to=run_to)
+            assert err == 0
+            rc = ref["CO2_concentration"][:nk]
+            assert (np.abs(got["CO2_concentration"][:, i] - rc) / rc).max() < 2e-8, (nb, i)
+            assert np.abs(got["global_tas"][:, i] - ref["global_tas"][:nk]).max() < 2e-8, (nb, i)
+            for v in ("veg_c", "soil_c", "permafrost_c"):
+                assert np.abs(got[v][:, i] - ref[v][:nk]).max() < 2e-8 * np.abs(ref[v]).max(), (nb, v, i)
+            assert np.array_equal(ts[:, i], ref["timesteps"][1:nk]), (nb, i)
+        assert (got[last + ".veg_c"] > 0).all() and (got[names[0] + ".soil_c"] > 0).all()
+        assert np.isfinite(got[last + ".NPP"]).all()
+        c.shutdown()
+
+
+def identical_split_equals_global(lib, nb=7, **kw):
+    """test_biome.R: an equal split with identical parameters reproduces the single-biome climate."""
+    one = hector_amd.Core(SCENARIO, 2, lib_path=lib, **kw).setvar("S", [2.5, 4.0]).run(2100)
+    many = hector_amd.Core(SCENARIO, 2, lib_path=lib, **kw).setvar("S", [2.5, 4.0])
+    many.split_biome(["x%d" % i for i in range(nb)])
+    many.run(2100)
+    for v in ("CO2_concentration", "global_tas"):
+        a, b = one.fetchvars(v, (Y0, 2100)), many.fetchvars(v, (Y0, 2100))
+        assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(a).max()), v
+
+
+def test_many_biomes_vs_oracle(emul_lib, oracle):
+    many_biome_checks(emul_lib, oracle, counts=(5, 11), n=2, run_to=2100, allow_emulation=True)
+    identical_split_equals_global(emul_lib, allow_emulation=True)
+
+
+def test_many_biomes_api(emul_lib):
+    c = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    c.split_biome(["a", "b", "c", "d", "e", "f"])
+    c.delete_biome("c")
+    c.create_biome("g")
+    assert c.biomes() == ["a", "b", "d", "e", "f", "g"]
+    c.setvar("g.veg_c", 10.0).setvar("g.soil_c", 50.0).setvar("g.npp_flux0", 1.0)
+    c.run(1800)
+    assert c.status()[0] == 0
+    with pytest.raises(hector_amd.HectorAmdError, match="tracking"):
+        t = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+        t.split_biome(["a", "b", "c", "d", "e"]); t.setvar("trackingDate", [1800.0]); t.run(1810)
+
+
+@pytest.mark.gpu
+def test_many_biomes_vs_oracle_on_gpu(hip_lib, oracle):
+    many_biome_checks(hip_lib, oracle, counts=(5, 8, 11, 16), n=6, device=0)
+    identical_split_equals_global(hip_lib, device=0)
