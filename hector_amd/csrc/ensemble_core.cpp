@@ -235,9 +235,22 @@ void EnsembleCore::init_from_scenario() {
         }
     }
   }
+  // "enabled=0" in a component's section removes it from the model (core.cpp:251-256).  The
+  // forcing component copes with missing halocarbons, aerosols, volcanic SO2 and ozone
+  // (forcing_component.cpp:392-484); sea-level rise has no dependants.  The components of the
+  // year loop itself cannot be taken out of this integrator.
+  for (const char *sec : {"simpleNbox", "ocean", "temperature", "forcing", "carbon-cycle-solver",
+                          "CH4", "N2O", "OH"})
+    if (component_disabled(sec))
+      throw std::runtime_error(std::string("[") + sec + "] enabled=0 is not supported: the component "
+                               "is part of the GPU year loop");
   if (s.scalar("ocean", "spinup_chem", 0) != 0)
     throw std::runtime_error("ocean.spinup_chem=1 is not supported by the GPU path");
   build_shared();
+}
+
+bool EnsembleCore::component_disabled(const std::string &section) const {
+  return scen_.scalar(section, "enabled", 1.0) <= 0;
 }
 
 EnsembleCore::~EnsembleCore() {
@@ -292,6 +305,9 @@ void EnsembleCore::build_shared() {
   // forcing_component.hpp:120-131
   const double aci_beta = 2.279759, s_BCOC = 111.05064063;
   const double s_SO2 = (260.34644166 * 1000) * (32.065 / 64.066);
+  const bool so2_off = component_disabled("so2");
+  const bool aerosols_off = so2_off || component_disabled("bc") || component_disabled("oc") ||
+                            component_disabled("nh3");
   std::vector<double> hconc(s.halocarbons.size());
   for (size_t h = 0; h < hconc.size(); ++h) hconc[h] = s.halocarbons[h].H0;
   // halocarbon forcings enter the total in std::map key order ("RF_<gas>")
@@ -367,6 +383,7 @@ void EnsembleCore::build_shared() {
       }
       for (size_t k = 0; k < horder.size(); ++k) {
         const Halocarbon &H = s.halocarbons[horder[k]];
+        if (component_disabled(H.name + "_halocarbon")) continue;  // forcing_component.cpp:413-419
         const double rf_un = H.rho * hconc[horder[k]];
         rf_h = rf_h + (rf_un + H.delta * rf_un);
       }
@@ -381,6 +398,10 @@ void EnsembleCore::build_shared() {
                         (-1 * aci_beta *
                          std::log(1 + (so2[iy] / s_SO2) + ((bc[iy] + oc[iy]) / s_BCOC)));
     row[HXSH_RF_VOL] = sv[iy];
+    // aerosol forcings need all four emission components, the volcanic one the SO2 component
+    // (forcing_component.cpp:422-425, 478)
+    if (aerosols_off) row[HXSH_RF_AERO] = 0.0;
+    if (so2_off) row[HXSH_RF_VOL] = 0.0;
   }
   HxConst &k = kc_;
   k.start_year = s.start; k.ns = ns;
@@ -408,6 +429,7 @@ void EnsembleCore::build_shared() {
   k.N0 = N0f; k.sqrtN0 = std::sqrt(N0f);
   k.delta_co2 = s.scalar("forcing", "delta_co2"); k.delta_ch4 = s.scalar("forcing", "delta_ch4");
   k.delta_n2o = s.scalar("forcing", "delta_n2o");
+  k.o3_rf = component_disabled("ozone") ? 0.0 : 0.042;
 }
 
 void EnsembleCore::free_device() {
@@ -1095,7 +1117,8 @@ void EnsembleCore::run_gas_kernel() {
     for (size_t k = 0; k < nh; ++k) {
       const Halocarbon &H = s.halocarbons[horder[k]];
       par[(3 + 3 * k) * np + l] = member_value("tau_" + H.name, H.tau, l);
-      par[(4 + 3 * k) * np + l] = member_value("rho_" + H.name, H.rho, l);
+      par[(4 + 3 * k) * np + l] = component_disabled(H.name + "_halocarbon")
+                                      ? 0.0 : member_value("rho_" + H.name, H.rho, l);
       par[(5 + 3 * k) * np + l] = member_value("delta_" + H.name, H.delta, l);
     }
   }
@@ -1731,8 +1754,31 @@ void EnsembleCore::compute_derived(const std::string &capability, int iy0, int n
   check(hx_launch_diag(d->kind, a, d_diag_, stream_), "diag kernel");
 }
 
+// A disabled component registers no capabilities: asking for its variables fails like
+// Core::sendMessage does for an unknown capability (core.cpp:716-778).
+void EnsembleCore::check_component_enabled(const std::string &capability_in) const {
+  const std::string cap = capability_in.compare(0, 4, "Fadj") == 0 ? "RF_" + capability_in.substr(4)
+                                                                   : capability_in;
+  std::string sec;
+  const bool so2_off = component_disabled("so2");
+  if (cap == "RF_BC" || cap == "RF_OC" || cap == "RF_SO2" || cap == "RF_NH3" || cap == "RF_aci") {
+    for (const char *s : {"bc", "oc", "so2", "nh3"}) if (component_disabled(s)) sec = s;
+  } else if (cap == "RF_vol" && so2_off) sec = "so2";
+  else if ((cap == "O3_concentration" || cap == "RF_O3_trop") && component_disabled("ozone")) sec = "ozone";
+  else if ((cap == "slr" || cap == "sl_rc" || cap == "slr_no_ice" || cap == "sl_rc_no_ice") &&
+           component_disabled("slr")) sec = "slr";
+  else
+    for (const Halocarbon &h : scen_.halocarbons)
+      if ((cap == "RF_" + h.name || cap == h.name + "_concentration") &&
+          component_disabled(h.name + "_halocarbon")) sec = h.name + "_halocarbon";
+  if (!sec.empty())
+    throw std::runtime_error("Caller is requesting unknown variable: " + capability_in +
+                             " (component [" + sec + "] is disabled)");
+}
+
 void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
                              double *out_host) {
+  check_component_enabled(capability);
   if (fetch_host(capability, year0, year1, out_host)) return;
   {  // whole-surface values: area-weighted low/high latitude (ocean_component.cpp:466-503)
     static const char *const combos[][3] = {{"pH", "LL_pH", "HL_pH"}, {"PCO2", "LL_PCO2", "HL_PCO2"},

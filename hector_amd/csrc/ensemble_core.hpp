@@ -141,6 +141,8 @@ class EnsembleCore {
   bool mseries_dirty_ = false;
   void upload_member_series();
   void upload_args();
+  bool component_disabled(const std::string &section) const;  // "enabled=0" in the INI section
+  void check_component_enabled(const std::string &capability) const;
   // N2O / halocarbon parameters that differ between members: capability -> [n_] (member order)
   std::map<std::string, std::vector<double>> gas_member_;
   double *d_gas_par_ = nullptr, *d_gas_ser_ = nullptr;

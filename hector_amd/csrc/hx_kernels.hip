@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
         const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
         const double fh2o = 0.0485 * ((ch4 - kc.M0f) * kc.inv_h2o_span);
-        const double fo3 = 0.042 * o3;
+        const double fo3 = kc.o3_rf * o3;  // (0 with [ozone] enabled=0, forcing_component.cpp:392)
         double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
                        p_aero * sh[HXSH_RF_AERO]) +
                       p_vol * sh[HXSH_RF_VOL];

@@ -147,6 +147,7 @@ struct HxConst {
   int trk_iy;          // year index of Core::trackingDate, -1 = no tracking
   double N0, sqrtN0;
   double delta_co2, delta_ch4, delta_n2o;
+  double o3_rf;        // 0.042 W/m2 per DU, or 0 when the ozone component is disabled
 };
 
 // pointers handed to the kernels

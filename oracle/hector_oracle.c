@@ -21,6 +21,7 @@ typedef struct {
   double tau, rho, delta, H0, molarMass;
   double *em;  /* [ns] */
   double *con; /* [ns] concentration constraint, NaN = none that year; NULL = none */
+  int disabled; /* "enabled=0" in the gas's section: Core removes the component (core.cpp:251-256) */
 } hxo_halo;
 
 struct hxo_scenario {
@@ -28,6 +29,9 @@ struct hxo_scenario {
   /* scalars */
   double tt, tu, twi, tid, preind_surface_c, preind_interdeep_c;
   int spinup_chem, do_spinup, max_spinup;
+  /* components switched off with "enabled=0" (core.cpp:251-256): the forcing component then
+   * finds no such capability and leaves the forcing out (forcing_component.cpp:392-484) */
+  int off_bc, off_oc, off_so2, off_nh3, off_ozone;
   double C0, npp_flux0, veg_c, detritus_c, soil_c, permafrost_c;
   double f_nppv, f_nppd, f_litterd, beta, q10_rh;
   double eps_abs, eps_rel, dt, eps_spinup;
@@ -79,6 +83,16 @@ static void set_scalar(hxo_scenario *s, const char *sec, const char *key,
   if (!strcmp(sec, "core") && !strcmp(key, "do_spinup")) { s->do_spinup = (int)v; return; }
   if (!strcmp(sec, "core") && !strcmp(key, "max_spinup")) { s->max_spinup = (int)v; return; }
   if (!strcmp(sec, "ocean") && !strcmp(key, "spinup_chem")) { s->spinup_chem = (int)v; return; }
+  if (!strcmp(key, "enabled")) {
+    const int off = v <= 0;
+    if (!strcmp(sec, "bc")) s->off_bc = off;
+    else if (!strcmp(sec, "oc")) s->off_oc = off;
+    else if (!strcmp(sec, "so2")) s->off_so2 = off;
+    else if (!strcmp(sec, "nh3")) s->off_nh3 = off;
+    else if (!strcmp(sec, "ozone")) s->off_ozone = off;
+    else { hxo_halo *hh = find_halo(s, sec, 1); if (hh) hh->disabled = off; }
+    return;
+  }
   SC("ocean", "tt", tt) SC("ocean", "tu", tu) SC("ocean", "twi", twi)
   SC("ocean", "tid", tid) SC("ocean", "preind_surface_c", preind_surface_c)
   SC("ocean", "preind_interdeep_c", preind_interdeep_c)
@@ -1804,14 +1818,16 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
   const double Ma_base = 1831, stratH2O_base = 0.0485;
   f[nf].name = "RF_H2O_strat";
   f[nf++].v = stratH2O_base * ((Ma - M0) / (Ma_base - M0));
-  f[nf].name = "RF_O3_trop"; f[nf++].v = 0.042 * m->o3;
+  if (!s->off_ozone) { f[nf].name = "RF_O3_trop"; f[nf++].v = 0.042 * m->o3; }  /* :392 */
   for (int h = 0; h < s->nhalo; h++) {
+    if (s->halo[h].disabled) continue;  /* :413-419 checkCapability */
     snprintf(names[h], sizeof names[h], "RF_%s", s->halo[h].name);
     f[nf].name = names[h]; f[nf++].v = m->halo_rf[h];
   }
   double E_BC = s->bc[iy], E_OC = s->oc[iy], E_NH3 = s->nh3[iy],
          E_SO2 = s->so2[iy];
   double alpha = p->aero_scalar;
+  if (!(s->off_bc || s->off_oc || s->off_so2 || s->off_nh3)) {  /* :422-425: all four or none */
   f[nf].name = "RF_BC"; f[nf++].v = alpha * s->rho_bc * E_BC;
   f[nf].name = "RF_OC"; f[nf++].v = alpha * s->rho_oc * E_OC;
   f[nf].name = "RF_SO2"; f[nf++].v = alpha * s->rho_so2 * E_SO2;
@@ -1819,8 +1835,9 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
   f[nf].name = "RF_aci";
   f[nf++].v = alpha * (-1 * aci_beta *
                        log(1 + (E_SO2 / s_SO2) + ((E_BC + E_OC) / s_BCOC)));
+  }
   f[nf].name = "RF_albedo"; f[nf++].v = s->albedo[iy];
-  f[nf].name = "RF_vol"; f[nf++].v = p->vol_scalar * s->sv[iy];
+  if (!s->off_so2) { f[nf].name = "RF_vol"; f[nf++].v = p->vol_scalar * s->sv[iy]; }  /* :478 */
   f[nf].name = "RF_misc"; f[nf++].v = s->rf_misc ? s->rf_misc[iy] : 0.0;
   /* Ftot = sum over std::map<string,unitval> in key order (:489-492) */
   qsort(f, (size_t)nf, sizeof f[0], rf_cmp);
@@ -1840,7 +1857,7 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
       for (int k = 0; k < 10; k++) if (!strcmp(f[i].name, want[k])) hit = k;
       if (hit >= 0) v[hit] = f[i].v;
     }
-    for (int h = 0; h < s->nhalo; h++) v[10] += m->halo_rf[h];
+    for (int h = 0; h < s->nhalo; h++) if (!s->halo[h].disabled) v[10] += m->halo_rf[h];
     if (year == s->baseyear) memcpy(m->rf_base_v, v, sizeof v);
     for (int k = 0; k < 11; k++) m->rf_item_v[k] = v[k] - m->rf_base_v[k];
   }
