@@ -245,7 +245,14 @@ void EnsembleCore::init_from_scenario() {
       throw std::runtime_error(std::string("[") + sec + "] enabled=0 is not supported: the component "
                                "is part of the GPU year loop");
   if (s.scalar("ocean", "spinup_chem", 0) != 0)
-    throw std::runtime_error("ocean.spinup_chem=1 is not supported by the GPU path");
+    // With spinup_chem = 1 the reference never tunes -- never even sets -- the surface boxes'
+    // alkalinity (oceanbox::chem_equilibrate runs only "if (!spinup_chem ...)",
+    // ocean_component.cpp:392-400; oceancsys starts with alk = 0, ocean_csys.cpp:88-91): the first
+    // carbonate solve of the spinup finds no root and the run aborts (the oracle's restatement
+    // stops at spinup step 1 with its root-not-found flag).  Nothing to integrate: say so.
+    throw std::runtime_error("ocean.spinup_chem=1: the reference aborts in its first spinup step "
+                             "with this setting (the surface boxes' alkalinity is never set, so the "
+                             "carbonate system has no root); every shipped scenario uses 0");
   build_shared();
 }
 
@@ -1658,7 +1665,7 @@ void EnsembleCore::set_tracking_date(int year) {
 
 std::vector<std::string> EnsembleCore::tracking_pools() const {
   // pool names as the fluxpools carry them (simpleNbox.cpp:45-79, ocean_component.cpp:246-258)
-  std::vector<std::string> n = {"atmos_c", "earth_c"};
+  std::vector<std::string> n = {"atmos_co2", "earth_c"};  // D_ATMOSPHERIC_CO2, simpleNbox.cpp:65
   for (int b = 0; b < B_; ++b) {
     const std::string pre = (B_ == 1 && biome_names_[0] == "global") ? "" : biome_names_[(size_t)b] + ".";
     for (const char *k : {"veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c"}) n.push_back(pre + k);

@@ -17,6 +17,12 @@ __device__ __forceinline__ double hx_recip(double b) {
   return r;
 }
 __device__ __forceinline__ double hx_div(double a, double b) { return a * hx_recip(b); }
+// a / b given r = hx_recip(b), with the final residual correction of a division routine: the
+// quotient is correctly rounded (exact where a / b is representable) for two more FMAs
+__device__ __forceinline__ double hx_div_cr(double a, double b, double r) {
+  const double q = a * r;
+  return fma(fma(-q, b, a), r, q);
+}
 // 2e-15: enough for a Newton correction, whose own error is squared away by the next iteration
 __device__ __forceinline__ double hx_div1(double a, double b) {
   double r = HX_RCP(b);

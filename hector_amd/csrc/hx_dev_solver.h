@@ -309,13 +309,17 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
 
   const double total = y[1] + y[2] + y[3];
   m.cum_luc_va += hx_div((m.luc_e - m.luc_u) * y[1], total);  // no yf: :388-393
+  // (hx_div_cr: the biome weights as correctly rounded quotients -- an equal split into 2 or 4
+  // identical biomes then gets weights of exactly 1/2, 1/4 and reproduces the single-biome run
+  // bit for bit, the reference's own property (test_biome.R))
   const double inv_nr = hx_recip(npp_rh);
   const double inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const double wt = (B == 1) ? 1.0
-        : (m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b))) * inv_nr;
-    const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : m.pf[b] * inv_pf;
+        : hx_div_cr(m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b)),
+                    npp_rh, inv_nr);
+    const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : hx_div_cr(m.pf[b], pf_t, inv_pf);
     if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
       const double a = m_rh_fda(m, b) * rh_adj, bb = m_rh_fsa(m, b) * rh_adj;
       const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;

@@ -112,7 +112,7 @@ class Oracle:
                        ctypes.POINTER(ctypes.c_int), dp, dp]
         err = fn(self.sc, ctypes.byref(p), int(run_to), int(tracking_date), out.ctypes.data_as(dp),
                  None, f.ctypes.data_as(dp), v.ctypes.data_as(dp))
-        names = ["atmos_c", "earth_c"]
+        names = ["atmos_co2", "earth_c"]
         for b in range(p.nbiome):
             names += ["b%d.%s" % (b, k) for k in ("veg_c", "detritus_c", "soil_c", "permafrost_c",
                                                     "thawedp_c")]

@@ -169,8 +169,12 @@ def test_concentration_forced_gases_like_reference_tests(emul_lib, tmp_path, gas
     c0 = hc.fetchvars(conc, (Y0, Y1))[:, 0].copy()
     hc.setvar_dated(gas + "_constrain", ALL, c0, unit)
     hc.reset(Y0); hc.run(Y1)
-    # (the R test asks for 1e-10 mean relative difference; the constrained run goes through the
-    # extended kernel instantiation, whose FMA contraction differs from the plain one)
+    # test_constraints.R:42,89,139: expect_equivalent(emissOut$value, conOut$value, tol = 1e-10),
+    # i.e. R's all.equal: mean absolute difference / mean absolute value <= 1e-10, over global_tas
+    # and the gas's concentration together
+    a = np.concatenate([tas0[:, 0], c0]); b = np.concatenate([hc.fetchvars("global_tas", (Y0, Y1))[:, 0],
+                                                              hc.fetchvars(conc, (Y0, Y1))[:, 0]])
+    assert np.abs(a - b).mean() / np.abs(a).mean() <= 1e-10
     assert np.abs(hc.fetchvars("global_tas", (Y0, Y1)) - tas0).max() < 1e-9
     assert np.abs(hc.fetchvars(conc, (Y0, Y1))[:, 0] - c0).max() == 0
     c1 = c0 * 1.5

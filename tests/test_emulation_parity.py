@@ -111,12 +111,22 @@ def test_four_biomes_vs_oracle(emul_lib, oracle):
 
 
 def test_identical_biome_split_equals_global(emul_lib):
-    """test_biome.R:193-256 on the kernel source."""
-    a = mk(emul_lib, 1).run(2100)
-    b = mk(emul_lib, 1); b.split_biome(["x", "y", "z", "w"]); b.run(2100)
-    for v in ("CO2_concentration", "global_tas"):
+    """test_biome.R:193-256 on the kernel source: an equal split into 2 or 4 identical biomes
+    reproduces the single-biome run BIT FOR BIT, like the reference -- biome
+    weights are correctly rounded quotients, so they come out as exactly 1/2 and 1/4."""
+    S = [2.5, 3.0, 4.5]
+    outs = ["CO2_concentration", "global_tas", "veg_c", "soil_c"]
+    a = mk(emul_lib, 3).setvar("S", S); a.set_outputs(outs); a.run(2300)
+    for nb in (2, 4):
+        b = mk(emul_lib, 3).setvar("S", S); b.split_biome(["x%d" % i for i in range(nb)])
+        b.set_outputs(outs); b.run(2300)
+        for v in outs:
+            assert np.array_equal(a.fetchvars(v), b.fetchvars(v)), (nb, v)
+    # 3 biomes: thirds are not representable, the property holds to rounding
+    b = mk(emul_lib, 3).setvar("S", S); b.split_biome(["x", "y", "z"]); b.set_outputs(outs); b.run(2300)
+    for v in outs:
         x, y = a.fetchvars(v), b.fetchvars(v)
-        assert np.abs(x - y).max() <= 1e-9 * np.abs(x).max(), v
+        assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(x).max()), v
 
 
 def test_run_in_segments_equals_one_run(emul_lib):

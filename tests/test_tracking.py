@@ -23,12 +23,15 @@ def check_tracking_vs_oracle(lib, oracle, **kw):
     q10 = c.getvar("q10_rh"); q10[1] *= 0.9; q10[2] = 2.6
     S = np.array([3.0, 3.0, 4.5])
     c.setvar("q10_rh", q10).setvar("S", S, "degC")
-    c.set_outputs(["CO2_concentration", "HL_ocean_c", "DO_ocean_c"])
+    POOL_VARS = {"atmos_co2": "atmos_co2", "earth_c": "earth_c", "veg_c": "veg_c",
+                 "detritus_c": "detritus_c", "soil_c": "soil_c", "HL": "HL_ocean_c",
+                 "LL": "LL_ocean_c", "intermediate": "IO_ocean_c", "deep": "DO_ocean_c"}
+    c.set_outputs(["CO2_concentration"] + list(POOL_VARS.values()))
     c.run(END)
     assert (c.status() == 0).all()
     assert c.getvar("trackingDate")[0] == T0
     names = c.tracking_pools()
-    assert names == ["atmos_c", "earth_c", "veg_c", "detritus_c", "soil_c", "permafrost_c",
+    assert names == ["atmos_co2", "earth_c", "veg_c", "detritus_c", "soil_c", "permafrost_c",
                      "thawedp_c", "HL", "LL", "intermediate", "deep"]
     for i in range(3):
         p = oracle.default_params(); p.q10_rh[0] = q10[i]; p.S = S[i]
@@ -45,8 +48,15 @@ def check_tracking_vs_oracle(lib, oracle, **kw):
         assert np.abs(gf.sum(axis=2) - 1.0).max() < 1e-12
         # first tracked year: mostly itself; the pool values are the model's (test_tracking.R:163-)
         assert gf[0, 1, 1] == 1.0
-        assert np.abs(gv[:, 7] - c.fetchvars("HL_ocean_c", (T0, END))[:, i]).max() == 0.0
-        assert np.abs(gv[:, 10] - c.fetchvars("DO_ocean_c", (T0, END))[:, i]).max() == 0.0
+        # test_tracking.R:164-262 "Pool names are valid": the value tracked for each of the nine
+        # pools equals fetchvars(<pool variable>) (the R test allows 1e-3; here every year, exactly)
+        # and carries its unit
+        for pool, var in POOL_VARS.items():
+            assert np.array_equal(gv[:, names.index(pool)], c.fetchvars(var, (T0, END))[:, i]), pool
+            assert c.getunits(var) == "Pg C"
+    # ... and the source names are the pool names (test_tracking.R:258-262)
+    rows = hector_amd.get_tracking_data(c, member=0)
+    assert sorted({r[5] for r in rows}) == sorted({r[2] for r in rows}) == sorted(names)
     return c
 
 
