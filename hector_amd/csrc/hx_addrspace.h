@@ -19,4 +19,6 @@ typedef const double HX_CONSTANT *hx_ccd;
 // hardware reciprocal-square-root seed (v_rsq_f64), refined in hx_sqrt()
 #define HX_RSQ(x) __builtin_amdgcn_rsq(x)
 // the fp64 matrix pipe (v_mfma_f64_16x16x4_f64) is there for DOECLIM's history contraction
+#ifndef HX_HAS_MFMA
 #define HX_HAS_MFMA 1
+#endif

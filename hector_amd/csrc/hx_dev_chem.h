@@ -134,7 +134,7 @@ __device__ __forceinline__ double chem_solve(const ChemK &k, double carbon,
 // tuner (Brent on |flux - target|, keeping "the last point evaluated") branches on comparisons
 // of objective values that differ in their last bits, so it gets the reference's own iteration
 // and therefore the reference's objective values.  Used ~120 times per member, once per run.
-__device__ __attribute__((noinline)) double chem_solve_ref(const ChemK &k, double carbon,
+__device__ __forceinline__ double chem_solve_ref(const ChemK &k, double carbon,
                                                            double inv_vol, double alk,
                                                            double &h_out, unsigned &status) {
 #pragma clang fp contract(off)

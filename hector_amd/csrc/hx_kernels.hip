@@ -245,17 +245,26 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
       }
     }
   };
-  // (the empty asm statements pin the accumulators to the AGPR half of the register file across
-  // the loop's back edge; left alone the compiler carries them in VGPRs and copies all 64 (128)
-  // registers into and out of AGPRs around every group of MFMAs)
+  // The accumulators are pinned to the AGPR half of the register file across the loop's back
+  // edge by passing them through an asm statement (left alone the compiler carries them in VGPRs
+  // and copies all 64 / 128 registers into and out of AGPRs around every group of MFMAs).  To the
+  // compiler that statement becomes the accumulators' last writer, so its hazard recogniser no
+  // longer sees that an MFMA result is read -- as SrcC of the next iteration's first MFMAs, by
+  // the stores after the loop: the statement therefore carries the wait itself, 48 states, more
+  // than the 8 passes of a v_mfma_f64_16x16x4_f64 issued just before it (once per 16 MFMAs =
+  // 512 cycles of matrix pipe).  Without it the code was only correct for instruction orders
+  // that happened to keep an accumulator's reuse 7 MFMAs apart.
   auto pin = [&]() {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        asm volatile("" : "+a"(acc[h][g]));
-        if (HF) asm volatile("" : "+a"(acc2[h][g]));
-      }
+    if constexpr (HF)
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]),
+                     "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
+                     "+a"(acc2[0][0]), "+a"(acc2[0][1]), "+a"(acc2[0][2]), "+a"(acc2[0][3]),
+                     "+a"(acc2[1][0]), "+a"(acc2[1][1]), "+a"(acc2[1][2]), "+a"(acc2[1][3]));
+    else
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+                   : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]),
+                     "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]));
   };
   load(0, a0, a1, e0, e1, b);
   pin();
