@@ -171,6 +171,8 @@ def roofline_object(members, biomes, kernel_ms):
         r["achieved"] = flops / secs / 1e12
         r["frac"] = r["achieved"] / r["peak"]
         r["fp64_flops_per_launch"] = flops
+        r["fp64_mfma_flops_per_launch"] = entry.get("fp64_mfma_flops_per_launch", 0.0)
+        r["fp64_mfma_tflops"] = entry.get("fp64_mfma_flops_per_launch", 0.0) / secs / 1e12
         r["valu_active_frac"] = entry["valu_active_frac"]
         r["traffic"] = entry["traffic_bytes_per_launch"]
         r["hbm_measured_frac"] = entry["traffic_bytes_per_launch"] / secs / HBM_PEAK
@@ -179,7 +181,9 @@ def roofline_object(members, biomes, kernel_ms):
     r["formula"] = ("achieved = executed fp64 flops per launch (SQ_INSTS_VALU_FLOPS_FP64 x 64 lanes "
                     "x lane utilisation; 2 per FMA, 1 per add / mul / rcp / sqrt; rocprofv3 --pmc "
                     "pass of this kernel source, profiles/) / mean HIP-event kernel time of this "
-                    "run; peak = fp64 vector 78.6 TFLOP/s; hbm_measured_frac = PMC traffic "
+                    "run; peak = fp64 vector 78.6 TFLOP/s (the DOECLIM history contraction runs on the fp64 "
+                    "matrix pipe beside it: fp64_mfma_tflops = SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 / time); "
+                    "hbm_measured_frac = PMC traffic "
                     "(2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s")
     r["hbm_yardstick"] = {
         "bound": "hbm", "achieved": yard, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

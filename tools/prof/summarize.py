@@ -66,6 +66,9 @@ def main():
         waves = c["SQ_WAVES"]
         lane_util = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
         flops = c["SQ_INSTS_VALU_FLOPS_FP64"] * 64.0 * lane_util
+        # DOECLIM history contraction on the matrix pipe: one v_mfma_f64_16x16x4_f64 = 4 MOPS of
+        # 512 flops (2 x 16 x 16 x 4); not part of the VALU figure
+        mfma_flops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) * 512.0
         bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
         der = {
             "VALU_insts_per_wave_year": c["SQ_INSTS_VALU"] / waves / YEARS,
@@ -83,6 +86,7 @@ def main():
             "wait_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
             "mean_wave_cycles_per_year": 4 * c["SQ_WAVE_CYCLES"] / waves / YEARS,
             "executed_fp64_flops_per_launch": flops,
+            "executed_fp64_mfma_flops_per_launch": mfma_flops,
             "executed_fp64_flops_per_member_year": flops / (members * YEARS),
             "hbm_traffic_bytes_per_launch": traffic,
             "fetch_size_correction_measured": factor,
@@ -101,6 +105,7 @@ def main():
         index["entries"].setdefault(h, {})[cfg] = {
             "traffic_bytes_per_launch": traffic,
             "fp64_flops_per_launch": flops,
+            "fp64_mfma_flops_per_launch": mfma_flops,
             "valu_active_frac": der["valu_active_frac"],
             "lane_utilisation": lane_util,
             "source": "profiles/%s_pmc_%s.json" % (tag, cfg),
