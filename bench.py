@@ -51,7 +51,7 @@ HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK = 78.6e12   # fp64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 YEARS = 555
 KERNEL_SOURCES = ["hx_kernels.hip", "hx_dev_chem.h", "hx_dev_const.h", "hx_dev_member.h",
-                  "hx_dev_solver.h", "hx_dev_track.h", "hx_dev_math.h", "hx_dev_clock.h",
+                  "hx_dev_solver.h", "hx_dev_track.h", "hx_dev_math.h", "hx_dev_clock.h", "hx_dev_pair.h",
                   "hx_layout.h", "hx_addrspace.h"]
 
 
@@ -154,7 +154,7 @@ def make_core(n, biomes, offset, device):
     return core
 
 
-def roofline_object(members, biomes, kernel_ms):
+def roofline_object(members, biomes, kernel_ms, kernel="run"):
     """The roofline object of one configuration from its measured kernel time (this run) and
     the committed counter profile of the same kernel source (profiles/pmc_index.json)."""
     entry, stale = pmc_entry(members, biomes)
@@ -164,7 +164,8 @@ def roofline_object(members, biomes, kernel_ms):
     yard = alg_bytes / secs / 1e9
     r = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VECTOR_PEAK / 1e12,
          "unit": "TFLOP/s", "frac": None, "traffic": None,
-         "kernel": "hx_run_kernel<%d>" % biomes, "kernel_ms": kernel_ms,
+         "kernel": "hx_pair_kernel" if kernel == "pair" else "hx_run_kernel<%d>" % biomes,
+         "kernel_ms": kernel_ms,
          "kernel_source_hash": kernel_source_hash()}
     if entry is not None:
         flops = entry["fp64_flops_per_launch"]
@@ -218,11 +219,12 @@ def time_config(n, biomes, steps, warmup, device):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     bad = int((core.status() != 0).sum())
+    which = core.last_run_kernel()
     core.shutdown()
     kernel_ms = float(np.mean(kms))
-    rf = roofline_object(n, biomes, kernel_ms)
+    rf = roofline_object(n, biomes, kernel_ms, which)
     return {"members": n, "biomes": biomes, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-            "kernel_ms": kernel_ms, "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
+            "kernel": rf["kernel"], "kernel_ms": kernel_ms, "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
             "members_with_model_errors": bad,
             "fp64_valu_frac": rf["frac"], "hbm_yardstick_frac": rf["hbm_yardstick"]["frac"],
             "pmc_profile_stale": rf.get("pmc_profile_stale")}
@@ -315,6 +317,7 @@ def main():
     kernel_ms = float(km.item())   # slowest rank's mean kernel time
     bad = int((core.status() != 0).sum())
     stats_host = stats.cpu().numpy()
+    which_kernel = core.last_run_kernel()
     core.shutdown()
 
     if rank == 0:
@@ -351,7 +354,7 @@ def main():
                 "co2_2300_mean_ppm": float(mean[0, -1]), "tgav_2300_mean_K": float(mean[1, -1]),
             },
             # per-rank maximum of the mean kernel time when N > 1
-            "roofline": roofline_object(n, args.biomes, kernel_ms),
+            "roofline": roofline_object(n, args.biomes, kernel_ms, which_kernel),
         }
         if world == 1 and not args.no_other_configs:
             others = []

@@ -274,6 +274,18 @@ class Core:
         self._ck(self._lib.hx_last_run_ms(self._h, ctypes.byref(v)))
         return v.value
 
+    def set_pair_kernel_limit(self, max_members):
+        """Ensembles of up to max_members (one biome, no constraints, default outputs) run on the
+        two-wavefront kernel (include/hector_amd.h); 0 switches it off."""
+        self._ck(self._lib.hx_set_pair_kernel_limit(self._h, int(max_members)))
+        return self
+
+    def last_run_kernel(self):
+        """'run' or 'pair': the kernel the last run() launched."""
+        s = ctypes.c_char_p()
+        self._ck(self._lib.hx_last_run_kernel(self._h, ctypes.byref(s)))
+        return s.value.decode()
+
     def last_spinup_ms(self):
         v = ctypes.c_double()
         self._ck(self._lib.hx_last_spinup_ms(self._h, ctypes.byref(v)))

@@ -1,6 +1,7 @@
 // ensemble_core.cpp -- see ensemble_core.hpp.
 #include "ensemble_core.hpp"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -10,6 +11,8 @@
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st);
 int hx_track_rows(int B);
+int hx_pair_available();
+hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, int iy_from, int iy_to, hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st);
 int hx_doeclim_block_years();
@@ -143,6 +146,7 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
   check(hipSetDevice(device_), "hipSetDevice");
   check(hipStreamCreate(&stream_), "hipStreamCreate");
+  if (const char *e2 = std::getenv("HECTOR_AMD_PAIR_MAX_MEMBERS")) pair_max_members_ = std::atoi(e2);
   try {  // a constructor that throws gets no destructor: release the stream and events here
     check(hipEventCreate(&ev0_), "hipEventCreate");
     check(hipEventCreate(&ev1_), "hipEventCreate");
@@ -1402,6 +1406,16 @@ void EnsembleCore::run(double runtodate) {
                                "supported (the constraint residual is an untracked source)");
     con = 2;
   }
+  // small ensembles (too few wavefronts to fill the SIMDs): two wavefronts per 64 members
+  bool pair = hx_pair_available() && B_ == 1 && con == 0 && !hf && !ker_per_member_ && !d_hist_ &&
+              n_ <= pair_max_members_;
+  for (int v = 0; v < HXO_NVAR && pair; ++v)
+    if (d_out_[v] && v != HXO_SST && v != HXO_TLAND && v != HXO_CO2 && v != HXO_TGAV && v != HXO_NSTASH)
+      pair = false;
+  last_run_pair_ = pair;
+  if (pair)
+    check(hx_launch_run_pair(d_args_, npad_, last_iy_, target, stream_), "run kernel (pair)");
+  else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
                       stream_),
         "run kernel");

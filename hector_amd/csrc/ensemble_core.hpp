@@ -110,6 +110,8 @@ class EnsembleCore {
   int spinup_steps(int member);
 
   double last_run_kernel_ms() const { return run_ms_; }
+  void set_pair_kernel_limit(int max_members) { pair_max_members_ = max_members < 0 ? 0 : max_members; }
+  const char *last_run_kernel() const { return last_run_pair_ ? "pair" : "run"; }
   double last_spinup_ms() const { return spin_ms_; }
   hipStream_t stream() const { return stream_; }
 
@@ -183,6 +185,8 @@ class EnsembleCore {
   hipStream_t stream_ = nullptr;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool run_timed_ = false;
+  int pair_max_members_ = 32768;  // ensembles up to this size use the two-wavefront kernel (0: never)
+  bool last_run_pair_ = false;
   mutable double run_ms_ = 0, spin_ms_ = 0;
 };
 

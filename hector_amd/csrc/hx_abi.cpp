@@ -247,5 +247,9 @@ int hx_last_run_ms(hx_core *core, double *ms) {
 }
 int hx_last_spinup_ms(hx_core *core, double *ms) { HX_TRY(*ms = core->core->last_spinup_ms()) }
 int hx_stream(hx_core *core, void **stream) { HX_TRY(*stream = (void *)core->core->stream()) }
+int hx_set_pair_kernel_limit(hx_core *core, int max_members) {
+  HX_TRY(core->core->set_pair_kernel_limit(max_members))
+}
+int hx_last_run_kernel(hx_core *core, const char **name) { HX_TRY(*name = core->core->last_run_kernel()) }
 
 }  // extern "C"

@@ -414,6 +414,120 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
   pco2H = pc[0]; pco2L = pc[1];
 }
 
+// The same iteration for a list of boxes (the small-ensemble kernel gives each of its two
+// wavefronts one box).
+template <int N>
+__device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], const double (&carbon)[N],
+                                                 const double (&alk)[N], const double (&inv_vol)[N],
+                                                 double (&h)[N], double (&pc)[N], unsigned &status) {
+  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
+  double dic[N], p4[N], p3[N], p2[N], p1[N], p0[N], h0[N];
+#pragma unroll
+  for (int b = 0; b < N; ++b) {
+    const double K1 = k[b]->K1, K2 = k[b]->K2, Kb = k[b]->Kb, Kw = k[b]->Kw;
+    h0[b] = h[b];
+    dic[b] = ((carbon[b] * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol[b]);
+    p4[b] = -alk[b] - Kb - K1;
+    p3[b] = dic[b] * K1 - alk[b] * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
+    double tmp = dic[b] * (Kb * K1 + 2.0 * K1 * K2) - alk[b] * (Kb * K1 + K1 * K2) +
+                 Kb * bor * K1;
+    p2[b] = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
+    tmp = 2.0 * dic[b] * Kb * K1 * K2 - alk[b] * Kb * K1 * K2 + Kb * bor * K1 * K2;
+    p1[b] = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
+    p0[b] = Kw * Kb * K1 * K2;
+  }
+  const double factor = 0x1p-30;
+  double q4[N], q3[N], q2[N];
+  bool conv[N];
+#pragma unroll
+  for (int b = 0; b < N; ++b) { q4[b] = 4.0 * p4[b]; q3[b] = 3.0 * p3[b]; q2[b] = 2.0 * p2[b]; conv[b] = false; }
+  auto all = [&](const bool (&f)[N]) { bool a = true;
+#pragma unroll
+    for (int b = 0; b < N; ++b) a = a && f[b];
+    return a; };
+  for (int it = 0; it < 8 && !all(conv); ++it) {
+    HX_COUNT(0, 18);  // (profiling build) Newton iterations
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+      const double x = h[b];
+      double f = -1.0;
+      f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
+      f = f * x + p0[b];
+      double fp = -5.0;
+      fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
+      fp = fp * x + p1[b];
+      const double delta = hx_div1(f, fp);
+      const double hn = x - delta;
+      const bool c = !(fabs(hn * factor) < fabs(delta));
+      h[b] = conv[b] ? h[b] : hn;
+      conv[b] = conv[b] || c;
+    }
+  }
+  bool ok = all(conv);
+#pragma unroll
+  for (int b = 0; b < N; ++b) ok = ok && h[b] > 0.0 && h[b] < 1.0;
+  if (__any(!ok)) {
+    HX_COUNT(0, 19);  // (profiling build) safeguarded restarts
+    // Safeguarded restart from the original [H+]: Newton inside a sign-maintained bracket of the
+    // largest root, bisection when a step leaves it (see chem_solve); sound from any start.
+    // EVERY lane runs it, under a wavefront-uniform loop, and the lanes that had converged keep
+    // their result through selects: no divergent region.  (With `if (!ok) { ... }` ROCm 7.2's
+    // register allocator parked live values in AGPRs at the top of the block where the branches
+    // rejoin, BEFORE the execution mask was restored -- with no lane in the branch nothing was
+    // saved and every lane read stale registers afterwards; tools/check_isa.py looks for that.)
+    double hc[N], lo[N], hi[N];
+    bool done[N];
+#pragma unroll
+    for (int b = 0; b < N; ++b) { hc[b] = h0[b]; lo[b] = 0.0; hi[b] = 1.0; done[b] = ok; }
+    for (int it = 0; it < 200 && __any(!all(done)); ++it) {
+#pragma unroll
+      for (int b = 0; b < N; ++b) {
+        const double x = hc[b];
+        double f = -1.0;
+        f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
+        f = f * x + p0[b];
+        double fp = -5.0;
+        fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
+        fp = fp * x + p1[b];
+        const bool zero = f == 0.0;
+        lo[b] = (f > 0) ? x : lo[b];
+        hi[b] = (f > 0) ? hi[b] : x;
+        const double delta = hx_div1(f, fp);
+        const double hn = x - delta;
+        const bool inside = hn > lo[b] && hn < hi[b];
+        const bool tiny = fabs(delta) <= fabs(x) * 0x1p-48;  // converged, see chem_solve
+        const double mid = 0.5 * (lo[b] + hi[b]);            // left the bracket (or fp == 0): bisect
+        const double hn2 = inside ? hn : (tiny ? x : mid);
+        const double d2 = (inside || tiny) ? delta : x - mid;
+        const bool fin = zero || !(fabs(hn2 * factor) < fabs(d2));
+        hc[b] = (done[b] || zero) ? hc[b] : hn2;
+        done[b] = done[b] || fin;
+      }
+    }
+    status |= all(done) ? 0u : HX_ERR_ROOT;
+#pragma unroll
+    for (int b = 0; b < N; ++b) h[b] = ok ? h[b] : hc[b];
+  }
+#pragma unroll
+  for (int b = 0; b < N; ++b) {
+    // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
+    const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
+    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
+    pc[b] = hx_div(co2st * 1e6, k[b]->Kh);
+  }
+}
+// one box (the small-ensemble kernel gives each of its two wavefronts one)
+__device__ __forceinline__ void chem_solve1(const ChemK &kb, double carbon_, double alk_,
+                                            double inv_vol_, double &h_, double &pco2,
+                                            unsigned &status) {
+  const ChemK *const k[1] = {&kb};
+  const double carbon[1] = {carbon_}, alk[1] = {alk_}, inv_vol[1] = {inv_vol_};
+  double h[1] = {h_}, pc[1];
+  chem_solve_boxes<1>(k, carbon, alk, inv_vol, h, pc, status);
+  h_ = h[0];
+  pco2 = pc[0];
+}
+
 // calc_annual_surface_flux  src/ocean_csys.cpp:375-396
 __device__ __forceinline__ double surf_flux(double co2, double pco2, double scale,
                                             double Tr, double As) {

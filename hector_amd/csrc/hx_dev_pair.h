@@ -1,0 +1,740 @@
+// hx_dev_pair.h -- the small-ensemble run kernel: TWO wavefronts per 64 members
+// Part of the device code of hx_kernels.hip (one translation unit).
+//
+// With one resident wavefront per SIMD a model year costs its instruction count, and an ensemble
+// that does not fill the machine (BASELINE configs[1]: 1 024 members = 16 wavefronts on 1 024
+// SIMDs) runs as long as one wavefront's sequential chain.  The chain is shortened by giving the
+// 64 members of a workgroup two wavefronts that work on DIFFERENT PARTS of each member's year at
+// the same time, on two SIMDs of the CU, and hand values over through LDS (lane i of one
+// wavefront to lane i of the other) at workgroup barriers:
+//
+//   wavefront 0 "ocean":  equilibrium constants + carbonate solves, the atmosphere and ocean
+//                         variables of the carbon-cycle solver, the ocean half of a stash (box
+//                         exchange, timestep controller), forcing, the DOECLIM year step, outputs
+//   wavefront 1 "land":   OH / CH4 / O3, slow parameters (Q10 factors, permafrost), the three land
+//                         variables of the solver and the constant-derivative pools, the land half
+//                         of a stash, the DOECLIM history sums (matrix-pipe pass + in-block terms)
+//
+// Within a stash interval the land and the atmosphere-ocean subsystems are decoupled (land
+// fluxes come from frozen pools, simpleNbox-runtime.cpp:809-840); they meet only in the error
+// norm of a dopri5 step, so a step attempt needs ONE hand-off: each side's largest error
+// quotient (and the ocean side's candidate atmosphere / ocean values, which the land side's mass
+// check needs if the step ends a segment).  Both wavefronts carry the solver's control state
+// (t, dt, target, retry count ...) and take every decision themselves from identical inputs, so
+// they walk the reference's control flow in step and meet the same barriers.
+//
+// Same formulas, same decisions as hx_run_kernel<1,false,false,0> (parity tests compare both with
+// the oracle); instantiated for one biome, no constraints, default outputs: the configuration
+// small perturbed-parameter ensembles use.  The host picks it below HX_PAIR_MAX_MEMBERS members.
+#pragma once
+
+namespace {
+
+enum PairStep {  // per step attempt, double-buffered
+  PS_N0 = 0, PS_D0, PS_N4, PS_D4, PS_X0, PS_X4,  // ocean -> land: error quotients of y0, y4; candidates
+  PS_NL, PS_DL,                                  // land -> ocean: largest quotient of y1..y3
+  PS_N
+};
+enum PairYear {  // per year / per stash, each slot written and read on opposite sides of a barrier
+  PY_PN = 0, PY_RHCH4, PY_DPAST, PY_STATUS1, PY_PCO2L,           // land -> ocean
+  PY_MAXTS, PY_STATUS0, PY_TLAND, PY_LNC, PY_CLL,                // ocean -> land
+  PY_KL_K1, PY_KL_K2, PY_KL_KB, PY_KL_KW, PY_KL_KH,              // ocean -> land, once a year
+  PY_N
+};
+
+struct PairCtl {  // the solver's control state: identical in both wavefronts
+  double t, dtl, t_target, t_start, sdt, ode_start, max_ts;
+  int retry, fails, nsteps;
+  bool first_call, stepping, alive;
+};
+
+// dopri5 tableau (odeint runge_kutta_dopri5)
+struct Dp5 {
+  static constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
+                          b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
+                          b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+                          b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247,
+                          b64 = 49.0 / 176, b65 = -5103.0 / 18656;
+  static constexpr double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192,
+                          c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+  static constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
+                          dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
+                          dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+};
+
+// one dopri5 attempt on NP variables: candidate xn, its derivative dn, and the error quotient
+// parts n_i = |xe_i|, d_i = eps_abs + eps_rel (|y_i| + dt |dy_i|) of every variable
+template <int NP, class Rhs>
+__device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double eps_abs,
+                                             double eps_rel, const double *y, const double *dxdt,
+                                             double *xn, double *dn, double *en, double *ed) {
+  double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5::b21 * dxdt[i];
+  rhs(xt, k2);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5::b31 * dxdt[i] + dtl * Dp5::b32 * k2[i];
+  rhs(xt, k3);
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    xt[i] = y[i] + dtl * Dp5::b41 * dxdt[i] + dtl * Dp5::b42 * k2[i] + dtl * Dp5::b43 * k3[i];
+  rhs(xt, k4);
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    xt[i] = y[i] + dtl * Dp5::b51 * dxdt[i] + dtl * Dp5::b52 * k2[i] + dtl * Dp5::b53 * k3[i] +
+            dtl * Dp5::b54 * k4[i];
+  rhs(xt, k5);
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    xt[i] = y[i] + dtl * Dp5::b61 * dxdt[i] + dtl * Dp5::b62 * k2[i] + dtl * Dp5::b63 * k3[i] +
+            dtl * Dp5::b64 * k4[i] + dtl * Dp5::b65 * k5[i];
+  rhs(xt, k6);
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    xn[i] = y[i] + dtl * Dp5::c1 * dxdt[i] + dtl * Dp5::c3 * k3[i] + dtl * Dp5::c4 * k4[i] +
+            dtl * Dp5::c5 * k5[i] + dtl * Dp5::c6 * k6[i];
+  rhs(xn, dn);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double xe = dtl * Dp5::dc1 * dxdt[i] + dtl * Dp5::dc3 * k3[i] + dtl * Dp5::dc4 * k4[i] +
+                      dtl * Dp5::dc5 * k5[i] + dtl * Dp5::dc6 * k6[i] + dtl * Dp5::dc7 * dn[i];
+    en[i] = fabs(xe);
+    ed[i] = eps_abs + eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
+  }
+}
+
+// default_error_checker over all five variables in the reference's order 0, 1..3, 4: the land side
+// hands over its first-largest quotient of 1..3, so the maximum (found by cross-multiplication,
+// divided once) is the one the single-wavefront kernel finds
+__device__ __forceinline__ double pair_err(double n0, double d0, double nl, double dl, double n4,
+                                           double d4) {
+#pragma clang fp contract(off)
+  double en = 0.0, ed = 1.0;
+  if (n0 * ed > en * d0) { en = n0; ed = d0; }
+  if (nl * ed > en * dl) { en = nl; ed = dl; }
+  if (n4 * ed > en * d4) { en = n4; ed = d4; }
+  return hx_div(en, ed);
+}
+
+// what both wavefronts do with the error of an attempt (controlled_runge_kutta::try_step +
+// integrate_adaptive, as in solve_year); returns true if the step was accepted
+// (fp contraction off in the three control functions: both wavefronts must get bit-identical
+// t / dt / targets from them, whatever code surrounds the inlined copy)
+__device__ __forceinline__ bool pair_control(PairCtl &c, double err, unsigned &status) {
+#pragma clang fp contract(off)
+  constexpr double EPS = 2.220446049250313e-16;
+  if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
+    c.dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
+    if (++c.fails > 500) { status |= HX_ERR_STEPFAIL; c.alive = false; c.stepping = false; }
+    return false;
+  }
+  c.t += c.dtl;
+  const double grow = 0.9 * pow_m15(fmax(0.00032, err));
+  if (err < 0.5) c.dtl *= grow;
+  c.fails = 0;
+  c.nsteps++;
+  if (!((c.t_target - c.t) > EPS)) c.stepping = false;  // integrate_adaptive done
+  if (c.nsteps > HX_MAX_STEPS_PER_YEAR) { status |= HX_ERR_STEPFAIL; c.alive = false; c.stepping = false; }
+  return true;
+}
+
+// the retries before an attempt (carbon-cycle-solver.cpp:266-276; see solve_year): bookkeeping
+// only; returns true if the caller has to reload its pools
+__device__ __forceinline__ bool pair_retry(PairCtl &c, unsigned &status) {
+#pragma clang fp contract(off)
+  constexpr double EPS = 2.220446049250313e-16;
+  if (((c.t + c.dtl) - c.t_target) > EPS) c.dtl = c.t_target - c.t;
+  bool reload = false;
+  while (c.stepping && ((c.t + c.dtl) - c.ode_start) > c.max_ts) {
+    ++c.retry;
+    c.t_target = c.t_start + (c.t_target - c.t_start) / 2.0;
+    c.t = c.t_start;
+    c.sdt = c.t_target - c.t;
+    c.dtl = c.sdt;
+    reload = true;
+    c.fails = 0;
+    if (c.retry >= 8) { status |= HX_ERR_RETRIES; c.alive = false; c.stepping = false; }
+  }
+  if (reload) c.first_call = true;
+  return reload;
+}
+
+#ifdef HX_PHASE_CLOCK
+__device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
+  volatile long long *clk = clkp;
+  asm volatile("" ::: "memory");
+  const long long now = (long long)__builtin_readcyclecounter();
+  clk[k] += now - clk[23];
+  clk[23] = now;
+  asm volatile("" ::: "memory");
+}
+#define PSTAMP(k) hx_pstamp(s_pclk[role], (k))
+#ifdef HX_PHASE_CLOCK_FINE
+#define PSTAMPF(k) PSTAMP(k)
+#else
+#define PSTAMPF(k)
+#endif
+#else
+#define PSTAMP(k)
+#define PSTAMPF(k)
+#endif
+
+}  // namespace
+
+// ===========================================================================
+// hx_pair_kernel: years (iy_from, iy_to], 128-thread workgroups = 2 wavefronts per 64 members
+//
+// One model year, left to right (| = workgroup barrier):
+//   ocean:  constants of both boxes | solve HL | interval | steps ... stash | (solve HL) | ... forcing, DOECLIM |
+//   land:   Tland-dependent factors | solve LL | flows    | steps ... stash | (solve LL) | ... next year's CH4/OH/O3,
+//                                                                                            Q10 window, history sums |
+// The carbonate solve a stash needs (pre-update carbon = the carbon left by the stash before) is
+// done right after that earlier stash, one box per wavefront, so no stash waits for it.
+// ===========================================================================
+__global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__ args, int iy_from,
+                                                      int iy_to) {
+  __shared__ double s_tblk[HX_DBLK + 1][64];  // SSTs of years blk0-1 .. blk0+31 (ocean writes, land reads)
+  __shared__ double s_st[2][PS_N][64];        // step hand-offs, double-buffered
+  __shared__ double s_yr[PY_N][64];           // year / stash hand-offs
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const int mem = blockIdx.x * 64 + lane;
+  const HxBuffers &buf = args->buf;
+  const HxConst &kc = args->kc;
+  const size_t np = (size_t)buf.npad;
+  unsigned status = HX_GU(buf.status)[mem];
+  PairCtl c;
+  c.sdt = lds_(buf, HXS_SOLVER_DT, mem);
+  c.max_ts = lds_(buf, HXS_MAX_TS, mem);
+  c.alive = status == 0;
+  c.nsteps = 0;
+  int par = 0;      // which half of s_st the next step hand-off uses
+  int blk0 = -1;    // first year index of the current DOECLIM block
+  const double eps_abs = kc.eps_abs, eps_rel = kc.eps_rel;
+#ifdef HX_PHASE_CLOCK
+  __shared__ long long s_pclk[2][24];
+  if (lane == 0) { for (int k = 0; k < 23; ++k) s_pclk[role][k] = 0; s_pclk[role][23] = (long long)__builtin_readcyclecounter(); }
+#endif
+
+  if (role == 0) {
+    // ======================= wavefront 0: atmosphere, ocean, climate =======================
+    double cHL = lds_(buf, HXS_C_HL, mem), cLL = lds_(buf, HXS_C_LL, mem),
+           cIO = lds_(buf, HXS_C_IO, mem), cDO = lds_(buf, HXS_C_DO, mem);
+    double atmos = lds_(buf, HXS_ATMOS, mem);
+    const double alkH = lds_(buf, HXS_ALK_HL, mem);
+    double hH = lds_(buf, HXS_H_HL, mem);
+    int ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
+    double lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
+    double tland = lds_(buf, HXS_TLAND, mem), sst = lds_(buf, HXS_SST, mem),
+           f_prev = lds_(buf, HXS_F_PREV, mem), base_tot = lds_(buf, HXS_BASE_TOT, mem),
+           base_co2 = lds_(buf, HXS_BASE_CO2, mem);
+    const double C0 = ldp(buf, HXP_C0, mem), p_aero = ldp(buf, HXP_AERO, mem),
+                 p_vol = ldp(buf, HXP_VOL, mem);
+    const double kLH = ldd(buf, HXD_KLH, mem), kLI = ldd(buf, HXD_KLI, mem),
+                 kHD = ldd(buf, HXD_KHD, mem), kIL = ldd(buf, HXD_KIL, mem),
+                 kIH = ldd(buf, HXD_KIH, mem), kID = ldd(buf, HXD_KID, mem),
+                 kDI = ldd(buf, HXD_KDI, mem);
+    const double dA0 = ldd(buf, HXD_A0, mem), dA1 = ldd(buf, HXD_A1, mem), dA2 = ldd(buf, HXD_A2, mem),
+                 dA3 = ldd(buf, HXD_A3, mem), dIB0 = ldd(buf, HXD_IB0, mem), dIB1 = ldd(buf, HXD_IB1, mem),
+                 dIB2 = ldd(buf, HXD_IB2, mem), dIB3 = ldd(buf, HXD_IB3, mem), dQC1 = ldd(buf, HXD_QC1, mem),
+                 dQC2 = ldd(buf, HXD_QC2, mem), dDQ1 = ldd(buf, HXD_DQ1, mem), dDQ2 = ldd(buf, HXD_DQ2, mem),
+                 dDPS = ldd(buf, HXD_DPSCALE, mem);
+    const double ker_lag1 = HX_CCD(buf.ker)[kc.ns - 2 + HX_KPAD];  // Ker entry of last year's SST
+    ChemK kH, kL;
+    double pco2H = 0, pco2L = 0;
+    double ch4 = lds_(buf, HXS_CH4, mem), ln_ch4 = hx_log(ch4), o3 = 0;
+    // OH / CH4 / O3 of year iyn from last year's CH4 and the land side's year-end CH4 respiration
+    // (ch4_component.cpp, oh_component.cpp, o3_component.cpp): done at the end of the year before
+    auto gas = [&](int iyn) {
+      hx_ccd shn = HX_CCD(buf.shared) + (size_t)iyn * HXSH_STRIDE;
+      const double prev_ch4 = ch4;
+      const double rh_ch4 = (iyn > 1) ? s_yr[PY_RHCH4][lane] : 0.0;
+      double toh = 0.0;
+      if (prev_ch4 != kc.M0)
+        toh = ((kc.CCH4 * (ln_ch4 - kc.lnM0) + shn[HXSH_OH_B]) + shn[HXSH_OH_C]) + shn[HXSH_OH_D];
+      const double tau_oh = kc.TOH0 * hx_exp(-toh);
+      const double emisTocon = ((shn[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + shn[HXSH_CH4N]) * kc.inv_UC_CH4;
+      const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
+                          hx_div(prev_ch4, tau_oh);
+      ch4 = prev_ch4 + dCH4;
+      ln_ch4 = hx_log(ch4);
+      o3 = ((5 * ln_ch4 + shn[HXSH_O3_NOX]) + shn[HXSH_O3_CO]) + shn[HXSH_O3_NMVOC];
+    };
+
+    for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
+      hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      // ---- year start (ocean): equilibrium constants of both boxes; LL's go to the land side ----
+      const double TcH = sst + 18 + (-16.4), TcL = sst + 18 + 2.9;
+      double lg[2] = {TcH + 273.15, TcL + 273.15};
+      hx_log_batch<2>(lg);
+      double ex[12];
+      chem_exponents(TcH, lg[0], &ex[0]);
+      chem_exponents(TcL, lg[1], &ex[6]);
+      hx_exp_chunks<12>(ex);
+      chem_from_exponentials(TcH, &ex[0], O_AsHL, kH);
+      chem_from_exponentials(TcL, &ex[6], O_AsLL, kL);
+      s_yr[PY_KL_K1][lane] = kL.K1; s_yr[PY_KL_K2][lane] = kL.K2; s_yr[PY_KL_KB][lane] = kL.Kb;
+      s_yr[PY_KL_KW][lane] = kL.Kw; s_yr[PY_KL_KH][lane] = kL.Kh;
+      PSTAMP(0);
+      __syncthreads();  // ---- barrier A0: LL constants published
+      PSTAMP(1);
+      if (iy == iy_from + 1) gas(iy);  // (later years: at the end of the year before)
+      chem_solve1(kH, cHL, alkH, 1.0 / O_vHL, hH, pco2H, status);
+      s_yr[PY_MAXTS][lane] = c.max_ts;
+      s_yr[PY_STATUS0][lane] = (double)status;
+      PSTAMP(2);
+      __syncthreads();  // ---- barrier A: the land side's flows, CH4, O3, history sum, LL pCO2
+      PSTAMP(3);
+      double Pn = s_yr[PY_PN][lane];
+      const double dpast_in = s_yr[PY_DPAST][lane];
+      pco2L = s_yr[PY_PCO2L][lane];
+      status |= (unsigned)s_yr[PY_STATUS1][lane];
+      // flux constants of the interval (make_interval)
+      double totC = cDO + cIO + cLL + cHL;
+      double pG = pco2H * kH.g + pco2L * kL.g;
+      double aoA = PGC2PPM * (kH.g + kL.g);
+      double aoB = pG * hx_recip(cLL + cHL);
+      auto rhs = [&](const double *y, double *d) {
+        const double ao = fma(y[0], aoA, -fma(y[1] - totC, aoB, pG));
+        d[0] = Pn - ao;
+        d[1] = ao;
+      };
+      // ---- solver (ocean): y[0] = atmosphere, y[1] = ocean total ----
+      const double year = (double)(kc.start_year + iy);
+      const double t0 = year - 1.0, tnew = year;
+      double y[2], dxdt[2];
+      auto load_pools = [&]() { y[0] = atmos; y[1] = cDO + cIO + cLL + cHL; };
+      load_pools();
+      c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
+      c.alive = status == 0;
+      PSTAMP(4);
+      while (__any(c.alive && c.t < tnew)) {
+        const bool seg = c.alive && c.t < tnew;
+        c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = true; c.fails = 0;
+        c.stepping = seg;
+        while (__any(c.stepping)) {
+          double xn[2], dn[2], en[2] = {0, 0}, ed[2] = {1, 1};
+          bool tried = false;
+          if (c.stepping) {
+            if (pair_retry(c, status)) load_pools();
+            if (c.stepping) {
+              if (c.first_call) { rhs(y, dxdt); c.first_call = false; }
+              pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+              tried = true;
+            }
+          }
+          s_st[par][PS_N0][lane] = en[0]; s_st[par][PS_D0][lane] = ed[0];
+          s_st[par][PS_N4][lane] = en[1]; s_st[par][PS_D4][lane] = ed[1];
+          s_st[par][PS_X0][lane] = xn[0]; s_st[par][PS_X4][lane] = xn[1];
+          PSTAMPF(12);
+          __syncthreads();
+          PSTAMPF(13);
+          if (tried) {
+            const double err = pair_err(en[0], ed[0], s_st[par][PS_NL][lane], s_st[par][PS_DL][lane],
+                                        en[1], ed[1]);
+            if (pair_control(c, err, status)) { y[0] = xn[0]; y[1] = xn[1]; dxdt[0] = dn[0]; dxdt[1] = dn[1]; }
+          }
+          par ^= 1;
+          PSTAMPF(14);
+        }
+        PSTAMP(5);
+        // ---- stash, ocean half (OceanComponent::stashCValues) ----
+        const bool more = seg && c.alive && c.t < tnew;
+        if (seg && c.alive) {
+          c.retry = 0;
+          const double t = c.t, yf = t - c.ode_start;
+          const bool in_partial_year = (t != floor(t));
+          const double co2 = y[0] * PGC2PPM;
+          // (pCO2 of the carbon this stash starts from: the year-start solve at the year's first
+          // stash, the solve that followed the previous stash otherwise)
+          pco2L = s_yr[PY_PCO2L][lane];
+          double aH = ((co2 - pco2H) * kH.g) * yf, aL = ((co2 - pco2L) * kL.g) * yf;
+          const double lHD = cHL * kHD * yf;
+          const double lLH = cLL * kLH * yf, lLI = cLL * kLI * yf;
+          const double lIL = cIO * kIL * yf, lIH = cIO * kIH * yf, lID = cIO * kID * yf;
+          const double lDI = cDO * kDI * yf;
+          const double currentflux = aH + aL;
+          const double tot = cDO + cIO + cLL + cHL;
+          const double solver_flux = y[1] - tot;
+          double adj = 0.0;
+          if (currentflux != 0.0) adj = (solver_flux - currentflux) / 2.0;
+          aH += adj; aL += adj;
+          const double inv_yf = hx_recip(yf);
+          const double cdiff = solver_flux * inv_yf - lastflux_ann;
+          if (cdiff > 0.1) {  // ocean_component.cpp:703-733
+            c.max_ts = fmax(0.3, c.max_ts * 0.5);
+            ts_timeout = 20;
+          } else if (!in_partial_year && ts_timeout) {
+            ts_timeout = max(0, ts_timeout - 1);
+            if (!ts_timeout) {
+              c.max_ts = fmin(1.0, c.max_ts / 0.5);
+              if (c.max_ts < 1.0) ts_timeout = 20;
+            }
+          }
+          const double lastflux = aL + aH;
+          lastflux_ann = lastflux * inv_yf;
+          cHL = ((cHL + (lLH + lIH)) + aH) - lHD;
+          cLL = ((cLL + lIL) + aL) - (lLH + lLI);
+          cIO = (cIO + (lLI + lDI)) - ((lIL + lIH) + lID);
+          cDO = (cDO + (lHD + lID)) - lDI;
+          if (y[0] < 0) status |= HX_ERR_NEGPOOL;
+          atmos = y[0];
+          c.ode_start = t;
+        }
+        s_yr[PY_MAXTS][lane] = c.max_ts;
+        s_yr[PY_STATUS0][lane] = (double)status;
+        s_yr[PY_CLL][lane] = cLL;
+        PSTAMP(6);
+        __syncthreads();  // ---- stash hand-off
+        PSTAMP(7);
+        status |= (unsigned)s_yr[PY_STATUS1][lane];
+        if (seg && c.alive) {
+          Pn = s_yr[PY_PN][lane];  // the next interval's land flows
+          totC = cDO + cIO + cLL + cHL;
+          pG = pco2H * kH.g + pco2L * kL.g;
+          aoA = PGC2PPM * (kH.g + kL.g);
+          aoB = pG * hx_recip(cLL + cHL);
+          if (status != 0) c.alive = false;
+        }
+        // the solve the next stash of this year will need (error flags travel with the next hand-off)
+        if (__any(more)) {
+          double h2 = hH, p2 = pco2H;
+          unsigned st2 = 0;
+          chem_solve1(kH, cHL, alkH, 1.0 / O_vHL, h2, p2, st2);
+          if (more) { hH = h2; pco2H = p2; status |= st2; }
+        }
+        PSTAMP(8);
+        __syncthreads();  // (the hand-off slots are free again)
+        PSTAMP(9);
+      }
+      // ---- year end (ocean): forcing, DOECLIM year step, outputs ----
+      if (blk0 < 0 || iy >= blk0 + HX_DBLK) blk0 = iy;
+      const int slot = iy - (blk0 - 1);
+      const double co2c = atmos * PGC2PPM;
+      const double ln_co2r = hx_log(hx_div(co2c, C0));
+      double rf_tot = 0;
+      if (iy >= kc.baseyear_idx) {
+        const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
+        const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
+        const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
+        const double sqN = sh[HXSH_SQRT_N2O], sqN0 = kc.sqrtN0, rf_other = sh[HXSH_RF_OTHER];
+        const double sqM = hx_sqrt(ch4), sqC = hx_sqrt(co2c);
+        const double C_alpha_max = C0 - (b1 / (2 * a1));
+        double alpha_prime;
+        if (co2c > C_alpha_max) alpha_prime = d1 - ((b1 * b1) / (4 * a1));
+        else if (C0 < co2c && co2c < C_alpha_max)
+          alpha_prime = d1 + a1 * ((co2c - C0) * (co2c - C0)) + b1 * (co2c - C0);
+        else alpha_prime = d1;
+        const double sarf_co2 = (alpha_prime + c1 * sqN) * ln_co2r;
+        const double fco2 = (sarf_co2 * kc.delta_co2) + sarf_co2;
+        const double sarf_n2o = (a2 * sqC + b2 * sqN + c2 * sqM + d2) * (sqN - sqN0);
+        const double fn2o = (kc.delta_n2o * sarf_n2o) + sarf_n2o;
+        const double sarf_ch4 = (a3 * sqM + b3 * sqN + d3) * (sqM - kc.sqrtM0);
+        const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
+        const double fh2o = 0.0485 * ((ch4 - kc.M0f) * kc.inv_h2o_span);
+        const double fo3 = kc.o3_rf * o3;
+        const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
+                             p_aero * sh[HXSH_RF_AERO]) + p_vol * sh[HXSH_RF_VOL];
+        if (iy == kc.baseyear_idx) { base_tot = ftot; base_co2 = fco2; }
+        else rf_tot = ftot - base_tot;
+      }
+      // history sum: the land side's part (years before last) + last year's SST
+      const double dpast = (dpast_in + sst * ker_lag1) * dDPS;
+      const double DelQ = rf_tot - f_prev;
+      const double DQ1 = dDQ1 * (rf_tot + f_prev) + DelQ * dQC1;
+      const double DQ2 = dDQ2 * (rf_tot + f_prev) + DelQ * dQC2;
+      const double X1 = DQ1 + (dA0 * tland + dA1 * sst);
+      const double X2 = (DQ2 + dpast) + (dA2 * tland + dA3 * sst);
+      const double tl_new = dIB0 * X1 + dIB1 * X2;
+      const double sst_new = dIB2 * X1 + dIB3 * X2;
+      const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+      s_tblk[slot][lane] = sst_new;
+      if (slot == HX_DBLK) s_tblk[0][lane] = sst_new;  // the year before the next block
+      s_yr[PY_TLAND][lane] = tl_new;
+      s_yr[PY_LNC][lane] = ln_co2r;
+      f_prev = rf_tot; tland = tl_new; sst = sst_new;
+      const size_t o = (size_t)iy * np + mem;
+      sto_(buf, HXO_SST, o, sst_new);
+      sto_(buf, HXO_TLAND, o, tl_new);
+      if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
+#ifdef PAIR_DBG_TGAV
+      if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, PAIR_DBG_TGAV);
+#else
+      if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
+#endif
+      if (iy < iy_to) gas(iy + 1);
+      PSTAMP(10);
+      __syncthreads();  // ---- barrier C: year end (SST and land temperature published)
+      PSTAMP(11);
+    }
+    // state back to the table
+    sts_(buf, HXS_C_HL, mem, cHL); sts_(buf, HXS_C_LL, mem, cLL);
+    sts_(buf, HXS_C_IO, mem, cIO); sts_(buf, HXS_C_DO, mem, cDO);
+    sts_(buf, HXS_ATMOS, mem, atmos);
+    sts_(buf, HXS_MAX_TS, mem, c.max_ts); sts_(buf, HXS_TS_TIMEOUT, mem, (double)ts_timeout);
+    sts_(buf, HXS_LASTFLUX_ANN, mem, lastflux_ann); sts_(buf, HXS_SOLVER_DT, mem, c.sdt);
+    sts_(buf, HXS_H_HL, mem, hH);
+    sts_(buf, HXS_TLAND, mem, tland); sts_(buf, HXS_SST, mem, sst);
+    sts_(buf, HXS_F_PREV, mem, f_prev); sts_(buf, HXS_BASE_TOT, mem, base_tot);
+    sts_(buf, HXS_BASE_CO2, mem, base_co2);
+    sts_(buf, HXS_CH4, mem, ch4);
+  } else {
+    // ======================= wavefront 1: land, gases, history sums =======================
+    double veg = lds_(buf, HXS_NGLOBAL + HXSB_VEG, mem), det = lds_(buf, HXS_NGLOBAL + HXSB_DET, mem),
+           soil = lds_(buf, HXS_NGLOBAL + HXSB_SOIL, mem), pf = lds_(buf, HXS_NGLOBAL + HXSB_PF, mem),
+           thawed = lds_(buf, HXS_NGLOBAL + HXSB_THAWED, mem),
+           tempferts = lds_(buf, HXS_NGLOBAL + HXSB_TEMPFERTS, mem),
+           ffrozen = lds_(buf, HXS_NGLOBAL + HXSB_F_FROZEN, mem);
+    double earth = lds_(buf, HXS_EARTH, mem), cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem),
+           cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem), masstot = lds_(buf, HXS_MASSTOT, mem);
+    const double eos = lds_(buf, HXS_EOS_VEGC, mem);
+    double twin = lds_(buf, HXS_TWIN, mem), tl_m1 = lds_(buf, HXS_TL_M1, mem),
+           tl_m2 = lds_(buf, HXS_TL_M2, mem);
+    double tland = lds_(buf, HXS_TLAND, mem);
+    double lnc = hx_log(hx_div(lds_(buf, HXS_ATMOS, mem) * PGC2PPM, ldp(buf, HXP_C0, mem)));
+    double cLL = lds_(buf, HXS_C_LL, mem), hL = lds_(buf, HXS_H_LL, mem);
+    const double alkL = lds_(buf, HXS_ALK_LL, mem);
+    const int r = HXP_NGLOBAL;
+    const double npp0 = ldp(buf, r + HXPB_NPP0, mem), f_nppv = ldp(buf, r + HXPB_F_NPPV, mem),
+                 f_nppd = ldp(buf, r + HXPB_F_NPPD, mem), f_litterd = ldp(buf, r + HXPB_F_LITTERD, mem),
+                 rh_ch4_frac = ldp(buf, r + HXPB_RH_CH4_FRAC, mem),
+                 fpf_static = ldp(buf, r + HXPB_FPF_STATIC, mem), beta = ldp(buf, r + HXPB_BETA, mem),
+                 wf = ldp(buf, r + HXPB_WF, mem), lnq10 = ldd(buf, HXD_NGLOBAL, mem),
+                 pmu = ldp(buf, r + HXPB_PF_MU, mem), psigma = ldp(buf, r + HXPB_PF_SIGMA, mem);
+    auto rh_tp_co2 = [&]() { return ((thawed * (1 - fpf_static)) * 0.02) * tempferts * (1.0 - rh_ch4_frac); };
+    auto rh_tp_ch4 = [&]() { return hx_div(rh_tp_co2(), 1.0 - rh_ch4_frac) * rh_ch4_frac; };
+    s_tblk[0][lane] = HX_GCD(buf.out[HXO_SST])[(size_t)iy_from * np + mem];  // the year before the block
+    ChemK kL;
+    kL.Tr = 0; kL.g = 0;
+    double pco2L = 0;
+    // what a year needs that does not depend on the year before's climate: the Q10 window, the
+    // history sums up to the year before last -- done while the ocean side finishes that year.
+    // Their two loads from memory are issued a phase earlier (prefetch()): with one wavefront on
+    // the SIMD a load's latency is otherwise waited out in full.
+    double tfs_cand = 0, dpast = 0, tl_old_pf = 0, dpart_pf = 0;
+    auto prefetch = [&](int iyn) {
+      const int iold = iyn - 203;
+      tl_old_pf = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * np + mem];
+      const bool newblk = blk0 < 0 || iyn >= blk0 + HX_DBLK;  // (then dpart is not there yet)
+      dpart_pf = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iyn - blk0) * np + mem];
+    };
+    auto prepare = [&](int iyn) {
+      const int iold = iyn - 203;
+      if (iyn >= 3) {  // Q10 window (runtime.cpp:1041-1052)
+        twin += tl_m2;
+        if (iold >= 1) twin -= tl_old_pf;
+      }
+      const double Trm = (iyn > 1) ? (twin * wf) * 0.005 : 0.0;
+      tfs_cand = hx_exp(lnq10 * (Trm * 0.1));
+      // DOECLIM history sums: the pass covers the years before blk0 - 1, the block's own years
+      // (from blk0 - 1 on) are in LDS; the last year's SST is added by the ocean side
+      if (blk0 < 0 || iyn >= blk0 + HX_DBLK) {
+        blk0 = iyn;
+        doeclim_pass_mfma<false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+                                 const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
+        HX_FENCE();
+        dpart_pf = HX_GCD(buf.dpart)[mem];
+      }
+      const int jb = iyn - blk0;
+      dpast = dpart_pf;
+      const int kq = kc.ns - iyn - 1 + HX_KPAD + (blk0 - 1);  // Ker index of slot 0
+      const int nchunk = (jb + 7) >> 3;
+      for (int cc = 0; cc < nchunk; ++cc) {
+        double T[8], K[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { T[q] = s_tblk[8 * cc + q][lane]; K[q] = HX_CCD(buf.ker)[kq + 8 * cc + q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dpast += ((8 * cc + q < jb) ? T[q] : 0.0) * K[q];
+      }
+    };
+    prefetch(iy_from + 1);
+    prepare(iy_from + 1);
+    s_yr[PY_RHCH4][lane] = rh_tp_ch4();  // (of the pools the launch starts from)
+
+    for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
+      hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      // ---- year start (land): what depends on last year's land temperature and CO2 ----
+      const double ffi = sh[HXSH_FFI], daccs = sh[HXSH_DACCS], luc_e = sh[HXSH_LUC_E], luc_u = sh[HXSH_LUC_U];
+      const double npp_luc_adjust = hx_div(eos - cum_luc_va, eos);
+      const double co2fert = 1 + beta * lnc;
+      const double Tb = tland * wf;
+      const double tempfertd = hx_exp(lnq10 * (Tb * 0.1));
+      double f_new_thaw = 0.0;
+      if (pf != 0.0) {
+        double ff = 1.0;
+        if (Tb > 0) {
+          const double d = hx_div(hx_log(Tb) - pmu, psigma * 1.4142135623730951);
+          ff = 1 - erfc(-d) / 2;
+        }
+        f_new_thaw = ffrozen - ff;
+        ffrozen = ff;
+      }
+      tempferts = fmax(tfs_cand, (iy > 1) ? tempferts : 0.0);  // sticky :1054-1059
+      tl_m2 = tl_m1; tl_m1 = tland;  // Tland of years iy-2, iy-1 for the next year
+      // ---- interval constants of the land side (compute_flows + make_interval, one biome) ----
+      double v1, d2c, s3c, k4, k5, k7, Pn;
+      auto prep = [&]() {
+        const double n = (npp0 * co2fert) * npp_luc_adjust;
+        const double fav = n * f_nppv, fad = n * f_nppd, fas = n * (1 - f_nppv - f_nppd);
+        const double fda = (det * 0.25) * tempfertd, fsa = (soil * 0.02) * tempferts;
+        const double tpc = rh_tp_co2(), tpm = rh_tp_ch4();
+        const double litter = veg * 0.035, lfvd = litter * f_litterd, lfvs = litter * (1 - f_litterd);
+        const double detsoil = det * 0.6;
+        double c_thaw = pf * f_new_thaw, r_tp = 0.0;
+        if (c_thaw < 0) { const double want = -c_thaw; c_thaw = 0.0; r_tp = fmin(want, thawed - tpc - tpm); }
+        const double rh = fda + fsa + tpc;
+        Pn = ((((ffi - daccs) + luc_e) - luc_u) - n) + rh;
+        v1 = fav - litter;
+        d2c = ((fad + lfvd) - detsoil) - fda;
+        s3c = ((fas + lfvs) + detsoil) - fsa;
+        k4 = -c_thaw + r_tp;
+        k5 = ((c_thaw - r_tp) - tpm) - tpc;
+        k7 = -ffi + daccs;
+      };
+      prep();
+      PSTAMP(0);
+      __syncthreads();  // ---- barrier A0
+      PSTAMP(1);
+      kL.K1 = s_yr[PY_KL_K1][lane]; kL.K2 = s_yr[PY_KL_K2][lane]; kL.Kb = s_yr[PY_KL_KB][lane];
+      kL.Kw = s_yr[PY_KL_KW][lane]; kL.Kh = s_yr[PY_KL_KH][lane];
+      chem_solve1(kL, cLL, alkL, 1.0 / O_vLL, hL, pco2L, status);
+      s_yr[PY_PN][lane] = Pn;
+      s_yr[PY_DPAST][lane] = dpast; s_yr[PY_STATUS1][lane] = (double)status;
+      s_yr[PY_PCO2L][lane] = pco2L;
+      PSTAMP(2);
+      __syncthreads();  // ---- barrier A
+      PSTAMP(3);
+      c.max_ts = s_yr[PY_MAXTS][lane];
+      status |= (unsigned)s_yr[PY_STATUS0][lane];
+      auto rhs = [&](const double *y, double *d) {
+        const double total = y[0] + y[1] + y[2];
+        const double rr = hx_div1(luc_e, total);
+        d[0] = (v1 - rr * y[0]) + luc_u;
+        d[1] = d2c - rr * y[1];
+        d[2] = s3c - rr * y[2];
+      };
+      // ---- solver (land): y = veg, detritus, soil; permafrost, thawed, earth advance exactly ----
+      const double year = (double)(kc.start_year + iy);
+      const double t0 = year - 1.0, tnew = year;
+      double y[3], dxdt[3], l4, l5, l7;
+      auto load_pools = [&]() { y[0] = veg; y[1] = det; y[2] = soil; l4 = pf; l5 = thawed; l7 = earth; };
+      load_pools();
+      c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
+      c.alive = status == 0;
+      int nstash = 0;
+      if (iy < iy_to) prefetch(iy + 1);
+      PSTAMP(4);
+      while (__any(c.alive && c.t < tnew)) {
+        const bool seg = c.alive && c.t < tnew;
+        c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = true; c.fails = 0;
+        c.stepping = seg;
+        double y0c = 0, y4c = 0;  // the ocean side's atmosphere / ocean totals after the last accepted step
+        while (__any(c.stepping)) {
+          double xn[3], dn[3], en[3] = {0, 0, 0}, ed[3] = {1, 1, 1};
+          bool tried = false;
+          if (c.stepping) {
+            if (pair_retry(c, status)) load_pools();
+            if (c.stepping) {
+              if (c.first_call) { rhs(y, dxdt); c.first_call = false; }
+              pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+              tried = true;
+            }
+          }
+          double bn = 0.0, bd = 1.0;  // first-largest quotient of the three
+#pragma unroll
+          for (int i = 0; i < 3; ++i) if (en[i] * bd > bn * ed[i]) { bn = en[i]; bd = ed[i]; }
+          s_st[par][PS_NL][lane] = bn; s_st[par][PS_DL][lane] = bd;
+          PSTAMPF(12);
+          __syncthreads();
+          PSTAMPF(13);
+          if (tried) {
+            const double err = pair_err(s_st[par][PS_N0][lane], s_st[par][PS_D0][lane], bn, bd,
+                                        s_st[par][PS_N4][lane], s_st[par][PS_D4][lane]);
+            const double used = c.dtl;
+            if (pair_control(c, err, status)) {
+              l4 += used * k4; l7 += used * k7; l5 += used * k5;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
+              y0c = s_st[par][PS_X0][lane]; y4c = s_st[par][PS_X4][lane];
+            }
+          }
+          par ^= 1;
+          PSTAMPF(14);
+        }
+        PSTAMP(5);
+        // ---- stash, land half (SimpleNbox::stashCValues, one biome) ----
+        const bool more = seg && c.alive && c.t < tnew;
+        if (seg && c.alive) {
+          c.retry = 0;
+          ++nstash;
+          const double t = c.t, yf = t - c.ode_start;
+          double tpf = l5;
+          if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
+          if (y[0] < 0 || y[1] < 0 || y[2] < 0 || l4 < 0 || tpf < 0) status |= HX_ERR_NEGPOOL;
+          const double total = y[0] + y[1] + y[2];
+          cum_luc_va += hx_div((luc_e - luc_u) * y[0], total);  // no yf: :388-393
+          cum_pf_ch4 += rh_tp_ch4() * yf;  // :481
+          const double wt_pf = (pf > 0) ? 1.0 : 0.0;
+          veg = y[0]; det = y[1]; soil = y[2];
+          pf = l4 * wt_pf; thawed = tpf * wt_pf;
+          earth = l7;
+          const double sum = ((((((y0c + y[0]) + y[1]) + y[2]) + l4) + l5) + y4c) + l7 + cum_pf_ch4;
+          if (masstot > 0.0 && !(fabs(sum - masstot) <= 0.001)) status |= HX_ERR_MASS;
+          masstot = sum;
+          c.ode_start = t;
+          if (t < tnew) prep();  // constants of the next segment
+        }
+        s_yr[PY_PN][lane] = Pn;
+        s_yr[PY_STATUS1][lane] = (double)status;
+        s_yr[PY_RHCH4][lane] = rh_tp_ch4();  // (the year's last one is what the CH4 budget takes)
+        PSTAMP(6);
+        __syncthreads();  // ---- stash hand-off
+        PSTAMP(7);
+        c.max_ts = s_yr[PY_MAXTS][lane];
+        status |= (unsigned)s_yr[PY_STATUS0][lane];
+        if (seg && c.alive) {
+          cLL = s_yr[PY_CLL][lane];
+          if (status != 0) c.alive = false;
+        }
+        if (__any(more)) {  // the LL solve the next stash of this year will need
+          double h2 = hL, p2 = pco2L;
+          unsigned st2 = 0;
+          chem_solve1(kL, cLL, alkL, 1.0 / O_vLL, h2, p2, st2);
+          if (more) { hL = h2; pco2L = p2; status |= st2; s_yr[PY_PCO2L][lane] = p2; }
+        }
+        PSTAMP(8);
+        __syncthreads();
+        PSTAMP(9);
+      }
+      // ---- year end (land): the stash count ("timesteps"), next year's climate-independent part ----
+      if (buf.out[HXO_NSTASH]) sto_(buf, HXO_NSTASH, (size_t)iy * np + mem, (double)nstash);
+      if (iy < iy_to) prepare(iy + 1);
+      PSTAMP(10);
+      __syncthreads();  // ---- barrier C
+      PSTAMP(11);
+      tland = s_yr[PY_TLAND][lane];
+      lnc = s_yr[PY_LNC][lane];
+    }
+    const int rr = HXS_NGLOBAL;
+    sts_(buf, rr + HXSB_VEG, mem, veg); sts_(buf, rr + HXSB_DET, mem, det);
+    sts_(buf, rr + HXSB_SOIL, mem, soil); sts_(buf, rr + HXSB_PF, mem, pf);
+    sts_(buf, rr + HXSB_THAWED, mem, thawed); sts_(buf, rr + HXSB_TEMPFERTS, mem, tempferts);
+    sts_(buf, rr + HXSB_F_FROZEN, mem, ffrozen);
+    sts_(buf, HXS_EARTH, mem, earth); sts_(buf, HXS_CUM_LUC_VA, mem, cum_luc_va);
+    sts_(buf, HXS_CUM_PF_CH4, mem, cum_pf_ch4); sts_(buf, HXS_MASSTOT, mem, masstot);
+    sts_(buf, HXS_TWIN, mem, twin);
+    sts_(buf, HXS_TL_M1, mem, tl_m1); sts_(buf, HXS_TL_M2, mem, tl_m2);
+    sts_(buf, HXS_H_LL, mem, hL);
+  }
+  // the two halves' error flags, merged
+  __syncthreads();
+  s_yr[role ? PY_STATUS1 : PY_STATUS0][lane] = (double)status;
+  __syncthreads();
+  if (role == 0)
+    HX_GU(buf.status)[mem] = status | (unsigned)s_yr[PY_STATUS1][lane];
+#ifdef HX_PHASE_CLOCK
+  __syncthreads();
+  if (role == 0 && buf.out[HXO_TGAV])
+    for (int k = 0; k < 46; ++k)
+      sto_(buf, HXO_TGAV, (size_t)(1 + k) * np + mem, (double)s_pclk[k / 23][k % 23]);
+#endif
+}

@@ -479,22 +479,26 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       HX_STAMP(m, 10);
       HX_COUNT(m, 16);  // step-loop iterations
       if (stepping) {
-        if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
         if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
         // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
         // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
-        // attempt throws CARBON_CYCLE_RETRY iff its last stage does.
-        if (((t + dtl) - m.ode_start) > m.max_ts) {
-          ++retry;  // carbon-cycle-solver.cpp:266-276
+        // attempt throws CARBON_CYCLE_RETRY iff its last stage does.  A retry
+        // (carbon-cycle-solver.cpp:266-276) is bookkeeping -- target halved, pools reloaded --
+        // and the attempt towards the new target follows in the same pass of the loop.
+        bool reload = false;
+        while (stepping && ((t + dtl) - m.ode_start) > m.max_ts) {
+          ++retry;
           t_target = t_start + (t_target - t_start) / 2.0;
           t = t_start;
           m.sdt = t_target - t;
           dtl = m.sdt;
-          load_pools();
-          first_call = true;
+          reload = true;
           fails = 0;
           if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
-        } else {
+        }
+        if (reload) { load_pools(); first_call = true; }
+        if (stepping) {
+          if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
           double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
 #pragma unroll
           for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];

@@ -207,7 +207,9 @@ template <bool HF>
 __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
                                                             const double *ker, double *part,
                                                             double *part2, int ns, int npad,
-                                                            int blk0, int mem) {
+                                                            int blk0, int mem, int hist_end) {
+  // (hist_end: history years i < hist_end enter the sums; the run kernel passes blk0, the
+  // small-ensemble kernel blk0 - 1 and adds the last year itself)
   typedef double d4 __attribute__((ext_vector_type(4)));
   const int lane = mem & 63, q = lane >> 4, c = lane & 15;
   const size_t np = (size_t)npad;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
     // rows >= blk0 must not contribute (they may hold values of an earlier run): read row 0
     // instead, the SST anomaly of startDate, which is 0 for every member -- the operands of the
     // MFMAs then come straight from loads, no VALU select in between
-    const size_t row = (size_t)(i < blk0 ? i : 0) * np;
+    const size_t row = (size_t)(i < hist_end ? i : 0) * np;
 #pragma unroll
     for (int g = 0; g < 4; ++g) Bv[g] = hist[row + 16 * g];
   };
@@ -268,7 +270,7 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
   };
   load(0, a0, a1, e0, e1, b);
   pin();
-  for (int i0 = 0; i0 < blk0; i0 += 8) {
+  for (int i0 = 0; i0 < hist_end; i0 += 8) {
     load(i0 + 4, c0, c1, f0, f1, d);
     mma(a0, a1, e0, e1, b);
     load(i0 + 8, a0, a1, e0, e1, b);
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
 #if HX_HAS_MFMA
         if constexpr (!KERPM)
           doeclim_pass_mfma<HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
-                                const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
+                                const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem, blk0);
         else
 #endif
         doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
@@ -1413,6 +1415,21 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     hipLaunchKernelGGL((hx_run_kernel<B, false, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else
     hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+}
+#if HX_HAS_MFMA
+#include "hx_dev_pair.h"
+#endif
+// the small-ensemble kernel (two wavefronts per 64 members, hx_dev_pair.h): one biome, no
+// constraints, outputs CO2 / tas / SST / land tas / timesteps only
+int hx_pair_available() { return HX_HAS_MFMA; }
+hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, int iy_from, int iy_to, hipStream_t st) {
+#if HX_HAS_MFMA
+  hipLaunchKernelGGL(hx_pair_kernel, dim3(npad / 64), dim3(128), 0, st, d_args, iy_from, iy_to);
+  return hipGetLastError();
+#else
+  (void)d_args; (void)npad; (void)iy_from; (void)iy_to; (void)st;
+  return hipErrorInvalidValue;
+#endif
 }
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st) {

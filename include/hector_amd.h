@@ -211,6 +211,16 @@ int hx_last_spinup_ms(hx_core *core, double *ms);
 /* the core's hipStream_t, as void* */
 int hx_stream(hx_core *core, void **stream);
 
+/* Small ensembles -- too few 64-member wavefronts to occupy the GPU's 1 024 SIMDs, BASELINE
+ * configs[1] -- are run by a kernel that gives every 64 members TWO wavefronts (ocean / climate and
+ * land / history sums, hx_dev_pair.h): same model, same decisions, ~20 % shorter launch.  It serves
+ * one-biome ensembles without constraints, per-member series, history or diagnostics beyond CO2,
+ * tas, SST, land tas and timesteps; everything else takes the one-wavefront kernels.
+ * hx_set_pair_kernel_limit: ensembles of up to max_members use it (default 32 768 = one workgroup
+ * per two SIMDs; 0 = never).  hx_last_run_kernel: "run" or "pair", whichever the last hx_run took. */
+int hx_set_pair_kernel_limit(hx_core *core, int max_members);
+int hx_last_run_kernel(hx_core *core, const char **name);
+
 #define HX_ERR_MASS 1u     /* mass not conserved        simpleNbox-runtime.cpp:553-563 */
 #define HX_ERR_RETRIES 2u  /* solver retries exhausted  carbon-cycle-solver.cpp:242-294 */
 #define HX_ERR_NEGPOOL 4u  /* negative pool             fluxpool.hpp:100-102 */

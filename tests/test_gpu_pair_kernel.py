@@ -1,0 +1,144 @@
+"""The small-ensemble kernel (two wavefronts per 64 members, hector_amd/csrc/hx_dev_pair.h) against
+the oracle and against the one-wavefront run kernel.
+
+Ensembles of up to 32 768 members (one biome, no constraints, default outputs) take it by
+default; `set_pair_kernel_limit(0)` forces the run kernel.  Same criterion as the other parity
+tests (test_gpu_parity.py); the per-year stash schedule ("timesteps": every retry and
+reduced-timestep decision of the reference) has to agree with the oracle member by
+member -- both wavefronts of a pair take those decisions independently from the same inputs."""
+import numpy as np
+import pytest
+
+import hector_amd
+from hector_amd import ensemble
+from conftest import SCENARIO
+
+pytestmark = pytest.mark.gpu
+
+REL_CO2 = 2e-8
+ABS_T = 2e-8
+
+
+def mk(hip_lib, n, S, q10, limit=None):
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    assert c.backend == "hip"
+    if limit is not None:
+        c.set_pair_kernel_limit(limit)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    return c
+
+
+def test_pair_kernel_vs_oracle_config2(hip_lib, oracle):
+    """BASELINE configs[1]: 1 024 members with perturbed ECS and Q10, every member, 555 years."""
+    from test_gpu_fullsize import _oracle_all
+    n = 1024
+    S, q10 = ensemble.ecs_q10(n)
+    c = mk(hip_lib, n, S, q10)
+    c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+    c.run(2300)
+    assert c.last_run_kernel() == "pair"
+    assert (c.status() == 0).all()
+
+    def mp(i):
+        p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        return p
+    oco2, otg, ots, oerr = _oracle_all(oracle, mp, n)
+    assert (oerr == 0).all()
+    co2 = c.fetchvars("CO2_concentration", (1745, 2300)).T
+    tg = c.fetchvars("global_tas", (1745, 2300)).T
+    ts = c.fetchvars("timesteps", (1745, 2300)).T
+    assert (np.abs(co2 - oco2) / oco2).max() < REL_CO2
+    assert np.abs(tg - otg).max() < ABS_T
+    assert int((ts.astype(np.int64) != ots.astype(np.int64)).any(axis=1).sum()) == 0
+
+
+@pytest.mark.parametrize("n", [1, 64, 100, 4096])
+def test_pair_kernel_equals_run_kernel(hip_lib, n):
+    """Both kernels on the same ensemble (ragged sizes too): trajectories to 1e-8 relative,
+    identical stash schedules, identical status."""
+    S, q10 = ensemble.ecs_q10(n)
+    out = {}
+    for name, limit in (("pair", None), ("run", 0)):
+        c = mk(hip_lib, n, S, q10, limit)
+        c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+        c.run(2300)
+        assert c.last_run_kernel() == name
+        out[name] = (c.status(), c.fetchvars("CO2_concentration"), c.fetchvars("global_tas"),
+                     c.fetchvars("sst"), c.fetchvars("land_tas"), c.fetchvars("timesteps"))
+    p, r = out["pair"], out["run"]
+    assert np.array_equal(p[0], r[0]) and (p[0] == 0).all()
+    assert (np.abs(p[1] - r[1]) / r[1]).max() < 1e-8
+    for k in (2, 3, 4):
+        assert np.abs(p[k] - r[k]).max() < 1e-8
+    assert np.array_equal(p[5], r[5])
+
+
+def test_pair_kernel_in_segments_reset_and_handover(hip_lib):
+    """A run in pieces, a reset, and a hand-over between the two kernels in the middle of a run
+    (the state table is common) give the one-launch trajectory."""
+    n = 200
+    S, q10 = ensemble.ecs_q10(n)
+    a = mk(hip_lib, n, S, q10).run(2300)
+    assert a.last_run_kernel() == "pair"
+    first = {v: a.fetchvars(v) for v in ("CO2_concentration", "global_tas", "sst", "land_tas")}
+    b = mk(hip_lib, n, S, q10)
+    for y in (1746, 1777, 1778, 1900, 2107, 2300):
+        b.run(y)
+        assert b.last_run_kernel() == "pair"
+    for v, x in first.items():
+        assert np.array_equal(x, b.fetchvars(v)), v
+    a.reset(0).run(2300)
+    assert np.array_equal(first["CO2_concentration"], a.fetchvars("CO2_concentration"))
+    # first half on one kernel, second half on the other
+    c = mk(hip_lib, n, S, q10).run(1990)
+    c.set_pair_kernel_limit(0)
+    c.run(2300)
+    assert c.last_run_kernel() == "run"
+    d = mk(hip_lib, n, S, q10, 0).run(1990)
+    d.set_pair_kernel_limit(32768)
+    d.run(2300)
+    assert d.last_run_kernel() == "pair"
+    for x in (c, d):
+        assert (x.status() == 0).all()
+        assert (np.abs(x.fetchvars("CO2_concentration") - first["CO2_concentration"]) /
+                first["CO2_concentration"]).max() < 1e-8
+        assert np.abs(x.fetchvars("global_tas") - first["global_tas"]).max() < 1e-8
+
+
+def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
+    n = 128
+    S, q10 = ensemble.ecs_q10(n)
+    c = mk(hip_lib, n, S, q10)
+    c.set_outputs(["CO2_concentration", "RF_tot"])           # a diagnostic it does not record
+    assert c.run(1800).last_run_kernel() == "run"
+    c = mk(hip_lib, n, S, q10)
+    c.split_biome(["a", "b"])                                 # more than one biome
+    assert c.run(1800).last_run_kernel() == "run"
+    c = mk(hip_lib, n, S, q10)
+    c.enable_history(True)                                    # state history for reset(date)
+    assert c.run(1800).last_run_kernel() == "run"
+    c = mk(hip_lib, n, S, q10)
+    c.setvar_dated_members("ffi_emissions", [1800], np.linspace(0.0, 1.0, n)[None, :])  # per-member series
+    assert c.run(1810).last_run_kernel() == "run"
+    c = mk(hip_lib, 40000, *ensemble.ecs_q10(40000))          # above the limit
+    assert c.run(1760).last_run_kernel() == "run"
+    c = mk(hip_lib, n, S, q10)
+    assert c.run(1800).last_run_kernel() == "pair"
+
+
+def test_pair_kernel_error_flags(hip_lib):
+    """A member that leaves the model's domain is flagged by whichever wavefront notices, stops
+    being integrated (no hang: both wavefronts must leave their loops together), and does not
+    disturb its neighbours."""
+    S = np.full(130, 3.0); npp = np.full(130, 56.2); npp[77] = 1e5
+    c = hector_amd.Core(SCENARIO, 130, device=0, lib_path=hip_lib)
+    c.setvar("S", S).setvar("npp_flux0", npp).run(1800)
+    assert c.last_run_kernel() == "pair"
+    st = c.status()
+    r = hector_amd.Core(SCENARIO, 130, device=0, lib_path=hip_lib)
+    r.set_pair_kernel_limit(0)
+    r.setvar("S", S).setvar("npp_flux0", npp).run(1800)
+    assert st[77] != 0 and (np.delete(st, 77) == 0).all()
+    assert st[77] == r.status()[77]
+    a = c.fetchvars("CO2_concentration")
+    assert np.array_equal(a[:, 0], a[:, 129]) and np.isfinite(a[:, 0]).all()

@@ -324,6 +324,7 @@ def test_dated_setvar_emissions_vs_oracle_on_gpu(hip_lib, oracle, tmp_path):
         assert (np.abs(co2[:, i] - oc) / oc).max() < REL_CO2
         assert np.abs(tg[:, i] - ot).max() < ABS_T
     d = mk(hip_lib, n).setvar("S", S, "degC")
+    d.set_pair_kernel_limit(0)  # (c records its state history: same kernel for the bitwise check)
     d.set_outputs(["CO2_concentration"]); d.setvar_dated("ffi_emissions", years, vals); d.run(2100)
     assert np.array_equal(d.fetchvars("CO2_concentration", (1745, 2100)), co2)
 

@@ -1,0 +1,63 @@
+"""tools/check_isa.py: the lint the build runs over the compiler's gfx950 assembly (a register
+save placed ahead of the exec restore of a join block loses the value for the lanes that skipped
+the branch -- see the tool's header).  Here: the two shapes it has to tell apart, and the assembly
+of the library that is in the tree."""
+import glob
+import os
+import sys
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_isa  # noqa: E402
+
+BUG = """
+_Z6kernelv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+; %bb.1:
+\tv_add_f64 v[32:33], v[32:33], v[4:5]
+.LBB0_2:
+\tv_writelane_b32 v254, s22, 52
+\tv_accvgpr_write_b32 a18, v80
+\ts_mov_b32 s28, s46
+\ts_or_b64 exec, exec, s[0:1]
+\tv_accvgpr_read_b32 v9, a18
+\ts_endpgm
+"""
+# the branch computed v80: its lanes may copy it under their mask
+FINE_COMPUTED = BUG.replace("v_add_f64 v[32:33], v[32:33], v[4:5]", "v_add_f64 v[80:81], v[32:33], v[4:5]")
+# if / else merging two values into a18
+FINE_MERGE = """
+_Z6kernelv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+; %bb.1:
+\tv_accvgpr_write_b32 a18, v70
+.LBB0_2:
+\ts_andn2_saveexec_b64 s[0:1], s[0:1]
+\tv_accvgpr_write_b32 a18, v80
+\ts_or_b64 exec, exec, s[0:1]
+\ts_endpgm
+"""
+
+
+def _scan(text, tmp_path, name):
+    p = tmp_path / name
+    p.write_text(text)
+    return check_isa.scan(str(p))
+
+
+def test_lint_tells_a_lost_save_from_a_merge(tmp_path):
+    hits = _scan(BUG, tmp_path, "bug.s")
+    assert len(hits) == 1 and "a18, v80" in hits[0][3]
+    assert _scan(FINE_COMPUTED, tmp_path, "fine1.s") == []
+    assert _scan(FINE_MERGE, tmp_path, "fine2.s") == []
+
+
+def test_assembly_of_the_built_library_is_clean():
+    files = glob.glob(os.path.join(ROOT, "hector_amd", "build", "hx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if not files:
+        import pytest
+        pytest.skip("no assembly in hector_amd/build (the library was not built in this tree)")
+    assert check_isa.scan(files[0]) == []

@@ -28,14 +28,19 @@ P = os.path.join(ROOT, "profiles")
 YEARS = 555
 
 
-def counters(d, kernel="hx_run_kernel"):
-    """counter -> value of the largest dispatch of `kernel` (summed over its XCD rows)."""
+def counters(d, kernel=("hx_run_kernel", "hx_pair_kernel"), name_out=None):
+    """counter -> value of the largest dispatch of `kernel` (summed over its XCD rows); small
+    one-biome ensembles are run by hx_pair_kernel (two wavefronts per 64 members)."""
+    if isinstance(kernel, str):
+        kernel = (kernel,)
     acc = {}
     path = os.path.join(d, "p_counter_collection.csv")
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
-        if kernel in r["Kernel_Name"]:
+        if any(kn in r["Kernel_Name"] for kn in kernel):
+            if name_out is not None:
+                name_out.add("hx_pair_kernel" if "hx_pair_kernel" in r["Kernel_Name"] else "hx_run_kernel")
             k = (r["Dispatch_Id"], r["Counter_Name"])
             acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
     best = {}
@@ -56,8 +61,10 @@ def main():
         members, biomes = (int(x) for x in cfg.split("x"))
         d = os.path.join(G, "%s_%s" % (tag, cfg))
         c = {}
+        names = set()
         for sub in ("fetch", "write", "sq_a", "sq_b", "sq_c"):
-            c.update(counters(os.path.join(d, sub)))
+            c.update(counters(os.path.join(d, sub), name_out=names))
+        kname = "hx_pair_kernel" if names == {"hx_pair_kernel"} else "hx_run_kernel<%d,...>" % biomes
         cal = counters(os.path.join(d, "fetch"), "hx_stats_kernel").get("FETCH_SIZE")
         npad = (members + 63) // 64 * 64
         known_kib = 556 * npad * 8 / 1024.0
@@ -91,7 +98,7 @@ def main():
             "hbm_traffic_bytes_per_launch": traffic,
             "fetch_size_correction_measured": factor,
         }
-        json.dump({"kernel": "hx_run_kernel<%d,...>" % biomes, "kernel_source_hash": h,
+        json.dump({"kernel": kname, "kernel_source_hash": h,
                    "workload": "%d members x 555 years, %d biome(s), one launch" % (members, biomes),
                    "counters_of_the_555_year_dispatch": c, "derived": der,
                    "bench_line_same_build": bench,
