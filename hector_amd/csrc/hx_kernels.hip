@@ -457,6 +457,25 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
+  // Two values a year come straight from HBM -- land temperature of 203 years ago (Q10 window)
+  // and the block's history partial sum -- and with one wavefront on the SIMD a load's latency is
+  // waited out in full: they are requested a phase ahead, before the solver (pf_*).
+  double pf_tl_old = 0.0, pf_dpart = 0.0;
+  {
+    const int iold0 = iy_from + 1 - 203;
+    pf_tl_old = HX_GCD(args->buf.out[HXO_TLAND])[(size_t)(iold0 >= 1 ? iold0 : 0) * args->buf.npad + mem];
+  }
+  // The same for the year's entries of the shared table (scalar loads, one exposed latency per
+  // phase otherwise): phase A's of next year and phase C's of this year are requested before the
+  // solver and wait in SGPRs.
+  double ya[12], yc4[4];  // OH_B/C/D, CH4_EM, CH4N, O3_NOX/CO/NMVOC, FFI, DACCS, LUC_E, LUC_U; SQRT_N2O, RF_OTHER, RF_AERO, RF_VOL
+  auto load_year_a = [&](int iyn) {
+    hx_ccd shn = HX_CCD(args->buf.shared) + (size_t)(iyn < args->kc.ns ? iyn : args->kc.ns - 1) * HXSH_STRIDE;
+    ya[0] = shn[HXSH_OH_B]; ya[1] = shn[HXSH_OH_C]; ya[2] = shn[HXSH_OH_D]; ya[3] = shn[HXSH_CH4_EM];
+    ya[4] = shn[HXSH_CH4N]; ya[5] = shn[HXSH_O3_NOX]; ya[6] = shn[HXSH_O3_CO]; ya[7] = shn[HXSH_O3_NMVOC];
+    ya[8] = shn[HXSH_FFI]; ya[9] = shn[HXSH_DACCS]; ya[10] = shn[HXSH_LUC_E]; ya[11] = shn[HXSH_LUC_U];
+  };
+  load_year_a(iy_from + 1);
   if constexpr (CON) m.bufp = &args->buf;
   if constexpr (CON == 2) m.trk_iy = args->kc.trk_iy;
 
@@ -522,8 +541,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       double twin = PKM(m, PK_TWIN);
       const double tl_m2 = PKM(m, PK_TL_M2);
       const int iold = iy - 203;
-      const double tl_old =
-          HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * buf.npad + mem];
+      const double tl_old = pf_tl_old;
       constexpr int SB = (B == HX_DYN) ? 1 : B;  // (the looped kernels read these where they use them)
       double p_beta[SB], p_wf[SB], p_lnq10[SB], p_mu[SB], p_sigma[SB], s_ffrozen[SB];
       LandK<B> lk;
@@ -569,8 +587,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       double toh = 0.0;
       if (prev_ch4 != kc.M0)
-        toh = ((kc.CCH4 * (PKM(m, PK_LN_CH4) - kc.lnM0) + sh[HXSH_OH_B]) + sh[HXSH_OH_C]) +
-              sh[HXSH_OH_D];
+        toh = ((kc.CCH4 * (PKM(m, PK_LN_CH4) - kc.lnM0) + ya[0]) + ya[1]) +
+              ya[2];
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
       // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
       if (iy >= 3) {
@@ -613,13 +631,13 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       }
       {
-        double ch4_em = sh[HXSH_CH4_EM];
+        double ch4_em = ya[3];
         if constexpr (CON) {
           if (buf.mseries[HXM_CH4_EM])
             ch4_em = HX_GCD(buf.mseries[HXM_CH4_EM])[(size_t)iy * buf.npad + mem];
         }
         const double emisTocon =
-            ((ch4_em + rh_ch4 * PG_C_TO_TG_CH4) + sh[HXSH_CH4N]) * kc.inv_UC_CH4;
+            ((ch4_em + rh_ch4 * PG_C_TO_TG_CH4) + ya[4]) * kc.inv_UC_CH4;
         const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
                             hx_div(prev_ch4, tau_oh);
         ch4 = prev_ch4 + dCH4;
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       PKM(m, PK_CH4) = ch4;
       const double ln_ch4 = hx_log(ch4);
       PKM(m, PK_LN_CH4) = ln_ch4;
-      o3 = ((5 * ln_ch4 + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
+      o3 = ((5 * ln_ch4 + ya[5]) + ya[6]) + ya[7];
       // ---- ocean: new year ----
       HX_STAMP(m, 1);   // park reads, the year's log / exp batches, OH / CH4 / O3
       chem_from_exponentials(TcH, &ex[0], O_AsHL, m.kH);
@@ -647,8 +665,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       m.chem_fresh = true;
       HX_STAMP(m, 3);   // year-start carbonate solve
       // ---- slowparameval (t = year-1) ----
-      m.ffi = sh[HXSH_FFI]; m.daccs = sh[HXSH_DACCS];
-      m.luc_e = sh[HXSH_LUC_E]; m.luc_u = sh[HXSH_LUC_U];
+      m.ffi = ya[8]; m.daccs = ya[9];
+      m.luc_e = ya[10]; m.luc_u = ya[11];
       if constexpr (CON) {  // emissions that differ between members
         const size_t o = (size_t)iy * buf.npad + mem;
         if (buf.mseries[HXM_FFI]) m.ffi = HX_GCD(buf.mseries[HXM_FFI])[o];
@@ -706,6 +724,16 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     HX_STAMP(m, 4);     // slow parameters
     // ======================= phase B: carbon-cycle solver ====================
     {
+      {  // next year's window entry, this year's history partial sum (see pf_* above)
+        const HxBuffers &buf = args->buf;
+        const int iold1 = iy + 1 - 203;
+        pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
+        const bool newblk = blk0 < 0 || iy >= blk0 + HX_DBLK;  // (then the pass has not run yet)
+        pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iy - blk0) * buf.npad + mem];
+        hx_ccd shc = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+        yc4[0] = shc[HXSH_SQRT_N2O]; yc4[1] = shc[HXSH_RF_OTHER]; yc4[2] = shc[HXSH_RF_AERO]; yc4[3] = shc[HXSH_RF_VOL];
+        load_year_a(iy + 1);
+      }
       const double year = (double)(args->kc.start_year + iy);
       YearCon yc{};
       if constexpr (CON) {
@@ -747,6 +775,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                     const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
         HX_FENCE();
+        pf_dpart = HX_GCD(buf.dpart)[mem];
         HX_STAMP(m, 11);  // DOECLIM history pass (once per HX_DBLK years)
       }
       // every HBM value this phase needs, issued back to back
@@ -763,7 +792,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
                    dHFS = want_hf ? HXDK(HXD_HFSCALE) : 0.0;
 #undef HXDK
       const int jb = iy - blk0;
-      double dpast = HX_GCD(buf.dpart)[(size_t)jb * buf.npad + mem];
+      double dpast = pf_dpart;
       double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
       // ---- forcing ----
       const double co2c = m.atmos * PGC2PPM;
@@ -774,7 +803,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
         const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
         const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
-        double sqN = sh[HXSH_SQRT_N2O], sqN0 = kc.sqrtN0, rf_other = sh[HXSH_RF_OTHER];
+        double sqN = yc4[0], sqN0 = kc.sqrtN0, rf_other = yc4[1];
         if constexpr (CON) {  // N2O / halocarbon parameters that differ between members
           if (buf.mseries[HXM_N2O]) {
             sqN = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[(size_t)iy * buf.npad + mem]);
@@ -798,8 +827,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         const double fh2o = 0.0485 * ((ch4 - kc.M0f) * kc.inv_h2o_span);
         const double fo3 = kc.o3_rf * o3;  // (0 with [ozone] enabled=0, forcing_component.cpp:392)
         double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
-                       p_aero * sh[HXSH_RF_AERO]) +
-                      p_vol * sh[HXSH_RF_VOL];
+                       p_aero * yc4[2]) +
+                      p_vol * yc4[3];
         if constexpr (CON) {  // forcing_component.cpp:498-505
           if (kc.con_mask & HXC_FTOT) {
             double c = sh[HXSH_FTOT_CON];

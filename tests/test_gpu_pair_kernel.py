@@ -142,3 +142,32 @@ def test_pair_kernel_error_flags(hip_lib):
     assert st[77] == r.status()[77]
     a = c.fetchvars("CO2_concentration")
     assert np.array_equal(a[:, 0], a[:, 129]) and np.isfinite(a[:, 0]).all()
+
+
+@pytest.mark.parametrize("name", ["picontrol", "ssp119", "ssp126", "ssp370", "ssp434", "ssp460",
+                                  "ssp534-over", "ssp585"])
+def test_pair_kernel_shipped_scenarios_vs_oracle(hip_lib, name):
+    """Every scenario the reference ships, 16 members each, on the two-wavefront kernel
+    (test_gpu_parity.py runs them on the one-wavefront kernel: it records RF_tot)."""
+    import oracle_binding
+    from test_scenarios import pack
+    path = pack(name)
+    o = oracle_binding.Oracle(path)
+    S, q10 = ensemble.ecs_q10(16, offset=1000)
+    c = hector_amd.Core(path, 16, device=0, lib_path=hip_lib)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10)
+    c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+    c.run(o.end)
+    # (picontrol prescribes its CO2 -- a constraint: that one stays on the run kernel)
+    assert c.last_run_kernel() == ("run" if name == "picontrol" else "pair")
+    assert (c.status() == 0).all()
+    co2 = c.fetchvars("CO2_concentration", (o.start, o.end))
+    tg = c.fetchvars("global_tas", (o.start, o.end))
+    ts = c.fetchvars("timesteps", (o.start + 1, o.end))
+    for i in range(16):
+        p = o.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        r, err, _ = o.run(p)
+        assert err == 0
+        assert (np.abs(co2[:, i] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < REL_CO2
+        assert np.abs(tg[:, i] - r["global_tas"]).max() < ABS_T
+        assert np.array_equal(ts[:, i], r["timesteps"][1:])
