@@ -479,8 +479,9 @@ void EnsembleCore::alloc_device() {
   }
   check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
   check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
-  // DOECLIM kernel table, zero-padded by HX_KPAD (= 32) entries on both sides
-  check(hipMalloc(&d_ker_, sizeof(double) * (ns + 64) * np), "hipMalloc ker");
+  // DOECLIM kernel table, zero-padded by HX_KPAD (= 32) entries in front and 64 behind (the
+  // history pass runs up to three slices of four years past the end)
+  check(hipMalloc(&d_ker_, sizeof(double) * (ns + 96) * np), "hipMalloc ker");
   check(hipMalloc(&d_status_, sizeof(unsigned) * np * 2), "hipMalloc status");
   check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
@@ -1260,7 +1261,7 @@ void EnsembleCore::upload_params() {
   // DOECLIM convolution kernel: one shared table when every member has the same
   // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]
   ker_per_member_ = !row_uniform_[HXP_DIFF];
-  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 64) * np, stream_),
+  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 96) * np, stream_),
         "zero ker");
   check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
                                  ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,

@@ -220,30 +220,27 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int g = 0; g < 4; ++g) { acc[h][g] = d4{0, 0, 0, 0}; acc2[h][g] = d4{0, 0, 0, 0}; }
-  double a0, a1, e0 = 0, e1 = 0, b[4];
-  auto load = [&](int i0, double &A0, double &A1, double &E0, double &E1, double (&Bv)[4]) {
+  struct Slice { double a0, a1, e0, e1, b[4]; };  // operands of four history years
+  auto load = [&](int i0, Slice &S) {
     const int i = i0 + q;
-    A0 = kg[i0];
-    A1 = kg[i0 - 16];
-    if (HF) { E0 = kg[i0 + 1]; E1 = kg[i0 - 15]; }
-    // rows >= blk0 must not contribute (they may hold values of an earlier run): read row 0
+    S.a0 = kg[i0];
+    S.a1 = kg[i0 - 16];
+    if (HF) { S.e0 = kg[i0 + 1]; S.e1 = kg[i0 - 15]; } else { S.e0 = 0; S.e1 = 0; }
+    // rows >= hist_end must not contribute (they may hold values of an earlier run): read row 0
     // instead, the SST anomaly of startDate, which is 0 for every member -- the operands of the
     // MFMAs then come straight from loads, no VALU select in between
     const size_t row = (size_t)(i < hist_end ? i : 0) * np;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Bv[g] = hist[row + 16 * g];
+    for (int g = 0; g < 4; ++g) S.b[g] = hist[row + 16 * g];
   };
-  // two register sets in turn: the loads of the next four history years are in flight while the
-  // MFMAs of the current ones execute (a set past the end loads clamped rows and is masked to 0)
-  double c0, c1, f0 = 0, f1 = 0, d[4];
-  auto mma = [&](double A0, double A1, double E0, double E1, const double (&Bv)[4]) {
+  auto mma = [&](const Slice &S) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      acc[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[g], acc[0][g], 0, 0, 0);
-      acc[1][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv[g], acc[1][g], 0, 0, 0);
+      acc[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.a0, S.b[g], acc[0][g], 0, 0, 0);
+      acc[1][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.a1, S.b[g], acc[1][g], 0, 0, 0);
       if (HF) {
-        acc2[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(E0, Bv[g], acc2[0][g], 0, 0, 0);
-        acc2[1][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(E1, Bv[g], acc2[1][g], 0, 0, 0);
+        acc2[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.e0, S.b[g], acc2[0][g], 0, 0, 0);
+        acc2[1][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(S.e1, S.b[g], acc2[1][g], 0, 0, 0);
       }
     }
   };
@@ -253,8 +250,8 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
   // compiler that statement becomes the accumulators' last writer, so its hazard recogniser no
   // longer sees that an MFMA result is read -- as SrcC of the next iteration's first MFMAs, by
   // the stores after the loop: the statement therefore carries the wait itself, 48 states, more
-  // than the 8 passes of a v_mfma_f64_16x16x4_f64 issued just before it (once per 16 MFMAs =
-  // 512 cycles of matrix pipe).  Without it the code was only correct for instruction orders
+  // than the 8 passes of a v_mfma_f64_16x16x4_f64 issued just before it (once per 32 MFMAs =
+  // 1024 cycles of matrix pipe).  Without it the code was only correct for instruction orders
   // that happened to keep an accumulator's reuse 7 MFMAs apart.
   auto pin = [&]() {
     if constexpr (HF)
@@ -268,13 +265,22 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
                    : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]),
                      "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]));
   };
-  load(0, a0, a1, e0, e1, b);
+  // Four register sets in turn, three of them in flight behind the one the matrix pipe is
+  // working on: a load from HBM / L2 takes several times the 8 MFMAs of a slice, and nothing else
+  // runs on this SIMD meanwhile.  (Sets past the end load row 0 = zeros and Ker entries of the
+  // table's zero padding: they add 0.)
+  Slice s0, s1, s2, s3;
+  load(0, s0); load(4, s1); load(8, s2);
   pin();
-  for (int i0 = 0; i0 < hist_end; i0 += 8) {
-    load(i0 + 4, c0, c1, f0, f1, d);
-    mma(a0, a1, e0, e1, b);
-    load(i0 + 8, a0, a1, e0, e1, b);
-    mma(c0, c1, f0, f1, d);
+  for (int i0 = 0; i0 < hist_end; i0 += 16) {
+    load(i0 + 12, s3);
+    mma(s0);
+    load(i0 + 16, s0);
+    mma(s1);
+    load(i0 + 20, s1);
+    mma(s2);
+    load(i0 + 24, s2);
+    mma(s3);
     pin();
   }
   hx_gd po = HX_GD(part) + (mem - lane) + c, po2 = HX_GD(part2) + (mem - lane) + c;
