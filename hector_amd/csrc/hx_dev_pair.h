@@ -36,7 +36,7 @@ enum PairStep {  // per step attempt, double-buffered
   PS_N
 };
 enum PairYear {  // per year / per stash, each slot written and read on opposite sides of a barrier
-  PY_PN = 0, PY_RHCH4, PY_DPAST, PY_STATUS1, PY_PCO2L,           // land -> ocean
+  PY_PN = 0, PY_CH4, PY_O3, PY_STATUS1, PY_PCO2L,               // land -> ocean
   PY_MAXTS, PY_STATUS0, PY_TLAND, PY_LNC, PY_CLL,                // ocean -> land
   PY_KL_K1, PY_KL_K2, PY_KL_KB, PY_KL_KW, PY_KL_KH,              // ocean -> land, once a year
   PY_N
@@ -193,7 +193,7 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // ===========================================================================
 __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__ args, int iy_from,
                                                       int iy_to) {
-  __shared__ double s_tblk[HX_DBLK + 1][64];  // SSTs of years blk0-1 .. blk0+31 (ocean writes, land reads)
+  __shared__ double s_tblk[HX_DBLK + 1][64];  // SSTs of years blk0-1 .. blk0+31 (the ocean side's)
   __shared__ double s_st[2][PS_N][64];        // step hand-offs, double-buffered
   __shared__ double s_yr[PY_N][64];           // year / stash hand-offs
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
@@ -241,23 +241,27 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
     const double ker_lag1 = HX_CCD(buf.ker)[kc.ns - 2 + HX_KPAD];  // Ker entry of last year's SST
     ChemK kH, kL;
     double pco2H = 0, pco2L = 0;
-    double ch4 = lds_(buf, HXS_CH4, mem), ln_ch4 = hx_log(ch4), o3 = 0;
-    // OH / CH4 / O3 of year iyn from last year's CH4 and the land side's year-end CH4 respiration
-    // (ch4_component.cpp, oh_component.cpp, o3_component.cpp): done at the end of the year before
-    auto gas = [&](int iyn) {
-      hx_ccd shn = HX_CCD(buf.shared) + (size_t)iyn * HXSH_STRIDE;
-      const double prev_ch4 = ch4;
-      const double rh_ch4 = (iyn > 1) ? s_yr[PY_RHCH4][lane] : 0.0;
-      double toh = 0.0;
-      if (prev_ch4 != kc.M0)
-        toh = ((kc.CCH4 * (ln_ch4 - kc.lnM0) + shn[HXSH_OH_B]) + shn[HXSH_OH_C]) + shn[HXSH_OH_D];
-      const double tau_oh = kc.TOH0 * hx_exp(-toh);
-      const double emisTocon = ((shn[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + shn[HXSH_CH4N]) * kc.inv_UC_CH4;
-      const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
-                          hx_div(prev_ch4, tau_oh);
-      ch4 = prev_ch4 + dCH4;
-      ln_ch4 = hx_log(ch4);
-      o3 = ((5 * ln_ch4 + shn[HXSH_O3_NOX]) + shn[HXSH_O3_CO]) + shn[HXSH_O3_NMVOC];
+    // The history sum of a year (all but last year's SST, which is added from the register): the
+    // pass over the years before the block was run by the land side, the block's own years are in
+    // LDS (this side wrote them).  Done in the wait for the land side's first step of the year
+    // (its attempt on three variables is the longer one), the HBM value requested at year start.
+    s_tblk[0][lane] = sst;  // the year before the first block
+    double dpart_pf = 0, dpast_in = 0;
+    bool sums_done = true;
+    auto history_sums = [&](int iy) {
+      const int jb = iy - blk0;
+      double acc = dpart_pf;
+      const int kq = kc.ns - iy - 1 + HX_KPAD + (blk0 - 1);  // Ker index of slot 0 (year blk0 - 1)
+      const int nchunk = (jb + 7) >> 3;
+      for (int cc = 0; cc < nchunk; ++cc) {
+        double T[8], K[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { T[q] = s_tblk[8 * cc + q][lane]; K[q] = HX_CCD(buf.ker)[kq + 8 * cc + q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += ((8 * cc + q < jb) ? T[q] : 0.0) * K[q];
+      }
+      dpast_in = acc;
+      sums_done = true;
     };
 
     for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
@@ -277,7 +281,6 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       PSTAMP(0);
       __syncthreads();  // ---- barrier A0: LL constants published
       PSTAMP(1);
-      if (iy == iy_from + 1) gas(iy);  // (later years: at the end of the year before)
       chem_solve1(kH, cHL, alkH, 1.0 / O_vHL, hH, pco2H, status);
       s_yr[PY_MAXTS][lane] = c.max_ts;
       s_yr[PY_STATUS0][lane] = (double)status;
@@ -285,7 +288,10 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       __syncthreads();  // ---- barrier A: the land side's flows, CH4, O3, history sum, LL pCO2
       PSTAMP(3);
       double Pn = s_yr[PY_PN][lane];
-      const double dpast_in = s_yr[PY_DPAST][lane];
+      const double ch4 = s_yr[PY_CH4][lane], o3 = s_yr[PY_O3][lane];
+      if (blk0 < 0 || iy >= blk0 + HX_DBLK) blk0 = iy;
+      dpart_pf = HX_GCD(buf.dpart)[(size_t)(iy - blk0) * np + mem];  // (the land side ran the pass last year end)
+      sums_done = false;
       pco2L = s_yr[PY_PCO2L][lane];
       status |= (unsigned)s_yr[PY_STATUS1][lane];
       // flux constants of the interval (make_interval)
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
               tried = true;
             }
           }
+          if (!sums_done) history_sums(iy);
           s_st[par][PS_N0][lane] = en[0]; s_st[par][PS_D0][lane] = ed[0];
           s_st[par][PS_N4][lane] = en[1]; s_st[par][PS_D4][lane] = ed[1];
           s_st[par][PS_X0][lane] = xn[0]; s_st[par][PS_X4][lane] = xn[1];
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         PSTAMP(9);
       }
       // ---- year end (ocean): forcing, DOECLIM year step, outputs ----
-      if (blk0 < 0 || iy >= blk0 + HX_DBLK) blk0 = iy;
+      if (!sums_done) history_sums(iy);  // (a year without a step: every lane retired)
       const int slot = iy - (blk0 - 1);
       const double co2c = atmos * PGC2PPM;
       const double ln_co2r = hx_log(hx_div(co2c, C0));
@@ -461,7 +468,6 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
 #else
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
 #endif
-      if (iy < iy_to) gas(iy + 1);
       PSTAMP(10);
       __syncthreads();  // ---- barrier C: year end (SST and land temperature published)
       PSTAMP(11);
@@ -476,7 +482,6 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
     sts_(buf, HXS_TLAND, mem, tland); sts_(buf, HXS_SST, mem, sst);
     sts_(buf, HXS_F_PREV, mem, f_prev); sts_(buf, HXS_BASE_TOT, mem, base_tot);
     sts_(buf, HXS_BASE_CO2, mem, base_co2);
-    sts_(buf, HXS_CH4, mem, ch4);
   } else {
     // ======================= wavefront 1: land, gases, history sums =======================
     double veg = lds_(buf, HXS_NGLOBAL + HXSB_VEG, mem), det = lds_(buf, HXS_NGLOBAL + HXSB_DET, mem),
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
     double earth = lds_(buf, HXS_EARTH, mem), cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem),
            cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem), masstot = lds_(buf, HXS_MASSTOT, mem);
     const double eos = lds_(buf, HXS_EOS_VEGC, mem);
+    double ch4 = lds_(buf, HXS_CH4, mem), ln_ch4 = hx_log(ch4), o3 = 0;
     double twin = lds_(buf, HXS_TWIN, mem), tl_m1 = lds_(buf, HXS_TL_M1, mem),
            tl_m2 = lds_(buf, HXS_TL_M2, mem);
     double tland = lds_(buf, HXS_TLAND, mem);
@@ -502,53 +508,52 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
                  pmu = ldp(buf, r + HXPB_PF_MU, mem), psigma = ldp(buf, r + HXPB_PF_SIGMA, mem);
     auto rh_tp_co2 = [&]() { return ((thawed * (1 - fpf_static)) * 0.02) * tempferts * (1.0 - rh_ch4_frac); };
     auto rh_tp_ch4 = [&]() { return hx_div(rh_tp_co2(), 1.0 - rh_ch4_frac) * rh_ch4_frac; };
-    s_tblk[0][lane] = HX_GCD(buf.out[HXO_SST])[(size_t)iy_from * np + mem];  // the year before the block
     ChemK kL;
     kL.Tr = 0; kL.g = 0;
     double pco2L = 0;
-    // what a year needs that does not depend on the year before's climate: the Q10 window, the
-    // history sums up to the year before last -- done while the ocean side finishes that year.
-    // Their two loads from memory are issued a phase earlier (prefetch()): with one wavefront on
-    // the SIMD a load's latency is otherwise waited out in full.
-    double tfs_cand = 0, dpast = 0, tl_old_pf = 0, dpart_pf = 0;
+    // what a year needs that does not depend on the year before's climate -- OH / CH4 / O3
+    // (ch4_component.cpp, oh_component.cpp, o3_component.cpp), the Q10 window, at the start of a
+    // DOECLIM block the pass over the SST history (years before blk0 - 1; the block's own years are
+    // summed by the ocean side from LDS) -- done while the ocean side finishes that year.  The
+    // window's load from memory is issued a phase earlier (prefetch()): with one wavefront on the
+    // SIMD a load's latency is otherwise waited out in full.
+    double tfs_cand = 0, tl_old_pf = 0;
     auto prefetch = [&](int iyn) {
       const int iold = iyn - 203;
       tl_old_pf = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * np + mem];
-      const bool newblk = blk0 < 0 || iyn >= blk0 + HX_DBLK;  // (then dpart is not there yet)
-      dpart_pf = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iyn - blk0) * np + mem];
     };
     auto prepare = [&](int iyn) {
+      hx_ccd shn = HX_CCD(buf.shared) + (size_t)iyn * HXSH_STRIDE;
       const int iold = iyn - 203;
+      const double prev_ch4 = ch4;
+      const double rh_ch4 = (iyn > 1) ? rh_tp_ch4() : 0.0;
+      double toh = 0.0;
+      if (prev_ch4 != kc.M0)
+        toh = ((kc.CCH4 * (ln_ch4 - kc.lnM0) + shn[HXSH_OH_B]) + shn[HXSH_OH_C]) + shn[HXSH_OH_D];
       if (iyn >= 3) {  // Q10 window (runtime.cpp:1041-1052)
         twin += tl_m2;
         if (iold >= 1) twin -= tl_old_pf;
       }
       const double Trm = (iyn > 1) ? (twin * wf) * 0.005 : 0.0;
-      tfs_cand = hx_exp(lnq10 * (Trm * 0.1));
-      // DOECLIM history sums: the pass covers the years before blk0 - 1, the block's own years
-      // (from blk0 - 1 on) are in LDS; the last year's SST is added by the ocean side
+      double ex[2] = {-toh, lnq10 * (Trm * 0.1)};
+      hx_exp_batch<2>(ex);
+      tfs_cand = ex[1];
+      const double tau_oh = kc.TOH0 * ex[0];
+      const double emisTocon = ((shn[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + shn[HXSH_CH4N]) * kc.inv_UC_CH4;
+      const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
+                          hx_div(prev_ch4, tau_oh);
+      ch4 = prev_ch4 + dCH4;
+      ln_ch4 = hx_log(ch4);
+      o3 = ((5 * ln_ch4 + shn[HXSH_O3_NOX]) + shn[HXSH_O3_CO]) + shn[HXSH_O3_NMVOC];
       if (blk0 < 0 || iyn >= blk0 + HX_DBLK) {
         blk0 = iyn;
         doeclim_pass_mfma<false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                  const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
         HX_FENCE();
-        dpart_pf = HX_GCD(buf.dpart)[mem];
-      }
-      const int jb = iyn - blk0;
-      dpast = dpart_pf;
-      const int kq = kc.ns - iyn - 1 + HX_KPAD + (blk0 - 1);  // Ker index of slot 0
-      const int nchunk = (jb + 7) >> 3;
-      for (int cc = 0; cc < nchunk; ++cc) {
-        double T[8], K[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { T[q] = s_tblk[8 * cc + q][lane]; K[q] = HX_CCD(buf.ker)[kq + 8 * cc + q]; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dpast += ((8 * cc + q < jb) ? T[q] : 0.0) * K[q];
       }
     };
     prefetch(iy_from + 1);
     prepare(iy_from + 1);
-    s_yr[PY_RHCH4][lane] = rh_tp_ch4();  // (of the pools the launch starts from)
 
     for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
@@ -597,8 +602,8 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       kL.K1 = s_yr[PY_KL_K1][lane]; kL.K2 = s_yr[PY_KL_K2][lane]; kL.Kb = s_yr[PY_KL_KB][lane];
       kL.Kw = s_yr[PY_KL_KW][lane]; kL.Kh = s_yr[PY_KL_KH][lane];
       chem_solve1(kL, cLL, alkL, 1.0 / O_vLL, hL, pco2L, status);
-      s_yr[PY_PN][lane] = Pn;
-      s_yr[PY_DPAST][lane] = dpast; s_yr[PY_STATUS1][lane] = (double)status;
+      s_yr[PY_PN][lane] = Pn; s_yr[PY_CH4][lane] = ch4; s_yr[PY_O3][lane] = o3;
+      s_yr[PY_STATUS1][lane] = (double)status;
       s_yr[PY_PCO2L][lane] = pco2L;
       PSTAMP(2);
       __syncthreads();  // ---- barrier A
@@ -685,7 +690,6 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         }
         s_yr[PY_PN][lane] = Pn;
         s_yr[PY_STATUS1][lane] = (double)status;
-        s_yr[PY_RHCH4][lane] = rh_tp_ch4();  // (the year's last one is what the CH4 budget takes)
         PSTAMP(6);
         __syncthreads();  // ---- stash hand-off
         PSTAMP(7);
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
     sts_(buf, rr + HXSB_F_FROZEN, mem, ffrozen);
     sts_(buf, HXS_EARTH, mem, earth); sts_(buf, HXS_CUM_LUC_VA, mem, cum_luc_va);
     sts_(buf, HXS_CUM_PF_CH4, mem, cum_pf_ch4); sts_(buf, HXS_MASSTOT, mem, masstot);
-    sts_(buf, HXS_TWIN, mem, twin);
+    sts_(buf, HXS_CH4, mem, ch4); sts_(buf, HXS_TWIN, mem, twin);
     sts_(buf, HXS_TL_M1, mem, tl_m1); sts_(buf, HXS_TL_M2, mem, tl_m2);
     sts_(buf, HXS_H_LL, mem, hL);
   }

@@ -213,7 +213,7 @@ int hx_stream(hx_core *core, void **stream);
 
 /* Small ensembles -- too few 64-member wavefronts to occupy the GPU's 1 024 SIMDs, BASELINE
  * configs[1] -- are run by a kernel that gives every 64 members TWO wavefronts (ocean / climate and
- * land / history sums, hx_dev_pair.h): same model, same decisions, ~20 % shorter launch.  It serves
+ * land, hx_dev_pair.h): same model, same decisions, ~20 % shorter launch.  It serves
  * one-biome ensembles without constraints, per-member series, history or diagnostics beyond CO2,
  * tas, SST, land tas and timesteps; everything else takes the one-wavefront kernels.
  * hx_set_pair_kernel_limit: ensembles of up to max_members use it (default 32 768 = one workgroup

@@ -4,7 +4,7 @@ sys.path.insert(0, os.getcwd())
 import hector_amd
 from hector_amd import ensemble
 SCEN = os.path.join(os.getcwd(), "hector_amd", "data", "ssp245.hxs")
-lib = os.path.join(os.getcwd(), "gpuwork", "libpairclk.so")  # tools/prof/build_variant.sh pairclk -DHX_PHASE_CLOCK
+lib = os.path.join(os.getcwd(), "gpuwork", "libpairclk.so")
 os.environ["HECTOR_AMD_PAIR_MAX_MEMBERS"] = str(1 << 30)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S, q10 = ensemble.ecs_q10(n)
