@@ -1,19 +1,21 @@
 // hx_dev_pair.h -- the small-ensemble run kernel: TWO wavefronts per 64 members
 // Part of the device code of hx_kernels.hip (one translation unit).
 //
-// With one resident wavefront per SIMD a model year costs its instruction count, and an ensemble
+// With one resident wavefront per SIMD a model year costs its instructions and its dependency
+// chains (nothing else hides a latency), and an ensemble
 // that does not fill the machine (BASELINE configs[1]: 1 024 members = 16 wavefronts on 1 024
 // SIMDs) runs as long as one wavefront's sequential chain.  The chain is shortened by giving the
 // 64 members of a workgroup two wavefronts that work on DIFFERENT PARTS of each member's year at
 // the same time, on two SIMDs of the CU, and hand values over through LDS (lane i of one
 // wavefront to lane i of the other) at workgroup barriers:
 //
-//   wavefront 0 "ocean":  equilibrium constants + carbonate solves, the atmosphere and ocean
+//   wavefront 0 "ocean":  equilibrium constants, the HL carbonate solves, the atmosphere and ocean
 //                         variables of the carbon-cycle solver, the ocean half of a stash (box
-//                         exchange, timestep controller), forcing, the DOECLIM year step, outputs
-//   wavefront 1 "land":   OH / CH4 / O3, slow parameters (Q10 factors, permafrost), the three land
+//                         exchange, timestep controller), the in-block terms of the DOECLIM history
+//                         sum, forcing, the DOECLIM year step, outputs
+//   wavefront 1 "land":   Q10 factors, permafrost curve, the LL carbonate solves, the three land
 //                         variables of the solver and the constant-derivative pools, the land half
-//                         of a stash, the DOECLIM history sums (matrix-pipe pass + in-block terms)
+//                         of a stash, OH / CH4 / O3, the matrix-pipe pass over the SST history
 //
 // Within a stash interval the land and the atmosphere-ocean subsystems are decoupled (land
 // fluxes come from frozen pools, simpleNbox-runtime.cpp:809-840); they meet only in the error
@@ -25,7 +27,8 @@
 //
 // Same formulas, same decisions as hx_run_kernel<1,false,false,0> (parity tests compare both with
 // the oracle); instantiated for one biome, no constraints, default outputs: the configuration
-// small perturbed-parameter ensembles use.  The host picks it below HX_PAIR_MAX_MEMBERS members.
+// small perturbed-parameter ensembles use.  The host picks it up to hx_set_pair_kernel_limit members
+// (default 32 768: one workgroup per two SIMDs).
 #pragma once
 
 namespace {
@@ -124,7 +127,7 @@ __device__ __forceinline__ bool pair_control(PairCtl &c, double err, unsigned &s
 #pragma clang fp contract(off)
   constexpr double EPS = 2.220446049250313e-16;
   if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
-    c.dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
+    c.dtl *= fmax(0.9 * pow_m13(err), 0.2);
     if (++c.fails > 500) { status |= HX_ERR_STEPFAIL; c.alive = false; c.stepping = false; }
     return false;
   }

@@ -395,9 +395,20 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   HX_STAMP(m, 9);   // stash: next segment's interval constants
 }
 
-// exp(p*log(x)) for the step-size controller (x in [5^-5, ~1e3]); the value only
-// scales the next trial step, so ~1e-15 relative error is immaterial.
-__device__ __forceinline__ double powr(double x, double p) { return exp(p * log(x)); }
+// x^(-1/3) for the step-shrink rule (x = err > 1): single-precision seed, two Newton steps on
+// y^-3 = x in fp64 (relative error e -> 2e^2).  A wavefront takes the rejection branch whenever
+// one of its 64 lanes rejects -- most passes of the step loop -- and exp(log(x) / -3) through the
+// device library was ~180 instructions of it.
+__device__ __forceinline__ double pow_m13(double x) {
+  x = fmin(x, 1e30);  // (a larger error shrinks by the cap of 0.2 anyway)
+  double y = (double)exp2f(-0.33333334f * log2f((float)x));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double y3 = y * y * y;
+    y = y + y * ((1.0 - x * y3) * (1.0 / 3.0));
+  }
+  return y;
+}
 
 // x^(-1/5) for the step-growth rule: single-precision seed, two Newton steps on
 // y^-5 = x in fp64 (relative error e -> 3e^2: 1e-6 -> 3e-12 -> ~1e-16).  The
@@ -541,7 +552,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           }
           double err = hx_div(en, ed);
           if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
-            dtl *= fmax(0.9 * powr(err, -1.0 / 3.0), 0.2);
+            dtl *= fmax(0.9 * pow_m13(err), 0.2);
             if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
           } else {          // accept
             // pools with a constant derivative over the interval advance exactly
