@@ -6,6 +6,7 @@ T.SCENARIOS = ["picontrol", "ssp119", "ssp126", "ssp245", "ssp370", "ssp434", "s
 t0 = time.time()
 for seed in (101, 202):
     gpu = "--gpu" in sys.argv
-    if gpu: w = T.sweep(R + "/hector_amd/lib/libhector_amd.so", 2048, seed=seed, check_every=16, device=0)
+    if gpu: w = T.sweep(R + "/hector_amd/lib/libhector_amd.so", 2048, seed=seed, check_every=16, device=0,
+                        pair="--pair" in sys.argv)  # --pair: the two-wavefront kernel's configuration
     else: w = T.sweep(R + "/tests/emul/libhector_amd_emul.so", 16, seed=seed, allow_emulation=True)
     print("seed", seed, {k: "%.2e" % v for k, v in w.items()}, "%.0fs" % (time.time() - t0), flush=True)
