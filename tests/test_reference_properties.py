@@ -72,6 +72,9 @@ def science_checks(lib, **kw):
     yr = lambda y: y - 1745
     assert co2[0, 0] == pytest.approx(base["C0"], rel=1e-12) and co2[0, 1] == pytest.approx(250.0, rel=1e-12)
     assert (co2[1:, 1] < co2[1:, 0]).all()                 # lowering initial CO2 lowers CO2
+    # ... by about the change in the initial concentration, growing with time (test_parameters.R:88:
+    # expect_lt(max(diff), -26.0) over 1750:2100)
+    assert (co2[yr(1750):, 1] - co2[yr(1750):, 0]).max() < -26.0
     late = slice(yr(2000), yr(2100) + 1)
     assert (tas[late, 2] < tas[late, 0]).all()             # lowering ECS lowers temperature
     assert (co2[late, 3] > co2[late, 0]).all()             # raising Q10 increases CO2
@@ -94,6 +97,11 @@ def science_checks(lib, **kw):
     assert np.unique(emergent).size == emergent.size
     ratio = lt[keep - 1745, 1] / ot[keep - 1745, 1]
     assert (np.abs(3.0 - ratio) <= 1e-5).all() and np.unique(np.round(ratio, 3)).size == 1
+    # the global mean barely moves, land and ocean air temperatures do (test_parameters.R:422-435)
+    gt = lo.fetchvars("global_tas", (1745, 2100))
+    assert np.abs(gt[keep - 1745, 0] - gt[keep - 1745, 1]).mean() < 1e-1
+    assert np.abs(lt[keep - 1745, 0] - lt[keep - 1745, 1]).mean() > 1e-1
+    assert np.abs(ot[keep - 1745, 0] - ot[keep - 1745, 1]).mean() > 1e-1
     # ---- test_hector.R / test_messages.R: errors --------------------------------------
     with pytest.raises(hector_amd.HectorAmdError):
         hc.fetchvars("no_such_variable", (1800, 1801))
