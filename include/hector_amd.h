@@ -217,7 +217,8 @@ int hx_stream(hx_core *core, void **stream);
  * one-biome ensembles without constraints, per-member series, history or diagnostics beyond CO2,
  * tas, SST, land tas and timesteps; everything else takes the one-wavefront kernels.
  * hx_set_pair_kernel_limit: ensembles of up to max_members use it (default 32 768 = one workgroup
- * per two SIMDs; 0 = never).  hx_last_run_kernel: "run" or "pair", whichever the last hx_run took. */
+ * per two SIMDs; 0 = never; the environment variable HECTOR_AMD_PAIR_MAX_MEMBERS sets the default of
+ * new cores).  hx_last_run_kernel: "run" or "pair", whichever the last hx_run took. */
 int hx_set_pair_kernel_limit(hx_core *core, int max_members);
 int hx_last_run_kernel(hx_core *core, const char **name);
 
