@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Soak / fuzz harnesses: larger versions of the randomised parity tests in tests/ (same code:
+tests/test_random_sweep.py, tests/test_workflow_fuzz.py, tests/test_diagnostics.py), for a GPU box.
+
+    python tools/soak/soak.py <harness> [--gpu] [--pair]      harness: one of HARNESSES, or "all"
+    gpurun -- 'python tools/soak/soak.py all --gpu'
+
+Without --gpu they run the host build of the kernel source (tests/emul/) at smaller sizes.
+--pair (all_parameters): the two-wavefront kernel's configuration.  README.md says what each
+harness draws and what it compares with the oracle."""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+R = os.environ.get("GRAFT_REPO_ROOT") or os.path.normpath(
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, R); sys.path.insert(0, R + "/oracle"); sys.path.insert(0, R + "/tests")
+HIP = R + "/hector_amd/lib/libhector_amd.so"
+EMUL = R + "/tests/emul/libhector_amd_emul.so"
+ALL_SCENARIOS = ["picontrol", "ssp119", "ssp126", "ssp245", "ssp370", "ssp434", "ssp460", "ssp534-over", "ssp585"]
+
+
+def _fmt(w):
+    return {k: "%.2e" % v for k, v in w.items()}
+
+
+def all_parameters(gpu, argv):
+    """19 parameters at once, 9 scenarios, 2 048 members each."""
+    import test_random_sweep as T
+    T.SCENARIOS = list(ALL_SCENARIOS)
+    t0 = time.time()
+    for seed in (101, 202):
+        if gpu:
+            w = T.sweep(HIP, 2048, seed=seed, check_every=16, device=0, pair="--pair" in argv)
+        else:
+            w = T.sweep(EMUL, 16, seed=seed, allow_emulation=True)
+        print("seed", seed, _fmt(w), "%.0fs" % (time.time() - t0), flush=True)
+
+
+def biomes(gpu, argv):
+    """2-4 biomes, per-member pool splits, every per-biome parameter."""
+    import test_random_sweep as T
+    t0 = time.time()
+    for seed in (313, 414):
+        if gpu:
+            w = T.sweep_biomes(HIP, 1024, seed=seed, scenarios=tuple(ALL_SCENARIOS), check_every=8, device=0)
+        else:
+            w = T.sweep_biomes(EMUL, 8, seed=seed, scenarios=tuple(ALL_SCENARIOS), allow_emulation=True)
+        print("seed", seed, _fmt(w), "%.0fs" % (time.time() - t0), flush=True)
+
+
+def mixed(gpu, argv):
+    """scenario x biomes x one random constraint window x land-ocean warming ratio."""
+    import test_random_sweep as T
+    t0 = time.time()
+    tmp = tempfile.mkdtemp()
+    for seed in ((511, 512, 513) if gpu else (601,)):
+        if gpu:
+            w = T.sweep_mixed(HIP, 512, seed=seed, rounds=40, tmpdir=tmp, check_every=16, device=0)
+        else:
+            w = T.sweep_mixed(EMUL, 4, seed=seed, rounds=60, tmpdir=tmp, allow_emulation=True)
+        print("seed", seed, _fmt(w), "%.0fs" % (time.time() - t0), flush=True)
+
+
+def workflows(gpu, argv):
+    """random run / reset(date) / emission edits / parameter changes: final trajectory = fresh run."""
+    import test_workflow_fuzz as W
+    tmp = tempfile.mkdtemp()
+    t0 = time.time()
+    for seed in (711, 712):
+        if gpu:
+            w = W.workflow_fuzz(HIP, seed, 40, tmp, n=70, device=0)
+        else:
+            w = W.workflow_fuzz(EMUL, seed, 60, tmp, n=2, allow_emulation=True)
+        print("seed", seed, "worst %.2e" % w, "%.0fs" % (time.time() - t0), flush=True)
+
+
+def diagnostics(gpu, argv):
+    """all ~60 output-stream variables under full perturbation."""
+    import hector_amd
+    import oracle_binding
+    from test_random_sweep import RANGES, ORACLE_FIELD
+    from test_diagnostics import KERNEL_VARS, DERIVED_VARS, HOST_VARS, ORACLE_NAME
+    kw = dict(device=0) if gpu else dict(lib_path=EMUL, allow_emulation=True)
+    n = 256 if gpu else 6
+    step = 8 if gpu else 1
+    worst = {}
+    for seed, name in [(1, "ssp245"), (2, "ssp585"), (3, "ssp119"), (4, "ssp534-over"), (5, "picontrol")]:
+        rng = np.random.default_rng(seed)
+        path = os.path.join(R, "hector_amd", "data", name + ".hxs")
+        vals = {k: rng.uniform(lo, hi, n) for k, (lo, hi, _) in RANGES.items()}
+        lo_ratio = np.where(rng.uniform(size=n) < 0.3, rng.uniform(1.1, 1.8, n), 0.0)
+        c = hector_amd.Core(path, n, **kw)
+        for k, (lo, hi, unit) in RANGES.items():
+            c.setvar(k, vals[k], unit)
+        c.setvar("lo_warming_ratio", lo_ratio)
+        allv = KERNEL_VARS + DERIVED_VARS
+        c.set_outputs(allv + ["RF_tot", "RF_CO2", "global_tas", "CO2_concentration", "land_tas", "sst"])
+        c.run(2300)
+        st = c.status()
+        got = {v: c.fetchvars(v, (1746, 2300)) for v in allv + HOST_VARS + ["land_tas", "sst", "CO2_concentration"]}
+        o = oracle_binding.Oracle(path)
+        for i in range(0, n, step):
+            p = o.default_params(); p.lo_warming_ratio = lo_ratio[i]
+            for k in RANGES:
+                if k in ORACLE_FIELD:
+                    setattr(p, ORACLE_FIELD[k], vals[k][i])
+                else:
+                    getattr(p, k)[0] = vals[k][i]
+            r, err, _ = o.run(p)
+            assert (err != 0) == (st[i] != 0)
+            if err:
+                continue
+            for v in got:
+                ref = r[ORACLE_NAME.get(v, v)][1:]
+                d = np.abs(got[v][:, i] - ref).max() / max(1.0, np.abs(ref).max())
+                if d > worst.get(v, (0,))[0]:
+                    worst[v] = (d, name, i)
+        print(name, "done", flush=True)
+    for v, w in sorted(worst.items(), key=lambda kv: -kv[1][0])[:12]:
+        print(v, "%.2e" % w[0], w[1:])
+
+
+def shared_parameters(gpu, argv):
+    """the member-independent components' parameters (M0, N0, lifetimes, delta and rho of every agent)."""
+    import hector_amd
+    import oracle_binding
+    from conftest import edited_pack
+    kw = dict(device=0) if gpu else dict(lib_path=EMUL, allow_emulation=True)
+    SH = {"M0": "CH4", "Tsoil": "CH4", "Tstrat": "CH4", "N0": "N2O", "PO3": "ozone", "TOH0": "OH",
+          "delta_co2": "forcing", "delta_ch4": "forcing", "delta_n2o": "forcing", "rho_bc": "forcing",
+          "rho_oc": "forcing", "rho_so2": "forcing", "rho_nh3": "forcing"}
+    rng = np.random.default_rng(3); tmp = tempfile.mkdtemp(); worst = 0
+    outs = ["CO2_concentration", "global_tas", "RF_tot", "CH4_concentration", "RF_CH4", "RF_N2O"]
+    for rd in range(10):
+        name = ["ssp119", "ssp245", "ssp585", "ssp370"][rd % 4]
+        path = os.path.join(R, "hector_amd", "data", name + ".hxs")
+        c = hector_amd.Core(path, 2, **kw); c.setvar("S", [2.5, 4.0], "degC")
+        sc = {}
+        for k, sec in SH.items():
+            v0 = c.getvar(k)[0]; v = v0 * rng.uniform(0.7, 1.3) if v0 != 0 else rng.uniform(-0.2, 0.2)
+            c.setvar(k, [v]); sc[(sec, k)] = v
+        for h in c.halocarbons()[:6]:
+            for pre in ("rho_", "delta_"):
+                v0 = c.getvar(pre + h)[0]; v = v0 * rng.uniform(0.7, 1.3) if v0 != 0 else rng.uniform(-0.2, 0.2)
+                c.setvar(pre + h, [v]); sc[(h + "_halocarbon", pre + h)] = v
+        c.set_outputs(outs); c.run(2300)
+        assert (c.status() == 0).all()
+        o = oracle_binding.Oracle(edited_pack(os.path.join(tmp, "s%d.hxs" % rd), None, None, [], [], base=path, scalars=sc))
+        for i, S in enumerate((2.5, 4.0)):
+            p = o.default_params(); p.S = S
+            r, err, _ = o.run(p); assert err == 0
+            for v in outs:
+                d = np.abs(c.fetchvars(v, (1745, 2300))[:, i] - r[v]).max() / max(1.0, np.abs(r[v]).max())
+                worst = max(worst, d)
+                assert d < 2e-8, (name, v, d)
+    print("shared-parameter fuzz ok, worst %.2e" % worst)
+
+
+def tracking(gpu, argv):
+    """carbon tracking: random tracking date / biomes / parameters, run in pieces with a reset."""
+    import hector_amd
+    import oracle_binding
+    kw = dict(device=0) if gpu else dict(lib_path=EMUL, allow_emulation=True)
+    seeds = [int(a) for a in argv[1:] if a.isdigit()]
+    rng = np.random.default_rng(seeds[0] if seeds else 9)
+    worst = [0.0, 0.0]
+    for rd in range(int(os.environ.get("ROUNDS", "12"))):
+        name = ["ssp119", "ssp245", "ssp585"][rng.integers(3)]
+        path = os.path.join(R, "hector_amd", "data", name + ".hxs")
+        B = int(rng.choice([1, 2, 4])); n = 3
+        T0 = int(rng.integers(1750, 2050)); END = int(rng.integers(T0 + 5, 2301))
+        c = hector_amd.Core(path, n, **kw); c.enable_history(True)
+        if B > 1:
+            c.split_biome(["b%d" % b for b in range(B)])
+        c.setvar("trackingDate", [T0])
+        S = rng.uniform(2, 5, n); q10 = rng.uniform(1.2, 2.8, (B, n)); wf = rng.uniform(0.8, 1.6, (B, n))
+        c.setvar("S", S, "degC")
+        for b in range(B):
+            pre = "b%d." % b if B > 1 else ""
+            c.setvar(pre + "q10_rh", q10[b]).setvar(pre + "warmingfactor", wf[b])
+        y1 = int(rng.integers(1746, END + 1)); c.run(y1)   # in pieces, with a reset in between
+        if y1 > 1750 and rng.uniform() < 0.7:
+            c.reset(int(rng.integers(1745, y1)))
+        c.run(END)
+        assert (c.status() == 0).all()
+        o = oracle_binding.Oracle(path)
+        for i in range(n):
+            p = o.default_params()
+            if B > 1:
+                p = o.split_equal(p, B)
+            p.S = S[i]
+            for b in range(B):
+                p.q10_rh[b] = q10[b][i]; p.warmingfactor[b] = wf[b][i]
+            ov, of, _, err = o.run_tracking(p, T0, END); assert err == 0
+            gv, gf = c.tracking_data(i, (T0, END))
+            k0, k1 = T0 - 1745, END - 1745 + 1
+            dv = np.abs(gv - ov[k0:k1]).max() / np.abs(ov).max(); df = np.abs(gf - of[k0:k1]).max()
+            worst = [max(worst[0], dv), max(worst[1], df)]
+            assert dv < 1e-10 and df < 1e-7, (name, B, T0, END, i, dv, df)
+            assert np.abs(gf.sum(2) - 1).max() < 1e-12
+    print("tracking fuzz ok: worst value dev %.2e fraction dev %.2e" % tuple(worst))
+
+
+HARNESSES = {"all_parameters": all_parameters, "biomes": biomes, "mixed": mixed, "workflows": workflows,
+             "diagnostics": diagnostics, "shared_parameters": shared_parameters, "tracking": tracking}
+
+if __name__ == "__main__":
+    which = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()]
+    if not which or (which[0] != "all" and which[0] not in HARNESSES):
+        sys.exit(__doc__ + "\nHARNESSES: " + " ".join(HARNESSES))
+    for name in (HARNESSES if which[0] == "all" else [which[0]]):
+        print("==", name, flush=True)
+        HARNESSES[name]("--gpu" in sys.argv, sys.argv)
