@@ -171,3 +171,35 @@ def test_pair_kernel_shipped_scenarios_vs_oracle(hip_lib, name):
         assert (np.abs(co2[:, i] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < REL_CO2
         assert np.abs(tg[:, i] - r["global_tas"]).max() < ABS_T
         assert np.array_equal(ts[:, i], r["timesteps"][1:])
+
+
+@pytest.mark.timeout(300)
+def test_pair_kernel_runaway_member_is_flagged_and_does_not_hang(hip_lib):
+    """The member of test_host_logic.runaway_member_checks (SSP1-1.9, a carbon cycle that runs
+    away around 2130) without its own diffusivity, so that the ensemble stays on the two-wavefront
+    kernel: flagged and retired by both wavefronts together, neighbours untouched."""
+    import os
+    from conftest import ROOT
+    from test_host_logic import RUNAWAY
+    path = os.path.join(ROOT, "hector_amd", "data", "ssp119.hxs")
+    out = {}
+    for which, limit in (("pair", 32768), ("run", 0)):
+        c = hector_amd.Core(path, 3, device=0, lib_path=hip_lib)
+        c.set_pair_kernel_limit(limit)
+        for k, v in RUNAWAY.items():
+            if k == "diff":
+                continue
+            base = c.getvar(k)[0]
+            c.setvar(k, [base, v, base])
+        c.set_outputs(["CO2_concentration", "timesteps"])
+        c.run(2300)
+        assert c.last_run_kernel() == which
+        out[which] = (c.status(), c.fetchvars("CO2_concentration", (1745, 2300)), c.fetchvars("timesteps", (1745, 2300)))
+    st, co2, ts = out["pair"]
+    assert np.array_equal(st, out["run"][0])
+    assert st[0] == 0 and st[2] == 0
+    assert np.isfinite(co2).all()
+    assert np.array_equal(co2[:, 0], co2[:, 2])
+    ok = [0, 2] if st[1] else [0, 1, 2]
+    assert (np.abs(co2[:, ok] - out["run"][1][:, ok]) / out["run"][1][:, ok]).max() < 1e-8
+    assert np.array_equal(ts[:, ok], out["run"][2][:, ok])
