@@ -1278,6 +1278,34 @@ void EnsembleCore::upload_params() {
   params_dirty_ = false;
 }
 
+// SimpleNbox::prepareToRun's checks of the biome parameters (simpleNbox-runtime.cpp:94-107) and
+// ForcingComponent::prepareToRun's of the forcing efficacies (forcing_component.cpp:291-293): the
+// reference throws there, before anything runs -- so does this, naming the biome and the first
+// member at fault (a configuration error, unlike the model errors a run reports as status flags).
+void EnsembleCore::check_parameters() const {
+  auto fail = [&](const char *what, int b, size_t i) {
+    throw std::runtime_error(std::string(what) + " (biome '" + biome_names_[(size_t)b] + "', member " +
+                             std::to_string(i) + ")");
+  };
+  for (int b = 0; b < B_; ++b) {
+    const int r = HXP_NGLOBAL + b * HXPB_N;
+    for (size_t i = 0; i < (size_t)n_; ++i) {
+      const double beta = params_[r + HXPB_BETA][i], q10 = params_[r + HXPB_Q10][i],
+                   fv = params_[r + HXPB_F_NPPV][i], fd = params_[r + HXPB_F_NPPD][i],
+                   fl = params_[r + HXPB_F_LITTERD][i];
+      if (!(beta >= 0.0)) fail("beta < 0", b, i);
+      if (!(q10 > 0.0)) fail("q10_rh <= 0.0", b, i);
+      if (!(fv >= 0.0)) fail("f_nppv <0", b, i);
+      if (!(fd >= 0.0)) fail("f_nppd <0", b, i);
+      if (!(fv + fd <= 1.0)) fail("f_nppv + f_nppd >1", b, i);
+      if (!(fl >= 0.0 && fl <= 1.0)) fail("f_litterd <0 or >1", b, i);
+    }
+  }
+  if (!(kc_.delta_ch4 >= -1 && kc_.delta_ch4 <= 1)) throw std::runtime_error("bad delta CH4 value");
+  if (!(kc_.delta_n2o >= -1 && kc_.delta_n2o <= 1)) throw std::runtime_error("bad delta N2O value");
+  if (!(kc_.delta_co2 >= -1 && kc_.delta_co2 <= 1)) throw std::runtime_error("bad delta CO2 value");
+}
+
 void EnsembleCore::prepare() {
   check(hipSetDevice(device_), "hipSetDevice");
   if (layout_dirty_) alloc_device();
@@ -1290,6 +1318,7 @@ void EnsembleCore::prepare() {
     params_dirty_ = true;  // HxConst (constraint mask, preindustrial values) is re-uploaded
   }
   if (params_dirty_) {
+    check_parameters();
     upload_params();
     for (int k = 0; k < HXM_N; ++k) if (!member_series_[k].empty()) mseries_dirty_ = true;  // lanes may have moved
     gas_dirty_ = true;

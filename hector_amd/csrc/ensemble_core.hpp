@@ -180,6 +180,7 @@ class EnsembleCore {
   size_t gather_cap_ = 0, diag_cap_ = 0;
   double *d_diag_ = nullptr, *d_slr_ = nullptr;
   int slr_valid_to_ = -1;
+  void check_parameters() const;
   bool fetch_host(const std::string &capability, int year0, int year1, double *out_host);
   void compute_derived(const std::string &capability, int iy0, int ny);
   hipStream_t stream_ = nullptr;
