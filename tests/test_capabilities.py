@@ -153,3 +153,22 @@ def test_remaining_r_level_helpers(emul_lib, golden):
     r = h.runscenario(SCENARIO, **kw)
     assert sorted(r) == sorted(h.core.DEFAULT_FETCHVARS) and r["global_tas"].shape == (556, 1)
     assert abs(r["global_tas"][-1, 0] - golden["global_tas"][-1]) < 2e-8
+
+
+def test_can_fetch_all_variables(emul_lib):
+    """test_set_get_data.R 'Can fetch all variables': every name of the reference's ALL_VARS()
+    (data/all_vars.rda, kept as tests/golden/all_vars.txt) can be recorded and fetched for a year
+    of a run -- 82 distinct variables, finite."""
+    import os
+    from conftest import ROOT
+    names = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "all_vars.txt"))
+             if l.strip() and not l.startswith("#")]
+    assert len(set(names)) == 82
+    c = hector_amd.Core(SCENARIO, 2, lib_path=emul_lib, allow_emulation=True)
+    c.setvar("S", [3.0, 4.2], "degC")
+    c.set_outputs(names)
+    c.run(1850)
+    assert (c.status() == 0).all()
+    for v in names:
+        x = c.fetchvars(v, (1845, 1845))
+        assert x.shape == (1, 2) and np.isfinite(x).all(), v
