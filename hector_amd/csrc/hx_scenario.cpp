@@ -205,7 +205,55 @@ void Scenario::set_series_value(const std::string &section, const std::string &k
       h.emissions[(size_t)(year - start)] = v;
 }
 
+namespace {
+struct IniKey { const char *component, *key; };
+const IniKey kIniKeys[] = {
+#include "hx_ini_keys.inc"
+};
+}  // namespace
+
+// Every key of every section has to be one its component reads: the reference's components throw
+// "Unknown variable name while parsing <component>: <key>" from setData() for anything else
+// (e.g. src/temperature_component.cpp, src/core.cpp:242-243), and a section that names no
+// component fails in Core::getComponentByName.  "enabled" / "output" are the core's, for every
+// component (core.cpp:251-262); simpleNbox keys may carry a biome ("<biome>.<key>").
+void Scenario::validate_keys() const {
+  const std::string suf = "_halocarbon";
+  auto check = [&](const std::string &name) {
+    const size_t dot = name.find('.');
+    if (dot == std::string::npos) return;
+    const std::string sec = name.substr(0, dot);
+    std::string key = name.substr(dot + 1);
+    std::string comp = sec, gas;
+    if (sec.size() > suf.size() && !sec.compare(sec.size() - suf.size(), suf.size(), suf)) {
+      comp = "*_halocarbon";
+      gas = sec.substr(0, sec.size() - suf.size());
+    }
+    if (comp == "simpleNbox") {
+      const size_t d2 = key.find('.');
+      if (d2 != std::string::npos) key = key.substr(d2 + 1);
+    }
+    bool known_component = false;
+    for (const IniKey &k : kIniKeys) {
+      if (comp != k.component) continue;
+      known_component = true;
+      std::string want = k.key;
+      const size_t g = want.find("<gas>");
+      if (g != std::string::npos) want.replace(g, 5, gas);
+      if (want == key) return;
+    }
+    if (!known_component)
+      throw std::runtime_error("Component not found: " + sec + " (section of " + source + ")");
+    if (sec != "core" && (key == "enabled" || key == "output")) return;
+    throw std::runtime_error("Unknown variable name while parsing " + sec + ": " + key);
+  };
+  for (auto &kv : scalars_) check(kv.first);
+  for (auto &kv : series_) check(kv.first);
+  for (auto &kv : con_points_) check(kv.first);
+}
+
 void Scenario::finish() {
+  validate_keys();
   start = (int)scalar("core", "startDate");
   end = (int)scalar("core", "endDate");
   if (end <= start) throw std::runtime_error("scenario: endDate <= startDate");

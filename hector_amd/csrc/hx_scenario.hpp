@@ -27,6 +27,7 @@ class Scenario {
   double scalar(const std::string &section, const std::string &key) const;
   double scalar(const std::string &section, const std::string &key, double dflt) const;
   bool has_scalar(const std::string &section, const std::string &key) const;
+  void validate_keys() const;  // every section a component, every key one it reads
   std::vector<std::string> scalar_keys(const std::string &section) const;
   void set_scalar(const std::string &section, const std::string &key, double v);
   std::string text(const std::string &section, const std::string &key,

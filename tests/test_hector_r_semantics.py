@@ -111,3 +111,24 @@ def test_future_edits_do_not_reset_past_edits_do(emul_lib):
         h.setvar_dated("ffi_emissions", yy, np.full(len(yy), vv), "Pg C/yr")
     h.run(1760)
     assert same(traj(h, 1745, 1760), traj(c, 1745, 1760))
+
+
+def test_unknown_ini_keys_and_sections_are_errors(emul_lib, tmp_path):
+    """A key no component reads, or a section that names no component, makes the reference throw
+    while it parses the INI ("Unknown variable name while parsing temperature: ...",
+    src/temperature_component.cpp setData; Core::getComponentByName) -- a typo does not pass
+    silently.  `enabled` / `output` are the core's, valid in every component's section."""
+    from conftest import edited_pack
+
+    def core(scalars):
+        p = edited_pack(tmp_path / "s.hxs", None, None, [], [], scalars=scalars)
+        return hector_amd.Core(str(p), 1, lib_path=emul_lib, allow_emulation=True)
+    with pytest.raises(hector_amd.HectorAmdError, match="Unknown variable name while parsing temperature: bogus_key"):
+        core({("temperature", "bogus_key"): 3.0})
+    with pytest.raises(hector_amd.HectorAmdError, match="Component not found: temprature"):
+        core({("temprature", "S"): 3.0})
+    with pytest.raises(hector_amd.HectorAmdError, match="Unknown variable name while parsing simpleNbox: bogus"):
+        core({("simpleNbox", "boreal.bogus"): 1.0})
+    with pytest.raises(hector_amd.HectorAmdError, match="Unknown variable name while parsing CF4_halocarbon: rho_C2F6"):
+        core({("CF4_halocarbon", "rho_C2F6"): 1.0})
+    core({("ozone", "output"): 1.0, ("temperature", "lo_warming_ratio"): 0.0}).run(1760)
