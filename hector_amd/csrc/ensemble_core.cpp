@@ -613,6 +613,9 @@ static bool gas_member_capable(const Scenario &scen, const std::string &capabili
 
 void EnsembleCore::setvar(const std::string &capability, const double *values, int nvalues,
                           const char *units) {
+  // R/messages.R (setvar): "<biome>.<variable>" at most
+  if (std::count(capability.begin(), capability.end(), '.') > 1)
+    throw std::runtime_error("Invalid input variable: '" + capability + "'");
   if (capability == "trackingDate") {  // Core::setData  core.cpp:230-236
     set_tracking_date((int)values[0]);
     return;

@@ -132,3 +132,13 @@ def test_unknown_ini_keys_and_sections_are_errors(emul_lib, tmp_path):
     with pytest.raises(hector_amd.HectorAmdError, match="Unknown variable name while parsing CF4_halocarbon: rho_C2F6"):
         core({("CF4_halocarbon", "rho_C2F6"): 1.0})
     core({("ozone", "output"): 1.0, ("temperature", "lo_warming_ratio"): 0.0}).run(1760)
+
+
+def test_messages(emul_lib):
+    """test_messages.R: a variable name with more than one '.' is invalid; fetchvars without
+    dates for the default variables is an error."""
+    c = mk(emul_lib)
+    with pytest.raises(hector_amd.HectorAmdError, match="Invalid input variable: '"):
+        c.setvar("global.permafrost.beta", [10.0], "")
+    with pytest.raises(hector_amd.HectorAmdError, match="all require dates"):
+        hector_amd.fetchvars(c, None)
