@@ -26,19 +26,23 @@ def science_checks(lib, **kw):
     for a, b in [("HL_ocean_c", "LL_ocean_c"), ("HL_pH", "LL_pH"), ("HL_PCO2", "LL_PCO2"),
                  ("HL_ocean_uptake", "LL_ocean_uptake"), ("HL_sst", "LL_sst"), ("HL_CO3", "LL_CO3")]:
         assert o[a].mean() != o[b].mean()                              # HL and LL boxes differ
-    # "Read and writing ocean parameters": halving a transport / preindustrial pool changes the ocean
+    # "Read and writing ocean parameters": each parameter times 1.1 moves the 1850-1900 mean of
+    # every ocean variable by more than the test's 1e-10; a parameter has no dates
     params = ["tt", "tu", "twi", "tid", "preind_surface_c", "preind_interdeep_c"]
+    with pytest.raises(hector_amd.HectorAmdError):
+        hc.fetchvars("tt", (1850, 1900))
     pc = mk(1 + len(params))
     for k, p in enumerate(params):
-        v = np.full(1 + len(params), pc.getvar(p)[0]); v[1 + k] *= 0.5
+        v = np.full(1 + len(params), pc.getvar(p)[0]); v[1 + k] *= 1.1
         pc.setvar(p, v)
         assert np.array_equal(pc.getvar(p), v)
-    pc.set_outputs(["ocean_uptake", "ocean_c", "HL_pH", "HL_PCO2"]); pc.run(1900)
+    ocean_vars = ["ocean_uptake", "ocean_c", "HL_pH", "HL_PCO2", "HL_DIC", "HL_sst", "HL_CO3"]
+    pc.set_outputs(ocean_vars); pc.run(1900)
     assert (pc.status() == 0).all()
-    for v in ["ocean_uptake", "ocean_c", "HL_pH", "HL_PCO2"]:
-        x = pc.fetchvars(v, (1850, 1900))
+    for v in ocean_vars:
+        x = pc.fetchvars(v, (1850, 1900)).mean(axis=0)
         for k in range(len(params)):
-            assert (x[:, 1 + k] != x[:, 0]).any(), (v, params[k])
+            assert abs(x[1 + k] - x[0]) > 1e-10, (v, params[k])
     # ---- test_atmosphere.R "Check Temp" ----------------------------------------------
     hc = mk(1); hc.set_outputs(["land_tas", "ocean_tas", "global_tas", "gmst"]); hc.run(2100)
     land, oc = hc.fetchvars("land_tas", (2020, 2100)), hc.fetchvars("ocean_tas", (2020, 2100))
