@@ -416,7 +416,12 @@ void EnsembleCore::build_shared() {
   }
   HxConst &k = kc_;
   k.start_year = s.start; k.ns = ns;
-  k.baseyear_idx = (int)s.scalar("forcing", "baseyear", 1750) - s.start;
+  {  // ForcingComponent::prepareToRun (forcing_component.cpp:278-289): default startDate + 1
+    double by = s.scalar("forcing", "baseyear", 0.0);
+    if (by == 0.0) by = s.start + 1;
+    if (!(by > s.start)) throw std::runtime_error("Base year must be >= model start date");
+    k.baseyear_idx = (int)by - s.start;
+  }
   k.max_spinup = (int)s.scalar("core", "max_spinup", 2000);
   if (s.scalar("core", "do_spinup", 1) == 0) k.max_spinup = 1;  // core.cpp:378-384: no spinup steps
   k.spinup_chem = 0;

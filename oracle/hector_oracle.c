@@ -196,6 +196,7 @@ hxo_scenario *hxo_scenario_load(const char *path) {
   fclose(f);
   s->ns = s->end - s->start + 1;
   if (!ok || s->ns <= 1) { hxo_scenario_free(s); return NULL; }
+  if (s->baseyear == 0.0) s->baseyear = s->start + 1;  /* forcing_component.cpp:278-283 */
   return s;
 }
 

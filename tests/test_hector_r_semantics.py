@@ -142,3 +142,26 @@ def test_messages(emul_lib):
         c.setvar("global.permafrost.beta", [10.0], "")
     with pytest.raises(hector_amd.HectorAmdError, match="all require dates"):
         hector_amd.fetchvars(c, None)
+
+
+def test_forcing_base_year_default_and_check(emul_lib, oracle, tmp_path):
+    """ForcingComponent::prepareToRun (forcing_component.cpp:278-289): without a `baseyear` the
+    forcings are reported relative to startDate + 1; a base year at or before the start date is
+    refused."""
+    import oracle_binding
+    lines = [l for l in open(SCENARIO) if " baseyear " not in l]
+    p = tmp_path / "nobase.hxs"
+    p.write_text("".join(lines))
+    assert len(lines) == len(open(SCENARIO).readlines()) - 1
+    c = hector_amd.Core(str(p), 1, lib_path=emul_lib, allow_emulation=True)
+    c.set_outputs(["RF_tot", "global_tas", "CO2_concentration"]); c.run(1800)
+    rf = c.fetchvars("RF_tot", (1745, 1800))[:, 0]
+    assert rf[0] == 0 and rf[1] == 0 and rf[2] != 0          # 1746 is the base year
+    r, err, _ = oracle_binding.Oracle(str(p)).run(None, run_to=1800)
+    assert err == 0
+    assert np.abs(rf - r["RF_tot"][:rf.size]).max() < 1e-12
+    assert np.abs(c.fetchvars("global_tas", (1745, 1800))[:, 0] - r["global_tas"][:rf.size]).max() < 1e-10
+    from conftest import edited_pack
+    bad = edited_pack(tmp_path / "bad.hxs", None, None, [], [], scalars={("forcing", "baseyear"): 1745.0})
+    with pytest.raises(hector_amd.HectorAmdError, match="Base year must be"):
+        hector_amd.Core(str(bad), 1, lib_path=emul_lib, allow_emulation=True).run(1760)
