@@ -18,6 +18,7 @@
 #include <cstring>
 #include <ctime>
 #include <map>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -65,7 +66,7 @@ std::vector<double> parse_values(const std::string &txt) {
 
 }  // namespace
 
-int main(int argc, char **argv) {
+static int run_main(int argc, char **argv) {
   std::string scenario, outdir = "output/";
   int members = 1, device = 0, precision = 0, runto = -1;
   std::vector<std::pair<std::string, std::string>> params;
@@ -273,4 +274,18 @@ int main(int argc, char **argv) {
   }
   ck(hx_shutdown(core));
   return 0;
+}
+
+// src/main.cpp:116-128: model errors (here: everything the C ABI reports) exit with 1, any other
+// C++ exception with 2, anything else with 3
+int main(int argc, char **argv) {
+  try {
+    return run_main(argc, argv);
+  } catch (std::exception &e) {
+    std::fprintf(stderr, "* Standard exception: %s\n", e.what());
+    return 2;
+  } catch (...) {
+    std::fprintf(stderr, "* Other exception!\n");
+    return 3;
+  }
 }
