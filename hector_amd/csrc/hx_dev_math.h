@@ -13,7 +13,7 @@
 //    (17 VALU per exponential, no special cases: arguments are model quantities, |x| < 700);
 //  * hx_log: the classic  log(m 2^k) = k ln2 + f - f^2/2 + s (f^2/2 + R(s^2)),  s = f / (2 + f)
 //    reduction with a degree-7 minimax R (fdlibm's scheme; < 1 ulp), the division through
-//    v_rcp_f64 + two Newton steps: ~30 VALU; positive normal arguments only;
+//    v_rcp_f64 + two Newton steps: ~30 VALU; normal arguments (<= 0 gives -inf / NaN like libm);
 //  * hx_sqrt: v_rsq_f64 seed + two coupled Newton steps (Goldschmidt), ~9 VALU, <= 1 ulp for
 //    normal-range arguments.
 // The reference calls std::exp / std::log / std::sqrt / std::pow (libm, <= 1 ulp); these agree
@@ -95,9 +95,10 @@ __device__ __forceinline__ void hx_log_batch(double (&x)[N]) {
                    Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                    Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                    Lg7 = 1.479819860511658591e-01;
-  double dk[N], f[N], s[N], w[N], z[N], t1[N], t2[N];
+  double dk[N], f[N], s[N], w[N], z[N], t1[N], t2[N], x0[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
+    x0[i] = x[i];
     int e;
     double m = frexp(x[i], &e);  // [0.5, 1)
     const bool lo = m < 0.70710678118654752440;
@@ -122,7 +123,10 @@ __device__ __forceinline__ void hx_log_batch(double (&x)[N]) {
   for (int i = 0; i < N; ++i) {
     const double R = fma(z[i], t2[i], w[i] * t1[i]);
     const double hfsq = 0.5 * f[i] * f[i];
-    x[i] = dk[i] * LN2_HI - ((hfsq - fma(s[i], hfsq + R, dk[i] * LN2_LO)) - f[i]);
+    const double r = dk[i] * LN2_HI - ((hfsq - fma(s[i], hfsq + R, dk[i] * LN2_LO)) - f[i]);
+    // (a concentration or pool that has gone to zero or below: libm's answers, so that the member
+    // turns NaN and raises its flag like it would in the reference instead of carrying on)
+    x[i] = (x0[i] > 0.0) ? r : ((x0[i] == 0.0) ? -__builtin_inf() : __builtin_nan(""));
   }
 }
 __device__ __forceinline__ double hx_log(double x) {

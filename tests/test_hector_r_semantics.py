@@ -165,3 +165,22 @@ def test_forcing_base_year_default_and_check(emul_lib, oracle, tmp_path):
     bad = edited_pack(tmp_path / "bad.hxs", None, None, [], [], scalars={("forcing", "baseyear"): 1745.0})
     with pytest.raises(hector_amd.HectorAmdError, match="Base year must be"):
         hector_amd.Core(str(bad), 1, lib_path=emul_lib, allow_emulation=True).run(1760)
+
+
+def test_a_concentration_driven_below_zero_raises_the_members_flag(emul_lib):
+    """CH4 emissions so negative that the concentration crosses zero: log(CH4) is NaN in the
+    reference (oh_component.cpp:156) and the member is lost; here it must raise its flag -- not
+    carry on with an arbitrary finite value -- and leave its neighbour alone."""
+    c = hector_amd.Core(SCENARIO, 2, lib_path=emul_lib, allow_emulation=True)
+    c.set_outputs(["CO2_concentration", "CH4_concentration"])
+    years = np.arange(1800, 1811)
+    em = np.zeros((years.size, 2)); em[:, 0] = c.fetchvars("CH4_emissions", (1800, 1810))[:, 0]
+    em[:, 1] = -5.0e4
+    c.setvar_dated_members("CH4_emissions", years, em, "Tg CH4")
+    c.run(1850)
+    st = c.status()
+    assert st[0] == 0 and st[1] != 0
+    d = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    d.set_outputs(["CO2_concentration"]); d.run(1850)
+    a, b = c.fetchvars("CO2_concentration", (1745, 1850))[:, 0], d.fetchvars("CO2_concentration", (1745, 1850))[:, 0]
+    assert np.abs(a - b).max() / b.max() < 1e-9   # (c runs the extended kernel: per-member series)
