@@ -110,6 +110,8 @@ class EnsembleCore {
   int spinup_steps(int member);
 
   double last_run_kernel_ms() const { return run_ms_; }
+  // "output=0" in a component's section: the output stream leaves its rows out (core.cpp:257-262)
+  bool component_output_enabled(const std::string &section) const { return scen_.scalar(section, "output", 1.0) > 0; }
   void set_pair_kernel_limit(int max_members) { pair_max_members_ = max_members < 0 ? 0 : max_members; }
   const char *last_run_kernel() const { return last_run_pair_ ? "pair" : "run"; }
   double last_spinup_ms() const { return spin_ms_; }

@@ -247,6 +247,9 @@ int hx_last_run_ms(hx_core *core, double *ms) {
 }
 int hx_last_spinup_ms(hx_core *core, double *ms) { HX_TRY(*ms = core->core->last_spinup_ms()) }
 int hx_stream(hx_core *core, void **stream) { HX_TRY(*stream = (void *)core->core->stream()) }
+int hx_component_output(hx_core *core, const char *component, int *enabled) {
+  HX_TRY(*enabled = core->core->component_output_enabled(component) ? 1 : 0)
+}
 int hx_set_pair_kernel_limit(hx_core *core, int max_members) {
   HX_TRY(core->core->set_pair_kernel_limit(max_members))
 }

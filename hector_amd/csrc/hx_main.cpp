@@ -177,8 +177,16 @@ static int run_main(int argc, char **argv) {
     if (hx_getvar(core, "baseyear", &b) == 0 && b > 0) base = (int)b;
   }
   const int slr_from = 1990;  // max(refperiod_high, normalize_year), :300-318
+  std::map<std::string, bool> comp_out;  // output=0 in a component's section silences its rows
   auto row = [&](int year, const std::string &run, const char *comp, const std::string &var,
                  double v, const char *units, int prec) {
+    auto it = comp_out.find(comp);
+    if (it == comp_out.end()) {
+      int en = 1;
+      ck(hx_component_output(core, comp, &en));
+      it = comp_out.emplace(comp, en != 0).first;
+    }
+    if (!it->second) return;
     std::fprintf(out, "%d,%s,0,%s,%s,%.*g,%s\n", year, run.c_str(), comp, var.c_str(), prec, v, units);
   };
   const int p_def = precision > 0 ? precision : 6, p_rf = precision > 0 ? precision : 4;

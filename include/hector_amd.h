@@ -220,6 +220,11 @@ int hx_stream(hx_core *core, void **stream);
  * per two SIMDs; 0 = never; the environment variable HECTOR_AMD_PAIR_MAX_MEMBERS sets the default of
  * new cores).  hx_last_run_kernel: "run" or "pair", whichever the last hx_run took. */
 int hx_set_pair_kernel_limit(hx_core *core, int max_members);
+
+/* Core::outputEnabled (src/core.cpp:257-262, 688-695): 0 if the scenario's section of that component
+ * says output=0 -- the output stream visitor then leaves the component's rows out
+ * (src/csv_outputstream_visitor.cpp, every visit()); hector-amd's stream does the same. */
+int hx_component_output(hx_core *core, const char *component, int *enabled);
 int hx_last_run_kernel(hx_core *core, const char **name);
 
 #define HX_ERR_MASS 1u     /* mass not conserved        simpleNbox-runtime.cpp:553-563 */

@@ -129,3 +129,26 @@ def test_cli_rh_ch4_row_is_what_the_reference_stream_prints(emul_lib, tmp_path):
     v = {(x["variable"], x["year"]): float(x["value"]) for x in rows if x["variable"] in ("RH", "rh_ch4")}
     for y in ("1800", "2000", "2050"):
         assert v[("rh_ch4", y)] == v[("RH", y)] and v[("RH", y)] > 10.0
+
+
+def test_cli_output_off_silences_a_components_rows(emul_lib, tmp_path):
+    """`output=0` in a component's section (Core::outputEnabled, src/core.cpp:257-262): the stream
+    visitor leaves that component's rows out (every visit() of csv_outputstream_visitor.cpp);
+    the run itself is unchanged."""
+    from conftest import edited_pack
+    p = edited_pack(tmp_path / "quiet.hxs", None, None, [], [],
+                    scalars={("ocean", "output"): 0.0, ("forcing", "output"): 0.0, ("CF4_halocarbon", "output"): 0.0})
+    r = subprocess.run([EMUL_CLI, str(p), "--output-dir", str(tmp_path), "--run-to", "1800"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = read_stream(next(tmp_path.glob("outputstream_*.csv")))
+    comps = {r["component"] for r in rows}
+    assert "ocean" not in comps and "forcing" not in comps and "CF4_halocarbon" not in comps
+    assert {"simpleNbox", "temperature", "C2F6_halocarbon", "OH"} <= comps
+    q = subprocess.run([EMUL_CLI, SCENARIO, "--output-dir", str(tmp_path / "full"), "--run-to", "1800"],
+                       capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    full = read_stream(next((tmp_path / "full").glob("outputstream_*.csv")))
+    keep = [(r["year"], r["component"], r["variable"], r["value"]) for r in full
+            if r["component"] not in ("ocean", "forcing", "CF4_halocarbon")]
+    assert keep == [(r["year"], r["component"], r["variable"], r["value"]) for r in rows]
