@@ -7,7 +7,10 @@
 // history, which is re-read ONCE PER BLOCK of HX_DBLK years instead of once per
 // year (block-causal evaluation of the same ascending sum, partials parked in
 // LDS).  Shared scenario series are wave-uniform and arrive through scalar
-// loads.  No MFMA: this is elementwise fp64 ODE stepping.
+// loads.  Elementwise fp64 ODE stepping on the vector ALU; the one dense
+// contraction, that history pass, on the fp64 matrix pipe (doeclim_pass_mfma).
+// Ensembles that leave SIMDs idle are run by hx_pair_kernel (hx_dev_pair.h), two
+// wavefronts per 64 members.
 //
 // What each device function restates (reference file:line, /root/reference):
 //   year loop / component order        src/core.cpp:483-504
@@ -24,8 +27,9 @@
 //   DOECLIM                             src/temperature_component.cpp:196-557
 //
 // Deliberate, tolerance-neutral departures from the reference's arithmetic
-// (all <= a few ulp, see DESIGN.md "numerics"): FMA contraction on; quintic
-// root by warm-started safeguarded Newton (same root, different path);
+// (all <= a few ulp, see DESIGN.md "numerics"): FMA contraction on; exp / log /
+// sqrt of hx_dev_math.h; quintic root by warm-started Newton with a safeguarded
+// restart (same root, different path);
 // T-only equilibrium constants computed once per year per box; LUC ratio via
 // one division; 200-year Q10 window as a running sum; forcing summed in groups.
 #include <hip/hip_runtime.h>
@@ -37,7 +41,7 @@
 #include "hx_layout.h"
 
 #define HX_DBLK 32  // DOECLIM block length = years per run-kernel launch
-#define HX_KPAD 32  // zero entries in front of / behind the Ker table
+#define HX_KPAD 32  // zero entries in front of the Ker table (the host pads 64 behind it)
 
 #include "hx_dev_const.h"
 #include "hx_dev_clock.h"

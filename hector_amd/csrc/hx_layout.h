@@ -157,7 +157,7 @@ struct HxBuffers {
   unsigned *status;      // [npad]
   const double *derived; // [HX_NDERIVED(B)][npad]
   const double *shared;  // [ns][HXSH_STRIDE]
-  const double *ker;     // zero-padded DOECLIM kernel: [ns+64] (shared diffusivity) or [ns+64][npad]
+  const double *ker;     // zero-padded DOECLIM kernel (32 in front, 64 behind): [ns+96] (shared diffusivity) or [ns+96][npad]
   const double *dpart;   // [HX_DBLK][npad] history partial sums of the current block
   const double *dpart2;  // same for the heat-flux diagnostic
   double *out[HXO_NVAR]; // each [ns][npad] or nullptr
