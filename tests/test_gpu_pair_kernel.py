@@ -28,10 +28,11 @@ def mk(hip_lib, n, S, q10, limit=None):
     return c
 
 
-def test_pair_kernel_vs_oracle_config2(hip_lib, oracle):
-    """BASELINE configs[1]: 1 024 members with perturbed ECS and Q10, every member, 555 years."""
+@pytest.mark.parametrize("n", [1024, 32768])
+def test_pair_kernel_vs_oracle_config2(hip_lib, oracle, n):
+    """BASELINE configs[1] (1 024 members with perturbed ECS and Q10) and the largest ensemble the
+    kernel serves (32 768: every SIMD busy), every member, 555 years."""
     from test_gpu_fullsize import _oracle_all
-    n = 1024
     S, q10 = ensemble.ecs_q10(n)
     c = mk(hip_lib, n, S, q10)
     c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
