@@ -29,7 +29,8 @@ Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
                    per member-year, SURVEY.md 8d, x members x 555): a yardstick the kernel
                    beats by design (block-causal DOECLIM pass, LDS-resident state), not a
                    ceiling.
-  other_configs -- the other single-GPU BASELINE configurations (1 024 members; 131 072
+  other_configs -- the other single-GPU BASELINE configurations (1 024 members and 32 768, the
+                   two-wavefront kernel's range; 131 072
                    members = configs[3]'s per-GPU share; 65 536 members x 4 biomes), 5 steps
                    each, timed the same way after the headline (N = 1 only)
   cpu_baseline  -- the CPU oracle (a scalar C port of the reference loop, pinned to the
@@ -358,7 +359,7 @@ def main():
         }
         if world == 1 and not args.no_other_configs:
             others = []
-            for (m2, b2) in ((1024, 1), (131072, 1), (65536, 4)):
+            for (m2, b2) in ((1024, 1), (32768, 1), (131072, 1), (65536, 4)):
                 if (m2, b2) == (n, args.biomes):
                     continue
                 others.append(time_config(m2, b2, 5, 1, local_rank))
