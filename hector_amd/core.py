@@ -11,30 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import HectorAmdError, DEFAULT_SCENARIO
 
-# capability strings (inst/include/component_data.hpp), R-style accessors
-def ECS(): return "S"
-def DIFFUSIVITY(): return "diff"
-def Q_CO2(): return "qco2"
-def AERO_SCALE(): return "aero_scalar"
-def VOLCANIC_SCALE(): return "vol_scalar"
-def PREINDUSTRIAL_CO2(): return "C0"
-def _b(biome, v): return v if biome in ("", None, "global") else "%s.%s" % (biome, v)
-def BETA(biome=""): return _b(biome, "beta")
-def Q10_RH(biome=""): return _b(biome, "q10_rh")
-def WARMINGFACTOR(biome=""): return _b(biome, "warmingfactor")
-def NPP_FLUX0(biome=""): return _b(biome, "npp_flux0")
-def VEG_C(biome=""): return _b(biome, "veg_c")
-def CONCENTRATIONS_CO2(): return "CO2_concentration"
-def GLOBAL_TAS(): return "global_tas"
-def RF_TOTAL(): return "RF_tot"
-def RF_CO2(): return "RF_CO2"
-def SST(): return "sst"
-def LAND_TAS(): return "land_tas"
-def OCEAN_C(): return "ocean_c"
-def ATMOSPHERIC_CO2(): return "atmos_co2"
-def PH_HL(): return "HL_pH"
-def PERMAFROST_C(): return "permafrost_c"
-def HEAT_FLUX(): return "heatflux"
+# (the R-style capability accessors -- ECS(), BETA(biome) ... -- live in hector_amd.capabilities)
 
 
 class Core:
