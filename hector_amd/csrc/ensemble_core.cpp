@@ -1448,7 +1448,8 @@ void EnsembleCore::run(double runtodate) {
   bool pair = hx_pair_available() && B_ == 1 && con == 0 && !hf && !ker_per_member_ && !d_hist_ &&
               n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
-    if (d_out_[v] && v != HXO_SST && v != HXO_TLAND && v != HXO_CO2 && v != HXO_TGAV && v != HXO_NSTASH)
+    if (d_out_[v] && v != HXO_SST && v != HXO_TLAND && v != HXO_CO2 && v != HXO_TGAV && v != HXO_NSTASH &&
+        v != HXO_RF_TOT && v != HXO_RF_CO2)
       pair = false;
   last_run_pair_ = pair;
   if (pair)

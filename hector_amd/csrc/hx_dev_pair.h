@@ -26,7 +26,8 @@
 // they walk the reference's control flow in step and meet the same barriers.
 //
 // Same formulas, same decisions as hx_run_kernel<1,false,false,0> (parity tests compare both with
-// the oracle); instantiated for one biome, no constraints, default outputs: the configuration
+// the oracle); instantiated for one biome, no constraints, default outputs (CO2, tas, RF_tot,
+// RF_CO2, SST, land tas, timesteps): the configuration
 // small perturbed-parameter ensembles use.  The host picks it up to hx_set_pair_kernel_limit members
 // (default 32 768: one workgroup per two SIMDs).
 #pragma once
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       const int slot = iy - (blk0 - 1);
       const double co2c = atmos * PGC2PPM;
       const double ln_co2r = hx_log(hx_div(co2c, C0));
-      double rf_tot = 0;
+      double rf_tot = 0, rf_co2 = 0;
       if (iy >= kc.baseyear_idx) {
         const double a1 = -2.4785e-7, b1 = 7.5906e-4, c1 = -2.1492e-3, d1 = 5.2488;
         const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
                              p_aero * sh[HXSH_RF_AERO]) + p_vol * sh[HXSH_RF_VOL];
         if (iy == kc.baseyear_idx) { base_tot = ftot; base_co2 = fco2; }
-        else rf_tot = ftot - base_tot;
+        else { rf_tot = ftot - base_tot; rf_co2 = fco2 - base_co2; }
       }
       // history sum: the land side's part (years before last) + last year's SST
       const double dpast = (dpast_in + sst * ker_lag1) * dDPS;
@@ -466,11 +467,9 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       sto_(buf, HXO_SST, o, sst_new);
       sto_(buf, HXO_TLAND, o, tl_new);
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
-#ifdef PAIR_DBG_TGAV
-      if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, PAIR_DBG_TGAV);
-#else
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
-#endif
+      if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);   // (with CO2 and tas: the R
+      if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);   //  wrapper's default variables)
       PSTAMP(10);
       __syncthreads();  // ---- barrier C: year end (SST and land temperature published)
       PSTAMP(11);

@@ -61,15 +61,16 @@ def test_pair_kernel_equals_run_kernel(hip_lib, n):
     out = {}
     for name, limit in (("pair", None), ("run", 0)):
         c = mk(hip_lib, n, S, q10, limit)
-        c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+        c.set_outputs(["CO2_concentration", "global_tas", "timesteps", "RF_tot", "RF_CO2"])
         c.run(2300)
         assert c.last_run_kernel() == name
         out[name] = (c.status(), c.fetchvars("CO2_concentration"), c.fetchvars("global_tas"),
-                     c.fetchvars("sst"), c.fetchvars("land_tas"), c.fetchvars("timesteps"))
+                     c.fetchvars("sst"), c.fetchvars("land_tas"), c.fetchvars("timesteps"),
+                     c.fetchvars("RF_tot"), c.fetchvars("RF_CO2"))
     p, r = out["pair"], out["run"]
     assert np.array_equal(p[0], r[0]) and (p[0] == 0).all()
     assert (np.abs(p[1] - r[1]) / r[1]).max() < 1e-8
-    for k in (2, 3, 4):
+    for k in (2, 3, 4, 6, 7):
         assert np.abs(p[k] - r[k]).max() < 1e-8
     assert np.array_equal(p[5], r[5])
 
@@ -110,7 +111,7 @@ def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     n = 128
     S, q10 = ensemble.ecs_q10(n)
     c = mk(hip_lib, n, S, q10)
-    c.set_outputs(["CO2_concentration", "RF_tot"])           # a diagnostic it does not record
+    c.set_outputs(["CO2_concentration", "ocean_c"])          # a diagnostic it does not record
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.split_biome(["a", "b"])                                 # more than one biome
@@ -157,7 +158,7 @@ def test_pair_kernel_shipped_scenarios_vs_oracle(hip_lib, name):
     S, q10 = ensemble.ecs_q10(16, offset=1000)
     c = hector_amd.Core(path, 16, device=0, lib_path=hip_lib)
     c.setvar("S", S, "degC").setvar("q10_rh", q10)
-    c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+    c.set_outputs(["CO2_concentration", "global_tas", "timesteps", "RF_tot", "RF_CO2"])
     c.run(o.end)
     # (picontrol prescribes its CO2 -- a constraint: that one stays on the run kernel)
     assert c.last_run_kernel() == ("run" if name == "picontrol" else "pair")
@@ -171,6 +172,8 @@ def test_pair_kernel_shipped_scenarios_vs_oracle(hip_lib, name):
         assert err == 0
         assert (np.abs(co2[:, i] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < REL_CO2
         assert np.abs(tg[:, i] - r["global_tas"]).max() < ABS_T
+        assert np.abs(c.fetchvars("RF_tot", (o.start, o.end))[:, i] - r["RF_tot"]).max() < ABS_T
+        assert np.abs(c.fetchvars("RF_CO2", (o.start, o.end))[:, i] - r["RF_CO2"]).max() < ABS_T
         assert np.array_equal(ts[:, i], r["timesteps"][1:])
 
 
