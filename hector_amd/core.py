@@ -252,7 +252,8 @@ class Core:
         return v.value
 
     def set_pair_kernel_limit(self, max_members):
-        """Ensembles of up to max_members (one biome, no constraints, default outputs) run on the
+        """Ensembles of up to max_members (one biome, no constraints, outputs within
+        CO2/tas/forcing/pools/NBP/pH) run on the
         two-wavefront kernel (include/hector_amd.h); 0 switches it off."""
         self._ck(self._lib.hx_set_pair_kernel_limit(self._h, int(max_members)))
         return self

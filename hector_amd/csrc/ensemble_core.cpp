@@ -1448,9 +1448,13 @@ void EnsembleCore::run(double runtodate) {
   bool pair = hx_pair_available() && B_ == 1 && con == 0 && !hf && !ker_per_member_ && !d_hist_ &&
               n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
-    if (d_out_[v] && v != HXO_SST && v != HXO_TLAND && v != HXO_CO2 && v != HXO_TGAV && v != HXO_NSTASH &&
-        v != HXO_RF_TOT && v != HXO_RF_CO2)
-      pair = false;
+    if (d_out_[v]) {  // what hx_pair_kernel records
+      static const int ok[] = {HXO_SST, HXO_TLAND, HXO_CO2, HXO_TGAV, HXO_NSTASH, HXO_RF_TOT, HXO_RF_CO2,
+                               HXO_ATMOS_C, HXO_OCEAN_C, HXO_OCEAN_UPTAKE, HXO_HL_PH, HXO_LL_PH, HXO_CH4,
+                               HXO_O3, HXO_NBP, HXO_VEG_C, HXO_DET_C, HXO_SOIL_C, HXO_PERMAFROST_C,
+                               HXO_THAWED_C, HXO_EARTH_C};
+      if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) pair = false;
+    }
   last_run_pair_ = pair;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, last_iy_, target, stream_), "run kernel (pair)");

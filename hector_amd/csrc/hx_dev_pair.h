@@ -26,8 +26,8 @@
 // they walk the reference's control flow in step and meet the same barriers.
 //
 // Same formulas, same decisions as hx_run_kernel<1,false,false,0> (parity tests compare both with
-// the oracle); instantiated for one biome, no constraints, default outputs (CO2, tas, RF_tot,
-// RF_CO2, SST, land tas, timesteps): the configuration
+// the oracle); instantiated for one biome, no constraints, the outputs listed at its launch site
+// (ensemble_core.cpp: CO2, tas, forcings, pools, NBP, pH ...): the configuration
 // small perturbed-parameter ensembles use.  The host picks it up to hx_set_pair_kernel_limit members
 // (default 32 768: one workgroup per two SIMDs).
 #pragma once
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       __syncthreads();  // ---- barrier A: the land side's flows, CH4, O3, history sum, LL pCO2
       PSTAMP(3);
       double Pn = s_yr[PY_PN][lane];
+      double annualflux_sum = 0;
       const double ch4 = s_yr[PY_CH4][lane], o3 = s_yr[PY_O3][lane];
       if (blk0 < 0 || iy >= blk0 + HX_DBLK) blk0 = iy;
       dpart_pf = HX_GCD(buf.dpart)[(size_t)(iy - blk0) * np + mem];  // (the land side ran the pass last year end)
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
             }
           }
           const double lastflux = aL + aH;
+          annualflux_sum += lastflux;
           lastflux_ann = lastflux * inv_yf;
           cHL = ((cHL + (lLH + lIH)) + aH) - lHD;
           cLL = ((cLL + lIL) + aL) - (lLH + lLI);
@@ -470,6 +472,14 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
       if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);   // (with CO2 and tas: the R
       if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);   //  wrapper's default variables)
+      if (buf.out_rare) {  // (one test for the rest of what this side can record)
+        if (buf.out[HXO_ATMOS_C]) sto_(buf, HXO_ATMOS_C, o, atmos);
+        if (buf.out[HXO_OCEAN_C]) sto_(buf, HXO_OCEAN_C, o, cDO + cIO + cLL + cHL);
+        if (buf.out[HXO_OCEAN_UPTAKE]) sto_(buf, HXO_OCEAN_UPTAKE, o, annualflux_sum);
+        if (buf.out[HXO_HL_PH]) sto_(buf, HXO_HL_PH, o, -log10(hH));
+        if (buf.out[HXO_CH4]) sto_(buf, HXO_CH4, o, ch4);
+        if (buf.out[HXO_O3]) sto_(buf, HXO_O3, o, o3);
+      }
       PSTAMP(10);
       __syncthreads();  // ---- barrier C: year end (SST and land temperature published)
       PSTAMP(11);
@@ -628,6 +638,8 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
       c.alive = status == 0;
       int nstash = 0;
+      double nbp = 0;
+      const bool want_nbp = buf.out_rare && buf.out[HXO_NBP];
       if (iy < iy_to) prefetch(iy + 1);
       PSTAMP(4);
       while (__any(c.alive && c.t < tnew)) {
@@ -674,6 +686,11 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
           c.retry = 0;
           ++nstash;
           const double t = c.t, yf = t - c.ode_start;
+          if (want_nbp) {  // NBP of the interval that ends here, from the pools it started with
+            const double npp_t = (npp0 * co2fert) * npp_luc_adjust;
+            const double rh_t = ((det * 0.25) * tempfertd + (soil * 0.02) * tempferts) + rh_tp_co2();
+            nbp = ((npp_t - rh_t) - luc_e) + luc_u;
+          }
           double tpf = l5;
           if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
           if (y[0] < 0 || y[1] < 0 || y[2] < 0 || l4 < 0 || tpf < 0) status |= HX_ERR_NEGPOOL;
@@ -713,6 +730,17 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       }
       // ---- year end (land): the stash count ("timesteps"), next year's climate-independent part ----
       if (buf.out[HXO_NSTASH]) sto_(buf, HXO_NSTASH, (size_t)iy * np + mem, (double)nstash);
+      if (buf.out_rare) {  // (one test for the rest of what this side can record)
+        const size_t o = (size_t)iy * np + mem;
+        if (buf.out[HXO_NBP]) sto_(buf, HXO_NBP, o, nbp);
+        if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, veg);
+        if (buf.out[HXO_DET_C]) sto_(buf, HXO_DET_C, o, det);
+        if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, soil);
+        if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, pf);
+        if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, thawed);
+        if (buf.out[HXO_EARTH_C]) sto_(buf, HXO_EARTH_C, o, earth);
+        if (buf.out[HXO_LL_PH]) sto_(buf, HXO_LL_PH, o, -log10(hL));
+      }
       if (iy < iy_to) prepare(iy + 1);
       PSTAMP(10);
       __syncthreads();  // ---- barrier C

@@ -1,7 +1,7 @@
 """The small-ensemble kernel (two wavefronts per 64 members, hector_amd/csrc/hx_dev_pair.h) against
 the oracle and against the one-wavefront run kernel.
 
-Ensembles of up to 32 768 members (one biome, no constraints, default outputs) take it by
+Ensembles of up to 32 768 members (one biome, no constraints, the usual outputs) take it by
 default; `set_pair_kernel_limit(0)` forces the run kernel.  Same criterion as the other parity
 tests (test_gpu_parity.py); the per-year stash schedule ("timesteps": every retry and
 reduced-timestep decision of the reference) has to agree with the oracle member by
@@ -75,6 +75,60 @@ def test_pair_kernel_equals_run_kernel(hip_lib, n):
     assert np.array_equal(p[5], r[5])
 
 
+POOLS = ["atmos_co2", "ocean_c", "ocean_uptake", "HL_pH", "LL_pH", "CH4_concentration",
+         "O3_concentration", "NBP", "veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c",
+         "earth_c"]
+
+
+@pytest.mark.parametrize("n", [100, 2048])
+def test_pair_kernel_pools_and_fluxes_equal_run_kernel(hip_lib, n):
+    """The carbon pools, NBP, ocean uptake, surface pH and the CH4/O3 concentrations are recorded
+    by the pair kernel too (each by the wavefront that holds them): same values as the run kernel,
+    and switching them on does not change the trajectory."""
+    S, q10 = ensemble.ecs_q10(n)
+    out = {}
+    for name, limit in (("pair", None), ("run", 0)):
+        c = mk(hip_lib, n, S, q10, limit)
+        c.set_outputs(["CO2_concentration", "global_tas", "timesteps"] + POOLS)
+        c.run(2300)
+        assert c.last_run_kernel() == name
+        assert (c.status() == 0).all()
+        out[name] = {v: c.fetchvars(v) for v in ["CO2_concentration", "global_tas", "timesteps"] + POOLS}
+    p, r = out["pair"], out["run"]
+    assert np.array_equal(p["timesteps"], r["timesteps"])
+    for v in POOLS + ["CO2_concentration", "global_tas"]:
+        if v in ("NBP", "ocean_uptake"):
+            # a year's flux is the change of a 600-40 000 Pg C pool that the two kernels hold to
+            # ~1e-10 relative: absolute criterion, on the pool's scale
+            assert np.abs(p[v] - r[v]).max() < 2e-6, v
+            continue
+        scale = np.maximum(np.abs(r[v]), 1.0)
+        assert (np.abs(p[v] - r[v]) / scale).max() < 1e-8, v
+    plain = mk(hip_lib, n, S, q10).run(2300)
+    assert plain.last_run_kernel() == "pair"
+    assert np.array_equal(plain.fetchvars("CO2_concentration"), p["CO2_concentration"])
+    assert np.array_equal(plain.fetchvars("global_tas"), p["global_tas"])
+
+
+def test_pair_kernel_pools_vs_oracle(hip_lib, oracle):
+    """The same outputs against the oracle's own trajectory of the default member."""
+    c = hector_amd.Core(SCENARIO, 64, device=0, lib_path=hip_lib)
+    c.set_outputs(["CO2_concentration"] + POOLS)
+    c.run(2300)
+    assert c.last_run_kernel() == "pair"
+    r, err, _ = oracle.run(oracle.default_params())
+    assert err == 0
+    checked = 0
+    for v in POOLS:
+        if v not in r:
+            continue
+        got = c.fetchvars(v, (1746, 2300))[:, 0]
+        ref = np.asarray(r[v])[1:]
+        assert np.abs(got - ref).max() < 2e-8 * max(1.0, np.abs(ref).max()), v
+        checked += 1
+    assert checked == len(POOLS)
+
+
 def test_pair_kernel_in_segments_reset_and_handover(hip_lib):
     """A run in pieces, a reset, and a hand-over between the two kernels in the middle of a run
     (the state table is common) give the one-launch trajectory."""
@@ -111,7 +165,7 @@ def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     n = 128
     S, q10 = ensemble.ecs_q10(n)
     c = mk(hip_lib, n, S, q10)
-    c.set_outputs(["CO2_concentration", "ocean_c"])          # a diagnostic it does not record
+    c.set_outputs(["CO2_concentration", "heatflux"])         # a diagnostic it does not record
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.split_biome(["a", "b"])                                 # more than one biome

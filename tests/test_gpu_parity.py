@@ -278,6 +278,7 @@ def test_state_history_and_reset_to_any_date_on_gpu(hip_lib):
     S, q10 = ensemble.ecs_q10(n)
     outs = ["CO2_concentration", "global_tas", "ocean_c", "CH4_concentration", "timesteps"]
     a = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    a.set_pair_kernel_limit(0)      # (bitwise comparison: the kernel the history runs on)
     a.set_outputs(outs); a.run(2300)
     ref = {v: a.fetchvars(v, (1745, 2300)) for v in outs}
     b = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
