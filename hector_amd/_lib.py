@@ -19,11 +19,33 @@ class HectorAmdError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME
+    libamdhip64.so.7) which libtorch_hip.so asks for by FILE name: if the system runtime is already
+    in the process under its SONAME (because this library was loaded first), the dynamic loader
+    does not recognise it, torch brings in a second runtime and its device init fails with "No HIP
+    GPUs are available".  The other order works (this library asks for the SONAME and gets torch's
+    copy).  So where a torch installation with its own runtime exists, load that copy first --
+    without importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+
+
 def load(path=None, allow_emulation=False):
     path = os.path.abspath(path or DEFAULT_LIB)
     if path in _cache:
         lib = _cache[path]
     else:
+        if os.sep + os.path.join("tests", "emul") + os.sep not in path:
+            _share_torch_hip_runtime()
         if not os.path.exists(path):
             raise HectorAmdError(
                 "hector_amd: native library %s not found -- build it with "

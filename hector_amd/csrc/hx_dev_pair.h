@@ -195,6 +195,9 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // The carbonate solve a stash needs (pre-update carbon = the carbon left by the stash before) is
 // done right after that earlier stash, one box per wavefront, so no stash waits for it.
 // ===========================================================================
+// KERPM: the members differ in ocean heat diffusivity, so each has its own DOECLIM kernel table
+// ([ns + pad][npad] in HBM instead of one shared table) and the history pass runs on the vector ALU.
+template <bool KERPM>
 __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__ args, int iy_from,
                                                       int iy_to) {
   __shared__ double s_tblk[HX_DBLK + 1][64];  // SSTs of years blk0-1 .. blk0+31 (the ocean side's)
@@ -242,7 +245,11 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
                  dIB2 = ldd(buf, HXD_IB2, mem), dIB3 = ldd(buf, HXD_IB3, mem), dQC1 = ldd(buf, HXD_QC1, mem),
                  dQC2 = ldd(buf, HXD_QC2, mem), dDQ1 = ldd(buf, HXD_DQ1, mem), dDQ2 = ldd(buf, HXD_DQ2, mem),
                  dDPS = ldd(buf, HXD_DPSCALE, mem);
-    const double ker_lag1 = HX_CCD(buf.ker)[kc.ns - 2 + HX_KPAD];  // Ker entry of last year's SST
+    auto ldk = [&](int idx) -> double {
+      if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * np + mem];
+      else return HX_CCD(buf.ker)[idx];
+    };
+    const double ker_lag1 = ldk(kc.ns - 2 + HX_KPAD);  // Ker entry of last year's SST
     ChemK kH, kL;
     double pco2H = 0, pco2L = 0;
     // The history sum of a year (all but last year's SST, which is added from the register): the
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       for (int cc = 0; cc < nchunk; ++cc) {
         double T[8], K[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { T[q] = s_tblk[8 * cc + q][lane]; K[q] = HX_CCD(buf.ker)[kq + 8 * cc + q]; }
+        for (int q = 0; q < 8; ++q) { T[q] = s_tblk[8 * cc + q][lane]; K[q] = ldk(kq + 8 * cc + q); }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += ((8 * cc + q < jb) ? T[q] : 0.0) * K[q];
       }
@@ -559,8 +566,12 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       o3 = ((5 * ln_ch4 + shn[HXSH_O3_NOX]) + shn[HXSH_O3_CO]) + shn[HXSH_O3_NMVOC];
       if (blk0 < 0 || iyn >= blk0 + HX_DBLK) {
         blk0 = iyn;
-        doeclim_pass_mfma<false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
-                                 const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
+        if constexpr (KERPM)
+          doeclim_pass_dev<true, false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+                                        const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
+        else
+          doeclim_pass_mfma<false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+                                   const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
         HX_FENCE();
       }
     };

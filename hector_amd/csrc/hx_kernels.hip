@@ -136,7 +136,9 @@ template <bool KERPM, bool HF>
 __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
                                                            const double *ker, double *part,
                                                            double *part2, int ns, int npad,
-                                                           int blk0, int mem) {
+                                                           int blk0, int mem, int hist_end) {
+  // (hist_end: the years before it enter the sums -- blk0, or blk0 - 1 where the caller adds
+  // last year's term itself, as doeclim_pass_mfma)
   hx_gcd hist = HX_GCD(sst_hist) + mem;
   const size_t np = (size_t)npad;
   auto ldk = [&](int idx) -> double {
@@ -158,7 +160,7 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
           const int i = i0 + ii;
           // rows >= blk0 may hold stale values of an earlier run: mask them
           const double v = hist[(size_t)(i < ns ? i : ns - 1) * np];
-          T[ii] = (i < blk0) ? v : 0.0;
+          T[ii] = (i < hist_end) ? v : 0.0;
         }
       };
       auto compute_chunk = [&](const double *T, int i0) {
@@ -176,10 +178,10 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
       };
       double Ta[16], Tb[16];
       load_chunk(Ta, 0);
-      for (int i0 = 0; i0 < blk0; i0 += 32) {
+      for (int i0 = 0; i0 < hist_end; i0 += 32) {
         load_chunk(Tb, i0 + 16);
         compute_chunk(Ta, i0);
-        if (i0 + 16 < blk0) {
+        if (i0 + 16 < hist_end) {
           load_chunk(Ta, i0 + 32);
           compute_chunk(Tb, i0 + 16);
         }
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         else
 #endif
         doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
-                                    const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem);
+                                    const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem, blk0);
         HX_FENCE();
         pf_dpart = HX_GCD(buf.dpart)[mem];
         HX_STAMP(m, 11);  // DOECLIM history pass (once per HX_DBLK years)
@@ -1459,14 +1461,18 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 #include "hx_dev_pair.h"
 #endif
 // the small-ensemble kernel (two wavefronts per 64 members, hx_dev_pair.h): one biome, no
-// constraints, outputs CO2 / tas / SST / land tas / timesteps only
+// constraints, the outputs listed in EnsembleCore::run; kpm: per-member DOECLIM kernel tables
 int hx_pair_available() { return HX_HAS_MFMA; }
-hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, int iy_from, int iy_to, hipStream_t st) {
+hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool kpm, int iy_from, int iy_to,
+                              hipStream_t st) {
 #if HX_HAS_MFMA
-  hipLaunchKernelGGL(hx_pair_kernel, dim3(npad / 64), dim3(128), 0, st, d_args, iy_from, iy_to);
+  if (kpm)
+    hipLaunchKernelGGL(hx_pair_kernel<true>, dim3(npad / 64), dim3(128), 0, st, d_args, iy_from, iy_to);
+  else
+    hipLaunchKernelGGL(hx_pair_kernel<false>, dim3(npad / 64), dim3(128), 0, st, d_args, iy_from, iy_to);
   return hipGetLastError();
 #else
-  (void)d_args; (void)npad; (void)iy_from; (void)iy_to; (void)st;
+  (void)d_args; (void)npad; (void)kpm; (void)iy_from; (void)iy_to; (void)st;
   return hipErrorInvalidValue;
 #endif
 }

@@ -217,7 +217,8 @@ int hx_stream(hx_core *core, void **stream);
  * one-biome ensembles without constraints, per-member series, history or diagnostics beyond CO2,
  * tas, RF_tot, RF_CO2, SST, land tas, timesteps, the carbon pools (atmos_co2, ocean_c, veg_c,
  * detritus_c, soil_c, permafrost_c, thawedp_c, earth_c), NBP, ocean_uptake, HL_pH, LL_pH and the
- * CH4 / O3 concentrations; everything else takes the one-wavefront kernels.
+ * CH4 / O3 concentrations (any scalar parameter may differ between members, diffusivity included);
+ * everything else takes the one-wavefront kernels.
  * hx_set_pair_kernel_limit: ensembles of up to max_members use it (default 32 768 = one workgroup
  * per two SIMDs; 0 = never; the environment variable HECTOR_AMD_PAIR_MAX_MEMBERS sets the default of
  * new cores).  hx_last_run_kernel: "run" or "pair", whichever the last hx_run took. */

@@ -129,6 +129,37 @@ def test_pair_kernel_pools_vs_oracle(hip_lib, oracle):
     assert checked == len(POOLS)
 
 
+@pytest.mark.parametrize("n", [96, 1000])
+def test_pair_kernel_with_per_member_diffusivity(hip_lib, oracle, n):
+    """Members that differ in ocean heat diffusivity have their own DOECLIM kernel table (the
+    history pass runs per lane instead of on the matrix pipe): against the run kernel for all
+    members, against the oracle for a sample, across several 32-year history blocks."""
+    S, q10 = ensemble.ecs_q10(n)
+    diff = np.linspace(0.6, 3.0, n)
+    out = {}
+    for name, limit in (("pair", None), ("run", 0)):
+        c = mk(hip_lib, n, S, q10, limit)
+        c.setvar("diff", diff, "cm2/s")
+        c.set_outputs(["CO2_concentration", "global_tas", "sst", "timesteps", "RF_tot"])
+        c.run(2300)
+        assert c.last_run_kernel() == name
+        assert (c.status() == 0).all()
+        out[name] = {v: c.fetchvars(v, (1745, 2300)) for v in
+                     ("CO2_concentration", "global_tas", "sst", "timesteps", "RF_tot")}
+    p, r = out["pair"], out["run"]
+    assert np.array_equal(p["timesteps"], r["timesteps"])
+    assert (np.abs(p["CO2_concentration"] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < 1e-8
+    for v in ("global_tas", "sst", "RF_tot"):
+        assert np.abs(p[v] - r[v]).max() < 1e-8, v
+    for i in range(0, n, max(1, n // 12)):
+        q = oracle.default_params(); q.S = S[i]; q.q10_rh[0] = q10[i]; q.diff = diff[i]
+        o, err, _ = oracle.run(q)
+        assert err == 0
+        assert (np.abs(p["CO2_concentration"][:, i] - o["CO2_concentration"]) / o["CO2_concentration"]).max() < REL_CO2
+        assert np.abs(p["global_tas"][:, i] - o["global_tas"]).max() < ABS_T
+        assert np.array_equal(p["timesteps"][1:, i].astype(np.int64), o["timesteps"][1:].astype(np.int64))
+
+
 def test_pair_kernel_in_segments_reset_and_handover(hip_lib):
     """A run in pieces, a reset, and a hand-over between the two kernels in the middle of a run
     (the state table is common) give the one-launch trajectory."""
@@ -234,8 +265,8 @@ def test_pair_kernel_shipped_scenarios_vs_oracle(hip_lib, name):
 @pytest.mark.timeout(300)
 def test_pair_kernel_runaway_member_is_flagged_and_does_not_hang(hip_lib):
     """The member of test_host_logic.runaway_member_checks (SSP1-1.9, a carbon cycle that runs
-    away around 2130) without its own diffusivity, so that the ensemble stays on the two-wavefront
-    kernel: flagged and retired by both wavefronts together, neighbours untouched."""
+    away around 2130) on the two-wavefront kernel: flagged and retired by both wavefronts
+    together, neighbours untouched."""
     import os
     from conftest import ROOT
     from test_host_logic import RUNAWAY
@@ -245,8 +276,6 @@ def test_pair_kernel_runaway_member_is_flagged_and_does_not_hang(hip_lib):
         c = hector_amd.Core(path, 3, device=0, lib_path=hip_lib)
         c.set_pair_kernel_limit(limit)
         for k, v in RUNAWAY.items():
-            if k == "diff":
-                continue
             base = c.getvar(k)[0]
             c.setvar(k, [base, v, base])
         c.set_outputs(["CO2_concentration", "timesteps"])

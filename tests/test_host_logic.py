@@ -128,9 +128,10 @@ def runaway_member_checks(lib, **kw):
         base = c.getvar(k)[0]
         c.setvar(k, [base, v, base])
     c.set_outputs(["CO2_concentration"]); d.set_outputs(["CO2_concentration"])
-    # (c's members differ in `diff` -> per-member DOECLIM table -> run kernel; the lone member of d
-    # would take the small-ensemble kernel: same kernel for the bitwise comparison below)
-    d.set_pair_kernel_limit(0)
+    # (c's members differ in `diff` -> per-member DOECLIM table, d's lone member uses the shared one:
+    # two instantiations of the small-ensemble kernel; the bitwise comparison below is between
+    # run kernels, whose history pass sums in the same order either way)
+    c.set_pair_kernel_limit(0); d.set_pair_kernel_limit(0)
     c.run(2300); d.run(2300)
     st = c.status()
     assert st[0] == 0 and st[2] == 0 and st[1] & 4          # HX_ERR_NEGPOOL

@@ -71,8 +71,8 @@ def check_member(o, p, d_by_var, tol_by_var, where, ill):
 
 
 def sweep(lib, n, seed, check_every=1, pair=False, **kw):
-    """pair=True: the configuration the two-wavefront kernel serves (shared diffusivity; it
-    records all of these outputs), every other parameter perturbed all the same."""
+    """pair=True: the ensemble has to run on the two-wavefront kernel (it records all of these
+    outputs; per-member diffusivity included)."""
     import oracle_binding
     rng = np.random.default_rng(seed)
     worst, ill = {}, []
@@ -80,8 +80,6 @@ def sweep(lib, n, seed, check_every=1, pair=False, **kw):
         path = os.path.join(ROOT, "hector_amd", "data", name + ".hxs")
         vals = {k: rng.uniform(lo, hi, n) for k, (lo, hi, _) in RANGES.items()}
         c = hector_amd.Core(path, n, lib_path=lib, **kw)
-        if pair:
-            vals["diff"] = np.full(n, c.getvar("diff")[0])
         for k, (lo, hi, unit) in RANGES.items():
             c.setvar(k, vals[k], unit)
         outs = ["CO2_concentration", "global_tas", "RF_tot", "NBP", "ocean_c", "timesteps"]
