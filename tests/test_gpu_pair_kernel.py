@@ -151,6 +151,15 @@ def test_pair_kernel_with_per_member_diffusivity(hip_lib, oracle, n):
     assert (np.abs(p["CO2_concentration"] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < 1e-8
     for v in ("global_tas", "sst", "RF_tot"):
         assert np.abs(p[v] - r[v]).max() < 1e-8, v
+    # the same run in pieces (history blocks restart at every launch): bit for bit
+    c = mk(hip_lib, n, S, q10)
+    c.setvar("diff", diff, "cm2/s")
+    c.set_outputs(["CO2_concentration", "global_tas", "sst", "timesteps", "RF_tot"])
+    for y in (1746, 1777, 1778, 1900, 2107, 2300):
+        c.run(y)
+        assert c.last_run_kernel() == "pair"
+    for v in ("CO2_concentration", "global_tas", "sst"):
+        assert np.array_equal(c.fetchvars(v, (1745, 2300)), p[v]), v
     for i in range(0, n, max(1, n // 12)):
         q = oracle.default_params(); q.S = S[i]; q.q10_rh[0] = q10[i]; q.diff = diff[i]
         o, err, _ = oracle.run(q)
