@@ -1446,7 +1446,7 @@ void EnsembleCore::run(double runtodate) {
     con = 2;
   }
   // small ensembles (too few wavefronts to fill the SIMDs): two wavefronts per 64 members
-  bool pair = hx_pair_available() && B_ == 1 && con == 0 && !hf && !d_hist_ && n_ <= pair_max_members_;
+  bool pair = hx_pair_available() && B_ == 1 && con == 0 && !hf && n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
     if (d_out_[v]) {  // what hx_pair_kernel records
       static const int ok[] = {HXO_SST, HXO_TLAND, HXO_CO2, HXO_TGAV, HXO_NSTASH, HXO_RF_TOT, HXO_RF_CO2,

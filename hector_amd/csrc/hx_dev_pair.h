@@ -43,6 +43,7 @@ enum PairYear {  // per year / per stash, each slot written and read on opposite
   PY_PN = 0, PY_CH4, PY_O3, PY_STATUS1, PY_PCO2L,               // land -> ocean
   PY_MAXTS, PY_STATUS0, PY_TLAND, PY_LNC, PY_CLL,                // ocean -> land
   PY_KL_K1, PY_KL_K2, PY_KL_KB, PY_KL_KW, PY_KL_KH,              // ocean -> land, once a year
+  PY_HSTAT,                                                      // ocean -> land at year end (state history)
   PY_N
 };
 
@@ -257,6 +258,21 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
     // LDS (this side wrote them).  Done in the wait for the land side's first step of the year
     // (its attempt on three variables is the longer one), the HBM value requested at year start.
     s_tblk[0][lane] = sst;  // the year before the first block
+    // this side's rows of the state table (base == nullptr) or of a year's history slab
+    auto store_ocean = [&](double *base) {
+      HxBuffers b2 = buf;
+      if (base) b2.state = base;
+      sts_(b2, HXS_C_HL, mem, cHL); sts_(b2, HXS_C_LL, mem, cLL);
+      sts_(b2, HXS_C_IO, mem, cIO); sts_(b2, HXS_C_DO, mem, cDO);
+      sts_(b2, HXS_ATMOS, mem, atmos);
+      sts_(b2, HXS_MAX_TS, mem, c.max_ts); sts_(b2, HXS_TS_TIMEOUT, mem, (double)ts_timeout);
+      sts_(b2, HXS_LASTFLUX_ANN, mem, lastflux_ann); sts_(b2, HXS_SOLVER_DT, mem, c.sdt);
+      sts_(b2, HXS_H_HL, mem, hH);
+      sts_(b2, HXS_TLAND, mem, tland); sts_(b2, HXS_SST, mem, sst);
+      sts_(b2, HXS_F_PREV, mem, f_prev); sts_(b2, HXS_BASE_TOT, mem, base_tot);
+      sts_(b2, HXS_BASE_CO2, mem, base_co2);
+      if (base) sts_(b2, HXS_ALK_HL, mem, alkH);  // (constant rows: a slab is a whole table)
+    };
     double dpart_pf = 0, dpast_in = 0;
     bool sums_done = true;
     auto history_sums = [&](int iy) {
@@ -487,20 +503,15 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         if (buf.out[HXO_CH4]) sto_(buf, HXO_CH4, o, ch4);
         if (buf.out[HXO_O3]) sto_(buf, HXO_O3, o, o3);
       }
+      if (buf.hist) {  // Core::reset(date) needs every component's state of every year
+        store_ocean(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
+        s_yr[PY_HSTAT][lane] = (double)status;
+      }
       PSTAMP(10);
       __syncthreads();  // ---- barrier C: year end (SST and land temperature published)
       PSTAMP(11);
     }
-    // state back to the table
-    sts_(buf, HXS_C_HL, mem, cHL); sts_(buf, HXS_C_LL, mem, cLL);
-    sts_(buf, HXS_C_IO, mem, cIO); sts_(buf, HXS_C_DO, mem, cDO);
-    sts_(buf, HXS_ATMOS, mem, atmos);
-    sts_(buf, HXS_MAX_TS, mem, c.max_ts); sts_(buf, HXS_TS_TIMEOUT, mem, (double)ts_timeout);
-    sts_(buf, HXS_LASTFLUX_ANN, mem, lastflux_ann); sts_(buf, HXS_SOLVER_DT, mem, c.sdt);
-    sts_(buf, HXS_H_HL, mem, hH);
-    sts_(buf, HXS_TLAND, mem, tland); sts_(buf, HXS_SST, mem, sst);
-    sts_(buf, HXS_F_PREV, mem, f_prev); sts_(buf, HXS_BASE_TOT, mem, base_tot);
-    sts_(buf, HXS_BASE_CO2, mem, base_co2);
+    store_ocean(nullptr);  // state back to the table
   } else {
     // ======================= wavefront 1: land, gases, history sums =======================
     double veg = lds_(buf, HXS_NGLOBAL + HXSB_VEG, mem), det = lds_(buf, HXS_NGLOBAL + HXSB_DET, mem),
@@ -537,6 +548,22 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
     // window's load from memory is issued a phase earlier (prefetch()): with one wavefront on the
     // SIMD a load's latency is otherwise waited out in full.
     double tfs_cand = 0, tl_old_pf = 0;
+    // this side's rows of the state table (base == nullptr) or of a year's history slab
+    auto store_land = [&](double *base) {
+      HxBuffers b2 = buf;
+      if (base) b2.state = base;
+      const int rr = HXS_NGLOBAL;
+      sts_(b2, rr + HXSB_VEG, mem, veg); sts_(b2, rr + HXSB_DET, mem, det);
+      sts_(b2, rr + HXSB_SOIL, mem, soil); sts_(b2, rr + HXSB_PF, mem, pf);
+      sts_(b2, rr + HXSB_THAWED, mem, thawed); sts_(b2, rr + HXSB_TEMPFERTS, mem, tempferts);
+      sts_(b2, rr + HXSB_F_FROZEN, mem, ffrozen);
+      sts_(b2, HXS_EARTH, mem, earth); sts_(b2, HXS_CUM_LUC_VA, mem, cum_luc_va);
+      sts_(b2, HXS_CUM_PF_CH4, mem, cum_pf_ch4); sts_(b2, HXS_MASSTOT, mem, masstot);
+      sts_(b2, HXS_CH4, mem, ch4); sts_(b2, HXS_TWIN, mem, twin);
+      sts_(b2, HXS_TL_M1, mem, tl_m1); sts_(b2, HXS_TL_M2, mem, tl_m2);
+      sts_(b2, HXS_H_LL, mem, hL);
+      if (base) { sts_(b2, HXS_ALK_LL, mem, alkL); sts_(b2, HXS_EOS_VEGC, mem, eos); }
+    };
     auto prefetch = [&](int iyn) {
       const int iold = iyn - 203;
       tl_old_pf = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold >= 1 ? iold : 0) * np + mem];
@@ -752,23 +779,17 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         if (buf.out[HXO_EARTH_C]) sto_(buf, HXO_EARTH_C, o, earth);
         if (buf.out[HXO_LL_PH]) sto_(buf, HXO_LL_PH, o, -log10(hL));
       }
+      if (buf.hist) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
       if (iy < iy_to) prepare(iy + 1);
       PSTAMP(10);
       __syncthreads();  // ---- barrier C
       PSTAMP(11);
       tland = s_yr[PY_TLAND][lane];
       lnc = s_yr[PY_LNC][lane];
+      if (buf.hist)
+        HX_GU(buf.hist_status)[(size_t)iy * np + mem] = status | (unsigned)s_yr[PY_HSTAT][lane];
     }
-    const int rr = HXS_NGLOBAL;
-    sts_(buf, rr + HXSB_VEG, mem, veg); sts_(buf, rr + HXSB_DET, mem, det);
-    sts_(buf, rr + HXSB_SOIL, mem, soil); sts_(buf, rr + HXSB_PF, mem, pf);
-    sts_(buf, rr + HXSB_THAWED, mem, thawed); sts_(buf, rr + HXSB_TEMPFERTS, mem, tempferts);
-    sts_(buf, rr + HXSB_F_FROZEN, mem, ffrozen);
-    sts_(buf, HXS_EARTH, mem, earth); sts_(buf, HXS_CUM_LUC_VA, mem, cum_luc_va);
-    sts_(buf, HXS_CUM_PF_CH4, mem, cum_pf_ch4); sts_(buf, HXS_MASSTOT, mem, masstot);
-    sts_(buf, HXS_CH4, mem, ch4); sts_(buf, HXS_TWIN, mem, twin);
-    sts_(buf, HXS_TL_M1, mem, tl_m1); sts_(buf, HXS_TL_M2, mem, tl_m2);
-    sts_(buf, HXS_H_LL, mem, hL);
+    store_land(nullptr);
   }
   // the two halves' error flags, merged
   __syncthreads();

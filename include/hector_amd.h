@@ -214,7 +214,7 @@ int hx_stream(hx_core *core, void **stream);
 /* Small ensembles -- too few 64-member wavefronts to occupy the GPU's 1 024 SIMDs, BASELINE
  * configs[1] -- are run by a kernel that gives every 64 members TWO wavefronts (ocean / climate and
  * land, hx_dev_pair.h): same model, same decisions, ~20 % shorter launch.  It serves
- * one-biome ensembles without constraints, per-member series, history or diagnostics beyond CO2,
+ * one-biome ensembles without constraints, per-member series or diagnostics beyond CO2,
  * tas, RF_tot, RF_CO2, SST, land tas, timesteps, the carbon pools (atmos_co2, ocean_c, veg_c,
  * detritus_c, soil_c, permafrost_c, thawedp_c, earth_c), NBP, ocean_uptake, HL_pH, LL_pH and the
  * CH4 / O3 concentrations (any scalar parameter may differ between members, diffusivity included);

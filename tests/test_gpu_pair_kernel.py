@@ -201,6 +201,61 @@ def test_pair_kernel_in_segments_reset_and_handover(hip_lib):
         assert np.abs(x.fetchvars("global_tas") - first["global_tas"]).max() < 1e-8
 
 
+def test_pair_kernel_state_history_and_reset_to_any_date(hip_lib):
+    """Core::reset(date), core.cpp:511-549, on the two-wavefront kernel: each wavefront writes its
+    rows of the year's state slab; the rerun from any computed year is bit-identical, the history
+    changes no result, and slabs written by one kernel restart the other."""
+    n = 1000
+    S, q10 = ensemble.ecs_q10(n)
+    outs = ["CO2_concentration", "global_tas", "ocean_c", "CH4_concentration", "timesteps", "NBP"]
+    a = mk(hip_lib, n, S, q10)
+    a.set_outputs(outs); a.run(2300)
+    assert a.last_run_kernel() == "pair"
+    ref = {v: a.fetchvars(v, (1745, 2300)) for v in outs}
+    b = mk(hip_lib, n, S, q10)
+    b.enable_history(True); b.set_outputs(outs); b.run(2300)
+    assert b.last_run_kernel() == "pair"
+    for v in outs:
+        assert np.array_equal(b.fetchvars(v, (1745, 2300)), ref[v]), v
+    for date in (2050, 1790, 1746, 2299):
+        b.reset(date)
+        assert b.current_date == date
+        b.run(2300)
+        assert b.last_run_kernel() == "pair"
+        for v in outs:
+            assert np.array_equal(b.fetchvars(v, (1745, 2300)), ref[v]), (v, date)
+    # a dated edit: the run restarts from the edited year's slab, as a fresh core with the edit
+    b.setvar_dated("ffi_emissions", [2030, 2031], [0.5, 0.5], "Pg C/yr")
+    b.run(2300)
+    f = mk(hip_lib, n, S, q10)
+    f.set_outputs(outs); f.setvar_dated("ffi_emissions", [2030, 2031], [0.5, 0.5], "Pg C/yr"); f.run(2300)
+    for v in outs:
+        assert np.array_equal(b.fetchvars(v, (1745, 2300)), f.fetchvars(v, (1745, 2300))), v
+    # slabs of one kernel, rerun on the other (the slab is the run kernel's state table)
+    r = mk(hip_lib, n, S, q10, 0)
+    r.enable_history(True); r.set_outputs(outs); r.run(2300)
+    r.set_pair_kernel_limit(32768)
+    r.reset(1900); r.run(2300)
+    assert r.last_run_kernel() == "pair"
+    b2 = mk(hip_lib, n, S, q10)
+    b2.enable_history(True); b2.set_outputs(outs); b2.run(2300)
+    b2.set_pair_kernel_limit(0)
+    b2.reset(1900); b2.run(2300)
+    assert b2.last_run_kernel() == "run"
+    for x in (r, b2):
+        assert (x.status() == 0).all()
+        assert (np.abs(x.fetchvars("CO2_concentration", (1745, 2300)) - ref["CO2_concentration"]) /
+                ref["CO2_concentration"]).max() < 1e-8
+        assert np.array_equal(x.fetchvars("timesteps", (1745, 2300)), ref["timesteps"])
+    # a member that fails keeps its flag in the year's status slab and loses it on a reset before
+    npp = np.full(130, 56.2); npp[77] = 1e5
+    e = hector_amd.Core(SCENARIO, 130, device=0, lib_path=hip_lib)
+    e.enable_history(True); e.setvar("npp_flux0", npp); e.run(1800)
+    assert e.last_run_kernel() == "pair"
+    st = e.status(); assert st[77] != 0 and (np.delete(st, 77) == 0).all()
+    e.reset(1799); assert e.status()[77] != 0
+
+
 def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     n = 128
     S, q10 = ensemble.ecs_q10(n)
@@ -209,9 +264,6 @@ def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.split_biome(["a", "b"])                                 # more than one biome
-    assert c.run(1800).last_run_kernel() == "run"
-    c = mk(hip_lib, n, S, q10)
-    c.enable_history(True)                                    # state history for reset(date)
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.setvar_dated_members("ffi_emissions", [1800], np.linspace(0.0, 1.0, n)[None, :])  # per-member series

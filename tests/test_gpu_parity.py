@@ -271,17 +271,19 @@ def test_model_errors_are_flags_on_gpu(hip_lib):
     assert np.array_equal(a[:, 0], a[:, 129]) and np.isfinite(a[:, 0]).all()
 
 
-def test_state_history_and_reset_to_any_date_on_gpu(hip_lib):
+@pytest.mark.parametrize("pair_limit", [0, 32768], ids=["run-kernel", "pair-kernel"])
+def test_state_history_and_reset_to_any_date_on_gpu(hip_lib, pair_limit):
     """Core::reset(date), core.cpp:511-549: back to any computed year from the per-year state
     history in HBM; the rerun is bit-identical and the history changes no result."""
     n = 1000
     S, q10 = ensemble.ecs_q10(n)
     outs = ["CO2_concentration", "global_tas", "ocean_c", "CH4_concentration", "timesteps"]
     a = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
-    a.set_pair_kernel_limit(0)      # (bitwise comparison: the kernel the history runs on)
+    a.set_pair_kernel_limit(pair_limit)
     a.set_outputs(outs); a.run(2300)
     ref = {v: a.fetchvars(v, (1745, 2300)) for v in outs}
     b = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    b.set_pair_kernel_limit(pair_limit)
     b.enable_history(True); b.set_outputs(outs); b.run(2300)
     for v in outs:
         assert np.array_equal(b.fetchvars(v, (1745, 2300)), ref[v]), v
@@ -325,7 +327,6 @@ def test_dated_setvar_emissions_vs_oracle_on_gpu(hip_lib, oracle, tmp_path):
         assert (np.abs(co2[:, i] - oc) / oc).max() < REL_CO2
         assert np.abs(tg[:, i] - ot).max() < ABS_T
     d = mk(hip_lib, n).setvar("S", S, "degC")
-    d.set_pair_kernel_limit(0)  # (c records its state history: same kernel for the bitwise check)
     d.set_outputs(["CO2_concentration"]); d.setvar_dated("ffi_emissions", years, vals); d.run(2100)
     assert np.array_equal(d.fetchvars("CO2_concentration", (1745, 2100)), co2)
 
