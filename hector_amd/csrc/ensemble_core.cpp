@@ -12,8 +12,8 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
                             hipStream_t st);
 int hx_track_rows(int B);
 int hx_pair_available();
-hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool kpm, int iy_from, int iy_to,
-                              hipStream_t st);
+hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
+                              int iy_to, hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st);
 int hx_doeclim_block_years();
@@ -1446,18 +1446,18 @@ void EnsembleCore::run(double runtodate) {
     con = 2;
   }
   // small ensembles (too few wavefronts to fill the SIMDs): two wavefronts per 64 members
-  bool pair = hx_pair_available() && B_ == 1 && con == 0 && !hf && n_ <= pair_max_members_;
+  bool pair = hx_pair_available() && B_ == 1 && con == 0 && n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
     if (d_out_[v]) {  // what hx_pair_kernel records
       static const int ok[] = {HXO_SST, HXO_TLAND, HXO_CO2, HXO_TGAV, HXO_NSTASH, HXO_RF_TOT, HXO_RF_CO2,
                                HXO_ATMOS_C, HXO_OCEAN_C, HXO_OCEAN_UPTAKE, HXO_HL_PH, HXO_LL_PH, HXO_CH4,
                                HXO_O3, HXO_NBP, HXO_VEG_C, HXO_DET_C, HXO_SOIL_C, HXO_PERMAFROST_C,
-                               HXO_THAWED_C, HXO_EARTH_C};
+                               HXO_THAWED_C, HXO_EARTH_C, HXO_HEATFLUX};
       if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) pair = false;
     }
   last_run_pair_ = pair;
   if (pair)
-    check(hx_launch_run_pair(d_args_, npad_, ker_per_member_, last_iy_, target, stream_), "run kernel (pair)");
+    check(hx_launch_run_pair(d_args_, npad_, hf, ker_per_member_, last_iy_, target, stream_), "run kernel (pair)");
   else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
                       stream_),

@@ -198,7 +198,9 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // ===========================================================================
 // KERPM: the members differ in ocean heat diffusivity, so each has its own DOECLIM kernel table
 // ([ns + pad][npad] in HBM instead of one shared table) and the history pass runs on the vector ALU.
-template <bool KERPM>
+// HF: the ocean heat flux is recorded ("heatflux"; its two parts are extended diagnostics of the run
+// kernel): a second history sum with the kernel table shifted by a year.
+template <bool KERPM, bool HF>
 __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__ args, int iy_from,
                                                       int iy_to) {
   __shared__ double s_tblk[HX_DBLK + 1][64];  // SSTs of years blk0-1 .. blk0+31 (the ocean side's)
@@ -251,6 +253,8 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       else return HX_CCD(buf.ker)[idx];
     };
     const double ker_lag1 = ldk(kc.ns - 2 + HX_KPAD);  // Ker entry of last year's SST
+    const double ker2_lag1 = HF ? ldk(kc.ns - 1 + HX_KPAD) : 0.0;  // ... in the heat-flux sum
+    const double dHFS = HF ? ldd(buf, HXD_HFSCALE, mem) : 0.0;
     ChemK kH, kL;
     double pco2H = 0, pco2L = 0;
     // The history sum of a year (all but last year's SST, which is added from the register): the
@@ -274,10 +278,12 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       if (base) sts_(b2, HXS_ALK_HL, mem, alkH);  // (constant rows: a slab is a whole table)
     };
     double dpart_pf = 0, dpast_in = 0;
+    [[maybe_unused]] double dpart2_pf = 0, hint_in = 0;
     bool sums_done = true;
     auto history_sums = [&](int iy) {
       const int jb = iy - blk0;
       double acc = dpart_pf;
+      [[maybe_unused]] double acc2 = dpart2_pf;
       const int kq = kc.ns - iy - 1 + HX_KPAD + (blk0 - 1);  // Ker index of slot 0 (year blk0 - 1)
       const int nchunk = (jb + 7) >> 3;
       for (int cc = 0; cc < nchunk; ++cc) {
@@ -286,8 +292,15 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         for (int q = 0; q < 8; ++q) { T[q] = s_tblk[8 * cc + q][lane]; K[q] = ldk(kq + 8 * cc + q); }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += ((8 * cc + q < jb) ? T[q] : 0.0) * K[q];
+        if constexpr (HF) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) K[q] = ldk(kq + 8 * cc + q + 1);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc2 += ((8 * cc + q < jb) ? T[q] : 0.0) * K[q];
+        }
       }
       dpast_in = acc;
+      if constexpr (HF) hint_in = acc2;
       sums_done = true;
     };
 
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       const double ch4 = s_yr[PY_CH4][lane], o3 = s_yr[PY_O3][lane];
       if (blk0 < 0 || iy >= blk0 + HX_DBLK) blk0 = iy;
       dpart_pf = HX_GCD(buf.dpart)[(size_t)(iy - blk0) * np + mem];  // (the land side ran the pass last year end)
+      if constexpr (HF) dpart2_pf = HX_GCD(buf.dpart2)[(size_t)(iy - blk0) * np + mem];
       sums_done = false;
       pco2L = s_yr[PY_PCO2L][lane];
       status |= (unsigned)s_yr[PY_STATUS1][lane];
@@ -487,8 +501,14 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       if (slot == HX_DBLK) s_tblk[0][lane] = sst_new;  // the year before the next block
       s_yr[PY_TLAND][lane] = tl_new;
       s_yr[PY_LNC][lane] = ln_co2r;
-      f_prev = rf_tot; tland = tl_new; sst = sst_new;
       const size_t o = (size_t)iy * np + mem;
+      if constexpr (HF) {  // heat fluxes into the mixed layer and the interior ocean (DOECLIM)
+        const double hint = hint_in + sst * ker2_lag1;
+        const double hmix = D_cas * (sst_new - sst);
+        const double hi = dHFS * (2.0 * sst_new - hint);
+        sto_(buf, HXO_HEATFLUX, o, hmix + D_fso * hi);
+      }
+      f_prev = rf_tot; tland = tl_new; sst = sst_new;
       sto_(buf, HXO_SST, o, sst_new);
       sto_(buf, HXO_TLAND, o, tl_new);
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
@@ -594,10 +614,10 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       if (blk0 < 0 || iyn >= blk0 + HX_DBLK) {
         blk0 = iyn;
         if constexpr (KERPM)
-          doeclim_pass_dev<true, false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+          doeclim_pass_dev<true, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                         const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
         else
-          doeclim_pass_mfma<false>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+          doeclim_pass_mfma<HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                    const_cast<double *>(buf.dpart2), kc.ns, buf.npad, blk0, mem, blk0 - 1);
         HX_FENCE();
       }

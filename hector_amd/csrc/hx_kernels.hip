@@ -1463,16 +1463,17 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 // the small-ensemble kernel (two wavefronts per 64 members, hx_dev_pair.h): one biome, no
 // constraints, the outputs listed in EnsembleCore::run; kpm: per-member DOECLIM kernel tables
 int hx_pair_available() { return HX_HAS_MFMA; }
-hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool kpm, int iy_from, int iy_to,
-                              hipStream_t st) {
+hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
+                              int iy_to, hipStream_t st) {
 #if HX_HAS_MFMA
-  if (kpm)
-    hipLaunchKernelGGL(hx_pair_kernel<true>, dim3(npad / 64), dim3(128), 0, st, d_args, iy_from, iy_to);
-  else
-    hipLaunchKernelGGL(hx_pair_kernel<false>, dim3(npad / 64), dim3(128), 0, st, d_args, iy_from, iy_to);
+  const dim3 g(npad / 64), b(128);
+  if (kpm && heatflux) hipLaunchKernelGGL((hx_pair_kernel<true, true>), g, b, 0, st, d_args, iy_from, iy_to);
+  else if (kpm) hipLaunchKernelGGL((hx_pair_kernel<true, false>), g, b, 0, st, d_args, iy_from, iy_to);
+  else if (heatflux) hipLaunchKernelGGL((hx_pair_kernel<false, true>), g, b, 0, st, d_args, iy_from, iy_to);
+  else hipLaunchKernelGGL((hx_pair_kernel<false, false>), g, b, 0, st, d_args, iy_from, iy_to);
   return hipGetLastError();
 #else
-  (void)d_args; (void)npad; (void)kpm; (void)iy_from; (void)iy_to; (void)st;
+  (void)d_args; (void)npad; (void)heatflux; (void)kpm; (void)iy_from; (void)iy_to; (void)st;
   return hipErrorInvalidValue;
 #endif
 }

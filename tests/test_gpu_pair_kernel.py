@@ -201,6 +201,48 @@ def test_pair_kernel_in_segments_reset_and_handover(hip_lib):
         assert np.abs(x.fetchvars("global_tas") - first["global_tas"]).max() < 1e-8
 
 
+@pytest.mark.parametrize("own_diffusivity", [False, True], ids=["shared-kernel-table", "per-member-table"])
+def test_pair_kernel_records_the_ocean_heat_flux(hip_lib, oracle, own_diffusivity):
+    """"heatflux" (the R package's HEAT_FLUX) needs DOECLIM's second history sum: both
+    instantiations that carry it, against the run kernel (all members) and the oracle (a sample),
+    in one launch and in pieces."""
+    n = 500
+    S, q10 = ensemble.ecs_q10(n)
+    diff = np.linspace(0.6, 3.0, n) if own_diffusivity else None
+    outs = ["CO2_concentration", "global_tas", "heatflux", "timesteps"]
+    out = {}
+    for name, limit in (("pair", None), ("run", 0)):
+        c = mk(hip_lib, n, S, q10, limit)
+        if own_diffusivity:
+            c.setvar("diff", diff, "cm2/s")
+        c.set_outputs(outs)
+        c.run(2300)
+        assert c.last_run_kernel() == name
+        assert (c.status() == 0).all()
+        out[name] = {v: c.fetchvars(v, (1745, 2300)) for v in outs}
+    p, r = out["pair"], out["run"]
+    assert np.array_equal(p["timesteps"], r["timesteps"])
+    assert np.abs(p["heatflux"] - r["heatflux"]).max() < 1e-8
+    assert np.abs(p["heatflux"]).max() > 0.5          # (W/m2: a real signal, not zeros)
+    assert np.abs(p["global_tas"] - r["global_tas"]).max() < 1e-8
+    for i in range(0, n, 50):
+        q = oracle.default_params(); q.S = S[i]; q.q10_rh[0] = q10[i]
+        if own_diffusivity:
+            q.diff = diff[i]
+        o, err, _ = oracle.run(q)
+        assert err == 0
+        assert np.abs(p["heatflux"][1:, i] - o["heatflux"][1:]).max() < 2e-8, i
+        assert np.abs(p["global_tas"][:, i] - o["global_tas"]).max() < ABS_T
+    c = mk(hip_lib, n, S, q10)
+    if own_diffusivity:
+        c.setvar("diff", diff, "cm2/s")
+    c.set_outputs(outs)
+    for y in (1746, 1777, 1778, 1900, 2107, 2300):
+        c.run(y)
+        assert c.last_run_kernel() == "pair"
+    assert np.array_equal(c.fetchvars("heatflux", (1745, 2300)), p["heatflux"])
+
+
 def test_pair_kernel_state_history_and_reset_to_any_date(hip_lib):
     """Core::reset(date), core.cpp:511-549, on the two-wavefront kernel: each wavefront writes its
     rows of the year's state slab; the rerun from any computed year is bit-identical, the history
@@ -260,7 +302,7 @@ def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     n = 128
     S, q10 = ensemble.ecs_q10(n)
     c = mk(hip_lib, n, S, q10)
-    c.set_outputs(["CO2_concentration", "heatflux"])         # a diagnostic it does not record
+    c.set_outputs(["CO2_concentration", "NPP"])              # an extended diagnostic: run kernel
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.split_biome(["a", "b"])                                 # more than one biome
