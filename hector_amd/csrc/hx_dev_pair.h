@@ -76,29 +76,29 @@ __device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double 
   double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5::b21 * dxdt[i];
-  rhs(xt, k2);
+  rhs(xt, k2, 1);
 #pragma unroll
   for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5::b31 * dxdt[i] + dtl * Dp5::b32 * k2[i];
-  rhs(xt, k3);
+  rhs(xt, k3, 2);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
     xt[i] = y[i] + dtl * Dp5::b41 * dxdt[i] + dtl * Dp5::b42 * k2[i] + dtl * Dp5::b43 * k3[i];
-  rhs(xt, k4);
+  rhs(xt, k4, 3);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
     xt[i] = y[i] + dtl * Dp5::b51 * dxdt[i] + dtl * Dp5::b52 * k2[i] + dtl * Dp5::b53 * k3[i] +
             dtl * Dp5::b54 * k4[i];
-  rhs(xt, k5);
+  rhs(xt, k5, 4);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
     xt[i] = y[i] + dtl * Dp5::b61 * dxdt[i] + dtl * Dp5::b62 * k2[i] + dtl * Dp5::b63 * k3[i] +
             dtl * Dp5::b64 * k4[i] + dtl * Dp5::b65 * k5[i];
-  rhs(xt, k6);
+  rhs(xt, k6, 5);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
     xn[i] = y[i] + dtl * Dp5::c1 * dxdt[i] + dtl * Dp5::c3 * k3[i] + dtl * Dp5::c4 * k4[i] +
             dtl * Dp5::c5 * k5[i] + dtl * Dp5::c6 * k6[i];
-  rhs(xn, dn);
+  rhs(xn, dn, 5);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const double xe = dtl * Dp5::dc1 * dxdt[i] + dtl * Dp5::dc3 * k3[i] + dtl * Dp5::dc4 * k4[i] +
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       double pG = pco2H * kH.g + pco2L * kL.g;
       double aoA = PGC2PPM * (kH.g + kL.g);
       double aoB = pG * hx_recip(cLL + cHL);
-      auto rhs = [&](const double *y, double *d) {
+      auto rhs = [&](const double *y, double *d, int) {
         const double ao = fma(y[0], aoA, -fma(y[1] - totC, aoB, pG));
         d[0] = Pn - ao;
         d[1] = ao;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
           if (c.stepping) {
             if (pair_retry(c, status)) load_pools();
             if (c.stepping) {
-              if (c.first_call) { rhs(y, dxdt); c.first_call = false; }
+              if (c.first_call) { rhs(y, dxdt, 0); c.first_call = false; }
               pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
               tried = true;
             }
@@ -680,9 +680,12 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       PSTAMP(3);
       c.max_ts = s_yr[PY_MAXTS][lane];
       status |= (unsigned)s_yr[PY_STATUS0][lane];
-      auto rhs = [&](const double *y, double *d) {
-        const double total = y[0] + y[1] + y[2];
-        const double rr = hx_div1(luc_e, total);
+      // the pools' sum moves at a constant rate within an interval (every LUC loss rr * y_i adds up to
+      // luc_e), and a Runge-Kutta stage preserves that: the loss rates of all stages of an attempt are
+      // known before it starts -- six independent divisions instead of one at the head of each stage
+      double rrs[6];
+      auto rhs = [&](const double *y, double *d, int s) {
+        const double rr = rrs[s];
         d[0] = (v1 - rr * y[0]) + luc_u;
         d[1] = d2c - rr * y[1];
         d[2] = s3c - rr * y[2];
@@ -711,7 +714,17 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
           if (c.stepping) {
             if (pair_retry(c, status)) load_pools();
             if (c.stepping) {
-              if (c.first_call) { rhs(y, dxdt); c.first_call = false; }
+              {
+                const double tot0 = y[0] + y[1] + y[2];
+                const double hC = c.dtl * ((((v1 + luc_u) + d2c) + s3c) - luc_e);
+                rrs[0] = hx_div1(luc_e, tot0);
+                rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
+                rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
+                rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
+                rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
+                rrs[5] = hx_div1(luc_e, tot0 + hC);
+              }
+              if (c.first_call) { rhs(y, dxdt, 0); c.first_call = false; }
               pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
               tried = true;
             }
