@@ -129,11 +129,11 @@ def test_pair_kernel_pools_vs_oracle(hip_lib, oracle):
     assert checked == len(POOLS)
 
 
-@pytest.mark.parametrize("n", [96, 1000])
+@pytest.mark.parametrize("n", [96, 4096])
 def test_pair_kernel_with_per_member_diffusivity(hip_lib, oracle, n):
     """Members that differ in ocean heat diffusivity have their own DOECLIM kernel table (the
-    history pass runs per lane instead of on the matrix pipe): against the run kernel for all
-    members, against the oracle for a sample, across several 32-year history blocks."""
+    history pass runs per lane instead of on the matrix pipe): against the run kernel and against
+    the oracle, every member, across several 32-year history blocks."""
     S, q10 = ensemble.ecs_q10(n)
     diff = np.linspace(0.6, 3.0, n)
     out = {}
@@ -160,13 +160,16 @@ def test_pair_kernel_with_per_member_diffusivity(hip_lib, oracle, n):
         assert c.last_run_kernel() == "pair"
     for v in ("CO2_concentration", "global_tas", "sst"):
         assert np.array_equal(c.fetchvars(v, (1745, 2300)), p[v]), v
-    for i in range(0, n, max(1, n // 12)):
+    from test_gpu_fullsize import _oracle_all
+
+    def mp(i):
         q = oracle.default_params(); q.S = S[i]; q.q10_rh[0] = q10[i]; q.diff = diff[i]
-        o, err, _ = oracle.run(q)
-        assert err == 0
-        assert (np.abs(p["CO2_concentration"][:, i] - o["CO2_concentration"]) / o["CO2_concentration"]).max() < REL_CO2
-        assert np.abs(p["global_tas"][:, i] - o["global_tas"]).max() < ABS_T
-        assert np.array_equal(p["timesteps"][1:, i].astype(np.int64), o["timesteps"][1:].astype(np.int64))
+        return q
+    oco2, otg, ots, oerr = _oracle_all(oracle, mp, n)          # every member
+    assert (oerr == 0).all()
+    assert (np.abs(p["CO2_concentration"].T - oco2) / oco2).max() < REL_CO2
+    assert np.abs(p["global_tas"].T - otg).max() < ABS_T
+    assert int((p["timesteps"].T.astype(np.int64) != ots.astype(np.int64)).any(axis=1).sum()) == 0
 
 
 def test_pair_kernel_in_segments_reset_and_handover(hip_lib):
