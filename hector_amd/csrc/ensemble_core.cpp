@@ -1446,18 +1446,22 @@ void EnsembleCore::run(double runtodate) {
     con = 2;
   }
   // small ensembles (too few wavefronts to fill the SIMDs): two wavefronts per 64 members
-  bool pair = hx_pair_available() && B_ == 1 && con == 0 && n_ <= pair_max_members_;
+  bool plain = con_mask == 0 && !d_track_;  // (the extended run kernel is also taken for diagnostics
+  for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) plain = false;  //  this one records itself)
+  bool pair = hx_pair_available() && B_ == 1 && plain && n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
     if (d_out_[v]) {  // what hx_pair_kernel records
       static const int ok[] = {HXO_SST, HXO_TLAND, HXO_CO2, HXO_TGAV, HXO_NSTASH, HXO_RF_TOT, HXO_RF_CO2,
                                HXO_ATMOS_C, HXO_OCEAN_C, HXO_OCEAN_UPTAKE, HXO_HL_PH, HXO_LL_PH, HXO_CH4,
                                HXO_O3, HXO_NBP, HXO_VEG_C, HXO_DET_C, HXO_SOIL_C, HXO_PERMAFROST_C,
-                               HXO_THAWED_C, HXO_EARTH_C, HXO_HEATFLUX};
+                               HXO_THAWED_C, HXO_EARTH_C, HXO_HEATFLUX, HXO_NPP, HXO_RH, HXO_RH_DET,
+                               HXO_RH_SOIL, HXO_RH_CH4, HXO_F_FROZEN, HXO_GMST};
       if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) pair = false;
     }
   last_run_pair_ = pair;
   if (pair)
-    check(hx_launch_run_pair(d_args_, npad_, hf, ker_per_member_, last_iy_, target, stream_), "run kernel (pair)");
+    check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,
+                             stream_), "run kernel (pair)");
   else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
                       stream_),

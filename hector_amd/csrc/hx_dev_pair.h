@@ -522,6 +522,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         if (buf.out[HXO_HL_PH]) sto_(buf, HXO_HL_PH, o, -log10(hH));
         if (buf.out[HXO_CH4]) sto_(buf, HXO_CH4, o, ch4);
         if (buf.out[HXO_O3]) sto_(buf, HXO_O3, o, o3);
+        if (buf.out[HXO_GMST]) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
       }
       if (buf.hist) {  // Core::reset(date) needs every component's state of every year
         store_ocean(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
@@ -701,6 +702,9 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       int nstash = 0;
       double nbp = 0;
       const bool want_nbp = buf.out_rare && buf.out[HXO_NBP];
+      // NPP / RH and its parts: the fluxes of the year's LAST interval (simpleNbox-runtime.cpp:420-440);
+      // every stash writes them, the last one stays (nothing carried through the step loop)
+      const bool want_flux = buf.stash_diag != 0;
       if (iy < iy_to) prefetch(iy + 1);
       PSTAMP(4);
       while (__any(c.alive && c.t < tnew)) {
@@ -762,6 +766,14 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
             const double rh_t = ((det * 0.25) * tempfertd + (soil * 0.02) * tempferts) + rh_tp_co2();
             nbp = ((npp_t - rh_t) - luc_e) + luc_u;
           }
+          if (want_flux) {
+            const size_t o = (size_t)iy * np + mem;
+            const double rhd = (det * 0.25) * tempfertd, rhs = (soil * 0.02) * tempferts;
+            if (buf.out[HXO_NPP]) sto_(buf, HXO_NPP, o, (npp0 * co2fert) * npp_luc_adjust);
+            if (buf.out[HXO_RH]) sto_(buf, HXO_RH, o, ((rhd + rhs) + rh_tp_co2()) + rh_tp_ch4());
+            if (buf.out[HXO_RH_DET]) sto_(buf, HXO_RH_DET, o, rhd);
+            if (buf.out[HXO_RH_SOIL]) sto_(buf, HXO_RH_SOIL, o, rhs);
+          }
           double tpf = l5;
           if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
           if (y[0] < 0 || y[1] < 0 || y[2] < 0 || l4 < 0 || tpf < 0) status |= HX_ERR_NEGPOOL;
@@ -811,6 +823,10 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, thawed);
         if (buf.out[HXO_EARTH_C]) sto_(buf, HXO_EARTH_C, o, earth);
         if (buf.out[HXO_LL_PH]) sto_(buf, HXO_LL_PH, o, -log10(hL));
+        // record_state: RH_ch4 of the year-end pools (simpleNbox.cpp:800-812); f_frozen is 1 without
+        // permafrost (:492-514)
+        if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rh_tp_ch4());
+        if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, pf > 0.0 ? ffrozen : 1.0);
       }
       if (buf.hist) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
       if (iy < iy_to) prepare(iy + 1);

@@ -216,7 +216,8 @@ int hx_stream(hx_core *core, void **stream);
  * land, hx_dev_pair.h): same model, same decisions, ~20 % shorter launch.  It serves
  * one-biome ensembles without constraints, per-member series or diagnostics beyond CO2,
  * tas, RF_tot, RF_CO2, SST, land tas, timesteps, the carbon pools (atmos_co2, ocean_c, veg_c,
- * detritus_c, soil_c, permafrost_c, thawedp_c, earth_c), NBP, ocean_uptake, heatflux, HL_pH, LL_pH and the
+ * detritus_c, soil_c, permafrost_c, thawedp_c, earth_c), NBP, NPP, RH and its parts, f_frozen,
+ * ocean_uptake, heatflux, gmst, HL_pH, LL_pH and the
  * CH4 / O3 concentrations (any scalar parameter may differ between members, diffusivity included);
  * everything else takes the one-wavefront kernels.
  * hx_set_pair_kernel_limit: ensembles of up to max_members use it (default 32 768 = one workgroup

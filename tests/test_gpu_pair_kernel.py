@@ -77,7 +77,7 @@ def test_pair_kernel_equals_run_kernel(hip_lib, n):
 
 POOLS = ["atmos_co2", "ocean_c", "ocean_uptake", "HL_pH", "LL_pH", "CH4_concentration",
          "O3_concentration", "NBP", "veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c",
-         "earth_c"]
+         "earth_c", "NPP", "RH", "rh_det", "rh_soil", "rh_ch4", "f_frozen", "gmst"]
 
 
 @pytest.mark.parametrize("n", [100, 2048])
@@ -97,7 +97,7 @@ def test_pair_kernel_pools_and_fluxes_equal_run_kernel(hip_lib, n):
     p, r = out["pair"], out["run"]
     assert np.array_equal(p["timesteps"], r["timesteps"])
     for v in POOLS + ["CO2_concentration", "global_tas"]:
-        if v in ("NBP", "ocean_uptake"):
+        if v in ("NBP", "ocean_uptake", "NPP", "RH", "rh_det", "rh_soil"):
             # a year's flux is the change of a 600-40 000 Pg C pool that the two kernels hold to
             # ~1e-10 relative: absolute criterion, on the pool's scale
             assert np.abs(p[v] - r[v]).max() < 2e-6, v
@@ -305,7 +305,7 @@ def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     n = 128
     S, q10 = ensemble.ecs_q10(n)
     c = mk(hip_lib, n, S, q10)
-    c.set_outputs(["CO2_concentration", "NPP"])              # an extended diagnostic: run kernel
+    c.set_outputs(["CO2_concentration", "HL_PCO2"])          # an ocean-chemistry diagnostic: run kernel
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.split_biome(["a", "b"])                                 # more than one biome
