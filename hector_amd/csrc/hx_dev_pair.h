@@ -26,8 +26,9 @@
 // they walk the reference's control flow in step and meet the same barriers.
 //
 // Same formulas, same decisions as hx_run_kernel<1,false,false,0> (parity tests compare both with
-// the oracle); instantiated for one biome, no constraints, the outputs listed at its launch site
-// (ensemble_core.cpp: CO2, tas, forcings, pools, NBP, pH ...): the configuration
+// the oracle); for one biome, no constraints, the outputs listed at its launch site
+// (ensemble_core.cpp: CO2, tas, forcings, pools, NBP / NPP / RH, pH, heat flux ...), with shared or
+// per-member diffusivity and with or without the per-year state history: the configuration
 // small perturbed-parameter ensembles use.  The host picks it up to hx_set_pair_kernel_limit members
 // (default 32 768: one workgroup per two SIMDs).
 #pragma once
@@ -515,7 +516,10 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
       if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);   // (with CO2 and tas: the R
       if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);   //  wrapper's default variables)
-      if (buf.out_rare) {  // (one test for the rest of what this side can record)
+      // (one test for the rest of what this side can record; marked unlikely, as the other optional
+      // blocks of this kernel: with the default outputs that keeps their code out of the hot path's
+      // register allocation -- 2.7 % of the launch)
+      if (__builtin_expect(!!(buf.out_rare), 0)) {
         if (buf.out[HXO_ATMOS_C]) sto_(buf, HXO_ATMOS_C, o, atmos);
         if (buf.out[HXO_OCEAN_C]) sto_(buf, HXO_OCEAN_C, o, cDO + cIO + cLL + cHL);
         if (buf.out[HXO_OCEAN_UPTAKE]) sto_(buf, HXO_OCEAN_UPTAKE, o, annualflux_sum);
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         if (buf.out[HXO_O3]) sto_(buf, HXO_O3, o, o3);
         if (buf.out[HXO_GMST]) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
       }
-      if (buf.hist) {  // Core::reset(date) needs every component's state of every year
+      if (__builtin_expect(!!(buf.hist), 0)) {  // Core::reset(date) needs every component's state of every year
         store_ocean(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
         s_yr[PY_HSTAT][lane] = (double)status;
       }
@@ -761,12 +765,12 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
           c.retry = 0;
           ++nstash;
           const double t = c.t, yf = t - c.ode_start;
-          if (want_nbp) {  // NBP of the interval that ends here, from the pools it started with
+          if (__builtin_expect(!!(want_nbp), 0)) {  // NBP of the interval that ends here, from the pools it started with
             const double npp_t = (npp0 * co2fert) * npp_luc_adjust;
             const double rh_t = ((det * 0.25) * tempfertd + (soil * 0.02) * tempferts) + rh_tp_co2();
             nbp = ((npp_t - rh_t) - luc_e) + luc_u;
           }
-          if (want_flux) {
+          if (__builtin_expect(!!(want_flux), 0)) {
             const size_t o = (size_t)iy * np + mem;
             const double rhd = (det * 0.25) * tempfertd, rhs = (soil * 0.02) * tempferts;
             if (buf.out[HXO_NPP]) sto_(buf, HXO_NPP, o, (npp0 * co2fert) * npp_luc_adjust);
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       }
       // ---- year end (land): the stash count ("timesteps"), next year's climate-independent part ----
       if (buf.out[HXO_NSTASH]) sto_(buf, HXO_NSTASH, (size_t)iy * np + mem, (double)nstash);
-      if (buf.out_rare) {  // (one test for the rest of what this side can record)
+      if (__builtin_expect(!!(buf.out_rare), 0)) {  // (one test for the rest of what this side can record)
         const size_t o = (size_t)iy * np + mem;
         if (buf.out[HXO_NBP]) sto_(buf, HXO_NBP, o, nbp);
         if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, veg);
@@ -828,14 +832,14 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
         if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rh_tp_ch4());
         if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, pf > 0.0 ? ffrozen : 1.0);
       }
-      if (buf.hist) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
+      if (__builtin_expect(!!(buf.hist), 0)) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
       if (iy < iy_to) prepare(iy + 1);
       PSTAMP(10);
       __syncthreads();  // ---- barrier C
       PSTAMP(11);
       tland = s_yr[PY_TLAND][lane];
       lnc = s_yr[PY_LNC][lane];
-      if (buf.hist)
+      if (__builtin_expect(!!(buf.hist), 0))
         HX_GU(buf.hist_status)[(size_t)iy * np + mem] = status | (unsigned)s_yr[PY_HSTAT][lane];
     }
     store_land(nullptr);
