@@ -129,7 +129,7 @@ __device__ __forceinline__ double pair_err(double n0, double d0, double nl, doub
 __device__ __forceinline__ bool pair_control(PairCtl &c, double err, unsigned &status) {
 #pragma clang fp contract(off)
   constexpr double EPS = 2.220446049250313e-16;
-  if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
+  if (__builtin_expect(err > 1.0, 0)) {  // reject (rare): default_step_adjuster::decrease_step
     c.dtl *= fmax(0.9 * pow_m13(err), 0.2);
     if (++c.fails > 500) { status |= HX_ERR_STEPFAIL; c.alive = false; c.stepping = false; }
     return false;

@@ -551,7 +551,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
             if (n * ed > en * d) { en = n; ed = d; }
           }
           double err = hx_div(en, ed);
-          if (err > 1.0) {  // reject: default_step_adjuster::decrease_step
+          if (__builtin_expect(err > 1.0, 0)) {  // reject (rare): default_step_adjuster::decrease_step
             dtl *= fmax(0.9 * pow_m13(err), 0.2);
             if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
           } else {          // accept
