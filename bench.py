@@ -4,6 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+--gpus N > 1 always drives N GPUs: under torch.distributed.run (WORLD_SIZE set) this process is
+one of N ranks; started as plain `python bench.py --gpus N` it launches those N ranks itself
+(one process per GPU, rendezvous on 127.0.0.1) and fails if the box has fewer than N devices;
+`--single-process` instead shards ONE core over N devices through the C ABI's device list
+(hx_newcore_devices).  In every mode the per-year statistics of all members are combined by ONE
+RCCL all-gather issued by libhector_amd.so itself (hx_ensemble_stats) on the core's stream.
+
 One "step" = one pass of the hot path over this rank's batch of synthetic
 members: reset to the post-spinup state (a device-to-device copy), integrate
 1745 -> 2300 (555 model years per member) with the HIP kernels, reduce the
@@ -136,12 +143,12 @@ def cpu_baseline(target_seconds=15.0, chunk=32):
     return n * YEARS / dt, dt, n, cores
 
 
-def make_core(n, biomes, offset, device):
+def make_core(n, biomes, offset, device, devices=None):
     """The synthetic perturbed-parameter ensemble of SURVEY.md 8(d) for members
     [offset, offset + n): ECS/Q10 (1 biome) or ECS + per-biome Q10 / warming factor (4)."""
     import hector_amd
     from hector_amd import ensemble
-    core = hector_amd.Core(n_members=n, device=device)
+    core = hector_amd.Core(n_members=n, device=device, devices=devices)
     if biomes == 1:
         S, q10 = ensemble.ecs_q10(n, offset=offset)
         core.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
@@ -231,6 +238,52 @@ def time_config(n, biomes, steps, warmup, device):
             "pmc_profile_stale": rf.get("pmc_profile_stale")}
 
 
+STAT_VARS = ["CO2_concentration", "global_tas"]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per
+    GPU over RCCL, like the driver's torch.distributed.run line) and hand their JSON line on."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.dist_backend == "nccl" and have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d asked for but this box has %d HIP device(s); RCCL needs "
+                         "one GPU per rank (a rehearsal of the multi-process flow on fewer GPUs: "
+                         "--dist-backend gloo)" % (args.gpus, have))
+    if have < 1:
+        raise SystemExit("bench.py needs an MI355X: the integrator has no CPU path")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+           str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def setup_native_collective(core, dist, world, rank):
+    """One RCCL communicator inside libhector_amd.so over all ranks (hx_comm_init_rank): rank 0's
+    unique id travels through torch.distributed's store.  -> (ok, message); every rank agrees."""
+    import torch
+    import hector_amd
+    from hector_amd import core as core_mod
+    ids = [core_mod.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ok, msg = 1, ""
+    try:
+        core.comm_init_rank(world, rank, ids[0])
+    except hector_amd.HectorAmdError as e:
+        ok, msg = 0, str(e)
+    flag = torch.tensor([ok], dtype=torch.int32,
+                        device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item()), msg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,7 +298,22 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                          "multi-process flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process, one core over --gpus devices (hx_newcore_devices) instead "
+                         "of one process per GPU")
+    ap.add_argument("--collective", default="native", choices=["native", "torch"],
+                    help="who issues the statistics collective: libhector_amd.so's own RCCL "
+                         "communicator (ncclAllGather on the core's stream) or torch.distributed")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: still create the communicator and run the collective "
+                         "(world size 1) -- the RCCL path on a one-GPU box")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1 and not args.single_process:
+        self_launch(args)   # does not return
 
     import numpy as np
     import torch
@@ -255,41 +323,69 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if launched and world != args.gpus:
+        raise SystemExit("--gpus (%d) must equal WORLD_SIZE (%d)" % (args.gpus, world))
+    if args.single_process and world > 1:
+        raise SystemExit("--single-process is for one process; do not combine it with a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the integrator has no CPU path")
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and (args.gpus if args.single_process else local_rank + 1) > ndev:
+        raise SystemExit("bench.py: %d GPUs needed, %d visible" % (args.gpus, ndev))
     if args.dist_backend != "nccl":  # rehearsal: ranks may share a GPU
-        local_rank %= torch.cuda.device_count()
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or (args.force_collective and not args.single_process)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     n = args.members
+    shards = args.gpus if args.single_process else 1   # GPUs this process drives
+    n_gpus = world * shards
     offset = rank * n  # weak scaling: contiguous member blocks, SURVEY.md 8(e)
-    core = make_core(n, args.biomes, offset, local_rank)
+    if args.single_process:
+        devices = list(range(args.gpus)) if args.dist_backend == "nccl" else [0] * args.gpus
+        core = make_core(n * shards, args.biomes, 0, 0, devices=devices)
+    else:
+        core = make_core(n, args.biomes, offset, local_rank)
     start, end = core.strtdate, core.enddate
     nyr = end - start + 1
     stats = torch.zeros((2, nyr, 5), dtype=torch.float64, device=dev)
 
-    # the core queues its kernels on its own HIP stream; the collective runs on torch's
-    core_stream = torch.cuda.ExternalStream(core.stream(), device=dev) if world > 1 else None
+    # Who combines the statistics across GPUs.  native: the library's own communicator,
+    # ncclAllGather on the core's stream.  torch: one all-reduce by torch.distributed on torch's
+    # stream, ordered against the core's stream through an ExternalStream.
+    collective = None
+    if use_dist:
+        collective = args.collective if args.dist_backend == "nccl" else "torch"
+        if collective == "native":
+            ok, msg = setup_native_collective(core, dist, world, rank)
+            if not ok:
+                sys.stderr.write("bench.py: rank %d: the library's RCCL communicator could not be "
+                                 "created (%s); falling back to torch.distributed's\n" % (rank, msg))
+                collective = "torch"
+    elif shards > 1:
+        collective = "native"
+    core_stream = torch.cuda.ExternalStream(core.stream(), device=dev) if collective == "torch" else None
 
     def step():
         core.reset(start)
         core.run(end, wait=False)
-        core.stats_device("CO2_concentration", start, end, stats[0].data_ptr())
-        core.stats_device("global_tas", start, end, stats[1].data_ptr())
-        if world > 1:
+        if collective == "torch":
+            core.stats_device("CO2_concentration", start, end, stats[0].data_ptr())
+            core.stats_device("global_tas", start, end, stats[1].data_ptr())
             cur = torch.cuda.current_stream()
             cur.wait_stream(core_stream)      # statistics written before they are reduced
-            allreduce_stats(stats, dist)
+            allreduce_stats(stats, dist, force=True)
             core_stream.wait_stream(cur)      # ... and reduced before the next step overwrites them
+        else:   # local reductions (+ the one all-gather when there are several ranks)
+            core.ensemble_stats(STAT_VARS, (start, end), d_out=stats.data_ptr(), host=False)
         return core.last_run_ms()
 
     core.status()  # upload + spinup + alkalinity tuning, outside every timed region
@@ -298,38 +394,49 @@ def main():
     spin_ms = core.last_spinup_ms()
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kern_ms = []
     for _ in range(args.steps):
         kern_ms.append(step())
+    core.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kernel_ms = float(km.item())   # slowest rank's mean kernel time
+    kernel_ms = float(km.item())   # slowest rank's (and slowest shard's) mean kernel time
     bad = int((core.status() != 0).sum())
     stats_host = stats.cpu().numpy()
     which_kernel = core.last_run_kernel()
+    comm_world, _, comm_backend = core.comm_info()
     core.shutdown()
 
     if rank == 0:
-        total_members = n * world
+        total_members = n * n_gpus
         value = total_members * YEARS * args.steps / elapsed
         mean, std, mn, mx = finalize(stats_host)
+        if collective == "native":
+            backend = "RCCL ncclAllGather issued by libhector_amd.so (%s)" % comm_backend
+            cworld = comm_world
+        elif collective == "torch":
+            backend = ("RCCL all-reduce through torch.distributed (nccl)" if args.dist_backend == "nccl"
+                       else "torch.distributed %s (rehearsal, not RCCL)" % args.dist_backend)
+            cworld = world
+        else:
+            backend, cworld = None, 1
         out = {
             "metric": "ensemble-member simulated years/sec",
             "value": value,
             "unit": "member-years/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -346,10 +453,11 @@ def main():
                              2 if args.biomes == 1 else 4),
                 "members_per_gpu": n, "global_members": total_members, "years_per_member": YEARS,
                 "biomes": args.biomes,
-                "parallelism": "member-sharded x%d, one packed stats all-reduce" % world,
-                "collective_backend": ("%s (RCCL)" % args.dist_backend if args.dist_backend == "nccl"
-                                       else args.dist_backend) if world > 1 else None,
-                "collective_world_size": world,
+                "parallelism": "member-sharded x%d (%s), one statistics collective per step" %
+                               (n_gpus, "one process, device list" if args.single_process
+                                else "one process per GPU"),
+                "collective_backend": backend,
+                "collective_world_size": cworld,
                 "spinup_ms_excluded": spin_ms, "members_with_model_errors": bad,
                 "members_in_statistics": int(stats_host[0, -1, 0]),
                 "co2_2300_mean_ppm": float(mean[0, -1]), "tgav_2300_mean_K": float(mean[1, -1]),
@@ -357,14 +465,14 @@ def main():
             # per-rank maximum of the mean kernel time when N > 1
             "roofline": roofline_object(n, args.biomes, kernel_ms, which_kernel),
         }
-        if world == 1 and not args.no_other_configs:
+        if n_gpus == 1 and not args.no_other_configs:
             others = []
             for (m2, b2) in ((1024, 1), (32768, 1), (131072, 1), (65536, 4)):
                 if (m2, b2) == (n, args.biomes):
                     continue
                 others.append(time_config(m2, b2, 5, 1, local_rank))
             out["other_configs"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline:
             v, dt, ns, cores = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": v, "unit": "member-years/s", "cores": cores, "kind": "port",
@@ -379,7 +487,8 @@ def main():
                               "2), i.e. the oracle is ~100-200x the reference per core",
             }
         print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -72,6 +72,14 @@ def _declare(lib):
     lib.hx_last_error.restype = c.c_char_p
     sig = {
         "hx_newcore": [c.c_char_p, c.c_int, c.c_int, c.POINTER(P)],
+        "hx_newcore_devices": [c.c_char_p, c.c_int, c.POINTER(c.c_int), c.c_int, c.POINTER(P)],
+        "hx_shards": [P, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)],
+        "hx_device_var_shard": [P, c.c_int, c.c_char_p, c.POINTER(P), c.POINTER(c.c_int)],
+        "hx_stream_shard": [P, c.c_int, c.POINTER(P)],
+        "hx_comm_unique_id": [c.c_char_p],
+        "hx_comm_init_rank": [P, c.c_int, c.c_int, c.c_char_p],
+        "hx_comm_info": [P, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_char_p)],
+        "hx_ensemble_stats": [P, c.c_int, c.POINTER(c.c_char_p), c.c_int, c.c_int, dp, P],
         "hx_shutdown": [P],
         "hx_setvar": [P, c.c_char_p, dp, c.c_int, c.c_char_p],
         "hx_getvar": [P, c.c_char_p, dp],
@@ -124,4 +132,6 @@ ABI_SYMBOLS = ["hx_backend", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_s
                "hx_set_member_sorting", "hx_lane_of_member", "hx_enable_history", "hx_setvar_dated", "hx_halocarbons", "hx_run_name", "hx_tracking_pools", "hx_tracking_data", "hx_var_info", "hx_biomes", "hx_setvar_dated_members", "hx_unit_csys", "hx_unit_doeclim_kernel", "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
                "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_state_row", "hx_dates", "hx_sizes",
                "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream", "hx_set_pair_kernel_limit",
-               "hx_last_run_kernel", "hx_component_output"]
+               "hx_last_run_kernel", "hx_component_output", "hx_newcore_devices", "hx_shards",
+               "hx_device_var_shard", "hx_stream_shard", "hx_comm_unique_id", "hx_comm_init_rank",
+               "hx_comm_info", "hx_ensemble_stats"]

@@ -15,14 +15,21 @@ from ._lib import HectorAmdError, DEFAULT_SCENARIO
 
 
 class Core:
-    """An N-member ensemble core bound to one GPU."""
+    """An N-member ensemble core bound to one GPU (device=) or sharded over a list of GPUs
+    (devices=[...]: contiguous member blocks, hx_newcore_devices)."""
 
     def __init__(self, scenario=None, n_members=1, device=0, lib_path=None,
-                 allow_emulation=False, name=None):
+                 allow_emulation=False, name=None, devices=None):
         self._lib = _lib.load(lib_path, allow_emulation)
         self._h = ctypes.c_void_p()
-        self._ck(self._lib.hx_newcore((scenario or DEFAULT_SCENARIO).encode(), int(n_members),
-                                      int(device), ctypes.byref(self._h)))
+        if devices is None:
+            self._ck(self._lib.hx_newcore((scenario or DEFAULT_SCENARIO).encode(), int(n_members),
+                                          int(device), ctypes.byref(self._h)))
+        else:
+            devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            self._ck(self._lib.hx_newcore_devices((scenario or DEFAULT_SCENARIO).encode(),
+                                                  int(n_members), devs, len(devices),
+                                                  ctypes.byref(self._h)))
         self.n_members = int(n_members)
         if name is None:   # newcore(..., name =): default here the INI's run_name
             rn = ctypes.c_char_p()
@@ -226,6 +233,53 @@ class Core:
         self._ck(self._lib.hx_device_var(self._h, var.encode(), ctypes.byref(p), ctypes.byref(npad)))
         return p.value, npad.value
 
+    def shards(self):
+        """-> (devices[n_shards], offsets[n_shards + 1]): shard s holds members
+        offsets[s] .. offsets[s + 1] - 1 on GPU devices[s]."""
+        n = ctypes.c_int()
+        self._ck(self._lib.hx_shards(self._h, ctypes.byref(n), None, None))
+        dev = (ctypes.c_int * n.value)()
+        off = (ctypes.c_int * (n.value + 1))()
+        self._ck(self._lib.hx_shards(self._h, None, dev, off))
+        return list(dev), list(off)
+
+    def device_var_shard(self, shard, var):
+        p, npad = ctypes.c_void_p(), ctypes.c_int()
+        self._ck(self._lib.hx_device_var_shard(self._h, int(shard), var.encode(), ctypes.byref(p),
+                                               ctypes.byref(npad)))
+        return p.value, npad.value
+
+    def comm_init_rank(self, n_procs, proc_rank, unique_id):
+        """Join an RCCL communicator of n_procs x n_shards ranks (hx_comm_init_rank);
+        unique_id: the 128 bytes of comm_unique_id() of ONE process."""
+        if len(unique_id) != 128:
+            raise HectorAmdError("comm_init_rank: the unique id is 128 bytes")
+        self._ck(self._lib.hx_comm_init_rank(self._h, int(n_procs), int(proc_rank), bytes(unique_id)))
+        return self
+
+    def comm_info(self):
+        """-> (world, first_rank, backend); world 0 = no communicator."""
+        w, r, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_char_p()
+        self._ck(self._lib.hx_comm_info(self._h, ctypes.byref(w), ctypes.byref(r), ctypes.byref(b)))
+        return w.value, r.value, (b.value or b"").decode()
+
+    def ensemble_stats(self, variables, dates=None, d_out=None, host=True):
+        """Per-year {count, sum, sumsq, min, max} of `variables` over every member on every GPU
+        and every process of the communicator (hx_ensemble_stats: local reductions + ONE RCCL
+        all-gather): -> ndarray [n_vars, n_years, 5] (host=True) and / or into the device buffer
+        d_out (an integer address on the first shard's GPU)."""
+        if isinstance(variables, str):
+            variables = [variables]
+        y0, y1 = (self.strtdate, self.current_date) if dates is None else \
+            (int(min(dates)), int(max(dates)))
+        arr = (ctypes.c_char_p * len(variables))(*[v.encode() for v in variables])
+        out = np.empty((len(variables), y1 - y0 + 1, 5)) if host else None
+        self._ck(self._lib.hx_ensemble_stats(
+            self._h, len(variables), arr, y0, y1,
+            out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if host else None,
+            ctypes.c_void_p(d_out) if d_out else None))
+        return out
+
     def stats_device(self, var, year0, year1, d_ptr):
         self._ck(self._lib.hx_stats_device(self._h, var.encode(), int(year0), int(year1),
                                            ctypes.c_void_p(d_ptr)))
@@ -279,6 +333,16 @@ class Core:
             self.shutdown()
         except Exception:
             pass
+
+
+def comm_unique_id(lib_path=None, allow_emulation=False):
+    """128 bytes that identify a new RCCL communicator (hx_comm_unique_id): made by ONE process,
+    handed to the others by the host's own means (MPI, a torch.distributed store, a file)."""
+    lib = _lib.load(lib_path, allow_emulation)
+    buf = ctypes.create_string_buffer(128)
+    if lib.hx_comm_unique_id(buf) != 0:
+        raise HectorAmdError(lib.hx_last_error().decode())
+    return buf.raw
 
 
 # R-style free functions

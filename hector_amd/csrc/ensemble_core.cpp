@@ -1913,6 +1913,12 @@ const double *EnsembleCore::device_var(const std::string &capability, int *npad)
 
 void EnsembleCore::stats_device(const std::string &capability, int year0, int year1,
                                 double *d_stats) {
+  stats_async(capability, year0, year1, d_stats);
+  check(hipStreamSynchronize(stream_), "stats sync");
+}
+
+void EnsembleCore::stats_async(const std::string &capability, int year0, int year1,
+                               double *d_stats) {
   const int v = out_index(capability);
   if (!d_out_[v])
     throw std::runtime_error("variable " + capability + " was not enabled with set_outputs()");
@@ -1920,7 +1926,6 @@ void EnsembleCore::stats_device(const std::string &capability, int year0, int ye
     throw std::runtime_error("stats: dates must lie between startDate and the current date");
   check(hx_launch_stats(d_out_[v], n_, npad_, year0 - scen_.start, year1 - year0 + 1, d_stats,
                         stream_), "stats kernel");
-  check(hipStreamSynchronize(stream_), "stats sync");
 }
 
 void EnsembleCore::status(unsigned *out_host) {

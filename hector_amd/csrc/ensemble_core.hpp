@@ -105,6 +105,9 @@ class EnsembleCore {
   // per-year ensemble statistics {count,sum,sumsq,min,max} into a DEVICE buffer
   // of (year1-year0+1)*5 doubles (caller-owned, e.g. a torch tensor for RCCL)
   void stats_device(const std::string &capability, int year0, int year1, double *d_stats);
+  // the same, queued on the core's stream without waiting (the fleet's collective follows it)
+  void stats_async(const std::string &capability, int year0, int year1, double *d_stats);
+  int device() const { return device_; }
   void status(unsigned *out_host);
   void state_row(int row, double *out_host);
   int spinup_steps(int member);

@@ -7,6 +7,7 @@
 
 #include "../../include/hector_amd.h"
 #include "ensemble_core.hpp"
+#include "hx_fleet.hpp"
 
 hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, const double *alk,
                                double inv_vol, double *out, hipStream_t st);
@@ -19,7 +20,7 @@ int hx_doeclim_kernel_pad();
 #endif
 
 struct hx_core {
-  hx::EnsembleCore *core;
+  hx::Fleet *core;  // one shard per GPU of the device list (one for hx_newcore)
 };
 
 namespace {
@@ -41,11 +42,62 @@ const char *hx_last_error(void) { return g_err.c_str(); }
 int hx_newcore(const char *scenario, int n_members, int device, hx_core **out) {
   if (!scenario || !out) return fail("hx_newcore: null argument");
   try {
-    hx::EnsembleCore *c = new hx::EnsembleCore(scenario, n_members, device);
+    hx::Fleet *c = new hx::Fleet(scenario, n_members, &device, 1);
     *out = new hx_core{c};
     return 0;
   } catch (const std::exception &e) { return fail(e); }
   catch (...) { return fail("unknown error"); }
+}
+
+int hx_newcore_devices(const char *scenario, int n_members, const int *devices, int n_devices,
+                       hx_core **out) {
+  if (!scenario || !out || !devices) return fail("hx_newcore_devices: null argument");
+  try {
+    hx::Fleet *c = new hx::Fleet(scenario, n_members, devices, n_devices);
+    *out = new hx_core{c};
+    return 0;
+  } catch (const std::exception &e) { return fail(e); }
+  catch (...) { return fail("unknown error"); }
+}
+int hx_shards(hx_core *core, int *n_shards, int *devices, int *offsets) {
+  HX_TRY({
+    const int k = core->core->n_shards();
+    if (n_shards) *n_shards = k;
+    for (int s = 0; s < k; ++s) {
+      if (devices) devices[s] = core->core->shard_device(s);
+      if (offsets) offsets[s] = core->core->shard_offset(s);
+    }
+    if (offsets) offsets[k] = core->core->shard_offset(k);
+  })
+}
+int hx_device_var_shard(hx_core *core, int shard, const char *capability, const double **d_ptr,
+                        int *npad) {
+  if (!capability || !d_ptr) return fail("hx_device_var_shard: null argument");
+  HX_TRY(*d_ptr = core->core->device_var(capability, npad, shard))
+}
+int hx_stream_shard(hx_core *core, int shard, void **stream) {
+  if (!stream) return fail("null argument");
+  HX_TRY(if (shard < 0 || shard >= core->core->n_shards()) throw std::runtime_error("bad shard index");
+         *stream = (void *)core->core->stream(shard))
+}
+int hx_comm_unique_id(char *id128) {
+  if (!id128) return fail("hx_comm_unique_id: null argument");
+  try { hx::Fleet::unique_id(id128); return 0; } catch (const std::exception &e) { return fail(e); }
+}
+int hx_comm_init_rank(hx_core *core, int n_procs, int proc_rank, const char *id128) {
+  HX_TRY(core->core->comm_init_rank(n_procs, proc_rank, id128))
+}
+int hx_comm_info(hx_core *core, int *world, int *first_rank, const char **backend) {
+  HX_TRY(if (world) *world = core->core->comm_world();
+         if (first_rank) *first_rank = core->core->comm_first_rank();
+         if (backend) *backend = core->core->comm_backend())
+}
+int hx_ensemble_stats(hx_core *core, int nvars, const char *const *capabilities, int year0,
+                      int year1, double *out_host, double *d_out) {
+  if (nvars < 1 || !capabilities) return fail("hx_ensemble_stats: bad arguments");
+  std::vector<std::string> caps;
+  for (int i = 0; i < nvars; ++i) caps.push_back(capabilities[i] ? capabilities[i] : "");
+  HX_TRY(core->core->ensemble_stats(caps, year0, year1, out_host, d_out))
 }
 
 int hx_shutdown(hx_core *core) {
@@ -243,7 +295,7 @@ int hx_sizes(hx_core *core, int *n_members, int *n_biomes) {
          if (n_biomes) *n_biomes = core->core->n_biomes())
 }
 int hx_last_run_ms(hx_core *core, double *ms) {
-  HX_TRY(core->core->sync(); *ms = core->core->last_run_kernel_ms())
+  HX_TRY(*ms = core->core->last_run_kernel_ms())
 }
 int hx_last_spinup_ms(hx_core *core, double *ms) { HX_TRY(*ms = core->core->last_spinup_ms()) }
 int hx_stream(hx_core *core, void **stream) { HX_TRY(*stream = (void *)core->core->stream()) }

@@ -1196,6 +1196,25 @@ __global__ __launch_bounds__(256) void hx_stats_kernel(const double *var, int n,
 }
 
 // ===========================================================================
+// The last step of the multi-GPU statistics (hx_fleet.cpp): slots[rank][row][5] holds every
+// rank's {count, sum, sum of squares, min, max} of a (variable, year) row, gathered by ONE
+// ncclAllGather; every rank folds them in rank order, so the result is bit-identical everywhere.
+// ===========================================================================
+__global__ __launch_bounds__(256) void hx_combine_stats_kernel(const double *slots, int world,
+                                                               int rows, double *out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const double *p = slots + (size_t)r * 5;
+  double cnt = p[0], s = p[1], s2 = p[2], mn = p[3], mx = p[4];
+  for (int k = 1; k < world; ++k) {
+    p += (size_t)rows * 5;
+    cnt += p[0]; s += p[1]; s2 += p[2]; mn = fmin(mn, p[3]); mx = fmax(mx, p[4]);
+  }
+  double *o = out + (size_t)r * 5;
+  o[0] = cnt; o[1] = s; o[2] = s2; o[3] = mn; o[4] = mx;
+}
+
+// ===========================================================================
 // DOECLIM convolution kernel table Ker[i] (temperature_component.cpp:303-371)
 // for `count` diffusivities: ker[i * stride + mem].  count = 1, stride = 1 when
 // every member shares the diffusivity.
@@ -1552,6 +1571,12 @@ hipError_t hx_launch_gather(const double *src, const int *lane_of_member, double
                             int npad, int nyears, hipStream_t st) {
   hipLaunchKernelGGL(hx_gather_kernel, dim3((n + 255) / 256, nyears), dim3(256), 0, st, src,
                      lane_of_member, dst, n, npad, nyears);
+  return hipGetLastError();
+}
+hipError_t hx_launch_combine_stats(const double *slots, int world, int rows, double *out,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(hx_combine_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, slots,
+                     world, rows, out);
   return hipGetLastError();
 }
 hipError_t hx_launch_stats(const double *var, int n, int npad, int iy0, int nyears,

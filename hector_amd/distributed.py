@@ -13,15 +13,15 @@ def shard_range(n_total, rank, world):
     return offset, count
 
 
-def allreduce_stats(stats, dist=None):
+def allreduce_stats(stats, dist=None, force=False):
     """stats: torch tensor [..., 5] = count,sum,sumsq,min,max per year.
     In-place reduction across ranks (SUM for the first three, MIN, MAX) with ONE
     collective: every rank writes its block into its own slot of a zero-filled
     [world, ...] buffer and a single SUM all-reduce hands every rank all the blocks
     (x + 0 is exact); the five statistics are then combined locally in rank order, so the
     result is bit-identical on every rank.  world x 44 KB per variable, latency-bound."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return stats
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return stats  # (force: run the collective even in a world of one)
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     buf = torch.zeros((world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)

@@ -19,8 +19,9 @@
  * (the reference throws h_exception; nothing is thrown across this ABI).
  * Per-member MODEL errors (mass balance, >8 solver retries, negative pool...)
  * do not fail a call: they set bits in the member's status word (hx_status).
- * A core is bound to one GPU; there is no CPU execution path -- hx_newcore
- * fails if no HIP device is present.  Not thread-safe per handle (like Core).
+ * A core is bound to one GPU (hx_newcore) or to a list of GPUs (hx_newcore_devices: contiguous
+ * member blocks, one per GPU, no exchange during integration); there is no CPU execution
+ * path -- hx_newcore fails if no HIP device is present.  Not thread-safe per handle (like Core).
  */
 #ifndef HECTOR_AMD_H
 #define HECTOR_AMD_H
@@ -42,6 +43,44 @@ const char *hx_last_error(void);
  * all members at the INI's parameter values; one biome "global", or the biomes the INI
  * defines with "<biome>.<variable>" keys (at most 16). */
 int hx_newcore(const char *scenario, int n_members, int device, hx_core **out);
+
+/* The same ensemble over SEVERAL GPUs of the node.  The reference keeps many
+ * independent cores in one process through its registry (Core::mkcore / getcore / delcore,
+ * inst/include/core.hpp:105-109, src/core.cpp:813-857) and the host loops over them; here the
+ * handle is that registry: shard s is an n_members / n_devices block of consecutive members on
+ * devices[s] (the remainder goes to the first shards), every call of this header is routed to the
+ * shards -- per-member arguments sliced, results returned in member order -- and hx_run queues
+ * the kernels of every GPU before it returns.  Nothing is exchanged while the model runs; the one
+ * collective is hx_ensemble_stats.  Each device may appear once (RCCL needs one rank per GPU;
+ * HECTOR_AMD_FLEET_REHEARSAL=1 admits duplicates on a smaller box and exchanges the statistics
+ * with device copies instead). */
+int hx_newcore_devices(const char *scenario, int n_members, const int *devices, int n_devices,
+                       hx_core **out);
+/* devices[n_shards], offsets[n_shards + 1] (offsets[s] = first member of shard s); NULL = skip */
+int hx_shards(hx_core *core, int *n_shards, int *devices, int *offsets);
+
+/* Per-year ensemble statistics {count, sum, sum of squares, min, max} of nvars recorded outputs
+ * over EVERY member on every GPU (and every process that joined the communicator):
+ * [nvars][year1 - year0 + 1][5] doubles into host memory out_host and / or device memory d_out
+ * (on the first shard's GPU); either may be NULL.  Every GPU reduces its own members
+ * (wavefront shuffles), ONE ncclAllGather over RCCL / xGMI hands every rank all blocks (44 KB per
+ * rank and variable), and every rank folds them in rank order -- the result is bit-identical on
+ * all ranks.  The north star's "RCCL gather of Tgav / CO2 stats"; the reference has no
+ * counterpart (its hosts aggregate fetchvars() data frames in R).  A one-GPU core that joined
+ * no communicator does no collective.  Returns when the result is in place. */
+int hx_ensemble_stats(hx_core *core, int nvars, const char *const *capabilities, int year0,
+                      int year1, double *out_host, double *d_out);
+/* One process per GPU (MPI / torchrun style hosts): ONE process calls hx_comm_unique_id and
+ * hands the 128 bytes to the others by its own means; every process then joins with its
+ * process rank.  The communicator has n_procs * n_shards ranks, this core's shards are ranks
+ * proc_rank * n_shards + s, and hx_ensemble_stats reduces over all of them.  A core made by
+ * hx_newcore_devices that never calls this gets a communicator of its own shards at the first
+ * hx_ensemble_stats.  RCCL is loaded when first needed (librccl.so.1 -- the copy already in the
+ * process if there is one; HECTOR_AMD_RCCL overrides the path). */
+int hx_comm_unique_id(char *id128);
+int hx_comm_init_rank(hx_core *core, int n_procs, int proc_rank, const char *id128);
+/* world: ranks of the communicator (0 = none yet); backend: "rccl <version> via <library>" */
+int hx_comm_info(hx_core *core, int *world, int *first_rank, const char **backend);
 
 /* shutdown(core)  src/rcpp_hector.cpp:88-101 (Core::shutDown + delcore) */
 int hx_shutdown(hx_core *core);
@@ -150,11 +189,16 @@ int hx_fetchvars(hx_core *core, const char *capability, int year0, int year1, do
  * [n_years_total][npad] array (row = year - startDate, npad >= n_members), columns in
  * LANE order (see hx_lane_of_member). */
 int hx_device_var(hx_core *core, const char *capability, const double **d_ptr, int *npad);
+/* ... of one shard of a multi-GPU core (memory of that shard's GPU, npad of that shard) */
+int hx_device_var_shard(hx_core *core, int shard, const char *capability, const double **d_ptr,
+                        int *npad);
 /* Per-year ensemble statistics {count, sum, sum of squares, min, max} of one
  * variable into a caller-owned DEVICE buffer of (year1-year0+1)*5 doubles --
  * the sufficient statistics that a multi-GPU job all-reduces over RCCL.  The kernel runs on the
  * core's stream (hx_stream) and has finished when the call returns; work the caller queued on
- * d_stats on another stream (e.g. a fill) must have completed before the call. */
+ * d_stats on another stream (e.g. a fill) must have completed before the call.  On a core that
+ * spans several GPUs or joined a communicator this is hx_ensemble_stats for one variable (d_stats
+ * on the first shard's GPU). */
 int hx_stats_device(hx_core *core, const char *capability, int year0, int year1,
                     double *d_stats);
 
@@ -210,6 +254,7 @@ int hx_last_run_ms(hx_core *core, double *ms);
 int hx_last_spinup_ms(hx_core *core, double *ms);
 /* the core's hipStream_t, as void* */
 int hx_stream(hx_core *core, void **stream);
+int hx_stream_shard(hx_core *core, int shard, void **stream);
 
 /* Small ensembles -- too few 64-member wavefronts to occupy the GPU's 1 024 SIMDs, BASELINE
  * configs[1] -- are run by a kernel that gives every 64 members TWO wavefronts (ocean / climate and

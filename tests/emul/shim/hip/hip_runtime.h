@@ -7,6 +7,7 @@
 // The library built with this shim reports hx_backend() == "host-emulation" and
 // the product loader (hector_amd/_lib.py) refuses to use it outside tests.
 #pragma once
+#define HX_HOST_EMULATION 1
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,0 +1,184 @@
+"""Multi-GPU behind the C ABI, on the one GPU the test box has:
+
+* RCCL itself, executed: a world-size-1 communicator inside libhector_amd.so (hx_comm_init_rank ->
+  ncclCommInitRank, hx_ensemble_stats -> ncclAllGather on the core's stream), with and without
+  PyTorch in the process, and torch.distributed's own nccl group at world size 1 through bench.py;
+* the sharded core (hx_newcore_devices) with the device list [0, 0] -- the rehearsal switch, since
+  RCCL refuses two ranks on one GPU: every routed verb against ONE core over the same members;
+* bench.py --gpus N: refuses a box with fewer GPUs, launches its own ranks when started as plain
+  python, reports n_gpus == N and the collective's world size.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hector_amd
+from hector_amd import ensemble
+from hector_amd.core import comm_unique_id
+from hector_amd.distributed import stats_numpy
+from conftest import ROOT, SCENARIO
+
+pytestmark = pytest.mark.gpu
+
+VARS = ["CO2_concentration", "global_tas"]
+
+
+def _check_stats(st, core, y0, y1):
+    for k, v in enumerate(VARS):
+        ref = stats_numpy(core.fetchvars(v, (y0, y1)))
+        np.testing.assert_array_equal(st[k][:, 0], ref[:, 0])          # count
+        np.testing.assert_allclose(st[k][:, 1:3], ref[:, 1:3], rtol=1e-12)
+        np.testing.assert_array_equal(st[k][:, 3:], ref[:, 3:])        # min, max
+
+
+def test_rccl_world_of_one_inside_the_library(hip_lib):
+    """ncclCommInitRank + ncclAllGather really execute on the device (world size 1)."""
+    n = 1000
+    S, q10 = ensemble.ecs_q10(n)
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    c.setvar("S", S).setvar("q10_rh", q10)
+    assert c.comm_info()[0] == 0
+    c.comm_init_rank(1, 0, comm_unique_id(hip_lib))
+    world, first, backend = c.comm_info()
+    assert (world, first) == (1, 0) and backend.startswith("rccl "), backend
+    c.run(1900)
+    st = c.ensemble_stats(VARS, (1745, 1900))
+    _check_stats(st, c, 1745, 1900)
+    # hx_stats_device of a core with a communicator takes the same path
+    import torch
+    d = torch.zeros((156, 5), dtype=torch.float64, device="cuda:0")
+    c.stats_device("global_tas", 1745, 1900, d.data_ptr())
+    np.testing.assert_array_equal(d.cpu().numpy(), st[1])
+    with pytest.raises(hector_amd.HectorAmdError, match="already has a communicator"):
+        c.comm_init_rank(1, 0, comm_unique_id(hip_lib))
+    c.shutdown()
+
+
+RCCL_WITHOUT_TORCH = """
+import sys, numpy as np, hector_amd
+from hector_amd.core import comm_unique_id
+assert "torch" not in sys.modules
+c = hector_amd.Core(hector_amd.DEFAULT_SCENARIO, 256, device=0)
+c.comm_init_rank(1, 0, comm_unique_id())
+c.run(1800)
+st = c.ensemble_stats(["global_tas"], (1745, 1800))
+x = c.fetchvars("global_tas", (1745, 1800))
+assert (st[0][:, 0] == 256).all() and (st[0][:, 3] == x.min(1)).all() and (st[0][:, 4] == x.max(1)).all()
+assert "torch" not in sys.modules
+rc = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+assert len(rc) == 1, rc
+print("ok", c.comm_info()[2], rc[0])
+"""
+
+
+def test_rccl_without_pytorch_in_the_process():
+    """An R / C++ host: no torch anywhere; the library loads the system's librccl.so.1 itself."""
+    r = subprocess.run([sys.executable, "-c", RCCL_WITHOUT_TORCH], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().startswith("ok rccl ")
+
+
+def test_sharded_core_on_a_duplicate_device_list_equals_one_core(hip_lib, monkeypatch):
+    monkeypatch.setenv("HECTOR_AMD_FLEET_REHEARSAL", "1")
+    n = 5000   # 1667 + 1667 + 1666
+    S, q10 = ensemble.ecs_q10(n)
+    one = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    many = hector_amd.Core(SCENARIO, n, devices=[0, 0, 0], lib_path=hip_lib)
+    assert many.shards() == ([0, 0, 0], [0, 1667, 3334, 5000])
+    for c in (one, many):
+        c.set_pair_kernel_limit(0)   # the same kernel on both sides: bitwise comparison
+        c.setvar("S", S, "degC").setvar("q10_rh", q10)
+        c.run(2300, wait=False)
+    for v in VARS:
+        np.testing.assert_array_equal(one.fetchvars(v, (1745, 2300)), many.fetchvars(v, (1745, 2300)))
+    assert (many.status() == 0).all()
+    st = many.ensemble_stats(VARS, (1745, 2300))
+    _check_stats(st, one, 1745, 2300)
+    assert many.comm_info()[0] == 3 and "rehearsal" in many.comm_info()[2]
+    assert many.last_run_ms() > 0
+    # reset + rerun on every shard
+    for c in (one, many):
+        c.reset(1745)
+        c.setvar("beta", [0.4])
+        c.run(1800)
+    np.testing.assert_array_equal(one.fetchvars("CO2_concentration", (1745, 1800)),
+                                  many.fetchvars("CO2_concentration", (1745, 1800)))
+    one.shutdown(); many.shutdown()
+
+
+def test_duplicate_devices_are_refused_without_the_switch(hip_lib, monkeypatch):
+    monkeypatch.delenv("HECTOR_AMD_FLEET_REHEARSAL", raising=False)
+    with pytest.raises(hector_amd.HectorAmdError, match="appears twice"):
+        hector_amd.Core(SCENARIO, 128, devices=[0, 0], lib_path=hip_lib)
+
+
+def test_a_device_the_box_does_not_have_is_an_error(hip_lib):
+    import torch
+    nd = torch.cuda.device_count()
+    with pytest.raises(hector_amd.HectorAmdError, match="invalid device"):
+        hector_amd.Core(SCENARIO, 128, devices=list(range(nd + 1)), lib_path=hip_lib)
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_PORT"] = str(29900 + os.getpid() % 90)
+    env.update(env_extra or {})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+           "--members", "2048", "--no-cpu-baseline", "--no-other-configs"] + args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import torch
+    nd = torch.cuda.device_count()
+    r, out = _bench(["--gpus", str(nd + 1)])
+    assert r.returncode != 0 and out is None
+    assert "HIP device(s)" in r.stderr
+    r, out = _bench(["--gpus", str(nd + 1), "--single-process"])
+    assert r.returncode != 0 and out is None
+
+
+@pytest.mark.parametrize("collective", ["native", "torch"])
+def test_bench_runs_the_rccl_collective_in_a_world_of_one(collective):
+    """dist.init_process_group("nccl", device_id=...) + the collective of each flavour, on
+    hardware, with one rank: the exact code path the 8-GPU run takes."""
+    r, out = _bench(["--gpus", "1", "--force-collective", "--collective", collective])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out["n_gpus"] == 1 and out["config"]["collective_world_size"] == 1
+    assert "RCCL" in out["config"]["collective_backend"], out["config"]["collective_backend"]
+    assert ("libhector_amd.so" in out["config"]["collective_backend"]) == (collective == "native")
+    assert out["config"]["members_in_statistics"] == 2048
+    assert out["config"]["members_with_model_errors"] == 0
+
+
+def test_plain_python_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed.run in front): two ranks, n_gpus 2.  On
+    this one-GPU box through the gloo rehearsal (two ranks share device 0)."""
+    r, out = _bench(["--gpus", "2", "--dist-backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["config"]["collective_world_size"] == 2
+    assert out["config"]["global_members"] == 4096 and out["config"]["members_in_statistics"] == 4096
+
+
+def test_single_process_bench_over_a_device_list():
+    r, out = _bench(["--gpus", "2", "--single-process", "--dist-backend", "gloo"],
+                    {"HECTOR_AMD_FLEET_REHEARSAL": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["config"]["collective_world_size"] == 2
+    assert out["config"]["members_in_statistics"] == 4096
+    S, q10 = ensemble.ecs_q10(4096)
+    c = hector_amd.Core(SCENARIO, 4096, device=0)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)").run(2300)
+    tg = c.fetchvars("global_tas", (2300, 2300))[0]
+    assert abs(out["config"]["tgav_2300_mean_K"] - tg.mean()) < 1e-9
+    c.shutdown()
