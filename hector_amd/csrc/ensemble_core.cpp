@@ -970,6 +970,7 @@ const MemberSeriesDef kMemberSeries[] = {
     {"CH4_constrain", HXM_CH4_CON, "CH4", "ppbv CH4", 0},
 };
 bool is_constraint_series(int k) { return k >= HXM_CO2_CON && k <= HXM_CH4_CON; }
+bool interpolated_constraint(int k) { return k == HXM_TAS_CON || k == HXM_FTOT_CON; }
 int constraint_bit(int k) {
   switch (k) {
     case HXM_CO2_CON: return HXC_CO2; case HXM_NBP_CON: return HXC_NBP;
@@ -1018,9 +1019,14 @@ void EnsembleCore::setvar_dated(const std::string &capability, const int *years,
   for (const MemberSeriesDef &d : kMemberSeries) {
     const int k = d.k;
     if (capability != d.name || member_series_[k].empty()) continue;
-    for (int i = 0; i < n; ++i)
-      std::fill(member_series_[k].begin() + (size_t)(years[i] - scen_.start) * n_,
-                member_series_[k].begin() + (size_t)(years[i] - scen_.start + 1) * n_, values[i]);
+    if (interpolated_constraint(k)) {  // the interpolated years move with the points
+      for (int i = 0; i < n; ++i) member_points_[k][years[i]].assign((size_t)n_, values[i]);
+      densify_member_constraint(k, capability);
+    } else {
+      for (int i = 0; i < n; ++i)
+        std::fill(member_series_[k].begin() + (size_t)(years[i] - scen_.start) * n_,
+                  member_series_[k].begin() + (size_t)(years[i] - scen_.start + 1) * n_, values[i]);
+    }
     mseries_dirty_ = true;
   }
   shared_dirty_ = true;
@@ -1052,6 +1058,11 @@ void EnsembleCore::setvar_dated_members(const std::string &capability, const int
             : std::vector<double>((size_t)ns, is_constraint_series(d->k) ? std::nan("") : 0.0);
     for (int iy = 0; iy < ns; ++iy)
       std::fill(ms.begin() + (size_t)iy * n_, ms.begin() + (size_t)(iy + 1) * n_, base[(size_t)iy]);
+    if (interpolated_constraint(d->k)) {  // ... and from the shared series' points
+      member_points_[d->k].clear();
+      for (auto &pt : scen_.constraint_points(d->section, capability))
+        member_points_[d->k][pt.first].assign((size_t)n_, pt.second);
+    }
   }
   int miny = scen_.end;
   for (int i = 0; i < nyears; ++i) {
@@ -1061,13 +1072,37 @@ void EnsembleCore::setvar_dated_members(const std::string &capability, const int
     // (ch4_component.cpp:137-147): that one cannot differ between members
     if (d->k == HXM_CH4_CON && years[i] == scen_.start)
       throw std::runtime_error("CH4_constrain at startDate: one value for the whole core (setvar_dated)");
-    std::copy(values + (size_t)i * n_, values + (size_t)(i + 1) * n_,
-              ms.begin() + (size_t)(years[i] - scen_.start) * n_);
+    if (interpolated_constraint(d->k))
+      member_points_[d->k][years[i]].assign(values + (size_t)i * n_, values + (size_t)(i + 1) * n_);
+    else
+      std::copy(values + (size_t)i * n_, values + (size_t)(i + 1) * n_,
+                ms.begin() + (size_t)(years[i] - scen_.start) * n_);
     miny = std::min(miny, years[i]);
   }
+  if (interpolated_constraint(d->k)) densify_member_constraint(d->k, capability);
   mseries_dirty_ = true;
   const int target = std::max(0, miny - 1 - scen_.start);
   if (target < last_iy_) dirty_from_iy_ = (dirty_from_iy_ < 0) ? target : std::min(dirty_from_iy_, target);
+}
+
+// member_points_[k] -> member_series_[k]: every member's points densified by the rule of the
+// shared series (Scenario::densify_points: interpolation between a member's first and last date,
+// RF_tot_constrain flat before its first one; NaN points are no points)
+void EnsembleCore::densify_member_constraint(int k, const std::string &capability) {
+  std::vector<double> &ms = member_series_[k];
+  for (auto it = member_points_[k].begin(); it != member_points_[k].end();) {  // dates nobody holds
+    bool any = false;
+    for (double v : it->second) if (!std::isnan(v)) { any = true; break; }
+    it = any ? std::next(it) : member_points_[k].erase(it);
+  }
+  std::map<int, double> pts;
+  for (int m = 0; m < n_; ++m) {
+    pts.clear();
+    for (auto &pt : member_points_[k])
+      if (!std::isnan(pt.second[(size_t)m])) pts.emplace_hint(pts.end(), pt.first, pt.second[(size_t)m]);
+    const std::vector<double> dense = Scenario::densify_points(pts, capability, scen_.start, scen_.end);
+    for (size_t iy = 0; iy < dense.size(); ++iy) ms[iy * (size_t)n_ + (size_t)m] = dense[iy];
+  }
 }
 
 void EnsembleCore::upload_member_series() {

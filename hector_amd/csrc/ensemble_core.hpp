@@ -144,6 +144,11 @@ class EnsembleCore {
   int last_iy_ = 0;
   HxConst kc_{};
   std::vector<double> member_series_[HXM_N];  // host [ns][n_], member order; empty = shared
+  // tas_constrain / RF_tot_constrain interpolate between the dates they were given at
+  // (temperature_component.cpp:112, forcing_component.cpp:112): per-member POINTS, year -> [n_]
+  // (NaN = none for that member), from which the dense member series is rebuilt
+  std::map<int, std::vector<double>> member_points_[HXM_N];
+  void densify_member_constraint(int k, const std::string &capability);
   double *d_mseries_[HXM_N] = {};
   bool mseries_dirty_ = false;
   void upload_member_series();

@@ -80,8 +80,12 @@ __device__ __forceinline__ void hx_exp_chunks(double (&x)[N]) {
     for (int i = 0; i < R; ++i) x[N - R + i] = t[i];
   }
 }
+// (single exponentials clamp their argument from below so that exp(-inf) = 0 like libm's; the
+// batches of the year start take finite model quantities -- pK polynomials in T, Q10 exponents,
+// the OH lifetime's log terms, whose -inf the reference does not survive either: a CH4
+// concentration of 0 gives tau_OH = 0 there and a division by it in the same year)
 __device__ __forceinline__ double hx_exp(double x) {
-  double a[1] = {x};
+  double a[1] = {fmax(x, -746.0)};
   hx_exp_batch<1>(a);
   return a[0];
 }
@@ -126,7 +130,9 @@ __device__ __forceinline__ void hx_log_batch(double (&x)[N]) {
     const double r = dk[i] * LN2_HI - ((hfsq - fma(s[i], hfsq + R, dk[i] * LN2_LO)) - f[i]);
     // (a concentration or pool that has gone to zero or below: libm's answers, so that the member
     // turns NaN and raises its flag like it would in the reference instead of carrying on)
-    x[i] = (x0[i] > 0.0) ? r : ((x0[i] == 0.0) ? -__builtin_inf() : __builtin_nan(""));
+    // log(+inf) = +inf: frexp's mantissa of inf is inf and the reduction would give NaN
+    x[i] = (x0[i] > 0.0) ? ((x0[i] == __builtin_inf()) ? x0[i] : r)
+                         : ((x0[i] == 0.0) ? -__builtin_inf() : __builtin_nan(""));
   }
 }
 __device__ __forceinline__ double hx_log(double x) {
@@ -135,7 +141,8 @@ __device__ __forceinline__ double hx_log(double x) {
   return a[0];
 }
 
-// sqrt(x), x positive and normal
+// sqrt(x), x >= 0 and normal (sqrt(0) = 0: rsq(0) = inf and 0 * inf would be NaN -- a zero
+// concentration in the forcing formulas, e.g. a constraint of 0, must stay finite like libm's)
 __device__ __forceinline__ double hx_sqrt(double x) {
   double y = HX_RSQ(x);            // ~1e-8 relative
   double g = x * y, h = 0.5 * y;   // g -> sqrt(x), h -> 1 / (2 sqrt(x))
@@ -145,7 +152,7 @@ __device__ __forceinline__ double hx_sqrt(double x) {
   r = fma(-g, g, x);               // residual
   g = fma(r, h, g);
   r = fma(-g, g, x);
-  return fma(r, h, g);
+  return (x == 0.0) ? x : fma(r, h, g);
 }
 
 }  // namespace

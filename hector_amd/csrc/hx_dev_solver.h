@@ -21,6 +21,9 @@ struct Interval {
   //        aoB = pG / surf
   // three operations per evaluation instead of seven; c4 - totC stays an exact small difference
   double aoA, aoB, pG;
+  // d(veg + detritus + soil)/dt: every land-use loss r * y_i adds up to luc_e, so the three
+  // pools' sum moves at this constant rate within the interval
+  double dtot;
 };
 
 template <int B> __device__ __forceinline__ double m_npp(const Member<B> &m, const LandK<B> &k, int b) {
@@ -67,6 +70,7 @@ __device__ __forceinline__ void make_interval(const Member<B> &m, const Flows &F
   K.pG = m.pco2H * m.kH.g + m.pco2L * m.kL.g;
   K.aoA = PGC2PPM * (m.kH.g + m.kL.g);
   K.aoB = K.pG * hx_recip(m.cLL + m.cHL);
+  K.dtot = (((K.v1 + m.luc_u) + K.d2) + K.s3) - m.luc_e;
 }
 
 // NBP constraint inside calcderivs: NPP and RH moved by +-diff/2, their parts scaled
@@ -150,16 +154,27 @@ __device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B>
 }
 
 // SimpleNbox::calcderivs + OceanComponent::calcderivs restricted to the five
-// pools whose derivative depends on c[] (atmos, veg, det, soil, ocean)
-template <int B, bool SPIN, int CON = 0>
+// pools whose derivative depends on c[] (atmos, veg, det, soil, ocean).
+// r: the land-use loss rate luc_e / (veg + det + soil) at this stage, if the caller knows it
+// (plain kernels: the sum of the three pools is linear in time within an interval and
+// Runge-Kutta stages preserve linear invariants, so the rates of all stages of an attempt are
+// computed side by side before it instead of one division at the head of every stage's
+// dependency chain -- see solve_year); NaN = divide here.
+template <int B, bool SPIN, int CON = 0, bool RATE = false>
 __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, const Interval &K2,
-                                    const YearCon &yc, double t, const double *y, double *d) {
+                                    const YearCon &yc, double t, const double *y, double *d,
+                                    double rate = 0.0) {
   // CON kernels carry the thawed-permafrost pool as a sixth solver variable: with an NBP
   // constraint its derivative changes where round(t) does, so it is no longer constant
   const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
   if constexpr (CON) d[5] = K.k5;
-  const double total = y[1] + y[2] + y[3];
-  const double r = hx_div1(m.luc_e, total);  // 2e-15 on a term that is itself ~1e-3 of the flux
+  double r;
+  if constexpr (RATE) {
+    r = rate;
+  } else {
+    const double total = y[1] + y[2] + y[3];
+    r = hx_div1(m.luc_e, total);  // 2e-15 on a term that is itself ~1e-3 of the flux
+  }
   double ao;
   if (SPIN) {
     ao = 0.0;  // preindustrial fluxes +1 / -1 PgC/yr  ocean_component.cpp:343-345
@@ -483,21 +498,29 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     const double t_start = t;
     double t_target = tnew, dtl = m.sdt;
     double dxdt[NP];
-    bool first_call = true;
+    // A freshly constructed stepper evaluates the RHS once before its first step (FSAL starts
+    // empty): here, ahead of the loop, for every lane -- only the lanes of this segment use it.
+    rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt);
     int fails = 0;
     bool stepping = seg;
+    // One pass = one dopri5 attempt of every stepping lane.  The attempt itself is straight-line
+    // code that ALL lanes execute (a lane that has reached its target computes on stale values
+    // and discards the result: ~2 % of the lanes, against the predication and register shuffling
+    // of a divergent region around 330 instructions); per-lane control is the clip of dt, the
+    // rare retry block, and ONE masked region at the end where an accepted step is committed.
     while (__any(stepping)) {
       HX_STAMP(m, 10);
       HX_COUNT(m, 16);  // step-loop iterations
-      if (stepping) {
-        if (((t + dtl) - t_target) > EPS) dtl = t_target - t;
-        // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
-        // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
-        // attempt throws CARBON_CYCLE_RETRY iff its last stage does.  A retry
-        // (carbon-cycle-solver.cpp:266-276) is bookkeeping -- target halved, pools reloaded --
-        // and the attempt towards the new target follows in the same pass of the loop.
+      if (stepping && ((t + dtl) - t_target) > EPS) dtl = t_target - t;
+      // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
+      // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
+      // attempt throws CARBON_CYCLE_RETRY iff its last stage does.  A retry
+      // (carbon-cycle-solver.cpp:266-276) is bookkeeping -- target halved, pools reloaded, a
+      // fresh stepper -- and the attempt towards the new target follows in the same pass.
+      bool need = stepping && ((t + dtl) - m.ode_start) > m.max_ts;
+      if (__builtin_expect(__any(need), 0)) {
         bool reload = false;
-        while (stepping && ((t + dtl) - m.ode_start) > m.max_ts) {
+        while (need) {
           ++retry;
           t_target = t_start + (t_target - t_start) / 2.0;
           t = t_start;
@@ -506,72 +529,90 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           reload = true;
           fails = 0;
           if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
+          need = stepping && ((t + dtl) - m.ode_start) > m.max_ts;
         }
-        if (reload) { load_pools(); first_call = true; }
-        if (stepping) {
-          if (first_call) { rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); first_call = false; }
-          double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
+        if (reload) { load_pools(); rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); }
+      }
+      double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
+      // the land-use loss rates of the attempt's stage times (see rhs): five independent
+      // reciprocals up front.  Not in the CON kernels: an NBP constraint switches the interval
+      // constants in mid-year, so the pools' sum is only piecewise linear there.
+#ifdef HX_NO_RATE   // (experiment builds: the division at the head of every stage)
+      constexpr bool RT = false;
+#else
+      constexpr bool RT = (CON == 0);
+#endif
+      double rr[5] = {0, 0, 0, 0, 0};
+      if constexpr (RT) {
+        const double tot0 = (y[1] + y[2]) + y[3];
+        const double hC = dtl * K.dtot;
+        rr[0] = hx_div1(m.luc_e, fma(hC, 1.0 / 5, tot0));
+        rr[1] = hx_div1(m.luc_e, fma(hC, 3.0 / 10, tot0));
+        rr[2] = hx_div1(m.luc_e, fma(hC, 4.0 / 5, tot0));
+        rr[3] = hx_div1(m.luc_e, fma(hC, 8.0 / 9, tot0));
+        rr[4] = hx_div1(m.luc_e, tot0 + hC);
+      }
 #pragma unroll
-          for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (1.0 / 5), xt, k2);
+      for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
+      rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl * (1.0 / 5), xt, k2, rr[0]);
 #pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (3.0 / 10), xt, k3);
+      for (int i = 0; i < NP; ++i)
+        xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
+      rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl * (3.0 / 10), xt, k3, rr[1]);
 #pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (4.0 / 5), xt, k4);
+      for (int i = 0; i < NP; ++i)
+        xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
+      rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl * (4.0 / 5), xt, k4, rr[2]);
 #pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] +
-                    dtl * b53 * k3[i] + dtl * b54 * k4[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl * (8.0 / 9), xt, k5);
+      for (int i = 0; i < NP; ++i)
+        xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] +
+                dtl * b53 * k3[i] + dtl * b54 * k4[i];
+      rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl * (8.0 / 9), xt, k5, rr[3]);
 #pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] +
-                    dtl * b63 * k3[i] + dtl * b64 * k4[i] + dtl * b65 * k5[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xt, k6);
+      for (int i = 0; i < NP; ++i)
+        xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] +
+                dtl * b63 * k3[i] + dtl * b64 * k4[i] + dtl * b65 * k5[i];
+      rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl, xt, k6, rr[4]);
 #pragma unroll
-          for (int i = 0; i < NP; ++i)
-            xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
-                    dtl * c5 * k5[i] + dtl * c6 * k6[i];
-          rhs<B, SPIN, CON>(m, K, K2, yc, t + dtl, xn, dn);
-          // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
-          // The maximum of the five quotients is found by cross-multiplication
-          // (all denominators > 0) and divided once.
-          double en = 0.0, ed = 1.0;
+      for (int i = 0; i < NP; ++i)
+        xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
+                dtl * c5 * k5[i] + dtl * c6 * k6[i];
+      rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl, xn, dn, rr[4]);
+      // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
+      // The maximum of the five quotients is found by cross-multiplication
+      // (all denominators > 0) and divided once.
+      double en = 0.0, ed = 1.0;
 #pragma unroll
-          for (int i = 0; i < NP; ++i) {
-            const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
-                              dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
-                              dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
-            const double n = fabs(xe);
-            const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
-            if (n * ed > en * d) { en = n; ed = d; }
-          }
-          double err = hx_div(en, ed);
-          if (__builtin_expect(err > 1.0, 0)) {  // reject (rare): default_step_adjuster::decrease_step
-            dtl *= fmax(0.9 * pow_m13(err), 0.2);
-            if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
-          } else {          // accept
-            // pools with a constant derivative over the interval advance exactly
-            l4 += dtl * K.k4; l7 += dtl * K.k7;
-            if constexpr (!CON) l5 += dtl * K.k5;
-            t += dtl;
-            // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
-            const double grow = 0.9 * pow_m15(fmax(0.00032, err));
-            if (err < 0.5) dtl *= grow;
+      for (int i = 0; i < NP; ++i) {
+        const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
+                          dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
+                          dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
+        const double n = fabs(xe);
+        const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
+        if (n * ed > en * d) { en = n; ed = d; }
+      }
+      const double err = hx_div(en, ed);
+      // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
+      const double grow = 0.9 * pow_m15(fmax(0.00032, err));
+      if (stepping) {
+        if (__builtin_expect(err > 1.0, 0)) {  // reject (rare): default_step_adjuster::decrease_step
+          dtl *= fmax(0.9 * pow_m13(err), 0.2);
+          if (++fails > 500) { m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false; }
+        } else {          // accept
+          // pools with a constant derivative over the interval advance exactly
+          l4 += dtl * K.k4; l7 += dtl * K.k7;
+          if constexpr (!CON) l5 += dtl * K.k5;
+          t += dtl;
+          if (err < 0.5) dtl *= grow;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
-            fails = 0;
-            m.nsteps++;
-            if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
-            // odeint puts no limit on accepted steps; a launch needs one (a member takes 3-8
-            // steps a year, a stiff one a few hundred)
-            if (m.nsteps > HX_MAX_STEPS_PER_YEAR) {
-              m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false;
-            }
+          for (int i = 0; i < NP; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
+          fails = 0;
+          m.nsteps++;
+          if (!((t_target - t) > EPS)) stepping = false;  // integrate_adaptive done
+          // odeint puts no limit on accepted steps; a launch needs one (a member takes 3-8
+          // steps a year, a stiff one a few hundred)
+          if (m.nsteps > HX_MAX_STEPS_PER_YEAR) {
+            m.status |= HX_ERR_STEPFAIL; alive = false; stepping = false;
           }
         }
       }

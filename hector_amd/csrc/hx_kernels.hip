@@ -597,10 +597,10 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
 #pragma unroll
         for (int b = 0; b < nbio<B>(m); ++b) rh_ch4 += m_rh_tp_ch4(m, lk, b);
       }
-      double toh = 0.0;
-      if (prev_ch4 != kc.M0)
-        toh = ((kc.CCH4 * (PKM(m, PK_LN_CH4) - kc.lnM0) + ya[0]) + ya[1]) +
-              ya[2];
+      // (a select, not a branch: four operations, and a divergent region here is one of the
+      // places where ROCm 7.2 put register saves ahead of the exec restore -- tools/check_isa.py)
+      const double toh_x = ((kc.CCH4 * (PKM(m, PK_LN_CH4) - kc.lnM0) + ya[0]) + ya[1]) + ya[2];
+      const double toh = (prev_ch4 != kc.M0) ? toh_x : 0.0;
       // Q10 window: mean over i in [t-200, t-1] of Tland_record(i) =
       // Tland(i-1), 0 before the first record (runtime.cpp:1041-1052)
       if (iy >= 3) {

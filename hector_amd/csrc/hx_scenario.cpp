@@ -157,10 +157,9 @@ bool Scenario::is_constraint(const std::string &key) {
   return key.size() > suf.size() && key.compare(key.size() - suf.size(), suf.size(), suf) == 0;
 }
 
-void Scenario::densify_constraint(const std::string &name) {
-  const std::map<int, double> &pts = con_points_[name];
-  std::vector<double> v((size_t)ns(), std::nan(""));
-  const std::string key = name.substr(name.find('.') + 1);
+std::vector<double> Scenario::densify_points(const std::map<int, double> &pts,
+                                             const std::string &key, int start, int end) {
+  std::vector<double> v((size_t)(end - start + 1), std::nan(""));
   const bool interp = (key == "tas_constrain" || key == "RF_tot_constrain");
   if (!pts.empty()) {
     for (int y = start; y <= end; ++y) {
@@ -178,7 +177,18 @@ void Scenario::densify_constraint(const std::string &name) {
                                                (double)(hi->first - lo->first);
     }
   }
-  series_[name] = std::move(v);
+  return v;
+}
+
+void Scenario::densify_constraint(const std::string &name) {
+  series_[name] = densify_points(con_points_[name], name.substr(name.find('.') + 1), start, end);
+}
+
+const std::map<int, double> &Scenario::constraint_points(const std::string &section,
+                                                         const std::string &key) const {
+  static const std::map<int, double> none;
+  auto it = con_points_.find(section + "." + key);
+  return it == con_points_.end() ? none : it->second;
 }
 
 void Scenario::set_constraint_point(const std::string &section, const std::string &key, int year,

@@ -44,6 +44,12 @@ class Scenario {
   static bool is_constraint(const std::string &key);
   void set_constraint_point(const std::string &section, const std::string &key, int year,
                             double v);
+  // the dates a constraint was given at (empty if none) and the dense [ns] series those
+  // points mean under the rules above -- also used per member (setvar_dated_members)
+  const std::map<int, double> &constraint_points(const std::string &section,
+                                                 const std::string &key) const;
+  static std::vector<double> densify_points(const std::map<int, double> &pts,
+                                            const std::string &key, int start, int end);
 
   std::vector<Halocarbon> halocarbons;
   std::string source;

@@ -59,7 +59,14 @@ def member_constraints_vs_oracle(lib, tmp_path, run_to=2150, **kw):
         for name, sec, vals, _ in sets:
             ok = ~np.isnan(vals[:, i])
             if ok.any():
-                path = edited_pack(tmp_path / ("m%d.hxs" % i), sec, name, yrs[ok], vals[ok, i],
+                yy, vv = yrs[ok], vals[ok, i]
+                if name == "RF_tot_constrain":
+                    # the reference's Ftot_constrain tseries extrapolates flat before its first
+                    # date (forcing_component.cpp:498 tests only the LAST date): the oracle reads
+                    # dense series, so its pack carries that back-fill
+                    yy = np.concatenate([np.arange(Y0, yy[0]), yy])
+                    vv = np.concatenate([np.full(yy.size - vv.size, vv[0]), vv])
+                path = edited_pack(tmp_path / ("m%d.hxs" % i), sec, name, yy, vv,
                                    base=None if first else path)
                 first = False
         o = oracle_binding.Oracle(path or SCENARIO)

@@ -9,4 +9,4 @@ NAME=$1; shift
 SRC=${HX_SRC_DIR:-$R/hector_amd/csrc}
 mkdir -p $R/gpuwork
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -disable-machine-licm -DHX_MINIMAL_BUILD "$@" \
-  -I$SRC -shared -o $R/gpuwork/lib$NAME.so $SRC/hx_kernels.hip $SRC/ensemble_core.cpp $SRC/hx_scenario.cpp $SRC/hx_abi.cpp
+  -I$SRC -shared -o $R/gpuwork/lib$NAME.so $SRC/hx_kernels.hip $SRC/ensemble_core.cpp $(ls $SRC/hx_fleet.cpp 2>/dev/null) $SRC/hx_scenario.cpp $SRC/hx_abi.cpp -ldl
