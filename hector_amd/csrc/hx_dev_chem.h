@@ -32,6 +32,7 @@ __device__ __forceinline__ double hx_div1(double a, double b) {
 
 struct ChemK {  // T-dependent equilibrium constants of one surface box
   double K1, K2, Kb, Kw, Kh, Tr;
+  double rKh;  // 1 / Kh (run kernels: exp(-a) from the year's batch; pCO2 = CO2* 1e6 rKh)
   double g;  // Tr * As * 12 / 1e15: annual flux per uatm of air-sea pCO2 difference
 };
 
@@ -288,8 +289,9 @@ __device__ __forceinline__ void chem_exponents(double Tc, double lnTk, double *a
          S * (0.027766 - 0.025888 * T100 + 0.0050578 * (T100 * T100));
   a[1] = (-13847.26 * rTk + 148.96502 - 23.6521 * lnTk) +
          ((118.67 * rTk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S);
-  a[2] = (9345.17 * rTk - 60.2409 + 23.3585 * lnTk100) +
-         S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk);
+  // (negated: the carbonate solve divides by Kh, so the batch delivers 1 / Kh = exp(-a))
+  a[2] = -((9345.17 * rTk - 60.2409 + 23.3585 * lnTk100) +
+           S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk));
   const double pK1 = 3633.86 * rTk - 61.2172 + 9.6777 * lnTk - 0.011555 * S + 0.0001152 * S * S;
   a[3] = -pK1 * LN10;
   const double pK2 = 471.78 * rTk + 25.9290 - 3.16967 * lnTk - 0.01781 * S + 0.0001122 * S * S;
@@ -302,7 +304,7 @@ __device__ __forceinline__ void chem_exponents(double Tc, double lnTk, double *a
 __device__ __forceinline__ void chem_from_exponentials(double Tc, const double *e, double As,
                                                        ChemK &k) {
   const double Sc = 2073.1 - (125.62 * Tc) + (3.6276 * Tc * Tc) - (0.043219 * Tc * Tc * Tc);
-  k.Kw = e[1]; k.Kh = e[2]; k.K1 = e[3]; k.K2 = e[4]; k.Kb = e[5];
+  k.Kw = e[1]; k.rKh = e[2]; k.K1 = e[3]; k.K2 = e[4]; k.Kb = e[5];
   k.Tr = (0.585 * e[0] * rsqrt(Sc) * O_U * O_U);
   k.g = k.Tr * As * (12.0 / 1e15);
 }
@@ -340,8 +342,14 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
   const double factor = 0x1p-30;
   const double q4[2] = {4.0 * p4[0], 4.0 * p4[1]}, q3[2] = {3.0 * p3[0], 3.0 * p3[1]},
                q2[2] = {2.0 * p2[0], 2.0 * p2[1]};
-  bool conv[2] = {false, false};
-  for (int it = 0; it < 8 && !(conv[0] && conv[1]); ++it) {
+  // A lane stops moving the moment one of its steps meets the stop rule -- its result must not
+  // depend on how long its 63 neighbours take (results are independent of the lane assignment,
+  // bit for bit).  The freeze is arithmetic, not a branch or a pair of selects per value: every
+  // step is scaled by act = 1.0 while the box iterates, 0.0 afterwards (h - 0 * delta = h
+  // exactly), so both boxes' chains stay interleaved and an iteration is ~40 instructions.
+  double act[2] = {1.0, 1.0};
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
     HX_COUNT(0, 18);  // (profiling build) Newton iterations
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -352,14 +360,16 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
       double fp = -5.0;
       fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
       fp = fp * x + p1[b];
-      const double delta = hx_div1(f, fp);
+      const double delta = hx_div1(f, fp) * act[b];
       const double hn = x - delta;
-      const bool c = !(fabs(hn * factor) < fabs(delta));
-      h[b] = conv[b] ? h[b] : hn;
-      conv[b] = conv[b] || c;
+      h[b] = hn;
+      // (a frozen box: delta = 0, the test holds again)
+      act[b] = (fabs(hn * factor) < fabs(delta)) ? act[b] : 0.0;
     }
+    if (!__any((act[0] + act[1]) != 0.0)) break;
   }
-  const bool ok = conv[0] && conv[1] && h[0] > 0.0 && h[1] > 0.0 && h[0] < 1.0 && h[1] < 1.0;
+  const bool conv = (act[0] + act[1]) == 0.0;
+  const bool ok = conv && h[0] > 0.0 && h[1] > 0.0 && h[0] < 1.0 && h[1] < 1.0;
   if (__any(!ok)) {
     HX_COUNT(0, 19);  // (profiling build) safeguarded restarts
     if (!ok) {
@@ -409,7 +419,7 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
     // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
     const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
     const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
-    pc[b] = hx_div(co2st * 1e6, k[b]->Kh);
+    pc[b] = (co2st * 1e6) * k[b]->rKh;
   }
   pco2H = pc[0]; pco2L = pc[1];
 }
@@ -445,8 +455,14 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
 #pragma unroll
     for (int b = 0; b < N; ++b) a = a && f[b];
     return a; };
-  for (int it = 0; it < 8 && !all(conv); ++it) {
+  // (a box stops moving once a step met the stop rule, through act = 1.0 / 0.0: see chem_solve2)
+  double act[N];
+#pragma unroll
+  for (int b = 0; b < N; ++b) act[b] = 1.0;
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
     HX_COUNT(0, 18);  // (profiling build) Newton iterations
+    double left = 0.0;
 #pragma unroll
     for (int b = 0; b < N; ++b) {
       const double x = h[b];
@@ -456,13 +472,16 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
       double fp = -5.0;
       fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
       fp = fp * x + p1[b];
-      const double delta = hx_div1(f, fp);
+      const double delta = hx_div1(f, fp) * act[b];
       const double hn = x - delta;
-      const bool c = !(fabs(hn * factor) < fabs(delta));
-      h[b] = conv[b] ? h[b] : hn;
-      conv[b] = conv[b] || c;
+      h[b] = hn;
+      act[b] = (fabs(hn * factor) < fabs(delta)) ? act[b] : 0.0;
+      left += act[b];
     }
+    if (!__any(left != 0.0)) break;
   }
+#pragma unroll
+  for (int b = 0; b < N; ++b) conv[b] = act[b] == 0.0;
   bool ok = all(conv);
 #pragma unroll
   for (int b = 0; b < N; ++b) ok = ok && h[b] > 0.0 && h[b] < 1.0;
@@ -513,7 +532,7 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
     // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
     const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
     const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
-    pc[b] = hx_div(co2st * 1e6, k[b]->Kh);
+    pc[b] = (co2st * 1e6) * k[b]->rKh;
   }
 }
 // one box (the small-ensemble kernel gives each of its two wavefronts one)
