@@ -91,6 +91,8 @@ def _declare(lib):
         "hx_set_outputs": [P, c.c_int, c.POINTER(c.c_char_p)],
         "hx_output_capabilities": [c.POINTER(c.POINTER(c.c_char_p)), c.POINTER(c.c_int)],
         "hx_set_member_sorting": [P, c.c_int],
+        "hx_set_lane_calibration": [P, c.c_int],
+        "hx_lanes_calibrated": [P, c.POINTER(c.c_int)],
         "hx_enable_history": [P, c.c_int],
         "hx_tracking_pools": [P, c.POINTER(c.POINTER(c.c_char_p)), c.POINTER(c.c_int)],
         "hx_tracking_data": [P, c.c_int, c.c_int, c.c_int, dp, dp, c.POINTER(c.c_ulonglong)],
@@ -134,4 +136,4 @@ ABI_SYMBOLS = ["hx_backend", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_s
                "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream", "hx_set_pair_kernel_limit",
                "hx_last_run_kernel", "hx_component_output", "hx_newcore_devices", "hx_shards",
                "hx_device_var_shard", "hx_stream_shard", "hx_comm_unique_id", "hx_comm_init_rank",
-               "hx_comm_info", "hx_ensemble_stats"]
+               "hx_comm_info", "hx_ensemble_stats", "hx_set_lane_calibration", "hx_lanes_calibrated"]

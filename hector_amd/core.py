@@ -182,6 +182,16 @@ class Core:
         self._ck(self._lib.hx_set_member_sorting(self._h, 1 if on else 0))
         return self
 
+    def set_lane_calibration(self, on=True):
+        """Lane order by measured cost after the first complete run (hx_set_lane_calibration)."""
+        self._ck(self._lib.hx_set_lane_calibration(self._h, 1 if on else 0))
+        return self
+
+    def lanes_calibrated(self):
+        v = ctypes.c_int()
+        self._ck(self._lib.hx_lanes_calibrated(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
     def lane_of_member(self):
         out = np.zeros(self.n_members, dtype=np.int32)
         self._ck(self._lib.hx_lane_of_member(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))

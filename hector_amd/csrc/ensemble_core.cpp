@@ -458,6 +458,7 @@ void EnsembleCore::free_device() {
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   fr(d_hist_status_);
   fr(d_gas_par_); fr(d_gas_ser_); d_gas_par_ = d_gas_ser_ = nullptr;
+  fr(d_cost_); d_cost_ = nullptr; cost_from_iy_ = -1;
   d_hist_ = nullptr; d_hist_status_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
   fr(d_diag_); fr(d_slr_); d_diag_ = d_slr_ = nullptr; diag_cap_ = 0; slr_valid_to_ = -1;
@@ -500,6 +501,8 @@ void EnsembleCore::alloc_device() {
   hist_valid_to_ = 0;
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
+  check(hipMalloc(&d_cost_, sizeof(double) * np), "hipMalloc lane cost");
+  cost_from_iy_ = -1;
   for (int v = 0; v < HXO_NVAR; ++v)
     if (out_enabled_[v]) {
       check(hipMalloc(&d_out_[v], sizeof(double) * ns * np), "hipMalloc out");
@@ -540,6 +543,7 @@ HxBuffers EnsembleCore::buffers() const {
     if (d_out_[HXO_B(HXOB_NPP, bb)] || d_out_[HXO_B(HXOB_RH, bb)]) b.stash_diag = 1;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   b.nbiome = B_;
+  b.cost = d_cost_;
   return b;
 }
 
@@ -668,6 +672,7 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
   }
   row_uniform_[row] = uniform;
   params_dirty_ = true;
+  lane_cost_.clear();  // measured with other parameters: back to the parameter key
   // R/messages.R:107-140: a parameter change invalidates the run from date 0
   last_iy_ = 0;
   need_spinup_ = true;
@@ -1280,8 +1285,31 @@ void EnsembleCore::assign_lanes() {
                          [&](int a, int b) { return q[a] < q[b]; });
     }
   }
+  if (sort_members_ && n_ > HX_WAVE && (int)lane_cost_.size() == n_) {
+    // measured cost, costliest first (ties keep the parameter order): wavefronts of members that
+    // really take the same number of steps and stashes, the expensive ones dispatched first
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return lane_cost_[(size_t)a] > lane_cost_[(size_t)b]; });
+  }
   for (int l = 0; l < npad_; ++l) member_of_lane_[(size_t)l] = order[(size_t)std::min(l, n_ - 1)];
   for (int l = 0; l < n_; ++l) lane_of_member_[(size_t)order[(size_t)l]] = l;
+}
+
+// reset(startDate) after a complete run: adopt the measured lane order (see the header)
+void EnsembleCore::maybe_calibrate_lanes() {
+  if (!calibrate_lanes_ || !sort_members_ || n_ <= HX_WAVE || !lane_cost_.empty() || !d_cost_) return;
+  if (cost_from_iy_ != 0 || last_iy_ != scen_.ns() - 1 || last_run_pair_) return;
+  sync();
+  std::vector<double> tmp((size_t)npad_);
+  check(hipMemcpy(tmp.data(), d_cost_, sizeof(double) * (size_t)npad_, hipMemcpyDeviceToHost), "lane cost");
+  lane_cost_.resize((size_t)n_);
+  for (int i = 0; i < n_; ++i) lane_cost_[(size_t)i] = tmp[(size_t)lane_of_member_[(size_t)i]];
+  // nothing to gain if the order stays (e.g. every member alike)
+  const std::vector<int> before = lane_of_member_;
+  assign_lanes();
+  if (lane_of_member_ == before) return;
+  params_dirty_ = true;   // parameters, state and series move to their new lanes:
+  need_spinup_ = true;    // upload and spin up again (prepare())
 }
 
 void EnsembleCore::upload_params() {
@@ -1419,6 +1447,7 @@ void EnsembleCore::reset(double date) {
     return;
   }
   const int iy = (int)date - scen_.start;
+  if (iy == 0 && !(need_spinup_ || layout_dirty_ || params_dirty_)) maybe_calibrate_lanes();
   if (need_spinup_ || layout_dirty_ || params_dirty_) {
     if (iy != 0) throw std::runtime_error("reset: the core has pending changes from date 0");
     prepare();
@@ -1445,6 +1474,7 @@ void EnsembleCore::reset(double date) {
                          hipMemcpyDeviceToDevice, stream_), "restore status from history");
   }
   last_iy_ = iy;
+  cost_from_iy_ = -1;  // (the lane-cost sums restart with the next launch from startDate)
   if (dirty_from_iy_ >= iy) dirty_from_iy_ = -1;
 }
 
@@ -1462,6 +1492,10 @@ void EnsembleCore::run(double runtodate) {
   }
   dirty_from_iy_ = -1;
   if (target < last_iy_ + 1) return;  // core.cpp:455-460: models not run
+  if (last_iy_ == 0) {  // the lane-cost sums of a pass over the scenario start here
+    check(hipMemsetAsync(d_cost_, 0, sizeof(double) * (size_t)npad_, stream_), "zero lane cost");
+    cost_from_iy_ = 0;
+  }
   check(hipEventRecord(ev0_, stream_), "event");
   // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
   // history pass every HX_DBLK years), so there is no global barrier to wait at

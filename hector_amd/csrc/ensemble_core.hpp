@@ -65,6 +65,14 @@ class EnsembleCore {
   // lane assignment: sort members by their perturbed parameters so that the lanes of a
   // wavefront follow similar solver schedules (default on; results do not depend on it)
   void set_member_sorting(bool on);
+  // Lane order by MEASURED cost: the run kernel adds up what every member's solver did (dopri5
+  // steps, stashes); after a run that covered startDate..endDate, the next reset(startDate)
+  // reorders the lanes by it, costliest wavefronts first (they are dispatched first, so an
+  // ensemble of more wavefronts than SIMDs ends on cheap ones), and spins up again.  Results do
+  // not depend on the order.  Default on; a parameter change falls back to the parameter key
+  // until the next complete run.
+  void set_lane_calibration(bool on) { calibrate_lanes_ = on; }
+  bool lanes_calibrated() const { return !lane_cost_.empty(); }
   // keep every year's component state in HBM (272 B per member-year for one biome) so that
   // reset(date) can go back to any computed year, like the reference's tseries records
   void enable_history(bool on);
@@ -138,7 +146,11 @@ class EnsembleCore {
   std::vector<std::vector<double>> params_;  // [row][npad]
   std::vector<bool> row_uniform_;
   std::vector<int> member_of_lane_, lane_of_member_;  // lane <-> member (size npad / n)
-  bool sort_members_ = true;
+  bool sort_members_ = true, calibrate_lanes_ = true;
+  std::vector<double> lane_cost_;  // [n_] measured cost per member (empty: parameter key)
+  double *d_cost_ = nullptr;
+  int cost_from_iy_ = -1;         // d_cost_ covers the years cost_from_iy_+1..last_iy_ (-1: nothing)
+  void maybe_calibrate_lanes();
   void assign_lanes();
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
   int last_iy_ = 0;

@@ -156,6 +156,11 @@ int hx_output_capabilities(const char *const **names, int *count) {
   return 0;
 }
 int hx_set_member_sorting(hx_core *core, int on) { HX_TRY(core->core->set_member_sorting(on != 0)) }
+int hx_set_lane_calibration(hx_core *core, int on) { HX_TRY(core->core->set_lane_calibration(on != 0)) }
+int hx_lanes_calibrated(hx_core *core, int *yes) {
+  if (!yes) return fail("null argument");
+  HX_TRY(*yes = core->core->lanes_calibrated() ? 1 : 0)
+}
 // ---- unit vectors (function-level parity tests; SURVEY 8c fixture iv) -------------------
 int hx_unit_csys(int device, int n, const double *Tc, const double *carbon, const double *alk,
                  double volume, double *out) {

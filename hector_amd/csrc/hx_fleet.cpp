@@ -170,6 +170,11 @@ void Fleet::delete_biome(const std::string &b) { HX_EACH(delete_biome(b)) }
 void Fleet::rename_biome(const std::string &a, const std::string &b) { HX_EACH(rename_biome(a, b)) }
 void Fleet::set_outputs(const std::vector<std::string> &caps) { HX_EACH(set_outputs(caps)) }
 void Fleet::set_member_sorting(bool on) { HX_EACH(set_member_sorting(on)) }
+void Fleet::set_lane_calibration(bool on) { HX_EACH(set_lane_calibration(on)) }
+bool Fleet::lanes_calibrated() const {
+  for (const Shard &s : shards_) if (!s.core->lanes_calibrated()) return false;
+  return true;
+}
 void Fleet::enable_history(bool on) { HX_EACH(enable_history(on)) }
 void Fleet::set_pair_kernel_limit(int m) { HX_EACH(set_pair_kernel_limit(m)) }
 void Fleet::setvar_dated(const std::string &cap, const int *years, const double *values, int n,

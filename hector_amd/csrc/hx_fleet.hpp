@@ -66,6 +66,8 @@ class Fleet {
   void rename_biome(const std::string &oldname, const std::string &newname);
   void set_outputs(const std::vector<std::string> &capabilities);
   void set_member_sorting(bool on);
+  void set_lane_calibration(bool on);
+  bool lanes_calibrated() const;
   void enable_history(bool on);
   void setvar_dated(const std::string &capability, const int *years, const double *values, int n,
                     const char *units);

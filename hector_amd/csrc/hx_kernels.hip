@@ -490,6 +490,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   load_year_a(iy_from + 1);
   if constexpr (CON) m.bufp = &args->buf;
   if constexpr (CON == 2) m.trk_iy = args->kc.trk_iy;
+  int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         yc.t_half = year - 0.5;
       }
       solve_year<B, false, CON>(m, args->kc, year - 1.0, year, yc);
+      cost_steps += m.nsteps; cost_stash += m.nstash;
     }
     HX_FENCE();
     HX_STAMP(m, 10);    // rest of the solver (loop control, lanes idling through others' segments)
@@ -1047,6 +1049,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   HX_FENCE();
   store_state<B>(args->buf, mem, m);
   store_park_state<B>(args->buf, mem, m);
+  // (a dopri5 pass of the wavefront costs ~2.7k cycles, a stash ~3.4k: tools/prof/phase_clock.py)
+  if (args->buf.cost) HX_GD(args->buf.cost)[mem] += (double)(4 * cost_steps + 5 * cost_stash);
 #ifdef HX_PHASE_CLOCK
   if (args->buf.out[HXO_TGAV])
     for (int k = 0; k < HX_NCLK; ++k)

@@ -176,6 +176,8 @@ struct HxBuffers {
                            // recorded: the year's output block tests the others only then
   int biome_diag;          // some "<biome>.<variable>" output is recorded
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
+  double *cost;          // [npad] what the launches since the last reset cost each lane (4 per dopri5
+                         // step + 5 per stash): the host orders the lanes by it (EnsembleCore::assign_lanes)
 };
 
 // ---- diagnostics derived on the device from recorded outputs (hx_diag_kernel) ----

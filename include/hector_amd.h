@@ -168,6 +168,15 @@ int hx_halocarbons(hx_core *core, const char *const **names, int *count);
  * returned in the caller's member order either way and does not depend on this switch.
  * hx_device_var exposes the raw lane-ordered arrays; hx_lane_of_member maps them. */
 int hx_set_member_sorting(hx_core *core, int on);
+/* The order is refined by MEASURED cost: the run kernel adds up every member's dopri5 steps and
+ * stashes, and the first hx_reset(startDate) after a run that covered startDate..endDate reorders
+ * the lanes by it -- wavefronts of members that really walk the same schedule, the costliest
+ * dispatched first, so that an ensemble of more wavefronts than SIMDs does not end on its most
+ * expensive ones -- and spins up again (once; a parameter change falls back to the parameter
+ * key until the next complete run).  Default on; results do not depend on it.
+ * hx_lanes_calibrated: 1 once the measured order is in use. */
+int hx_set_lane_calibration(hx_core *core, int on);
+int hx_lanes_calibrated(hx_core *core, int *yes);
 int hx_lane_of_member(hx_core *core, int *out /* n_members */);
 
 /* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.

@@ -220,6 +220,40 @@ def test_member_sorting_is_transparent_on_gpu(hip_lib):
     assert np.array_equal(a.status(), b.status())
 
 
+@pytest.mark.parametrize("biomes", [1, 4])
+def test_lane_calibration_is_transparent_on_gpu(hip_lib, biomes):
+    """The lane order by MEASURED cost (adopted at the first reset(startDate) after a complete
+    run): other lanes, costliest wavefronts first, the same results bit for bit."""
+    import bench
+    n = 4096
+    hector_amd_core = hector_amd.Core
+    c = bench.make_core(n, biomes, 0, 0)
+    c.set_pair_kernel_limit(0)
+    c.set_outputs(["CO2_concentration", "global_tas", "solver_steps", "timesteps"])
+    c.run(2300)
+    assert not c.lanes_calibrated()
+    lane0 = c.lane_of_member().copy()
+    ref = {v: c.fetchvars(v).copy() for v in ("CO2_concentration", "global_tas", "timesteps")}
+    cost = 4 * c.fetchvars("solver_steps", (1746, 2300)).sum(0) + 5 * c.fetchvars("timesteps", (1746, 2300)).sum(0)
+    ms0 = c.last_run_ms()
+    c.reset(1745)
+    assert c.lanes_calibrated()
+    lane1 = c.lane_of_member()
+    assert not np.array_equal(lane0, lane1)
+    by_lane = cost[np.argsort(lane1)]
+    assert (np.diff(by_lane) <= 0).all()            # costliest first
+    c.run(2300)
+    for v, x in ref.items():
+        assert np.array_equal(c.fetchvars(v), x), v
+    assert (c.status() == 0).all()
+    # a parameter change falls back to the parameter key until the next complete run
+    c.setvar("beta" if biomes == 1 else "b1.beta", [0.5])
+    assert not c.lanes_calibrated()
+    c.run(1800)
+    assert hector_amd_core is hector_amd.Core
+    print("kernel ms before / after calibration: %.3f / %.3f" % (ms0, c.last_run_ms()))
+
+
 def test_spinup_relevant_parameters_per_member_on_gpu(hip_lib, oracle):
     """Every lane spins up on its own when C0 / npp_flux0 / transports / pools vary."""
     n = 96

@@ -158,3 +158,34 @@ def test_run_to_an_earlier_date_is_an_error_in_the_r_style_api(emul_lib):
     c.setvar_dated("ffi_emissions", [1780], [0.5], "Pg C/yr")   # pending auto-reset to 1779
     c.run(1790)                      # fine: the core goes back first
     assert c.current_date == 1790
+
+
+def test_lane_calibration_reorders_lanes_and_keeps_results(emul_lib):
+    """Measured-cost lane order (hx_set_lane_calibration) on the host build: adopted at the first
+    reset(startDate) after a COMPLETE run, costliest members first, results bit for bit."""
+    import hector_amd
+    from hector_amd import ensemble
+    n = 130
+    S, q = ensemble.ecs_q10(n)
+    c = hector_amd.Core(n_members=n, lib_path=emul_lib, allow_emulation=True)
+    c.setvar("S", S).setvar("q10_rh", q)
+    c.set_outputs(["global_tas", "solver_steps", "timesteps"])
+    c.run(1900)
+    c.reset(1745)
+    assert not c.lanes_calibrated()            # a partial run measures nothing
+    c.run(2300)
+    lane0 = c.lane_of_member().copy()
+    tas = c.fetchvars("global_tas").copy()
+    cost = 4 * c.fetchvars("solver_steps", (1746, 2300)).sum(0) + 5 * c.fetchvars("timesteps", (1746, 2300)).sum(0)
+    c.reset(1745)
+    assert c.lanes_calibrated()
+    lane1 = c.lane_of_member()
+    assert sorted(lane1) == list(range(n)) and not np.array_equal(lane0, lane1)
+    assert (np.diff(cost[np.argsort(lane1)]) <= 0).all()
+    c.run(2300)
+    assert np.array_equal(c.fetchvars("global_tas"), tas)
+    off = hector_amd.Core(n_members=n, lib_path=emul_lib, allow_emulation=True)
+    off.set_lane_calibration(False).setvar("S", S).setvar("q10_rh", q)
+    off.run(2300); off.reset(1745)
+    assert not off.lanes_calibrated()
+    c.shutdown(); off.shutdown()
