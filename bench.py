@@ -72,6 +72,18 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def compiler_id():
+    """The compiler that built (or would build) the kernels: the counters of a profile belong to
+    ONE compiler's code -- the register allocation, and with it every figure, moves with it."""
+    import subprocess
+    try:
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True,
+                             timeout=60).stdout.splitlines()
+        return " | ".join(l.strip() for l in out[:2])
+    except Exception:
+        return "unknown"
+
+
 def pmc_entry(members, biomes):
     """-> (entry, stale).  entry: the committed counter figures for THIS kernel source and
     configuration.  If the kernels changed since the last collection: the newest entry of the
@@ -84,7 +96,13 @@ def pmc_entry(members, biomes):
         index = {"entries": {}, "order": []}
     h = kernel_source_hash()
     if cfg in index["entries"].get(h, {}):
-        return index["entries"][h][cfg], False
+        e = index["entries"][h][cfg]
+        if e.get("compiler") in (None, compiler_id()):
+            return e, False
+        sys.stderr.write("bench.py: the PMC profile of kernel source %s, configuration %s was collected "
+                         "on a build by another compiler (%s; here %s): flagged stale\n"
+                         % (h, cfg, e.get("compiler"), compiler_id()))
+        return e, True
     sys.stderr.write("bench.py: NO PMC PROFILE for kernel source %s, configuration %s in "
                      "profiles/pmc_index.json (tools/prof/collect.sh + summarize.py): roofline "
                      "figures that need counters are null or flagged stale\n" % (h, cfg))

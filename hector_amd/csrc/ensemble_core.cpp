@@ -1299,6 +1299,18 @@ void EnsembleCore::assign_lanes() {
 void EnsembleCore::maybe_calibrate_lanes() {
   if (!calibrate_lanes_ || !sort_members_ || n_ <= HX_WAVE || !lane_cost_.empty() || !d_cost_) return;
   if (cost_from_iy_ != 0 || last_iy_ != scen_.ns() - 1 || last_run_pair_) return;
+#ifndef HX_HOST_EMULATION
+  {  // With no more wavefronts than SIMDs every wavefront has a SIMD to itself from start to end
+    // and the launch lasts as long as its costliest one under any order: nothing to gain.
+    static int simds[64] = {};
+    if (device_ < 64 && !simds[device_]) {
+      hipDeviceProp_t prop;
+      check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+      simds[device_] = 4 * prop.multiProcessorCount;
+    }
+    if (device_ < 64 && npad_ / HX_WAVE <= simds[device_] && !std::getenv("HECTOR_AMD_CALIBRATE_ALWAYS")) return;
+  }
+#endif
   sync();
   std::vector<double> tmp((size_t)npad_);
   check(hipMemcpy(tmp.data(), d_cost_, sizeof(double) * (size_t)npad_, hipMemcpyDeviceToHost), "lane cost");

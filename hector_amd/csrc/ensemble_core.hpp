@@ -68,8 +68,9 @@ class EnsembleCore {
   // Lane order by MEASURED cost: the run kernel adds up what every member's solver did (dopri5
   // steps, stashes); after a run that covered startDate..endDate, the next reset(startDate)
   // reorders the lanes by it, costliest wavefronts first (they are dispatched first, so an
-  // ensemble of more wavefronts than SIMDs ends on cheap ones), and spins up again.  Results do
-  // not depend on the order.  Default on; a parameter change falls back to the parameter key
+  // ensemble of more wavefronts than SIMDs ends on cheap ones), and spins up again.  Only for
+  // ensembles of more wavefronts than the GPU has SIMDs (otherwise the launch lasts as long as
+  // its costliest wavefront under any order).  Results do not depend on the order.  Default on; a parameter change falls back to the parameter key
   // until the next complete run.
   void set_lane_calibration(bool on) { calibrate_lanes_ = on; }
   bool lanes_calibrated() const { return !lane_cost_.empty(); }

@@ -18,6 +18,9 @@ typedef const double HX_CONSTANT *hx_ccd;
 #define HX_RCP(x) __builtin_amdgcn_rcp(x)
 // hardware reciprocal-square-root seed (v_rsq_f64), refined in hx_sqrt()
 #define HX_RSQ(x) __builtin_amdgcn_rsq(x)
+// v_log_f32 / v_exp_f32 themselves (base 2, normal-range arguments: no denormal scaling around them)
+#define HX_LOG2F(x) __builtin_amdgcn_logf(x)
+#define HX_EXP2F(x) __builtin_amdgcn_exp2f(x)
 // the fp64 matrix pipe (v_mfma_f64_16x16x4_f64) is there for DOECLIM's history contraction
 #ifndef HX_HAS_MFMA
 #define HX_HAS_MFMA 1

@@ -416,7 +416,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
 // device library was ~180 instructions of it.
 __device__ __forceinline__ double pow_m13(double x) {
   x = fmin(x, 1e30);  // (a larger error shrinks by the cap of 0.2 anyway)
-  double y = (double)exp2f(-0.33333334f * log2f((float)x));
+  double y = (double)HX_EXP2F(-0.33333334f * HX_LOG2F((float)x));  // (x in [1, 1e30])
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const double y3 = y * y * y;
@@ -430,7 +430,7 @@ __device__ __forceinline__ double pow_m13(double x) {
 // fp64 log/exp pair it replaces is a ~75-instruction dependent chain, the longest
 // in the step block, and a single resident wavefront cannot hide it.
 __device__ __forceinline__ double pow_m15(double x) {
-  double y = (double)exp2f(-0.2f * log2f((float)x));
+  double y = (double)HX_EXP2F(-0.2f * HX_LOG2F((float)x));  // (x in [3.2e-4, 1]: normal range)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const double y2 = y * y;
@@ -578,20 +578,18 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] +
                 dtl * c5 * k5[i] + dtl * c6 * k6[i];
       rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl, xn, dn, rr[4]);
-      // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)).
-      // The maximum of the five quotients is found by cross-multiplication
-      // (all denominators > 0) and divided once.
-      double en = 0.0, ed = 1.0;
+      // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)):
+      // the quotients side by side (five independent reciprocals), then their maximum -- odeint's
+      // own order of operations, and no chain of compare-and-select from one variable to the next.
+      double err = 0.0;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
                           dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
                           dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
-        const double n = fabs(xe);
         const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
-        if (n * ed > en * d) { en = n; ed = d; }
+        err = fmax(err, hx_div(fabs(xe), d));
       }
-      const double err = hx_div(en, ed);
       // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
       const double grow = 0.9 * pow_m15(fmax(0.00032, err));
       if (stepping) {

@@ -173,7 +173,9 @@ int hx_set_member_sorting(hx_core *core, int on);
  * the lanes by it -- wavefronts of members that really walk the same schedule, the costliest
  * dispatched first, so that an ensemble of more wavefronts than SIMDs does not end on its most
  * expensive ones -- and spins up again (once; a parameter change falls back to the parameter
- * key until the next complete run).  Default on; results do not depend on it.
+ * key until the next complete run).  Only ensembles of more wavefronts than the GPU has SIMDs
+ * (65 536 members on an MI355X) are reordered: a smaller one lasts as long as its costliest
+ * wavefront under any order.  Default on; results do not depend on it.
  * hx_lanes_calibrated: 1 once the measured order is in use. */
 int hx_set_lane_calibration(hx_core *core, int on);
 int hx_lanes_calibrated(hx_core *core, int *yes);

@@ -12,4 +12,6 @@ typedef const double *hx_ccd;
 #define HX_GU(p) ((hx_gu)(p))
 #define HX_RCP(x) (1.0 / (x))
 #define HX_RSQ(x) (1.0 / sqrt(x))
+#define HX_LOG2F(x) log2f(x)
+#define HX_EXP2F(x) exp2f(x)
 #define HX_HAS_MFMA 0

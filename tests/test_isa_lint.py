@@ -55,9 +55,50 @@ def test_lint_tells_a_lost_save_from_a_merge(tmp_path):
     assert _scan(FINE_MERGE, tmp_path, "fine2.s") == []
 
 
+MFMA_EARLY = """
+_Z6kernelv:
+\tv_mfma_f64_16x16x4_f64 a[0:7], v[0:1], v[2:3], a[0:7]
+\tv_mfma_f64_16x16x4_f64 a[8:15], v[0:1], v[4:5], a[8:15]
+\tv_accvgpr_read_b32 v9, a8
+\ts_endpgm
+.Lfunc_end0:
+"""
+# the pin of doeclim_pass_mfma between the last v_mfma and the first reader
+MFMA_PINNED = MFMA_EARLY.replace("\tv_accvgpr_read_b32 v9, a8", "\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 v9, a8")
+# an accumulator re-used as SrcC by the very next v_mfma (what a reordering scheduler produced once)
+MFMA_BACK_TO_BACK = """
+_Z6kernelv:
+.LBB0_1:
+\tv_mfma_f64_16x16x4_f64 a[0:7], v[0:1], v[2:3], a[0:7]
+\tv_mfma_f64_16x16x4_f64 a[0:7], v[0:1], v[4:5], a[0:7]
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+"""
+# eight accumulator tiles in turn: the loop's own rhythm, across the back edge too
+MFMA_ROUND_ROBIN = "\n_Z6kernelv:\n.LBB0_1:\n" + "".join(
+    "\tv_mfma_f64_16x16x4_f64 a[%d:%d], v[0:1], v[2:3], a[%d:%d]\n" % (8 * k, 8 * k + 7, 8 * k, 8 * k + 7)
+    for k in range(8)) + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n.Lfunc_end0:\n"
+
+
+def _scan_mfma(text, tmp_path, name):
+    p = tmp_path / name
+    p.write_text(text)
+    return check_isa.scan_mfma(str(p))
+
+
+def test_lint_sees_a_matrix_result_read_too_early(tmp_path):
+    hits = _scan_mfma(MFMA_EARLY, tmp_path, "early.s")
+    assert len(hits) == 1 and "v_accvgpr_read_b32 v9, a8" in hits[0][2]
+    assert _scan_mfma(MFMA_PINNED, tmp_path, "pinned.s") == []
+    assert len(_scan_mfma(MFMA_BACK_TO_BACK, tmp_path, "b2b.s")) >= 1
+    assert _scan_mfma(MFMA_ROUND_ROBIN, tmp_path, "rr.s") == []
+
+
 def test_assembly_of_the_built_library_is_clean():
     files = glob.glob(os.path.join(ROOT, "hector_amd", "build", "hx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"))
     if not files:
         import pytest
         pytest.skip("no assembly in hector_amd/build (the library was not built in this tree)")
     assert check_isa.scan(files[0]) == []
+    assert check_isa.scan_mfma(files[0]) == []

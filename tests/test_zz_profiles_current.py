@@ -21,3 +21,6 @@ def test_pmc_index_matches_the_kernel_sources():
         assert e, "no counters for configuration %s of kernel source %s" % (cfg, h)
         assert e["traffic_bytes_per_launch"] > 0 and e["fp64_flops_per_launch"] > 0
         assert os.path.exists(os.path.join(ROOT, e["source"]))
+        assert e.get("compiler") == bench.compiler_id(), (
+            "the counters of %s were collected on a build by %r, this tree builds with %r"
+            % (cfg, e.get("compiler"), bench.compiler_id()))

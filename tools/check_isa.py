@@ -18,7 +18,19 @@ between the label of an s_cbranch_execz target and that block's exec restore, an
 was NOT written inside the branch that ends there, unless the same AGPR was also assigned a few
 hundred lines earlier (the other arm of an if / else that merges two values into it).  (A value
 the branch computed may be copied under the branch's mask: the other lanes got theirs before
-the branch.  A value from outside the branch may not.)  Exit status 1 if there is any."""
+the branch.  A value from outside the branch may not.)  Exit status 1 if there is any.
+
+Second check (scan_mfma): the fp64 matrix-pipe pass keeps its accumulators in AGPRs across the
+loop by an `asm` statement that hides the v_mfma results from the compiler's hazard recogniser
+and carries the wait states itself (hx_kernels.hip, doeclim_pass_mfma).  That is only correct
+while the wait really sits between every v_mfma_f64_16x16x4_f64 and the first instruction that
+reads its destination: here every read of an AGPR range (SrcC of a later v_mfma, v_accvgpr_read,
+a store straight from AGPRs) is required to be at least MFMA_WAIT wait states behind the last
+v_mfma that wrote that range (an `s_nop N` counts N + 1, a v_mfma its 8 passes, anything else
+1; a back-to-back
+accumulate into the SAME range by the next-but-seven v_mfma, the loop's own rhythm, is counted
+the same way), with loop bodies that hold v_mfma's walked twice so that the back edge is
+covered."""
 import re
 import sys
 
@@ -93,12 +105,93 @@ def scan(path):
     return found
 
 
+MFMA = re.compile(r"^\s*v_mfma_f64_16x16x4_f64\s+a\[(\d+):(\d+)\],\s*\S+,\s*\S+,\s*(a\[(\d+):(\d+)\]|\S+)")
+AREAD = re.compile(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b")
+MFMA_WAIT = 18   # 8 passes of a 16x16x4 fp64 MFMA: its result may be read 18 wait states later
+MFMA_PASSES = 8  # issue slots a v_mfma_f64_16x16x4_f64 itself occupies
+
+
+def scan_mfma(path):
+    """-> [(kernel, line number, text, wait states seen)]: AGPR reads too close behind the
+    v_mfma that produced them."""
+    lines = open(path, errors="replace").read().split("\n")
+    found = []
+    kernels, cur = [], None
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+|hx_\w+):", l)
+        if m:
+            cur = (m.group(1), [])
+            kernels.append(cur)
+            continue
+        if cur is None:
+            continue
+        s = l.strip()
+        if s.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        if not s or s[0] == ";" or (s[0] == "." and not s.startswith(".LBB")):
+            continue
+        cur[1].append((i + 1, s))
+    for name, ins in kernels:
+        if not any(t.startswith("v_mfma_f64") for _, t in ins):
+            continue
+        # walk loop bodies with MFMAs twice (the back edge)
+        labels = {t.split(":")[0]: k for k, (_, t) in enumerate(ins) if t.startswith(".LBB")}
+        stream = []
+        for k, (ln, t) in enumerate(ins):
+            stream.append((ln, t))
+            op = t.split()[0]
+            if op.startswith(("s_cbranch", "s_branch")):
+                tgt = t.split()[-1]
+                if tgt in labels and labels[tgt] < k and any(x.startswith("v_mfma_f64") for _, x in ins[labels[tgt]:k]):
+                    stream.extend(ins[labels[tgt]:k + 1])
+        clock = 0
+        written = {}   # AGPR index -> clock of the v_mfma that last wrote it
+        for ln, t in stream:
+            if t.startswith(".LBB"):
+                continue
+            op = t.split()[0]
+            m = MFMA.match(t)
+            reads = []
+            if m:
+                if m.group(4) is not None:
+                    reads = list(range(int(m.group(4)), int(m.group(5)) + 1))
+            elif op.startswith(("v_accvgpr_read", "v_accvgpr_mov", "global_store", "scratch_store", "ds_write", "buffer_store")):
+                body = t[len(op):]
+                if op.startswith("v_accvgpr"):
+                    body = body.split(",", 1)[1] if "," in body else ""
+                for r in AREAD.finditer(body):
+                    if r.group(1) is not None:
+                        reads.extend(range(int(r.group(1)), int(r.group(2)) + 1))
+                    else:
+                        reads.append(int(r.group(3)))
+            for a in reads:
+                if a in written and clock - written[a] < MFMA_WAIT:
+                    found.append((name, ln, t, clock - written[a]))
+                    break
+            if m:
+                for a in range(int(m.group(1)), int(m.group(2)) + 1):
+                    written[a] = clock
+            elif op.startswith("v_accvgpr_write"):
+                mm = re.match(r"v_accvgpr_write_b32\s+a(\d+)", t)
+                if mm:
+                    written.pop(int(mm.group(1)), None)
+            n = re.match(r"s_nop\s+(\d+)", t)
+            clock += int(n.group(1)) + 1 if n else (MFMA_PASSES if m else 1)
+    return found
+
+
 def main():
     found = scan(sys.argv[1])
     for k, b, ln, text in found:
         print("%s %s line %d: %s  <- saved under the branch's execution mask, not written in the branch" % (k, b, ln, text))
+    hazards = scan_mfma(sys.argv[1])
+    for k, ln, text, seen in hazards:
+        print("%s line %d: %s  <- reads a v_mfma result after %d wait state(s), needs %d" % (k, ln, text, seen, MFMA_WAIT))
     print("%d suspicious register save(s)" % len(found))
-    sys.exit(1 if found else 0)
+    if hazards:
+        print("%d v_mfma result(s) read too early" % len(hazards))
+    sys.exit(1 if (found or hazards) else 0)
 
 
 if __name__ == "__main__":

@@ -49,6 +49,9 @@ def counters(d, kernel=("hx_run_kernel", "hx_pair_kernel"), name_out=None):
     return best
 
 
+import bench  # noqa: E402
+
+
 def main():
     tag = sys.argv[1]
     index_path = os.path.join(P, "pmc_index.json")
@@ -116,6 +119,7 @@ def main():
             "valu_active_frac": der["valu_active_frac"],
             "lane_utilisation": lane_util,
             "source": "profiles/%s_pmc_%s.json" % (tag, cfg),
+            "compiler": bench.compiler_id(),   # bench.py refuses the figures for another compiler's build
         }
         print(cfg, json.dumps(der, indent=1))
     json.dump(index, open(index_path, "w"), indent=1, sort_keys=True)
