@@ -144,6 +144,14 @@ __device__ __forceinline__ bool pair_control(PairCtl &c, double err, unsigned &s
   return true;
 }
 
+// before an attempt: the clip of dt to the target, and whether a retry is due (see solve_year)
+__device__ __forceinline__ bool pair_clip_need(PairCtl &c) {
+#pragma clang fp contract(off)
+  constexpr double EPS = 2.220446049250313e-16;
+  if (c.stepping && ((c.t + c.dtl) - c.t_target) > EPS) c.dtl = c.t_target - c.t;
+  return c.stepping && ((c.t + c.dtl) - c.ode_start) > c.max_ts;
+}
+
 // the retries before an attempt (carbon-cycle-solver.cpp:266-276; see solve_year): bookkeeping
 // only; returns true if the caller has to reload its pools
 __device__ __forceinline__ bool pair_retry(PairCtl &c, unsigned &status) {
@@ -358,19 +366,18 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       PSTAMP(4);
       while (__any(c.alive && c.t < tnew)) {
         const bool seg = c.alive && c.t < tnew;
-        c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = true; c.fails = 0;
+        c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = false; c.fails = 0;
         c.stepping = seg;
+        // (as in solve_year: the fresh stepper's first RHS ahead of the loop, the attempt as
+        // straight-line code for every lane, retries behind a uniform rare branch)
+        rhs(y, dxdt, 0);
         while (__any(c.stepping)) {
-          double xn[2], dn[2], en[2] = {0, 0}, ed[2] = {1, 1};
-          bool tried = false;
-          if (c.stepping) {
-            if (pair_retry(c, status)) load_pools();
-            if (c.stepping) {
-              if (c.first_call) { rhs(y, dxdt, 0); c.first_call = false; }
-              pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
-              tried = true;
-            }
+          double xn[2], dn[2], en[2], ed[2];
+          if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
+            if (c.stepping && pair_retry(c, status)) { load_pools(); rhs(y, dxdt, 0); }
           }
+          const bool tried = c.stepping;
+          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
           if (!sums_done) history_sums(iy);
           s_st[par][PS_N0][lane] = en[0]; s_st[par][PS_D0][lane] = ed[0];
           s_st[par][PS_N4][lane] = en[1]; s_st[par][PS_D4][lane] = ed[1];
@@ -713,30 +720,27 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       PSTAMP(4);
       while (__any(c.alive && c.t < tnew)) {
         const bool seg = c.alive && c.t < tnew;
-        c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = true; c.fails = 0;
+        c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = false; c.fails = 0;
         c.stepping = seg;
         double y0c = 0, y4c = 0;  // the ocean side's atmosphere / ocean totals after the last accepted step
+        auto first_rhs = [&]() { rrs[0] = hx_div1(luc_e, y[0] + y[1] + y[2]); rhs(y, dxdt, 0); };
+        first_rhs();  // (the fresh stepper's first RHS, ahead of the loop: see the ocean side)
         while (__any(c.stepping)) {
-          double xn[3], dn[3], en[3] = {0, 0, 0}, ed[3] = {1, 1, 1};
-          bool tried = false;
-          if (c.stepping) {
-            if (pair_retry(c, status)) load_pools();
-            if (c.stepping) {
-              {
-                const double tot0 = y[0] + y[1] + y[2];
-                const double hC = c.dtl * ((((v1 + luc_u) + d2c) + s3c) - luc_e);
-                rrs[0] = hx_div1(luc_e, tot0);
-                rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
-                rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
-                rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
-                rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
-                rrs[5] = hx_div1(luc_e, tot0 + hC);
-              }
-              if (c.first_call) { rhs(y, dxdt, 0); c.first_call = false; }
-              pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
-              tried = true;
-            }
+          double xn[3], dn[3], en[3], ed[3];
+          if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
+            if (c.stepping && pair_retry(c, status)) { load_pools(); first_rhs(); }
           }
+          const bool tried = c.stepping;
+          {
+            const double tot0 = y[0] + y[1] + y[2];
+            const double hC = c.dtl * ((((v1 + luc_u) + d2c) + s3c) - luc_e);
+            rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
+            rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
+            rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
+            rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
+            rrs[5] = hx_div1(luc_e, tot0 + hC);
+          }
+          pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
           double bn = 0.0, bd = 1.0;  // first-largest quotient of the three
 #pragma unroll
           for (int i = 0; i < 3; ++i) if (en[i] * bd > bn * ed[i]) { bn = en[i]; bd = ed[i]; }
