@@ -68,8 +68,9 @@ struct Dp5 {
                           dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
 };
 
-// one dopri5 attempt on NP variables: candidate xn, its derivative dn, and the error quotient
-// parts n_i = |xe_i|, d_i = eps_abs + eps_rel (|y_i| + dt |dy_i|) of every variable
+// one dopri5 attempt on NP variables: candidate xn, its derivative dn, and the error quotients
+// en_i = |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)) of every variable (the divisions side
+// by side here, BEFORE the hand-off: after the barrier an attempt's error is two maxima away)
 template <int NP, class Rhs>
 __device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double eps_abs,
                                              double eps_rel, const double *y, const double *dxdt,
@@ -104,22 +105,15 @@ __device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double 
   for (int i = 0; i < NP; ++i) {
     const double xe = dtl * Dp5::dc1 * dxdt[i] + dtl * Dp5::dc3 * k3[i] + dtl * Dp5::dc4 * k4[i] +
                       dtl * Dp5::dc5 * k5[i] + dtl * Dp5::dc6 * k6[i] + dtl * Dp5::dc7 * dn[i];
-    en[i] = fabs(xe);
-    ed[i] = eps_abs + eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
+    en[i] = hx_div(fabs(xe), eps_abs + eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i])));
   }
+  (void)ed;
 }
 
-// default_error_checker over all five variables in the reference's order 0, 1..3, 4: the land side
-// hands over its first-largest quotient of 1..3, so the maximum (found by cross-multiplication,
-// divided once) is the one the single-wavefront kernel finds
-__device__ __forceinline__ double pair_err(double n0, double d0, double nl, double dl, double n4,
-                                           double d4) {
-#pragma clang fp contract(off)
-  double en = 0.0, ed = 1.0;
-  if (n0 * ed > en * d0) { en = n0; ed = d0; }
-  if (nl * ed > en * dl) { en = nl; ed = dl; }
-  if (n4 * ed > en * d4) { en = n4; ed = d4; }
-  return hx_div(en, ed);
+// default_error_checker over all five variables: the maximum of the quotients (the land side
+// hands over the largest of its three), like odeint and like solve_year
+__device__ __forceinline__ double pair_err(double q0, double ql, double q4) {
+  return fmax(fmax(fmax(0.0, q0), ql), q4);
 }
 
 // what both wavefronts do with the error of an attempt (controlled_runge_kutta::try_step +
@@ -379,15 +373,14 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
           const bool tried = c.stepping;
           pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
           if (!sums_done) history_sums(iy);
-          s_st[par][PS_N0][lane] = en[0]; s_st[par][PS_D0][lane] = ed[0];
-          s_st[par][PS_N4][lane] = en[1]; s_st[par][PS_D4][lane] = ed[1];
+          s_st[par][PS_N0][lane] = en[0];
+          s_st[par][PS_N4][lane] = en[1];
           s_st[par][PS_X0][lane] = xn[0]; s_st[par][PS_X4][lane] = xn[1];
           PSTAMPF(12);
           __syncthreads();
           PSTAMPF(13);
           if (tried) {
-            const double err = pair_err(en[0], ed[0], s_st[par][PS_NL][lane], s_st[par][PS_DL][lane],
-                                        en[1], ed[1]);
+            const double err = pair_err(en[0], s_st[par][PS_NL][lane], en[1]);
             if (pair_control(c, err, status)) { y[0] = xn[0]; y[1] = xn[1]; dxdt[0] = dn[0]; dxdt[1] = dn[1]; }
           }
           par ^= 1;
@@ -741,16 +734,13 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
             rrs[5] = hx_div1(luc_e, tot0 + hC);
           }
           pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
-          double bn = 0.0, bd = 1.0;  // first-largest quotient of the three
-#pragma unroll
-          for (int i = 0; i < 3; ++i) if (en[i] * bd > bn * ed[i]) { bn = en[i]; bd = ed[i]; }
-          s_st[par][PS_NL][lane] = bn; s_st[par][PS_DL][lane] = bd;
+          const double bn = fmax(fmax(en[0], en[1]), en[2]);  // largest quotient of the three
+          s_st[par][PS_NL][lane] = bn;
           PSTAMPF(12);
           __syncthreads();
           PSTAMPF(13);
           if (tried) {
-            const double err = pair_err(s_st[par][PS_N0][lane], s_st[par][PS_D0][lane], bn, bd,
-                                        s_st[par][PS_N4][lane], s_st[par][PS_D4][lane]);
+            const double err = pair_err(s_st[par][PS_N0][lane], bn, s_st[par][PS_N4][lane]);
             const double used = c.dtl;
             if (pair_control(c, err, status)) {
               l4 += used * k4; l7 += used * k7; l5 += used * k5;
