@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from bench import kernel_source_hash  # noqa: E402
+from bench import kernel_source_hash, compiler_id  # noqa: E402
 
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
@@ -47,9 +47,6 @@ def counters(d, kernel=("hx_run_kernel", "hx_pair_kernel"), name_out=None):
     for (_, cn), v in acc.items():
         best[cn] = max(best.get(cn, 0.0), v)
     return best
-
-
-import bench  # noqa: E402
 
 
 def main():
@@ -119,7 +116,7 @@ def main():
             "valu_active_frac": der["valu_active_frac"],
             "lane_utilisation": lane_util,
             "source": "profiles/%s_pmc_%s.json" % (tag, cfg),
-            "compiler": bench.compiler_id(),   # bench.py refuses the figures for another compiler's build
+            "compiler": compiler_id(),   # bench.py refuses the figures for another compiler's build
         }
         print(cfg, json.dumps(der, indent=1))
     json.dump(index, open(index_path, "w"), indent=1, sort_keys=True)
