@@ -3,6 +3,9 @@
 // reference file:line map).
 #pragma once
 
+// the looped kernels' park (dynamic LDS: hx_npark_dyn(nbiome) x 512 B, set at launch)
+extern __shared__ double hx_dyn_park[][64];
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -37,10 +40,17 @@ constexpr int HX_NBIOME_ARR = 9;
 // reference creates any number of biomes (simpleNbox.cpp:864-1124); 1-4 have unrolled kernels.
 constexpr int HX_DYN = 0;
 template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : B; }
+// The looped kernels size their park for the core's biome count at launch (dynamic LDS) and do
+// NOT park the 21 DOECLIM / ocean-exchange constants (read from the derived table where they are
+// used: three loads a year against a model year of ~100k cycles): 14 + 10 nb slots -- 33 KB for
+// five biomes, 49 KB for eight -- so that up to four wavefronts share a CU where the fixed
+// 97.5 KB allowed one.
+template <int B> constexpr int pk_ff0() { return B == HX_DYN ? (int)PK_D0 : (int)PK_FFROZEN0; }
 template <int B> constexpr int hx_npark() {
-  return PK_FFROZEN0 + hx_bmax<B>() + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * hx_bmax<B>());
+  return pk_ff0<B>() + hx_bmax<B>() + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * hx_bmax<B>());
 }
-template <int B> constexpr int hx_pkb1() { return PK_FFROZEN0 + hx_bmax<B>(); }
+__host__ __device__ inline int hx_npark_dyn(int nb) { return PK_D0 + nb + HX_NBIOME_ARR * nb; }
+template <int B> constexpr int hx_pkb1() { return pk_ff0<B>() + hx_bmax<B>(); }
 
 // Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
 // registers, 36 doubles for B = 4 on top of the solver's working set overflow 256 VGPRs +
@@ -97,6 +107,12 @@ template <int B> __device__ __forceinline__ int nbio(const Member<B> &m) {
   if constexpr (B == HX_DYN) return m.nb; else return B;
 }
 #define PKM(m, slot) ((m).pk[(slot)][(m).lane])
+// a member's DOECLIM / ocean-exchange constant (row HXD_A0.. / HXD_KLH.. of the derived table):
+// from the park, or -- looped kernels -- from the table itself
+template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, int row) {
+  if constexpr (B == HX_DYN) return m.der[(size_t)row * m.npad];
+  else return PKM(m, row >= HXD_KLH && row < HXD_KLH + 7 ? PK_K0 + (row - HXD_KLH) : PK_D0 + (row - HXD_A0));
+}
 
 // biome constants of the land model, fetched where they are used
 template <int B>
@@ -186,12 +202,13 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   m.upar = (B != 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
   m.nb = buf.nbiome;
   if constexpr (B != 1) {
-    constexpr int o = hx_pkb1<B>();
+    const int bm = (B == HX_DYN) ? buf.nbiome : hx_bmax<B>();   // slots per array
+    const int o = pk_ff0<B>() + bm;
     ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
                                    &m.co2fert, &m.tempfertd, &m.f_new_thaw};
 #pragma unroll
     for (int k = 0; k < HX_NBIOME_ARR; ++k) {
-      arr[k]->base = park + o + k * hx_bmax<B>();
+      arr[k]->base = park + o + k * bm;
       arr[k]->lane = lane;
     }
   }
@@ -199,10 +216,12 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   // constants -> park
   PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
   PKM(m, PK_VOL) = ldp(buf, HXP_VOL, mem);
+  if constexpr (B != HX_DYN) {
 #pragma unroll
-  for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
+    for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
 #pragma unroll
-  for (int k = 0; k < 7; ++k) PKM(m, PK_K0 + k) = ldd(buf, HXD_KLH + k, mem);
+    for (int k = 0; k < 7; ++k) PKM(m, PK_K0 + k) = ldd(buf, HXD_KLH + k, mem);
+  }
   if constexpr (B == 1) {
     constexpr int o = hx_pkb1<B>();
     const int r = HXP_NGLOBAL;
@@ -290,7 +309,7 @@ __device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
   if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
 #pragma unroll
   for (int b = 0; b < nbio<B>(m); ++b)
-    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, PK_FFROZEN0 + b));
+    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, pk_ff0<B>() + b));
 }
 
 }  // namespace

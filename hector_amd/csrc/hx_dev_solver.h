@@ -199,10 +199,9 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
                                       Interval &K2, const YearCon &yc, bool more) {
   LandK<B> lk;
   load_landk<B>(m, lk);
-  const double kHD = PKM(m, PK_K0 + (HXD_KHD - HXD_KLH)), kLH = PKM(m, PK_K0 + 0),
-               kLI = PKM(m, PK_K0 + (HXD_KLI - HXD_KLH)), kIL = PKM(m, PK_K0 + (HXD_KIL - HXD_KLH)),
-               kIH = PKM(m, PK_K0 + (HXD_KIH - HXD_KLH)), kID = PKM(m, PK_K0 + (HXD_KID - HXD_KLH)),
-               kDI = PKM(m, PK_K0 + (HXD_KDI - HXD_KLH));
+  const double kHD = dconst<B>(m, HXD_KHD), kLH = dconst<B>(m, HXD_KLH), kLI = dconst<B>(m, HXD_KLI),
+               kIL = dconst<B>(m, HXD_KIL), kIH = dconst<B>(m, HXD_KIH), kID = dconst<B>(m, HXD_KID),
+               kDI = dconst<B>(m, HXD_KDI);
   const double yf = t - m.ode_start;
   m.nstash++;
   const bool in_partial_year = (t != floor(t));

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   const HxConst &kc = args->kc;
   const int mem = blockIdx.x * 64 + threadIdx.x;
   if (mem >= buf.npad) return;
-  __shared__ double s_park[hx_npark<B>()][64];
+  __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
+  double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
   bind_member<B>(buf, mem, m, s_park, (int)threadIdx.x);
   // initial conditions: ocean_component.cpp:234-260, simpleNbox.cpp:45-79,
@@ -445,7 +446,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   const int lane = threadIdx.x;
   const int mem = blockIdx.x * 64 + lane;
   if (mem >= args->buf.npad) return;
-  __shared__ double s_park[hx_npark<B>()][64];
+  __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
+  double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
   bind_member<B>(args->buf, mem, m, s_park, lane);
 #ifdef HX_PHASE_CLOCK
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     PKM(m, PK_LN_CO2R) = hx_log(hx_div(m.atmos * PGC2PPM, m.C0));
 #pragma unroll
     for (int b = 0; b < nbio<B>(m); ++b)
-      PKM(m, PK_FFROZEN0 + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
+      PKM(m, pk_ff0<B>() + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
   }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       if constexpr (B != HX_DYN) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        s_ffrozen[b] = PKM(m, PK_FFROZEN0 + b);
+        s_ffrozen[b] = PKM(m, pk_ff0<B>() + b);
         if constexpr (B == 1) {
           constexpr int o = hx_pkb1<B>();
           p_beta[b] = PKM(m, o + PKB_BETA); p_wf[b] = PKM(m, o + PKB_WF);
@@ -705,8 +707,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
                                       ldp(buf, pr + HXPB_PF_SIGMA, mem) * 1.4142135623730951);
               ff = 1 - erfc(-d) / 2;
             }
-            m.f_new_thaw[b] = PKM(m, PK_FFROZEN0 + b) - ff;
-            PKM(m, PK_FFROZEN0 + b) = ff;
+            m.f_new_thaw[b] = PKM(m, pk_ff0<B>() + b) - ff;
+            PKM(m, pk_ff0<B>() + b) = ff;
           }
           const double Trm = (iy > 1) ? (twin * wf) * 0.005 : 0.0;
           const double tfs = hx_exp(lnq10 * (Trm * 0.1));
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
             ff = 1 - erfc(-d) / 2;
           }
           m.f_new_thaw[b] = s_ffrozen[b] - ff;
-          PKM(m, PK_FFROZEN0 + b) = ff;
+          PKM(m, pk_ff0<B>() + b) = ff;
         }
         const double tfs = ex[14 + 2 * b];  // exp(ln q10 * Trm / 10), Trm = 200-year mean
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       const double base_tot = PKM(m, PK_BASE_TOT), base_co2 = PKM(m, PK_BASE_CO2);
       const double tl_m1 = PKM(m, PK_TL_M1);
       const double p_aero = PKM(m, PK_AERO), p_vol = PKM(m, PK_VOL);
-#define HXDK(row) PKM(m, PK_D0 + ((row) - HXD_A0))
+#define HXDK(row) dconst<B>(m, (row))
       const double dA0 = HXDK(HXD_A0), dA1 = HXDK(HXD_A1), dA2 = HXDK(HXD_A2), dA3 = HXDK(HXD_A3),
                    dIB0 = HXDK(HXD_IB0), dIB1 = HXDK(HXD_IB1), dIB2 = HXDK(HXD_IB2),
                    dIB3 = HXDK(HXD_IB3), dQC1 = HXDK(HXD_QC1), dQC2 = HXDK(HXD_QC2),
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
           putb(HXOB_VEG, m.veg[b]); putb(HXOB_DET, m.det[b]); putb(HXOB_SOIL, m.soil[b]);
           putb(HXOB_PF, m.pf[b]); putb(HXOB_THAWED, m.thawed[b]);
           putb(HXOB_RH_CH4, m_rh_tp_ch4(m, lkb, b));
-          putb(HXOB_F_FROZEN, PKM(m, PK_FFROZEN0 + b));
+          putb(HXOB_F_FROZEN, PKM(m, pk_ff0<B>() + b));
           putb(HXOB_TEMPFERTD, m.tempfertd[b]); putb(HXOB_TEMPFERTS, m.tempferts[b]);
         }
       }
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         for (int b = 0; b < nbio<B>(m); ++b) { rch4 += m_rh_tp_ch4(m, lk, b); ptot += m.pf[b]; }
         if (ptot > 0.0) {
 #pragma unroll
-          for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * PKM(m, PK_FFROZEN0 + b);
+          for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * PKM(m, pk_ff0<B>() + b);
         } else ff = 1.0;
         if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rch4);
         if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);
@@ -1421,6 +1423,17 @@ __global__ void hx_unit_csys_kernel(int n, const double *Tc, const double *carbo
 // host-callable launchers (the only symbols the host runtime uses)
 // ---------------------------------------------------------------------------
 extern "C++" {
+// dynamic LDS of a looped kernel for nb biomes (hx_dev_member.h: hx_npark_dyn)
+static size_t hx_dyn_lds_bytes(int nb) { return (size_t)hx_npark_dyn(nb) * 64 * sizeof(double); }
+static void hx_allow_dynamic_lds(const void *kernel, size_t bytes) {
+#if HX_HAS_MFMA   // (the host-emulation build has no such attribute)
+  if (bytes > 64 * 1024)   // beyond the default window a kernel has to be told
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+#else
+  (void)kernel; (void)bytes;
+#endif
+}
+
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st) {
   const int blocks = (nmem_launch + 63) / 64;
@@ -1433,7 +1446,11 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
     case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     default:
       if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
-      hipLaunchKernelGGL(hx_spinup_kernel<HX_DYN>, dim3(blocks), dim3(64), 0, st, d_args, d_steps);
+      {
+        const size_t lds = hx_dyn_lds_bytes(B);
+        hx_allow_dynamic_lds(reinterpret_cast<const void *>(&hx_spinup_kernel<HX_DYN>), lds);
+        hipLaunchKernelGGL(hx_spinup_kernel<HX_DYN>, dim3(blocks), dim3(64), lds, st, d_args, d_steps);
+      }
   }
   return hipGetLastError();
 }
@@ -1446,9 +1463,22 @@ hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) 
 
 template <int B>
 static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st) {
+                         int iy_from, int iy_to, hipStream_t st, int nb = B) {
   const int blocks = npad / 64;
-  const size_t lds = 0;
+  const size_t lds = (B == HX_DYN) ? hx_dyn_lds_bytes(nb) : 0;
+  if constexpr (B == HX_DYN) {
+    for (const void *k : {reinterpret_cast<const void *>(&hx_run_kernel<B, false, false, 0>),
+#ifndef HX_MINIMAL_BUILD
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 0>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, false, true, 0>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 0>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 1>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 1>),
+#endif
+                          static_cast<const void *>(nullptr)})
+      if (k)
+      hx_allow_dynamic_lds(k, lds);
+  }
   if constexpr (B == HX_DYN) {  // the looped kernels: no carbon tracking
     if (con == 2) return;
   }
@@ -1511,7 +1541,7 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     default:
       if (B < 1 || B > HX_BDYN || con == 2) return hipErrorInvalidValue;
-      launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st);
+      launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B);
   }
   return hipGetLastError();
 }
