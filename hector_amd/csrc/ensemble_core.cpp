@@ -447,6 +447,7 @@ void EnsembleCore::build_shared() {
   k.delta_co2 = s.scalar("forcing", "delta_co2"); k.delta_ch4 = s.scalar("forcing", "delta_ch4");
   k.delta_n2o = s.scalar("forcing", "delta_n2o");
   k.o3_rf = component_disabled("ozone") ? 0.0 : 0.042;
+  hx_fill_tableau(k.tab);
 }
 
 void EnsembleCore::free_device() {

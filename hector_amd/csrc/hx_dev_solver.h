@@ -451,6 +451,44 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                                            double t0, double tnew, const YearCon &yc) {
   constexpr int NP = CON ? 6 : 5;  // solver variables (see rhs)
   // dopri5 tableau (odeint runge_kutta_dopri5)
+#ifndef HX_TAB_LITERALS
+  // The tableau as DATA (HxConst::tab, in the order a step uses it) behind wide scalar loads:
+  // as literals its 30 constants cost 60 s_mov in every pass of the step loop (a 64-bit literal
+  // is two s_mov_b32, and with machine LICM off -- see the Makefile -- they are materialised where
+  // they are used), 12 % of the pass's instructions; five s_load_dwordx8/x16 a pass instead.
+  // (-DHX_TAB_LITERALS: the old form, for experiment builds.)
+  const double *const T = kc.tab;
+#define b21 T[0]
+#define f2 T[1]
+#define b31 T[2]
+#define b32 T[3]
+#define f3 T[4]
+#define b41 T[5]
+#define b42 T[6]
+#define b43 T[7]
+#define f4 T[8]
+#define b51 T[9]
+#define b52 T[10]
+#define b53 T[11]
+#define b54 T[12]
+#define f5 T[13]
+#define b61 T[14]
+#define b62 T[15]
+#define b63 T[16]
+#define b64 T[17]
+#define b65 T[18]
+#define c1 T[19]
+#define c3 T[20]
+#define c4 T[21]
+#define c5 T[22]
+#define c6 T[23]
+#define dc1 T[24]
+#define dc3 T[25]
+#define dc4 T[26]
+#define dc5 T[27]
+#define dc6 T[28]
+#define dc7 T[29]
+#else
   constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45,
                    b42 = -56.0 / 15, b43 = 32.0 / 9, b51 = 19372.0 / 6561,
                    b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
@@ -461,6 +499,8 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   constexpr double dc1 = c1 - 5179.0 / 57600, dc3 = c3 - 7571.0 / 16695,
                    dc4 = c4 - 393.0 / 640, dc5 = c5 - (-92097.0 / 339200),
                    dc6 = c6 - 187.0 / 2100, dc7 = -1.0 / 40;
+  constexpr double f2 = 1.0 / 5, f3 = 3.0 / 10, f4 = 4.0 / 5, f5 = 8.0 / 9;
+#endif
   constexpr double EPS = 2.220446049250313e-16;
 
   Interval K, K2s;
@@ -545,10 +585,10 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       if constexpr (RT) {
         const double tot0 = (y[1] + y[2]) + y[3];
         const double hC = dtl * K.dtot;
-        rr[0] = hx_div1(m.luc_e, fma(hC, 1.0 / 5, tot0));
-        rr[1] = hx_div1(m.luc_e, fma(hC, 3.0 / 10, tot0));
-        rr[2] = hx_div1(m.luc_e, fma(hC, 4.0 / 5, tot0));
-        rr[3] = hx_div1(m.luc_e, fma(hC, 8.0 / 9, tot0));
+        rr[0] = hx_div1(m.luc_e, fma(hC, f2, tot0));
+        rr[1] = hx_div1(m.luc_e, fma(hC, f3, tot0));
+        rr[2] = hx_div1(m.luc_e, fma(hC, f4, tot0));
+        rr[3] = hx_div1(m.luc_e, fma(hC, f5, tot0));
         rr[4] = hx_div1(m.luc_e, tot0 + hC);
       }
 #pragma unroll
@@ -628,3 +668,35 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 }
 
 }  // namespace
+#ifndef HX_TAB_LITERALS
+#undef b21
+#undef f2
+#undef b31
+#undef b32
+#undef f3
+#undef b41
+#undef b42
+#undef b43
+#undef f4
+#undef b51
+#undef b52
+#undef b53
+#undef b54
+#undef f5
+#undef b61
+#undef b62
+#undef b63
+#undef b64
+#undef b65
+#undef c1
+#undef c3
+#undef c4
+#undef c5
+#undef c6
+#undef dc1
+#undef dc3
+#undef dc4
+#undef dc5
+#undef dc6
+#undef dc7
+#endif

@@ -148,7 +148,24 @@ struct HxConst {
   double N0, sqrtN0;
   double delta_co2, delta_ch4, delta_n2o;
   double o3_rf;        // 0.042 W/m2 per DU, or 0 when the ozone component is disabled
+  // dopri5 tableau in the order a step uses it (hx_fill_tableau), for builds that read it as data
+  double tab[32];
 };
+// stage 2: b21, 1/5 | 3: b31 b32 3/10 | 4: b41 b42 b43 4/5 | 5: b51..b54 8/9 | 6: b61..b65 |
+// candidate: c1 c3 c4 c5 c6 | error: dc1 dc3 dc4 dc5 dc6 dc7
+inline void hx_fill_tableau(double *t) {
+  const double c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+  const double v[30] = {1.0 / 5, 1.0 / 5,
+                        3.0 / 40, 9.0 / 40, 3.0 / 10,
+                        44.0 / 45, -56.0 / 15, 32.0 / 9, 4.0 / 5,
+                        19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 8.0 / 9,
+                        9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656,
+                        c1, c3, c4, c5, c6,
+                        c1 - 5179.0 / 57600, c3 - 7571.0 / 16695, c4 - 393.0 / 640,
+                        c5 - (-92097.0 / 339200), c6 - 187.0 / 2100, -1.0 / 40};
+  for (int i = 0; i < 30; ++i) t[i] = v[i];
+  t[30] = t[31] = 0.0;
+}
 
 // pointers handed to the kernels
 struct HxBuffers {
