@@ -19,15 +19,52 @@ class HectorAmdError(RuntimeError):
     pass
 
 
-def _share_torch_hip_runtime():
+def _elf_dynamic_strings(path, tags):
+    """Values of string-valued entries of an ELF64 file's dynamic section (DT_NEEDED = 1,
+    DT_SONAME = 14) -> {tag: [strings]}; {} if the file cannot be read that way."""
+    import struct
+    out = {t: [] for t in tags}
+    try:
+        with open(path, "rb") as f:
+            d = f.read()
+        if d[:4] != b"\x7fELF" or d[4] != 2:
+            return {}
+        shoff, = struct.unpack_from("<Q", d, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", d, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", d, shoff + i * shentsize) for i in range(shnum)]
+        for (_n, typ, _fl, _ad, off, size, link, _i, _al, ent) in secs:
+            if typ != 6:     # SHT_DYNAMIC
+                continue
+            stroff = secs[link][4]
+            for k in range(size // (ent or 16)):
+                tag, val = struct.unpack_from("<qQ", d, off + k * 16)
+                if tag in out:
+                    end = d.index(b"\0", stroff + val)
+                    out[tag].append(d[stroff + val:end].decode())
+        return out
+    except Exception:
+        return {}
+
+
+def _share_torch_hip_runtime(lib_path):
     """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME
     libamdhip64.so.7) which libtorch_hip.so asks for by FILE name: if the system runtime is already
     in the process under its SONAME (because this library was loaded first), the dynamic loader
     does not recognise it, torch brings in a second runtime and its device init fails with "No HIP
     GPUs are available".  The other order works (this library asks for the SONAME and gets torch's
     copy).  So where a torch installation with its own runtime exists, load that copy first --
-    without importing torch."""
+    without importing torch -- PROVIDED it is the runtime this library was linked against: its
+    SONAME has to be one of the library's DT_NEEDED entries (a wheel built for another ROCm major
+    version is left alone: the library then runs on the system runtime it was built for, and a
+    process that also wants that torch has to import torch first).  HECTOR_AMD_NO_TORCH_HIP=1
+    switches the preload off; HECTOR_AMD_VERBOSE=1 says which runtime was chosen."""
     import importlib.util
+    import sys
+    verbose = os.environ.get("HECTOR_AMD_VERBOSE") == "1"
+    if os.environ.get("HECTOR_AMD_NO_TORCH_HIP") == "1":
+        if verbose:
+            sys.stderr.write("hector_amd: HECTOR_AMD_NO_TORCH_HIP=1, system HIP runtime\n")
+        return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
@@ -35,8 +72,20 @@ def _share_torch_hip_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(rt):
-        ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+    if not os.path.exists(rt):
+        return
+    soname = (_elf_dynamic_strings(rt, (14,)).get(14) or [None])[0]
+    needed = _elf_dynamic_strings(lib_path, (1,)).get(1) or []
+    if soname is not None and needed and soname not in needed:
+        sys.stderr.write("hector_amd: PyTorch's bundled HIP runtime (%s) is not the one %s was linked "
+                         "against (%s): not preloading it; import torch BEFORE hector_amd if both are "
+                         "needed in one process\n"
+                         % (soname, os.path.basename(lib_path),
+                            ", ".join(n for n in needed if "amdhip" in n) or "?"))
+        return
+    ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+    if verbose:
+        sys.stderr.write("hector_amd: HIP runtime %s (%s)\n" % (rt, soname))
 
 
 def load(path=None, allow_emulation=False):
@@ -44,13 +93,13 @@ def load(path=None, allow_emulation=False):
     if path in _cache:
         lib = _cache[path]
     else:
-        if os.sep + os.path.join("tests", "emul") + os.sep not in path:
-            _share_torch_hip_runtime()
         if not os.path.exists(path):
             raise HectorAmdError(
                 "hector_amd: native library %s not found -- build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); there is no Python/CPU fallback" % path)
+        if os.sep + os.path.join("tests", "emul") + os.sep not in path:
+            _share_torch_hip_runtime(path)
         lib = ctypes.CDLL(path)
         _declare(lib)
         _cache[path] = lib

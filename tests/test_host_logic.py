@@ -189,3 +189,23 @@ def test_lane_calibration_reorders_lanes_and_keeps_results(emul_lib):
     off.run(2300); off.reset(1745)
     assert not off.lanes_calibrated()
     c.shutdown(); off.shutdown()
+
+
+def test_hip_runtime_preload_checks_the_soname(hip_lib, monkeypatch, capsys):
+    """PyTorch's bundled HIP runtime is preloaded only if it is the runtime the library
+    was linked against (its SONAME among the library's DT_NEEDED), and not at all with
+    HECTOR_AMD_NO_TORCH_HIP=1."""
+    from hector_amd import _lib
+    needed = _lib._elf_dynamic_strings(hip_lib, (1,))[1]
+    assert any(n.startswith("libamdhip64.so") for n in needed)
+    assert _lib._elf_dynamic_strings(__file__, (1,)) == {}        # not an ELF file
+    loaded = []
+    monkeypatch.setattr(_lib.ctypes, "CDLL", lambda path, mode=0: loaded.append(path))
+    monkeypatch.setenv("HECTOR_AMD_NO_TORCH_HIP", "1")
+    _lib._share_torch_hip_runtime(hip_lib)
+    assert loaded == []
+    monkeypatch.delenv("HECTOR_AMD_NO_TORCH_HIP")
+    monkeypatch.setattr(_lib, "_elf_dynamic_strings",
+                        lambda path, tags: {14: ["libamdhip64.so.6"]} if 14 in tags else {1: needed})
+    _lib._share_torch_hip_runtime(hip_lib)
+    assert loaded == [] and "not preloading" in capsys.readouterr().err
