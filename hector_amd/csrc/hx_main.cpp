@@ -69,6 +69,7 @@ std::vector<double> parse_values(const std::string &txt) {
 static int run_main(int argc, char **argv) {
   std::string scenario, outdir = "output/";
   int members = 1, device = 0, precision = 0, runto = -1;
+  std::vector<int> devices;  // --devices 0,1,...: the members sharded over several GPUs
   std::vector<std::pair<std::string, std::string>> params;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -78,6 +79,7 @@ static int run_main(int argc, char **argv) {
     };
     if (a == "--members") members = std::atoi(next().c_str());
     else if (a == "--device") device = std::atoi(next().c_str());
+    else if (a == "--devices") for (double d : parse_values(next())) devices.push_back((int)d);
     else if (a == "--output-dir") { outdir = next(); if (outdir.back() != '/') outdir += '/'; }
     else if (a == "--precision") precision = std::atoi(next().c_str());
     else if (a == "--run-to") runto = std::atoi(next().c_str());
@@ -88,7 +90,8 @@ static int run_main(int argc, char **argv) {
       params.emplace_back(kv.substr(0, eq), kv.substr(eq + 1));
     } else if (a == "-h" || a == "--help") {
       std::printf("Usage: hector-amd <config file name> [--members N] [--set cap=v[,v...]]...\n"
-                  "       [--run-to year] [--output-dir dir] [--precision digits] [--device i]\n");
+                  "       [--run-to year] [--output-dir dir] [--precision digits] [--device i]\n"
+                  "       [--devices i,j,...]   (the members in contiguous blocks over several GPUs)\n");
       return 0;
     } else if (scenario.empty()) scenario = a;
     else die("unexpected argument " + a, 1);
@@ -99,7 +102,8 @@ static int run_main(int argc, char **argv) {
   else die("Couldn't find input file " + scenario, 1);
 
   hx_core *core = nullptr;
-  ck(hx_newcore(scenario.c_str(), members, device, &core));
+  if (devices.empty()) ck(hx_newcore(scenario.c_str(), members, device, &core));
+  else ck(hx_newcore_devices(scenario.c_str(), members, devices.data(), (int)devices.size(), &core));
   for (auto &kv : params) {
     const std::vector<double> v = parse_values(kv.second);
     if ((int)v.size() != 1 && (int)v.size() != members)

@@ -79,6 +79,19 @@ def test_cli_ensemble_members_and_errors(emul_lib, golden, tmp_path):
     assert r.returncode == 1 and "Usage" in r.stderr
 
 
+def test_cli_shards_the_members_over_a_device_list(emul_lib, tmp_path):
+    """hector-amd --devices i,j,...: the C++ host path over hx_newcore_devices -- the same stream
+    as one core, value for value (host build: the device list [0, 0], statistics aside)."""
+    args = ["--members", "5", "--set", "S=2.0,2.5,3.0,3.5,4.5", "--run-to", "1900", "--precision", "17"]
+    a, b = tmp_path / "one", tmp_path / "many"
+    for d, extra in ((a, []), (b, ["--devices", "0,0"])):
+        r = subprocess.run([EMUL_CLI, SCENARIO] + args + extra + ["--output-dir", str(d)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    body = lambda p: [l for l in open(p / "outputstream_ssp245.csv") if not l.startswith("#")]
+    assert body(a) == body(b) and len(body(a)) > 1000
+
+
 def test_cli_prints_biome_rows_for_multi_biome_scenarios(emul_lib, tmp_path):
     """csv_outputstream_visitor.cpp:169-198: per-biome rows when the core has several biomes."""
     from test_biomes_ini import biome_pack

@@ -101,3 +101,29 @@ def test_product_library_refuses_duplicate_devices_without_the_rehearsal_switch(
     monkeypatch.delenv("HECTOR_AMD_FLEET_REHEARSAL", raising=False)
     with pytest.raises(hector_amd.HectorAmdError, match="appears twice"):
         hector_amd.Core(n_members=128, devices=[0, 0], lib_path=hip_lib)
+
+
+def test_c_host_example_builds_and_runs_over_a_device_list(emul_lib, tmp_path):
+    """examples/multi_gpu_host.c: a plain C99 host on the C ABI alone -- what an R / C++ embedding
+    compiles against -- over the device list [0, 0] of the host build."""
+    import os
+    import subprocess
+    from conftest import ROOT, SCENARIO
+    exe = str(tmp_path / "multi_gpu_host")
+    libdir = os.path.dirname(emul_lib)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "multi_gpu_host.c"), "-o", exe,
+                           "-L", libdir, "-lhector_amd_emul", "-Wl,-rpath," + libdir, "-lm"])
+    r = subprocess.run([exe, SCENARIO, "6", "0,0", "1800"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "shard 0: GPU 0, members 0..2" in r.stdout and "shard 1: GPU 0, members 3..5" in r.stdout
+    assert "members with model errors: 0" in r.stdout
+    one = hector_amd.Core(n_members=6, lib_path=emul_lib, allow_emulation=True)
+    n = 6
+    one.setvar("S", 1.5 + 4.5 * (np.arange(n) + 0.5) / n).setvar("q10_rh", 1.0 + 2.0 * np.fmod(np.arange(n) * 0.6180339887498949, 1.0))
+    one.run(1800)
+    tas = one.fetchvars("global_tas", (1800, 1800))[0]
+    line = [l for l in r.stdout.splitlines() if l.startswith("global_tas(1800)")][0]
+    got = [float(x) for x in line.split(":")[1].split()]
+    np.testing.assert_allclose(got, [tas[0], tas[3], tas[5]], atol=5e-7)
+    one.shutdown()

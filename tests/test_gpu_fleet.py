@@ -182,3 +182,20 @@ def test_single_process_bench_over_a_device_list():
     tg = c.fetchvars("global_tas", (2300, 2300))[0]
     assert abs(out["config"]["tgav_2300_mean_K"] - tg.mean()) < 1e-9
     c.shutdown()
+
+
+def test_c_host_example_on_the_gpu(hip_lib, tmp_path):
+    """examples/multi_gpu_host.c against the product library: one GPU listed once -- the
+    statistics still go through hx_ensemble_stats -- and, with the rehearsal switch, twice."""
+    exe = str(tmp_path / "multi_gpu_host")
+    libdir = os.path.dirname(hip_lib)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "multi_gpu_host.c"), "-o", exe,
+                           "-L", libdir, "-lhector_amd", "-Wl,-rpath," + libdir, "-lm"])
+    env = dict(os.environ)
+    for devs, extra in (("0", {}), ("0,0", {"HECTOR_AMD_FLEET_REHEARSAL": "1"})):
+        env.update(extra)
+        r = subprocess.run([exe, SCENARIO, "4096", devs, "2100"], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "global_tas 2100: members 4096 " in r.stdout and "members with model errors: 0" in r.stdout
