@@ -34,6 +34,11 @@ struct ChemK {  // T-dependent equilibrium constants of one surface box
   double K1, K2, Kb, Kw, Kh, Tr;
   double rKh;  // 1 / Kh (run kernels: exp(-a) from the year's batch; pCO2 = CO2* 1e6 rKh)
   double g;  // Tr * As * 12 / 1e15: annual flux per uatm of air-sea pCO2 difference
+  // Run kernels: the quintic's coefficients as functions of DIC, p_i = A_i dic + C_i -- the box's
+  // equilibrium constants and the member's alkalinity are fixed for the year, so a solve sets
+  // its polynomial up with three multiply-adds instead of ~40 operations (chem_poly_constants):
+  //   p4 = C4,  p3 = K1 dic + C3,  p2 = A2 dic + C2,  p1 = A1 dic + C1,  p0 = C0
+  double A2, A1, C4, C3, C2, C1, C0, K1K2;
 };
 
 // oceancsys::ocean_csys_run, the part that depends only on T (S = 34.5, U = 6.7)
@@ -308,6 +313,20 @@ __device__ __forceinline__ void chem_from_exponentials(double Tc, const double *
   k.Tr = (0.585 * e[0] * rsqrt(Sc) * O_U * O_U);
   k.g = k.Tr * As * (12.0 / 1e15);
 }
+// ocean_csys.cpp:289-330 (the coefficients of the polynomial in [H+]) sorted by powers of DIC
+__device__ __forceinline__ void chem_poly_constants(double alk, ChemK &k) {
+  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
+  const double K1 = k.K1, K2 = k.K2, Kb = k.Kb, Kw = k.Kw;
+  const double K1K2 = K1 * K2, KbK1 = Kb * K1, Kbbor = Kb * bor;
+  k.K1K2 = K1K2;
+  k.C4 = -alk - Kb - K1;
+  k.C3 = (((-alk * (Kb + K1) + Kbbor) + Kw) - KbK1) - K1K2;
+  k.A2 = KbK1 + 2.0 * K1K2;
+  k.C2 = (-alk * (KbK1 + K1K2) + Kbbor * K1) + ((Kw * Kb + Kw * K1) - KbK1 * K2);
+  k.A1 = 2.0 * KbK1 * K2;
+  k.C1 = (-alk * KbK1 * K2 + Kbbor * K1K2) + (Kw * KbK1 + Kw * K1K2);
+  k.C0 = Kw * KbK1 * K2;
+}
 
 // The yearly / per-stash solve of both boxes.  From a warm start (the previous [H+], a fraction
 // of a percent away) the safeguards of the bracketed iteration never engage: the iterates approach the
@@ -321,23 +340,19 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
                                             double cL, double alkH, double alkL, double &hH,
                                             double &hL, double &pco2H, double &pco2L,
                                             unsigned &status) {
-  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
   const ChemK *k[2] = {&kH, &kL};
-  const double carbon[2] = {cH, cL}, alk[2] = {alkH, alkL};
+  const double carbon[2] = {cH, cL};
+  (void)alkH; (void)alkL;   // (inside the year's polynomial constants)
   const double inv_vol[2] = {1.0 / O_vHL, 1.0 / O_vLL};
   double dic[2], p4[2], p3[2], p2[2], p1[2], p0[2], h[2] = {hH, hL};
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const double K1 = k[b]->K1, K2 = k[b]->K2, Kb = k[b]->Kb, Kw = k[b]->Kw;
     dic[b] = ((carbon[b] * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol[b]);
-    p4[b] = -alk[b] - Kb - K1;
-    p3[b] = dic[b] * K1 - alk[b] * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
-    double tmp = dic[b] * (Kb * K1 + 2.0 * K1 * K2) - alk[b] * (Kb * K1 + K1 * K2) +
-                 Kb * bor * K1;
-    p2[b] = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
-    tmp = 2.0 * dic[b] * Kb * K1 * K2 - alk[b] * Kb * K1 * K2 + Kb * bor * K1 * K2;
-    p1[b] = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
-    p0[b] = Kw * Kb * K1 * K2;
+    p4[b] = k[b]->C4;
+    p3[b] = fma(dic[b], k[b]->K1, k[b]->C3);
+    p2[b] = fma(dic[b], k[b]->A2, k[b]->C2);
+    p1[b] = fma(dic[b], k[b]->A1, k[b]->C1);
+    p0[b] = k[b]->C0;
   }
   const double factor = 0x1p-30;
   const double q4[2] = {4.0 * p4[0], 4.0 * p4[1]}, q3[2] = {3.0 * p3[0], 3.0 * p3[1]},
@@ -417,8 +432,8 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
-    const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
-    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
+    const double K1 = k[b]->K1, x = h[b];
+    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + k[b]->K1K2);
     pc[b] = (co2st * 1e6) * k[b]->rKh;
   }
   pco2H = pc[0]; pco2L = pc[1];
@@ -430,21 +445,17 @@ template <int N>
 __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], const double (&carbon)[N],
                                                  const double (&alk)[N], const double (&inv_vol)[N],
                                                  double (&h)[N], double (&pc)[N], unsigned &status) {
-  const double bor = 1 * (416.0 * (O_S / 35.0)) * 1.e-6;
   double dic[N], p4[N], p3[N], p2[N], p1[N], p0[N], h0[N];
+  (void)alk;   // (inside the year's polynomial constants)
 #pragma unroll
   for (int b = 0; b < N; ++b) {
-    const double K1 = k[b]->K1, K2 = k[b]->K2, Kb = k[b]->Kb, Kw = k[b]->Kw;
     h0[b] = h[b];
     dic[b] = ((carbon[b] * 1e15) * (1.0 / 12.01) * (1.0 / 1027.0) * inv_vol[b]);
-    p4[b] = -alk[b] - Kb - K1;
-    p3[b] = dic[b] * K1 - alk[b] * (Kb + K1) + Kb * bor + Kw - Kb * K1 - K1 * K2;
-    double tmp = dic[b] * (Kb * K1 + 2.0 * K1 * K2) - alk[b] * (Kb * K1 + K1 * K2) +
-                 Kb * bor * K1;
-    p2[b] = tmp + (Kw * Kb + Kw * K1 - Kb * K1 * K2);
-    tmp = 2.0 * dic[b] * Kb * K1 * K2 - alk[b] * Kb * K1 * K2 + Kb * bor * K1 * K2;
-    p1[b] = tmp + (Kw * Kb * K1 + Kw * K1 * K2);
-    p0[b] = Kw * Kb * K1 * K2;
+    p4[b] = k[b]->C4;
+    p3[b] = fma(dic[b], k[b]->K1, k[b]->C3);
+    p2[b] = fma(dic[b], k[b]->A2, k[b]->C2);
+    p1[b] = fma(dic[b], k[b]->A1, k[b]->C1);
+    p0[b] = k[b]->C0;
   }
   const double factor = 0x1p-30;
   double q4[N], q3[N], q2[N];
@@ -530,8 +541,8 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
 #pragma unroll
   for (int b = 0; b < N; ++b) {
     // co2* = dic / (1 + K1/h + K1 K2/h^2), one division
-    const double K1 = k[b]->K1, K2 = k[b]->K2, x = h[b];
-    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + K1 * K2);
+    const double K1 = k[b]->K1, x = h[b];
+    const double co2st = hx_div(dic[b] * (x * x), (x * x + K1 * x) + k[b]->K1K2);
     pc[b] = (co2st * 1e6) * k[b]->rKh;
   }
 }

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       hx_exp_chunks<12>(ex);
       chem_from_exponentials(TcH, &ex[0], O_AsHL, kH);
       chem_from_exponentials(TcL, &ex[6], O_AsLL, kL);
+      chem_poly_constants(alkH, kH);
       s_yr[PY_KL_K1][lane] = kL.K1; s_yr[PY_KL_K2][lane] = kL.K2; s_yr[PY_KL_KB][lane] = kL.Kb;
       s_yr[PY_KL_KW][lane] = kL.Kw; s_yr[PY_KL_KH][lane] = kL.rKh;
       PSTAMP(0);
@@ -676,6 +677,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       PSTAMP(1);
       kL.K1 = s_yr[PY_KL_K1][lane]; kL.K2 = s_yr[PY_KL_K2][lane]; kL.Kb = s_yr[PY_KL_KB][lane];
       kL.Kw = s_yr[PY_KL_KW][lane]; kL.rKh = s_yr[PY_KL_KH][lane];
+      chem_poly_constants(alkL, kL);
       chem_solve1(kL, cLL, alkL, 1.0 / O_vLL, hL, pco2L, status);
       s_yr[PY_PN][lane] = Pn; s_yr[PY_CH4][lane] = ch4; s_yr[PY_O3][lane] = o3;
       s_yr[PY_STATUS1][lane] = (double)status;

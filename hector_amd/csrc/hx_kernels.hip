@@ -672,6 +672,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       HX_STAMP(m, 1);   // park reads, the year's log / exp batches, OH / CH4 / O3
       chem_from_exponentials(TcH, &ex[0], O_AsHL, m.kH);
       chem_from_exponentials(TcL, &ex[6], O_AsLL, m.kL);
+      chem_poly_constants(m.alkH, m.kH);
+      chem_poly_constants(m.alkL, m.kL);
       HX_STAMP(m, 2);   // T-only equilibrium constants of both boxes (from the exponentials)
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
       // (the alkalinities were tuned once, right after the spinup: hx_alk_kernel)
