@@ -17,6 +17,7 @@ hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, boo
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st);
 int hx_doeclim_block_years();
+void hx_fill_chem_table_host(double *t);
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
 hipError_t hx_launch_broadcast_u32(unsigned *v, int npad, hipStream_t st);
 hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st);
@@ -448,6 +449,8 @@ void EnsembleCore::build_shared() {
   k.delta_n2o = s.scalar("forcing", "delta_n2o");
   k.o3_rf = component_disabled("ozone") ? 0.0 : 0.042;
   hx_fill_tableau(k.tab);
+  hx_fill_math_table(k.mtab);
+  hx_fill_chem_table_host(k.ctab);
 }
 
 void EnsembleCore::free_device() {

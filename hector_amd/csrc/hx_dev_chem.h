@@ -281,30 +281,50 @@ __device__ __forceinline__ void chem_constants2(double TcH, double TcL, ChemK &k
 // K0, Kw, Kh, K1, K2, Kb, same formulas as above, 10^-pK as exp(-pK ln 10) -- and
 // chem_from_exponentials() builds the box's constants from their values.  (The alkalinity tuner
 // keeps chem_constants2: it runs once, and Brent's branch decisions see the last bits.)
-__device__ __forceinline__ void chem_exponents(double Tc, double lnTk, double *a) {
+// C: the formulas' constants as DATA (HxConst::ctab, hx_fill_chem_table's layout: wide scalar
+// loads instead of two s_mov per constant and use), or null for the literals.
+#define HXC(i, lit) (C ? C[(i)] : (lit))
+__device__ __forceinline__ void chem_exponents(double Tc, double lnTk, double *a,
+                                               const double *C = nullptr) {
   const double S = O_S;
   const double sqrtS = 5.873670062235365;      // sqrt(34.5)
   const double S15 = 202.64161714712009;       // 34.5^1.5
   const double LN10 = 2.302585092994045684;
-  const double Tk = Tc + 273.15;
+  const double Tk = Tc + HXC(0, 273.15);
   const double rTk = hx_recip(Tk);
-  const double T100 = Tk * 0.01;
-  const double lnTk100 = lnTk - 4.605170185988092;  // ln(Tk/100)
-  a[0] = (-58.0931 + 9050.69 * rTk + 22.2940 * lnTk100) +
-         S * (0.027766 - 0.025888 * T100 + 0.0050578 * (T100 * T100));
-  a[1] = (-13847.26 * rTk + 148.96502 - 23.6521 * lnTk) +
-         ((118.67 * rTk - 5.977 + 1.0495 * lnTk) * sqrtS - 0.01615 * S);
+  const double T100 = Tk * HXC(1, 0.01);
+  const double lnTk100 = lnTk - HXC(2, 4.605170185988092);  // ln(Tk/100)
+  a[0] = (HXC(3, -58.0931) + HXC(4, 9050.69) * rTk + HXC(5, 22.2940) * lnTk100) +
+         HXC(6, S) * (HXC(7, 0.027766) - HXC(8, 0.025888) * T100 + HXC(9, 0.0050578) * (T100 * T100));
+  a[1] = (HXC(10, -13847.26) * rTk + HXC(11, 148.96502) - HXC(12, 23.6521) * lnTk) +
+         ((HXC(13, 118.67) * rTk - HXC(14, 5.977) + HXC(15, 1.0495) * lnTk) * HXC(16, sqrtS) - HXC(17, 0.01615 * S));
   // (negated: the carbonate solve divides by Kh, so the batch delivers 1 / Kh = exp(-a))
-  a[2] = -((9345.17 * rTk - 60.2409 + 23.3585 * lnTk100) +
-           S * (0.023517 - 0.00023656 * Tk + 0.0047036e-4 * Tk * Tk));
-  const double pK1 = 3633.86 * rTk - 61.2172 + 9.6777 * lnTk - 0.011555 * S + 0.0001152 * S * S;
-  a[3] = -pK1 * LN10;
-  const double pK2 = 471.78 * rTk + 25.9290 - 3.16967 * lnTk - 0.01781 * S + 0.0001122 * S * S;
-  a[4] = -pK2 * LN10;
-  const double tmp1 = (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 - 0.0996 * S * S) * rTk;
-  const double tmp2 = +148.0248 + 137.1942 * sqrtS + 1.62142 * S;
-  const double tmp3 = +(-24.4344 - 25.085 * sqrtS - 0.2474 * S) * lnTk + 0.053105 * sqrtS * Tk;
+  a[2] = -((HXC(18, 9345.17) * rTk - HXC(19, 60.2409) + HXC(20, 23.3585) * lnTk100) +
+           HXC(6, S) * (HXC(21, 0.023517) - HXC(22, 0.00023656) * Tk + HXC(23, 0.0047036e-4) * Tk * Tk));
+  const double pK1 = HXC(24, 3633.86) * rTk - HXC(25, 61.2172) + HXC(26, 9.6777) * lnTk - HXC(27, 0.011555 * S) + HXC(28, 0.0001152 * S * S);
+  a[3] = -pK1 * HXC(29, LN10);
+  const double pK2 = HXC(30, 471.78) * rTk + HXC(31, 25.9290) - HXC(32, 3.16967) * lnTk - HXC(33, 0.01781 * S) + HXC(34, 0.0001122 * S * S);
+  a[4] = -pK2 * HXC(29, LN10);
+  const double tmp1 = HXC(35, (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 - 0.0996 * S * S)) * rTk;
+  const double tmp2 = HXC(36, +148.0248 + 137.1942 * sqrtS + 1.62142 * S);
+  const double tmp3 = HXC(37, +(-24.4344 - 25.085 * sqrtS - 0.2474 * S)) * lnTk + HXC(38, 0.053105 * sqrtS) * Tk;
   a[5] = tmp1 + tmp2 + tmp3;
+}
+#undef HXC
+// the table behind chem_exponents' C (same expressions, evaluated by the host compiler in double)
+inline void hx_fill_chem_table(double *t) {
+  const double S = O_S;
+  const double sqrtS = 5.873670062235365, S15 = 202.64161714712009, LN10 = 2.302585092994045684;
+  const double v[39] = {273.15, 0.01, 4.605170185988092, -58.0931, 9050.69, 22.2940, S, 0.027766, 0.025888,
+                        0.0050578, -13847.26, 148.96502, 23.6521, 118.67, 5.977, 1.0495, sqrtS, 0.01615 * S,
+                        9345.17, 60.2409, 23.3585, 0.023517, 0.00023656, 0.0047036e-4, 3633.86, 61.2172, 9.6777,
+                        0.011555 * S, 0.0001152 * S * S, LN10, 471.78, 25.9290, 3.16967, 0.01781 * S,
+                        0.0001122 * S * S,
+                        (-8966.90 - 2890.53 * sqrtS - 77.942 * S + 1.728 * S15 - 0.0996 * S * S),
+                        +148.0248 + 137.1942 * sqrtS + 1.62142 * S,
+                        +(-24.4344 - 25.085 * sqrtS - 0.2474 * S), 0.053105 * sqrtS};
+  for (int i = 0; i < 39; ++i) t[i] = v[i];
+  t[39] = 0.0;
 }
 __device__ __forceinline__ void chem_from_exponentials(double Tc, const double *e, double As,
                                                        ChemK &k) {

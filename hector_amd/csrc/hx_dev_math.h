@@ -25,18 +25,22 @@ namespace {
 
 // exp(x[i]) in place, i < N.  Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2; degree-13 Taylor
 // polynomial in r (remainder r^14/14! < 5e-18); scaled by 2^k with v_ldexp_f64.
+// T: the constants as DATA (HxConst::mtab, hx_fill_math_table's layout) behind wide scalar loads,
+// or null for literals.  A 64-bit literal is two s_mov_b32 where it is used; the year loop's exp /
+// log batches materialise ~110 of them a year, the table costs a dozen s_load.
 template <int N>
-__device__ __forceinline__ void hx_exp_batch(double (&x)[N]) {
+__device__ __forceinline__ void hx_exp_batch(double (&x)[N], const double *T = nullptr) {
   constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
                    LN2_LO = 1.90821492927058770002e-10;
   double r[N], p[N];
   int k[N];
+  const double log2e = T ? T[12] : LOG2E, mln2hi = T ? T[13] : -LN2_HI, mln2lo = T ? T[14] : -LN2_LO;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const double kd = rint(x[i] * LOG2E);
+    const double kd = rint(x[i] * log2e);
     k[i] = (int)kd;
-    r[i] = fma(kd, -LN2_HI, x[i]);
-    r[i] = fma(kd, -LN2_LO, r[i]);
+    r[i] = fma(kd, mln2hi, x[i]);
+    r[i] = fma(kd, mln2lo, r[i]);
   }
   // 1/13! ... 1/2!
   constexpr double c[12] = {1.6059043836821613e-10, 2.0876756987868099e-09, 2.5052108385441719e-08,
@@ -44,11 +48,12 @@ __device__ __forceinline__ void hx_exp_batch(double (&x)[N]) {
                             1.9841269841269841e-04, 1.3888888888888889e-03, 8.3333333333333332e-03,
                             4.1666666666666664e-02, 1.6666666666666666e-01, 0.5};
 #pragma unroll
-  for (int i = 0; i < N; ++i) p[i] = c[0];
+  for (int i = 0; i < N; ++i) p[i] = T ? T[0] : c[0];
 #pragma unroll
   for (int j = 1; j < 12; ++j) {
+    const double cj = T ? T[j] : c[j];
 #pragma unroll
-    for (int i = 0; i < N; ++i) p[i] = fma(p[i], r[i], c[j]);
+    for (int i = 0; i < N; ++i) p[i] = fma(p[i], r[i], cj);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -59,14 +64,14 @@ __device__ __forceinline__ void hx_exp_batch(double (&x)[N]) {
 }
 // the same for a longer list, eight at a time (the working set of a batch is 5 VGPRs per entry)
 template <int N>
-__device__ __forceinline__ void hx_exp_chunks(double (&x)[N]) {
+__device__ __forceinline__ void hx_exp_chunks(double (&x)[N], const double *T = nullptr) {
   constexpr int C = 8;
 #pragma unroll
   for (int i0 = 0; i0 + C <= N; i0 += C) {
     double t[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) t[i] = x[i0 + i];
-    hx_exp_batch<C>(t);
+    hx_exp_batch<C>(t, T);
 #pragma unroll
     for (int i = 0; i < C; ++i) x[i0 + i] = t[i];
   }
@@ -75,7 +80,7 @@ __device__ __forceinline__ void hx_exp_chunks(double (&x)[N]) {
     double t[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) t[i] = x[N - R + i];
-    hx_exp_batch<R>(t);
+    hx_exp_batch<R>(t, T);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[N - R + i] = t[i];
   }
@@ -93,19 +98,19 @@ __device__ __forceinline__ double hx_exp(double x) {
 // log(x[i]) in place, i < N; x positive and normal.  Evaluated coefficient by coefficient like
 // hx_exp_batch.
 template <int N>
-__device__ __forceinline__ void hx_log_batch(double (&x)[N]) {
-  constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-  constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                   Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                   Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                   Lg7 = 1.479819860511658591e-01;
+__device__ __forceinline__ void hx_log_batch(double (&x)[N], const double *T = nullptr) {
+  const double LN2_HI = T ? T[23] : 6.93147180369123816490e-01, LN2_LO = T ? T[24] : 1.90821492927058770002e-10;
+  const double Lg1 = T ? T[16] : 6.666666666666735130e-01, Lg2 = T ? T[17] : 3.999999999940941908e-01,
+               Lg3 = T ? T[18] : 2.857142874366239149e-01, Lg4 = T ? T[19] : 2.222219843214978396e-01,
+               Lg5 = T ? T[20] : 1.818357216161805012e-01, Lg6 = T ? T[21] : 1.531383769920937332e-01,
+               Lg7 = T ? T[22] : 1.479819860511658591e-01;
   double dk[N], f[N], s[N], w[N], z[N], t1[N], t2[N], x0[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     x0[i] = x[i];
     int e;
     double m = frexp(x[i], &e);  // [0.5, 1)
-    const bool lo = m < 0.70710678118654752440;
+    const bool lo = m < (T ? T[25] : 0.70710678118654752440);
     m = lo ? m + m : m;
     dk[i] = (double)(lo ? e - 1 : e);
     f[i] = m - 1.0;
@@ -135,9 +140,9 @@ __device__ __forceinline__ void hx_log_batch(double (&x)[N]) {
                          : ((x0[i] == 0.0) ? -__builtin_inf() : __builtin_nan(""));
   }
 }
-__device__ __forceinline__ double hx_log(double x) {
+__device__ __forceinline__ double hx_log(double x, const double *T = nullptr) {
   double a[1] = {x};
-  hx_log_batch<1>(a);
+  hx_log_batch<1>(a, T);
   return a[0];
 }
 

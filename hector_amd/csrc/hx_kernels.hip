@@ -623,10 +623,17 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         Tb[b] = tland * p_wf[b];
         lg[2 + b] = (Tb[b] > 0) ? Tb[b] : 1.0;  // ln(Tb) of the permafrost curve, if Tb > 0
       }
-      hx_log_batch<2 + B>(lg);
+      hx_log_batch<2 + B>(lg, kc.mtab);
       double ex[13 + 2 * B];
+      // (literals here: as data -- HxConst::ctab, -DHX_CHEM_TABLE -- the 39 constants arrive in
+      // one sweep of scalar loads, 78 SGPRs at once, and 73 of the kernel's SGPRs spill)
+#ifdef HX_CHEM_TABLE
+      chem_exponents(TcH, lg[0], &ex[0], kc.ctab);
+      chem_exponents(TcL, lg[1], &ex[6], kc.ctab);
+#else
       chem_exponents(TcH, lg[0], &ex[0]);
       chem_exponents(TcL, lg[1], &ex[6]);
+#endif
       ex[12] = -toh;
 #pragma unroll
       for (int b = 0; b < B; ++b) {
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         ex[13 + 2 * b] = p_lnq10[b] * (Tb[b] * 0.1);
         ex[14 + 2 * b] = p_lnq10[b] * (Trm * 0.1);
       }
-      hx_exp_chunks<13 + 2 * B>(ex);
+      hx_exp_chunks<13 + 2 * B>(ex, kc.mtab);
       const double tau_oh = kc.TOH0 * ex[12];
       if constexpr (CON) {
       if (buf.out[HXO_TAU_OH]) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
         }
       }
       PKM(m, PK_CH4) = ch4;
-      const double ln_ch4 = hx_log(ch4);
+      const double ln_ch4 = hx_log(ch4, kc.mtab);
       PKM(m, PK_LN_CH4) = ln_ch4;
       o3 = ((5 * ln_ch4 + ya[5]) + ya[6]) + ya[7];
       // ---- ocean: new year ----
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
       // ---- forcing ----
       const double co2c = m.atmos * PGC2PPM;
-      const double ln_co2r = hx_log(hx_div(co2c, m.C0));
+      const double ln_co2r = hx_log(hx_div(co2c, m.C0), kc.mtab);
       PKM(m, PK_LN_CO2R) = ln_co2r;
       double rf_tot = 0, rf_co2 = 0;
       if (iy >= kc.baseyear_idx) {
@@ -1549,6 +1556,7 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
 }
 
 int hx_doeclim_block_years() { return HX_DBLK; }
+void hx_fill_chem_table_host(double *t) { hx_fill_chem_table(t); }
 int hx_track_rows(int B) {
   switch (B) { case 1: return hx_trk_rows<1>(); case 2: return hx_trk_rows<2>();
                case 3: return hx_trk_rows<3>(); default: return hx_trk_rows<4>(); }

@@ -150,7 +150,26 @@ struct HxConst {
   double o3_rf;        // 0.042 W/m2 per DU, or 0 when the ozone component is disabled
   // dopri5 tableau in the order a step uses it (hx_fill_tableau), for builds that read it as data
   double tab[32];
+  // coefficients of the year loop's exp / log batches, the same way (hx_fill_math_table)
+  double mtab[32];
+  // ... and the constants of the equilibrium-constant formulas (hx_fill_chem_table, hx_dev_chem.h)
+  double ctab[40];
 };
+// [0..11] exp Taylor 1/13! .. 1/2!, [12] log2 e, [13] -ln2_hi, [14] -ln2_lo; [16..22] Lg1..Lg7,
+// [23] ln2_hi, [24] ln2_lo, [25] sqrt(1/2)   (hx_dev_math.h)
+inline void hx_fill_math_table(double *t) {
+  const double v[26] = {1.6059043836821613e-10, 2.0876756987868099e-09, 2.5052108385441719e-08,
+                        2.7557319223985893e-07, 2.7557319223985888e-06, 2.4801587301587302e-05,
+                        1.9841269841269841e-04, 1.3888888888888889e-03, 8.3333333333333332e-03,
+                        4.1666666666666664e-02, 1.6666666666666666e-01, 0.5,
+                        1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10, 0.0,
+                        6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01,
+                        2.222219843214978396e-01, 1.818357216161805012e-01, 1.531383769920937332e-01,
+                        1.479819860511658591e-01, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+                        0.70710678118654752440};
+  for (int i = 0; i < 26; ++i) t[i] = v[i];
+  for (int i = 26; i < 32; ++i) t[i] = 0.0;
+}
 // stage 2: b21, 1/5 | 3: b31 b32 3/10 | 4: b41 b42 b43 4/5 | 5: b51..b54 8/9 | 6: b61..b65 |
 // candidate: c1 c3 c4 c5 c6 | error: dc1 dc3 dc4 dc5 dc6 dc7
 inline void hx_fill_tableau(double *t) {
