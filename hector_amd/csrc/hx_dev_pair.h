@@ -563,7 +563,7 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
                  wf = ldp(buf, r + HXPB_WF, mem), lnq10 = ldd(buf, HXD_NGLOBAL, mem),
                  pmu = ldp(buf, r + HXPB_PF_MU, mem), psigma = ldp(buf, r + HXPB_PF_SIGMA, mem);
     auto rh_tp_co2 = [&]() { return ((thawed * (1 - fpf_static)) * 0.02) * tempferts * (1.0 - rh_ch4_frac); };
-    auto rh_tp_ch4 = [&]() { return hx_div(rh_tp_co2(), 1.0 - rh_ch4_frac) * rh_ch4_frac; };
+    auto rh_tp_ch4 = [&]() { return ((thawed * (1 - fpf_static)) * 0.02) * tempferts * rh_ch4_frac; };  // (see m_rh_tp_ch4)
     ChemK kL;
     kL.Tr = 0; kL.g = 0;
     double pco2L = 0;

@@ -39,8 +39,11 @@ template <int B> __device__ __forceinline__ double m_rh_tp_co2(const Member<B> &
   return ((m.thawed[b] * (1 - k.fpf_static[b])) * 0.02) * m.tempferts[b] *
          (1.0 - k.rh_ch4_frac[b]);  // :689-701
 }
+// :707-711: rh_ftpa_co2 / (1 - rh_ch4_frac) * rh_ch4_frac -- the same product as rh_ftpa_co2 with
+// rh_ch4_frac in the place of (1 - rh_ch4_frac), so no division (an ulp of a flux that is zero
+// until permafrost thaws; the reference divides what it has just multiplied)
 template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &m, const LandK<B> &k, int b) {
-  return hx_div(m_rh_tp_co2(m, k, b), 1.0 - k.rh_ch4_frac[b]) * k.rh_ch4_frac[b];  // :707-711
+  return ((m.thawed[b] * (1 - k.fpf_static[b])) * 0.02) * m.tempferts[b] * k.rh_ch4_frac[b];
 }
 
 // constraints of one model year, as the solver and the stash see them (CON kernels only)
