@@ -57,10 +57,15 @@ __device__ __forceinline__ TV<TP> tv_add(const TV<TP> &a, const TV<TP> &b) {  //
   r.val = a.val + b.val;
   r.mask = a.mask | b.mask;
   const double share = 1.0 / (double)__popcll(r.mask);
+  // ONE reciprocal of the new total for the TP fractions (the reference divides source by source,
+  // fluxpool.hpp:197-257: an IEEE division each -- ~30 instructions on this machine, TP of them
+  // in each of the ~35 additions of a stash were most of the tracking kernels' time); a
+  // fraction then differs from the quotient in its last place
+  const double inv = hx_recip(r.val);
 #pragma unroll
   for (int s = 0; s < TP; ++s) {
     const double pool_s = a.val * a.f[s] + b.val * b.f[s];
-    double v = (r.val != 0.0) ? pool_s / r.val : share;
+    double v = (r.val != 0.0) ? pool_s * inv : share;
     r.f[s] = (r.mask >> s & 1ull) ? v : 0.0;
   }
   return r;
