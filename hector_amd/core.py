@@ -120,12 +120,14 @@ class Core:
         tp = len(self.tracking_pools())
         v = np.zeros((y1 - y0 + 1, tp)); f = np.zeros((y1 - y0 + 1, tp, tp))
         dp = ctypes.POINTER(ctypes.c_double)
-        mk = np.zeros((y1 - y0 + 1, tp), dtype=np.uint64)
+        w = (tp + 63) // 64   # mask words per pool (2 from 12 biomes on)
+        mk = np.zeros((y1 - y0 + 1, tp, w), dtype=np.uint64)
         self._ck(self._lib.hx_tracking_data(self._h, int(member), y0, y1, v.ctypes.data_as(dp),
                                             f.ctypes.data_as(dp),
                                             mk.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong))))
         if masks:
-            bits = (mk[:, :, None] >> np.arange(tp, dtype=np.uint64)[None, None, :]) & np.uint64(1)
+            src = np.arange(tp)
+            bits = (mk[:, :, src // 64] >> (src % 64).astype(np.uint64)[None, None, :]) & np.uint64(1)
             return v, f, bits.astype(bool)
         return v, f
 

@@ -10,7 +10,7 @@
 // launchers defined in hx_kernels.hip
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st);
-int hx_track_rows(int B);
+int hx_track_value_rows(int B);
 int hx_pair_available();
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
                               int iy_to, hipStream_t st);
@@ -457,8 +457,8 @@ void EnsembleCore::free_device() {
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(d_params_); fr(d_state_); fr(d_shared_); fr(d_ker_); fr(d_status_); fr(d_spin_steps_);
   fr(d_uparams_); d_uparams_ = nullptr;
-  fr(d_track_); fr(d_track_out_f_); fr(d_track_out_v_);
-  d_track_ = d_track_out_f_ = d_track_out_v_ = nullptr;
+  fr(d_track_out_f_); fr(d_track_out_v_);
+  d_track_out_f_ = d_track_out_v_ = nullptr;
   fr(d_args_); fr(d_derived_); fr(d_dpart_); fr(d_gather_); fr(d_lane_of_member_); fr(d_hist_);
   fr(d_hist_status_);
   fr(d_gas_par_); fr(d_gas_ser_); d_gas_par_ = d_gas_ser_ = nullptr;
@@ -479,14 +479,26 @@ void EnsembleCore::alloc_device() {
   const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
   check(hipMalloc(&d_uparams_, sizeof(double) * HX_NPARAM(B_)), "hipMalloc uniform params");
-  if (trk_iy() >= 0) {  // carbon tracking: origin matrix + its yearly record from the tracking date
+  if (trk_iy() >= 0) {  // carbon tracking: the yearly record of the origin matrices from the tracking
+    // date on (the kernels update the current year's matrix in place, hx_dev_track.h)
     const size_t TP = (size_t)(2 + 5 * B_ + 4), nyt = ns - (size_t)trk_iy();
-    check(hipMalloc(&d_track_, sizeof(double) * (size_t)hx_track_rows(B_) * np), "hipMalloc track");
-    check(hipMemsetAsync(d_track_, 0, sizeof(double) * (size_t)hx_track_rows(B_) * np, stream_), "zero");
-    check(hipMalloc(&d_track_out_f_, sizeof(double) * nyt * TP * TP * np), "hipMalloc tracking record");
-    check(hipMalloc(&d_track_out_v_, sizeof(double) * nyt * 2 * TP * np), "hipMalloc tracking record");
-    check(hipMemsetAsync(d_track_out_f_, 0, sizeof(double) * nyt * TP * TP * np, stream_), "zero");
-    check(hipMemsetAsync(d_track_out_v_, 0, sizeof(double) * nyt * 2 * TP * np, stream_), "zero");
+    const size_t vr = (size_t)hx_track_value_rows(B_);
+    // (slot 0: the identity of the tracking date; 4 rows of padding: the last chunk of source
+    //  columns is read whole)
+    const size_t bytes_f = sizeof(double) * ((nyt + 1) * TP * TP * np + 4 * 64),
+                 bytes_v = sizeof(double) * (nyt + 1) * vr * np;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes_f + bytes_v > free_b)
+      throw std::runtime_error("carbon tracking: the record of " + std::to_string(nyt) + " years x " +
+                               std::to_string(TP) + " x " + std::to_string(TP) + " fractions x " +
+                               std::to_string(npad_) + " members needs " +
+                               std::to_string((bytes_f + bytes_v) >> 20) + " MiB of device memory, " +
+                               std::to_string(free_b >> 20) + " MiB are free: track fewer members or "
+                               "set a later trackingDate");
+    check(hipMalloc(&d_track_out_f_, bytes_f), "hipMalloc tracking record");
+    check(hipMalloc(&d_track_out_v_, bytes_v), "hipMalloc tracking record");
+    check(hipMemsetAsync(d_track_out_f_, 0, bytes_f, stream_), "zero");
+    check(hipMemsetAsync(d_track_out_v_, 0, bytes_v, stream_), "zero");
   }
   check(hipMalloc(&d_state_, sizeof(double) * np * HX_NSTATE(B_) * 2), "hipMalloc state");
   check(hipMalloc(&d_shared_, sizeof(double) * shared_.size()), "hipMalloc shared");
@@ -529,7 +541,8 @@ HxBuffers EnsembleCore::buffers() const {
   b.hist = d_hist_; b.hist_status = d_hist_status_;
   for (int k = 0; k < HXM_N; ++k) b.mseries[k] = d_mseries_[k];
   b.uparams = d_uparams_;
-  b.track = d_track_; b.track_out_f = d_track_out_f_; b.track_out_v = d_track_out_v_;
+  b.track_out_f = d_track_out_f_; b.track_out_v = d_track_out_v_;
+  b.trk_slots = trk_iy() >= 0 ? scen_.ns() - trk_iy() + 1 : 0;
   b.uni_landk = b.uni_bio = 1;
   for (int bb = 0; bb < B_; ++bb) {
     const int r = HXP_NGLOBAL + bb * HXPB_N;
@@ -1521,17 +1534,14 @@ void EnsembleCore::run(double runtodate) {
   for (int v = HXO_NPP; v < HXO_NVAR; ++v) if (d_out_[v]) ext = true;
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) ext = true;
   int con = ext ? 1 : 0;
-  if (d_track_) {
-    if (B_ > HX_MAXB)
-      throw std::runtime_error("carbon tracking is available for up to " + std::to_string(HX_MAXB) +
-                               " biomes (the looped kernels for more biomes carry no origin maps)");
+  if (d_track_out_f_) {
     if (con_mask & (HXC_CO2 | HXC_NBP))
       throw std::runtime_error("carbon tracking together with a CO2 or NBP constraint is not "
                                "supported (the constraint residual is an untracked source)");
     con = 2;
   }
   // small ensembles (too few wavefronts to fill the SIMDs): two wavefronts per 64 members
-  bool plain = con_mask == 0 && !d_track_;  // (the extended run kernel is also taken for diagnostics
+  bool plain = con_mask == 0 && !d_track_out_f_;  // (the extended run kernel is also taken for diagnostics
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) plain = false;  //  this one records itself)
   bool pair = hx_pair_available() && B_ == 1 && plain && n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
@@ -1827,24 +1837,29 @@ void EnsembleCore::tracking_data(int member, int year0, int year1, double *value
   if (year0 < tracking_year_ || year1 > last_date() || year1 < year0)
     throw std::runtime_error("tracking_data: dates must lie between trackingDate and the current date");
   sync();
-  const size_t TP = (size_t)(2 + 5 * B_ + 4), np = (size_t)npad_;
+  const size_t TP = (size_t)(2 + 5 * B_ + 4);
+  const size_t vr = (size_t)hx_track_value_rows(B_), W = vr / TP - 1;
   const size_t k0 = (size_t)(year0 - tracking_year_), ny = (size_t)(year1 - year0 + 1);
   const int lane = lane_of_member_[(size_t)member];
-  // one column (this member's lane) of the [rows][npad] records (per year: TP values, TP masks)
-  check(hipMemcpy2D(fractions, sizeof(double), d_track_out_f_ + k0 * TP * TP * np + lane,
-                    np * sizeof(double), sizeof(double), ny * TP * TP, hipMemcpyDeviceToHost),
-        "tracking fractions");
-  for (size_t y = 0; y < ny; ++y)
-    check(hipMemcpy2D(values + y * TP, sizeof(double), d_track_out_v_ + (k0 + y) * 2 * TP * np + lane,
-                      np * sizeof(double), sizeof(double), TP, hipMemcpyDeviceToHost),
-          "tracking values");
-  if (source_masks) {  // which sources a pool's map holds (a held source can have fraction 0)
-    std::vector<double> mk(ny * TP);
-    for (size_t y = 0; y < ny; ++y)
-      check(hipMemcpy2D(mk.data() + y * TP, sizeof(double),
-                        d_track_out_v_ + ((k0 + y) * 2 + 1) * TP * np + lane, np * sizeof(double),
-                        sizeof(double), TP, hipMemcpyDeviceToHost), "tracking masks");
-    for (size_t i = 0; i < ny * TP; ++i) source_masks[i] = (unsigned long long)mk[i];
+  // this member's lane of its block's tiles ([block][slot][row][64]; per year: TP values, then the
+  // TP mask words as bit patterns -- W = 1, or 2 for more than 64 pools, per pool, low words first)
+  const size_t blk = (size_t)lane / 64, l = (size_t)lane % 64;
+  const size_t slots = (size_t)(scen_.ns() - trk_iy() + 1);
+  std::vector<double> col(ny * vr);
+  // (the block's slots are contiguous: rows of consecutive years follow each other)
+  check(hipMemcpy2D(fractions, sizeof(double),
+                    d_track_out_f_ + (blk * slots + k0 + 1) * TP * TP * 64 + l, 64 * sizeof(double),
+                    sizeof(double), ny * TP * TP, hipMemcpyDeviceToHost), "tracking fractions");
+  check(hipMemcpy2D(col.data(), sizeof(double),
+                    d_track_out_v_ + (blk * slots + k0 + 1) * vr * 64 + l, 64 * sizeof(double),
+                    sizeof(double), ny * vr, hipMemcpyDeviceToHost), "tracking values");
+  for (size_t y = 0; y < ny; ++y) {
+    std::memcpy(values + y * TP, col.data() + y * vr, sizeof(double) * TP);
+    if (source_masks)  // which sources a pool's map holds (a held source can have fraction 0)
+      for (size_t p = 0; p < TP; ++p)
+        for (size_t w = 0; w < W; ++w)
+          std::memcpy(source_masks + (y * TP + p) * W + w, col.data() + y * vr + TP * (1 + w) + p,
+                      sizeof(double));
   }
 }
 

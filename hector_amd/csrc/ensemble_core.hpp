@@ -187,7 +187,7 @@ class EnsembleCore {
   HxArgs *d_args_ = nullptr;
   double *d_uparams_ = nullptr;
   int tracking_year_ = 0;  // 0 = off
-  double *d_track_ = nullptr, *d_track_out_f_ = nullptr, *d_track_out_v_ = nullptr;
+  double *d_track_out_f_ = nullptr, *d_track_out_v_ = nullptr;
   // SimpleNbox::run starts tracking when runToDate == trackingDate (simpleNbox-runtime.cpp:215-220):
   // a date at or before startDate, or past endDate, never engages
   int trk_iy() const {

@@ -101,6 +101,8 @@ struct Member {
   int iy;                 // year index being integrated
   int trk_iy;             // first tracked year index (tracking kernels)
   int nb;                 // biome count (looped kernels)
+  double (*trk_rec)[64];  // CON == 3: hand-over slots to the tracking companion wavefront
+  int *trk_cmd;
 };
 // trip count of the per-biome loops
 template <int B> __device__ __forceinline__ int nbio(const Member<B> &m) {

@@ -262,8 +262,8 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
     }
   }
-  [[maybe_unused]] TrkStashIn<(B == HX_DYN ? 1 : B)> tk;  // (no tracking in the looped kernels)
-  if constexpr (CON == 2 && !SPIN) {
+  [[maybe_unused]] TrkStashIn tk;
+  if constexpr (CON >= 2 && !SPIN) {
     tk.yf = yf;
     tk.pre[0] = m.cHL; tk.pre[1] = m.cLL; tk.pre[2] = m.cIO; tk.pre[3] = m.cDO;
     tk.closs[0] = lHD; tk.closs[1] = lLH; tk.closs[2] = lLI; tk.closs[3] = lIL;
@@ -278,7 +278,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   m.cLL = ((m.cLL + lIL) + aL) - (lLH + lLI);
   m.cIO = (m.cIO + (lLI + lDI)) - ((lIL + lIH) + lID);
   m.cDO = (m.cDO + (lHD + lID)) - lDI;
-  if constexpr (CON == 2 && !SPIN) {
+  if constexpr (CON >= 2 && !SPIN) {
     tk.post[0] = m.cHL; tk.post[1] = m.cLL; tk.post[2] = m.cIO; tk.post[3] = m.cDO;
   }
 
@@ -331,6 +331,15 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   // bit for bit, the reference's own property (test_biome.R))
   const double inv_nr = hx_recip(npp_rh);
   const double inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
+  if constexpr (CON >= 2 && !SPIN) {
+    // the origin maps, from the pools and fluxes as they are BEFORE the new pools are written
+    if (m.bufp->track_out_f && m.trk_iy >= 0 && m.iy >= m.trk_iy) {
+      tk.npp_total = npp_fin_total; tk.rh_adj = rh_adj; tk.total = total;
+      tk.npp_rh = npp_rh; tk.inv_nr = inv_nr;
+      if constexpr (CON == 3) track_post_stash<B>(m, lk, tk);  // (one biome: the companion wavefront mixes)
+      else track_stash<B>(m, lk, tk);
+    }
+  }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const double wt = (B == 1) ? 1.0
@@ -348,13 +357,6 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       fin_det += a;
       fin_soil += bb;
     }
-    if constexpr (CON == 2 && !SPIN) {
-      tk.veg[b] = m.veg[b]; tk.det[b] = m.det[b]; tk.soil[b] = m.soil[b]; tk.pf[b] = m.pf[b];
-      tk.tp[b] = m.thawed[b]; tk.wt[b] = wt; tk.wt_pf[b] = wt_pf;
-      tk.f_new_thaw[b] = m.f_new_thaw[b];
-      tk.rh_fda[b] = m_rh_fda(m, b); tk.rh_fsa[b] = m_rh_fsa(m, b);
-      tk.rh_co2[b] = m_rh_tp_co2(m, lk, b); tk.rh_ch4[b] = m_rh_tp_ch4(m, lk, b);
-    }
     if constexpr (CON) m.cum_pf_ch4 += (m_rh_tp_ch4(m, lk, b) * rh_adj) * yf;
     else m.cum_pf_ch4 += m_rh_tp_ch4(m, lk, b) * yf;  // :481
     m.veg[b] = nveg * wt;
@@ -362,16 +364,6 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     m.soil[b] = nsoil * wt;
     m.pf[b] = c4 * wt_pf;
     m.thawed[b] = tpf * wt_pf;
-  }
-  if constexpr (CON == 2 && !SPIN) {
-    if (m.bufp->track && m.iy >= m.trk_iy) {
-      tk.atmos = m.atmos; tk.earth = m.earth;
-      tk.npp_total = npp_fin_total; tk.rh_adj = rh_adj; tk.total = total;
-      tk.nveg = nveg; tk.ndet = ndet; tk.nsoil = nsoil; tk.npf = c4; tk.ntp = tpf;
-      tk.natm = y[0]; tk.nearth = c7;
-      tk.ffi = m.ffi; tk.daccs = m.daccs; tk.luc_e = m.luc_e; tk.luc_u = m.luc_u;
-      track_stash<B>(*m.bufp, blockIdx.x * 64 + m.lane, lk, tk);
-    }
   }
   m.earth = c7;
   m.atmos = y[0];

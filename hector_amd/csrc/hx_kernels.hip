@@ -33,6 +33,7 @@
 // T-only equilibrium constants computed once per year per box; LUC ratio via
 // one division; 200-year Q10 window as a running sum; forcing summed in groups.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <math.h>
 #include <stdint.h>
 
@@ -436,16 +437,34 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // CON: the extended kernel -- the scenario holds constraints (HxConst::con_mask), a member has
 // a land-ocean warming ratio, or diagnostics beyond HXO_SST_LO are recorded.  A separate
 // instantiation, so that plain runs carry none of it.
+// CON = 2: ... with carbon tracking inside the stash (hx_dev_track.h); CON = 3 (one biome): ...
+// with carbon tracking on a companion wavefront -- 128 threads a block, wave 1 only tracks.
 template <int B, bool HF, bool KERPM, int CON>
-__global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ args,
-                                                    int iy_from, int iy_to) {
+__global__ __launch_bounds__(CON == 3 ? 128 : 64) void hx_run_kernel(const HxArgs *__restrict__ args,
+                                                                     int iy_from, int iy_to) {
+  static_assert(CON != 3 || B == 1, "the tracking companion holds the maps of one biome");
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
   // (multi-biome kernels need that LDS for the per-biome arrays and re-read the block's SSTs
   // from the output array instead)
   __shared__ double s_tblk[B == 1 ? HX_DBLK : 1][64];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int mem = blockIdx.x * 64 + lane;
   if (mem >= args->buf.npad) return;
+  [[maybe_unused]] double (*s_trk_rec)[64] = nullptr;
+  [[maybe_unused]] int *s_trk_cmd = nullptr;
+  if constexpr (CON == 3) {
+    __shared__ double s_rec[2 * TRKR_N][64];  // two sets of hand-over slots
+    __shared__ int s_cmd[5];                  // {what, year} of each set; wave 0's event counter
+    s_trk_rec = s_rec; s_trk_cmd = s_cmd;
+    if (threadIdx.x >= 64) {
+      s_rec[TRKR_ACTIVE][lane] = 0.0; s_rec[TRKR_N + TRKR_ACTIVE][lane] = 0.0;
+      s_cmd[4] = 0;
+      __syncthreads();
+      track_companion(args, iy_from, lane, s_trk_rec, s_trk_cmd);
+      return;
+    }
+    __syncthreads();  // (the companion has cleared the hand-over flags)
+  }
   __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
   double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
@@ -491,7 +510,8 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
   };
   load_year_a(iy_from + 1);
   if constexpr (CON) m.bufp = &args->buf;
-  if constexpr (CON == 2) m.trk_iy = args->kc.trk_iy;
+  if constexpr (CON >= 2) m.trk_iy = args->kc.trk_iy;
+  if constexpr (CON == 3) { m.trk_rec = s_trk_rec; m.trk_cmd = s_trk_cmd; }
   int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
@@ -507,36 +527,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       // every HBM value this phase needs, issued back to back (one exposed latency:
       // with one wavefront per SIMD nothing else hides it)
       if constexpr (CON == 2) {
-        // carbon tracking: start_tracking() at Core::trackingDate (every pool 100 % itself),
-        // then every year the ocean's copy of the atmosphere's origins
-        // (SimpleNbox::run, simpleNbox-runtime.cpp:215-227)
-        if (buf.track && kc.trk_iy >= 0 && iy >= kc.trk_iy) {
-          constexpr int TP = hx_tp<B>();
-          hx_gd tr = HX_GD(buf.track) + mem;
-          const size_t np = (size_t)buf.npad;
-          if (iy == kc.trk_iy) {
-#pragma unroll 1
-            for (int p = 0; p < TP; ++p) {
-              for (int s2 = 0; s2 < TP; ++s2) tr[(size_t)trk_row_f<B>(p, s2) * np] = (p == s2) ? 1.0 : 0.0;
-              tr[(size_t)trk_row_mask<B>(p) * np] = (double)(1ull << p);
-            }
-          } else if (iy == iy_from + 1) {
-            // resuming past the tracking date (run() again, or reset(date) -- the reference's
-            // pools come back from their time series with their maps, simpleNbox.cpp reset):
-            // the maps of the end of last year are in the record
-            const size_t k1 = (size_t)(iy - 1 - kc.trk_iy);
-            hx_gd pf = HX_GD(buf.track_out_f) + k1 * (size_t)(TP * TP) * np + mem;
-            hx_gd pm = HX_GD(buf.track_out_v) + (k1 * 2 + 1) * (size_t)TP * np + mem;
-#pragma unroll 1
-            for (int r = 0; r < TP * TP; ++r) tr[(size_t)r * np] = pf[(size_t)r * np];
-#pragma unroll 1
-            for (int p = 0; p < TP; ++p) tr[(size_t)trk_row_mask<B>(p) * np] = pm[(size_t)p * np];
-          }
-#pragma unroll 1
-          for (int s2 = 0; s2 < TP; ++s2)
-            tr[(size_t)trk_row_atmcopy<B>(s2) * np] = tr[(size_t)trk_row_f<B>(TKP_ATM, s2) * np];
-          tr[(size_t)trk_row_atmcopy_mask<B>() * np] = tr[(size_t)trk_row_mask<B>(TKP_ATM) * np];
-        }
+        if (buf.track_out_f && iy == kc.trk_iy) track_start<B>(m);
       }
       const double prev_ch4 = PKM(m, PK_CH4);
       double sst = PKM(m, PK_SST);
@@ -1025,27 +1016,23 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
       }
       }
       }  // out_rare
-      if constexpr (CON == 2) {  // CSVFluxPoolVisitor: pools and their origins, once a year
+      if constexpr (CON >= 2) {  // CSVFluxPoolVisitor: the pools, once a year (their origins -- the
+        // year's matrix and masks -- are where the year's last stash left them, hx_dev_track.h)
         if (buf.track_out_f && kc.trk_iy >= 0 && iy >= kc.trk_iy) {
-          constexpr int TP = hx_tp<B>();
-          hx_gd tr = HX_GD(buf.track) + mem;
-          const size_t np = (size_t)buf.npad, k = (size_t)(iy - kc.trk_iy);
-          hx_gd of = HX_GD(buf.track_out_f) + k * (size_t)(TP * TP) * np + mem;
+          const int nbt = nbio<B>(m);
+          const size_t slot = (size_t)(iy - kc.trk_iy) + 1;
+          hx_gd ov = HX_GD(buf.track_out_v) +
+                     (((size_t)blockIdx.x * buf.trk_slots + slot) * (size_t)hx_trk_vrows(nbt) * 64 + m.lane);
+          ov[TKP_ATM * 64] = m.atmos; ov[TKP_EARTH * 64] = m.earth;
 #pragma unroll 1
-          for (int r = 0; r < TP * TP; ++r) of[(size_t)r * np] = tr[(size_t)r * np];
-          hx_gd ov = HX_GD(buf.track_out_v) + k * 2 * (size_t)TP * np + mem;  // values, then masks
-#pragma unroll 1
-          for (int p = 0; p < TP; ++p)
-            ov[(size_t)(TP + p) * np] = tr[(size_t)trk_row_mask<B>(p) * np];
-          ov[(size_t)TKP_ATM * np] = m.atmos; ov[(size_t)TKP_EARTH * np] = m.earth;
-#pragma unroll
-          for (int b = 0; b < B; ++b) {
-            ov[(size_t)tkp_land<B>(b, 0) * np] = m.veg[b]; ov[(size_t)tkp_land<B>(b, 1) * np] = m.det[b];
-            ov[(size_t)tkp_land<B>(b, 2) * np] = m.soil[b]; ov[(size_t)tkp_land<B>(b, 3) * np] = m.pf[b];
-            ov[(size_t)tkp_land<B>(b, 4) * np] = m.thawed[b];
+          for (int b = 0; b < nbt; ++b) {
+            hx_gd ob = ov + (2 + 5 * b) * 64;
+            ob[0] = m.veg[b]; ob[64] = m.det[b]; ob[128] = m.soil[b]; ob[192] = m.pf[b];
+            ob[256] = m.thawed[b];
           }
-          ov[(size_t)tkp_ocean<B>(0) * np] = m.cHL; ov[(size_t)tkp_ocean<B>(1) * np] = m.cLL;
-          ov[(size_t)tkp_ocean<B>(2) * np] = m.cIO; ov[(size_t)tkp_ocean<B>(3) * np] = m.cDO;
+          hx_gd oo = ov + (2 + 5 * nbt) * 64;
+          oo[0] = m.cHL; oo[64] = m.cLL; oo[128] = m.cIO; oo[192] = m.cDO;
+          if constexpr (CON == 3) track_post(s_trk_cmd, TRKC_YEAR, iy);  // the companion writes the maps
         }
       }
       HX_STAMP(m, 14);    // outputs
@@ -1058,6 +1045,7 @@ __global__ __launch_bounds__(64) void hx_run_kernel(const HxArgs *__restrict__ a
     }
   }
   HX_FENCE();
+  if constexpr (CON == 3) track_post(s_trk_cmd, TRKC_DONE, 0);
   store_state<B>(args->buf, mem, m);
   store_park_state<B>(args->buf, mem, m);
   // (a dopri5 pass of the wavefront costs ~2.7k cycles, a stash ~3.4k: tools/prof/phase_clock.py)
@@ -1483,28 +1471,47 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 0>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 1>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 2>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 2>),
 #endif
                           static_cast<const void *>(nullptr)})
       if (k)
       hx_allow_dynamic_lds(k, lds);
   }
-  if constexpr (B == HX_DYN) {  // the looped kernels: no carbon tracking
-    if (con == 2) return;
-  }
 #ifdef HX_MINIMAL_BUILD  // experiment builds (tools/prof): the plain kernel only
   (void)hf; (void)kpm; (void)con;
+#ifdef HX_MINIMAL_TRACK  // ... and the carbon-tracking ones
+  if constexpr (B == 1) {
+    if (con == 2 && !getenv("HECTOR_AMD_TRACK_INLINE")) {
+      hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(128), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
+  }
+  if (con == 2) {
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    return;
+  }
+#endif
   hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   return;
 #endif
-  if constexpr (B != HX_DYN) {
-    if (con == 2 && kpm) {
-      hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+#ifndef HX_HOST_EMULATION   // (the host build runs a block's threads one after the other)
+  if constexpr (B == 1) {    // one biome: the maps live on a companion wavefront
+    static const bool inline_maps = getenv("HECTOR_AMD_TRACK_INLINE") != nullptr;
+    if (con == 2 && !inline_maps) {
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<1, true, true, 3>), dim3(blocks), dim3(128), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(128), lds, st, d_args, iy_from, iy_to);
       return;
     }
-    if (con == 2) {
-      hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
-      return;
-    }
+  }
+#endif
+  if (con == 2 && kpm) {
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    return;
+  }
+  if (con == 2) {
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    return;
   }
   if (con && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
@@ -1549,7 +1556,7 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
 #endif
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     default:
-      if (B < 1 || B > HX_BDYN || con == 2) return hipErrorInvalidValue;
+      if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
       launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B);
   }
   return hipGetLastError();
@@ -1557,10 +1564,7 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
 
 int hx_doeclim_block_years() { return HX_DBLK; }
 void hx_fill_chem_table_host(double *t) { hx_fill_chem_table(t); }
-int hx_track_rows(int B) {
-  switch (B) { case 1: return hx_trk_rows<1>(); case 2: return hx_trk_rows<2>();
-               case 3: return hx_trk_rows<3>(); default: return hx_trk_rows<4>(); }
-}
+int hx_track_value_rows(int B) { return hx_trk_vrows(B); }
 int hx_doeclim_kernel_pad() { return HX_KPAD; }
 hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, const double *alk,
                                double inv_vol, double *out, hipStream_t st) {

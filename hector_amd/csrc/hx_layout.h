@@ -204,10 +204,13 @@ struct HxBuffers {
   const double *mseries[HXM_N];  // per-member series (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
   int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)
-  // carbon tracking (CON == 2 kernels): per-member origin matrix and its yearly record
-  double *track;         // [hx_trk_rows(B)][npad]
-  double *track_out_f;   // [ns - trk_iy][TP*TP][npad] fractions from the tracking date on
-  double *track_out_v;   // [ns - trk_iy][TP][npad] pool values
+  // carbon tracking (CON == 2 kernels): the yearly record of every member's origin matrix; the
+  // current year's matrix is updated in place by every stash (hx_dev_track.h)
+  // both tiled by wavefront, [npad/64][trk_slots][rows][64]: slot 0 the identity of the tracking
+  // date, slot 1 + k tracked year k
+  double *track_out_f;   // rows: TP*TP fractions
+  double *track_out_v;   // rows: TP pool values, then W mask words per pool (bit patterns)
+  int trk_slots;         // ns - trk_iy + 1
   int out_rare;            // some output besides sst, land_tas, CO2_concentration, global_tas is
                            // recorded: the year's output block tests the others only then
   int biome_diag;          // some "<biome>.<variable>" output is recorded

@@ -264,7 +264,8 @@ static int run_main(int argc, char **argv) {
     ck(hx_tracking_pools(core, &pools, &tp));
     const int t0 = (int)tdate, nyt = runto - t0 + 1;
     std::vector<double> tv((size_t)nyt * tp), tfr((size_t)nyt * tp * tp);
-    std::vector<unsigned long long> tm((size_t)nyt * tp);
+    const int tw = (tp + 63) / 64;  // mask words per pool
+    std::vector<unsigned long long> tm((size_t)nyt * tp * tw);
     for (int mbr = 0; mbr < members; ++mbr) {  // one file per member ("<run_name>.<member>")
       const std::string run = members > 1 ? rn + "." + std::to_string(mbr) : rn;
       const std::string tpath = outdir + (run.empty() ? "tracking.csv" : "tracking_" + run + ".csv");
@@ -275,7 +276,7 @@ static int run_main(int argc, char **argv) {
       for (int y = 0; y < nyt; ++y)
         for (int p = 0; p < tp; ++p)
           for (int s2 = 0; s2 < tp; ++s2)
-            if (tm[(size_t)y * tp + p] >> s2 & 1ull)
+            if (tm[((size_t)y * tp + p) * tw + s2 / 64] >> (s2 % 64) & 1ull)
               std::fprintf(tf, "%d,%s,%s,%.*g,Pg C,%s,%.*g\n", t0 + y,
                            p >= tp - 4 ? "ocean" : "simpleNbox", pools[p], p_def,
                            tv[(size_t)y * tp + p], pools[s2], p_def,

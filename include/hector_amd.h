@@ -139,8 +139,7 @@ int hx_split_biome_of(hx_core *core, const char *old_biome, int n_biomes,
  * SimpleNbox::createBiome / deleteBiome / renameBiome, src/simpleNbox.cpp:864-1060).  A created
  * biome has empty pools and npp_flux0 = 0 and the other parameters of the most recent biome
  * (set them with hx_setvar("<biome>.veg_c", ...), like R's create_biome does); at most 16 biomes
- * (1-4 run fully unrolled kernels, 5-16 kernels that loop over the biomes; no carbon tracking
- * beyond 4).
+ * (1-4 run fully unrolled kernels, 5-16 kernels that loop over the biomes).
  * All three invalidate the run (spinup again), like any parameter change. */
 int hx_create_biome(hx_core *core, const char *biome);
 int hx_delete_biome(hx_core *core, const char *biome);
@@ -230,11 +229,13 @@ int hx_state_row(hx_core *core, int row, double *out);
  * atmos_c, earth_c, [<biome>.]veg_c/detritus_c/soil_c/permafrost_c/thawedp_c, and the ocean
  * boxes HL, LL, intermediate, deep.  hx_tracking_data: for one member and year0..year1,
  * values[(y-year0)*TP + pool] (Pg C), fractions[((y-year0)*TP + pool)*TP + source] and, if
- * source_masks is not NULL, source_masks[(y-year0)*TP + pool] with bit s set where source s is
- * in the pool's map (the rows CSVFluxPoolVisitor::print_pool writes).  A [core] trackingDate in
- * the INI switches tracking on as well; hector-amd then writes tracking_<run_name>.csv.
- * Costs TP*TP*8 B per member-year of HBM (968 B for one biome); not combinable with a CO2 or
- * NBP constraint. */
+ * source_masks is not NULL, source_masks[((y-year0)*TP + pool)*W + s/64] with bit s%64 set where
+ * source s is in the pool's map (the rows CSVFluxPoolVisitor::print_pool writes); W = (TP+63)/64
+ * words per pool: 1 up to 11 biomes (TP = 6 + 5 biomes <= 64), 2 from 12 biomes on.  A [core]
+ * trackingDate in the INI switches tracking on as well; hector-amd then writes
+ * tracking_<run_name>.csv.  Any biome count (1-16).  Costs TP*TP*8 B per member-year of HBM
+ * (968 B for one biome, 59 KB for sixteen; a record that does not fit is refused with the
+ * numbers); not combinable with a CO2 or NBP constraint. */
 int hx_tracking_pools(hx_core *core, const char *const **names, int *count);
 int hx_tracking_data(hx_core *core, int member, int year0, int year1, double *values,
                      double *fractions, unsigned long long *source_masks);

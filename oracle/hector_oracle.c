@@ -496,7 +496,7 @@ enum { HL = 0, LL = 1, IO = 2, DO = 3 };
 typedef struct {
   double val;
   double f[TP_MAX]; /* fraction that originated in pool s (0 if s is not in the map) */
-  unsigned long mask; /* which sources are in the map (ctmap keys) */
+  unsigned __int128 mask; /* which sources are in the map (ctmap keys); 86 pools for 16 biomes */
 } tv_t;
 
 typedef struct {
@@ -796,7 +796,7 @@ enum { TP_ATM = 0, TP_EARTH = 1 };
 static tv_t tv_self(int self, double val) { /* fluxpool::set: ctmap[name] = 1 */
   tv_t r;
   memset(&r, 0, sizeof r);
-  r.val = val; r.f[self] = 1.0; r.mask = 1ul << self;
+  r.val = val; r.f[self] = 1.0; r.mask = (unsigned __int128)1 << self;
   return r;
 }
 /* flux_from_fluxpool / flux_from_unitval: the pool's origins, another value */
@@ -808,9 +808,9 @@ static tv_t tv_add(tv_t a, tv_t b, int TP) {
   r.val = a.val + b.val;
   r.mask = a.mask | b.mask;
   int nsrc = 0;
-  for (int s = 0; s < TP; s++) if (r.mask >> s & 1ul) nsrc++;
+  for (int s = 0; s < TP; s++) if ((r.mask >> s) & 1) nsrc++;
   for (int s = 0; s < TP; s++) {
-    if (!(r.mask >> s & 1ul)) continue;
+    if (!((r.mask >> s) & 1)) continue;
     const double pool_s = a.val * a.f[s] + b.val * b.f[s];
     r.f[s] = (r.val != 0.0) ? pool_s / r.val : 1.0 / nsrc;
   }

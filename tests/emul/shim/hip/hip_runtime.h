@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 
 #define __global__
 #define __device__
@@ -50,6 +51,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 struct double2 { double x, y; };
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline long long __double_as_longlong(double x) { long long r; std::memcpy(&r, &x, 8); return r; }
+inline double __longlong_as_double(long long x) { double r; std::memcpy(&r, &x, 8); return r; }
+inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
+  *free_b = *total_b = (size_t)1 << 40; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

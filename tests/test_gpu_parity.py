@@ -513,13 +513,14 @@ def test_biome_api_on_gpu(hip_lib, oracle):
 
 def test_carbon_tracking_on_gpu(hip_lib, oracle):
     """Origin maps of every pool (get_tracking_data) from the tracking instantiation of the run
-    kernel: vs the oracle for 1 and 4 biomes, reset/resume, and sum-to-one for 300 members."""
+    kernels: vs the oracle for 1-16 biomes, reset/resume, and sum-to-one for 300 members."""
     from test_tracking import (check_tracking_vs_oracle, tracking_reset_checks,
-                               tracking_four_biomes, tracked_core)
+                               tracking_n_biomes, tracked_core)
     c = check_tracking_vs_oracle(hip_lib, oracle, device=0)
     assert c.backend == "hip"
     tracking_reset_checks(hip_lib, device=0)
-    tracking_four_biomes(hip_lib, oracle, device=0)
+    for nb in (2, 4, 5, 16):   # unrolled kernels; looped kernels, 16 biomes = 86 pools, two mask words
+        tracking_n_biomes(hip_lib, oracle, nb, run_to=2050 if nb <= 5 else 1900, device=0)
     n = 300
     S, q10 = ensemble.ecs_q10(n, offset=77)
     c = tracked_core(hip_lib, n, date=1850, device=0)

@@ -132,25 +132,48 @@ def test_tracking_four_biomes(emul_lib, oracle):
 
 
 def tracking_four_biomes(lib, oracle, **kw):
+    tracking_n_biomes(lib, oracle, 4, **kw)
+
+
+def tracking_n_biomes(lib, oracle, nb, run_to=2050, **kw):
+    """`nb` equal biomes with their own Q10 per member: pools, fractions and which sources are in
+    the maps, against the oracle.  5-16 biomes take the looped kernels (run-time pool count), 12
+    and more have over 64 pools: two mask words per pool."""
     c = tracked_core(lib, 2, date=1800, **kw)
-    names = ["b1", "b2", "b3", "b4"]
+    names = ["b%d" % (b + 1) for b in range(nb)]
     c.split_biome(names)
-    q = [[1.8, 2.2], [2.0, 2.0], [2.4, 1.7], [2.1, 2.6]]
+    q = [[1.8 + 0.07 * ((5 * b) % 11), 2.6 - 0.05 * ((3 * b) % 13)] for b in range(nb)]
     for b, nm in enumerate(names):
         c.setvar(nm + ".q10_rh", q[b])
-    c.run(2050)
+    c.run(run_to)
+    assert (c.status() == 0).all()
     pools = c.tracking_pools()
-    assert len(pools) == 26 and pools[2] == "b1.veg_c" and pools[21] == "b4.thawedp_c"
+    tp = 6 + 5 * nb
+    assert len(pools) == tp and pools[2] == "b1.veg_c" and pools[tp - 5] == "b%d.thawedp_c" % nb
+    k0, k1 = 1800 - 1745, run_to - 1745 + 1
     for i in range(2):
-        p = oracle.split_equal(oracle.default_params(), 4)
-        for b in range(4):
+        p = oracle.split_equal(oracle.default_params(), nb)
+        for b in range(nb):
             p.q10_rh[b] = q[b][i]
-        ov, of, _, err = oracle.run_tracking(p, 1800, 2050)
+        ov, of, _, err = oracle.run_tracking(p, 1800, run_to)
         assert err == 0
-        gv, gf = c.tracking_data(i, (1800, 2050))
-        assert np.abs(gv - ov[55:306]).max() < 1e-10 * np.abs(ov).max()
-        assert np.abs(gf - of[55:306]).max() < FRAC_TOL
+        gv, gf, held = c.tracking_data(i, (1800, run_to), masks=True)
+        assert np.abs(gv - ov[k0:k1]).max() < 1e-10 * np.abs(ov).max()
+        assert np.abs(gf - of[k0:k1]).max() < FRAC_TOL
         assert np.abs(gf.sum(axis=2) - 1.0).max() < 1e-12
+        # a source outside the map has no share; every pool holds itself; the atmosphere ends up
+        # holding every pool that has carbon to give (the highest-numbered ones included)
+        assert (gf[~held] == 0.0).all()
+        assert held[:, np.arange(tp), np.arange(tp)].all()
+        assert held[-1, 0, tp - 4:].all() and held[-1, 0, 2:tp - 4:5].all()
+    return c
+
+
+@pytest.mark.parametrize("nb", [5, 12])
+def test_tracking_beyond_four_biomes(emul_lib, oracle, nb):
+    """The reference tracks any number of biomes (fluxpool maps are string-keyed); here 5-16 run
+    on the looped kernels.  12 biomes = 66 pools: the second mask word."""
+    tracking_n_biomes(emul_lib, oracle, nb, run_to=1900, allow_emulation=True)
 
 
 def test_tracking_refuses_carbon_constraints(emul_lib, tmp_path):
