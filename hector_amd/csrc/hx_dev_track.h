@@ -150,8 +150,9 @@ struct TrkIo {
     for (int c = 0; c < TRK_C; ++c) r.f[c] = row[off_f + c * 64];
     hx_gd mrow = blk_v + (size_t)(TP + p) * 64;
 #pragma unroll
-    for (int i = 0; i < W; ++i)
-      r.mask.w[i] = (unsigned long long)__double_as_longlong(mrow[off_v + (unsigned)(i * TP * 64)]);
+    for (int i = 0; i < W; ++i)  // (the looped kernels carry two words; the record has the high
+      r.mask.w[i] = (i == 0 || TP > 64)  // ones only when there are more than 64 pools)
+          ? (unsigned long long)__double_as_longlong(mrow[off_v + (unsigned)(i * TP * 64)]) : 0ull;
     r.win = tm_window<W>(r.mask, s0);
     return r;
   }
@@ -167,7 +168,7 @@ struct TrkIo {
       hx_gd mrow = blk_v + (size_t)(TP + p) * 64;
 #pragma unroll
       for (int i = 0; i < W; ++i)
-        mrow[dst_v + (unsigned)(i * TP * 64)] = __longlong_as_double((long long)t.mask.w[i]);
+        if (i == 0 || TP > 64) mrow[dst_v + (unsigned)(i * TP * 64)] = __longlong_as_double((long long)t.mask.w[i]);
     }
   }
 };

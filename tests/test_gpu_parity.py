@@ -521,6 +521,14 @@ def test_carbon_tracking_on_gpu(hip_lib, oracle):
     tracking_reset_checks(hip_lib, device=0)
     for nb in (2, 4, 5, 16):   # unrolled kernels; looped kernels, 16 biomes = 86 pools, two mask words
         tracking_n_biomes(hip_lib, oracle, nb, run_to=2050 if nb <= 5 else 1900, device=0)
+    # the looped kernels carry two mask words whatever the pool count; the record has the second
+    # one only beyond 64 pools (8 biomes = 46 pools wrote it past the record's end once)
+    c = tracked_core(hip_lib, 8192, date=2298, device=0)
+    c.split_biome(["b%d" % b for b in range(8)])
+    c.run(2300)
+    v, f, held = c.tracking_data(8191, (2298, 2300), masks=True)
+    assert v.shape == (3, 46) and np.abs(f.sum(axis=2) - 1.0).max() < 1e-12 and (f[~held] == 0).all()
+    c.shutdown()
     n = 300
     S, q10 = ensemble.ecs_q10(n, offset=77)
     c = tracked_core(hip_lib, n, date=1850, device=0)
