@@ -485,7 +485,7 @@ void EnsembleCore::alloc_device() {
     const size_t vr = (size_t)hx_track_value_rows(B_);
     // (slot 0: the identity of the tracking date; 4 rows of padding: the last chunk of source
     //  columns is read whole)
-    const size_t bytes_f = sizeof(double) * ((nyt + 1) * TP * TP * np + 4 * 64),
+    const size_t bytes_f = sizeof(double) * ((nyt + 1) * TP * TP * np + 8 * 64),
                  bytes_v = sizeof(double) * (nyt + 1) * vr * np;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes_f + bytes_v > free_b)

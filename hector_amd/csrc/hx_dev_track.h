@@ -17,16 +17,18 @@
 //
 // Every mixing operation acts on each source column separately (only the rare "a zero total is
 // shared equally among the sources of the map" needs the whole map, and that is a bit mask), so a
-// stash walks the matrix in chunks of TRK_C source columns: the pools' values, the reciprocals of
+// stash walks the matrix in chunks of 4 (looped kernels: 8) source columns: the pools' values, the reciprocals of
 // the totals and the masks are recomputed for every chunk, the fractions of a chunk live in
-// registers (~14 maps x TRK_C doubles) whatever the number of pools.  The biome count may
+// registers (~14 maps x 4 or 8 doubles) whatever the number of pools.  The biome count may
 // therefore be the looped kernels' run-time value (up to 16 biomes: 86 pools, two mask words).
 // Only the tracking instantiations of the run kernel (CON == 2) contain this code.
 #pragma once
 
 namespace {
 
-constexpr int TRK_C = 4;  // source columns per pass
+// source columns per pass: 4 in the unrolled kernels (8 spill: 8 192 x 4 biomes 83 -> 114 ms), 8 in
+// the looped ones (1 024 x 8 biomes 288 -> 224 ms, 256 x 16 966 -> 671 ms)
+template <int B> constexpr int trk_c() { return B == 0 ? 8 : 4; }
 enum { TKP_ATM = 0, TKP_EARTH = 1 };
 __host__ __device__ constexpr int hx_trk_pools(int nb) { return 2 + 5 * nb + 4; }
 __host__ __device__ constexpr int hx_trk_mask_words(int nb) { return hx_trk_pools(nb) > 64 ? 2 : 1; }
@@ -55,40 +57,40 @@ template <int W> __device__ __forceinline__ int tm_count(const TMask<W> &a) {
   for (int i = 0; i < W; ++i) n += __popcll(a.w[i]);
   return n;
 }
-// bits s0 .. s0 + TRK_C - 1 of a mask
-template <int W> __device__ __forceinline__ unsigned tm_window(const TMask<W> &a, int s0) {
+// bits s0 .. s0 + C - 1 of a mask
+template <int W, int C> __device__ __forceinline__ unsigned tm_window(const TMask<W> &a, int s0) {
   unsigned long long x = a.w[0];
   if constexpr (W == 2) x = (s0 >= 64) ? a.w[1] : x;  // (chunks are aligned: never across words)
-  return (unsigned)(x >> (s0 & 63)) & ((1u << TRK_C) - 1u);
+  return (unsigned)(x >> (s0 & 63)) & ((1u << C) - 1u);
 }
 
-template <int W>
-struct TV {  // a pool or a flux with its origins, columns s0 .. s0 + TRK_C - 1 of its map
+template <int W, int C>
+struct TV {  // a pool or a flux with its origins, columns s0 .. s0 + C - 1 of its map
   double val;
-  double f[TRK_C];
+  double f[C];
   TMask<W> mask;  // which sources are in the map (all of them)
   unsigned win;   // ... and the bits of this chunk's columns
 };
 
-template <int W>
-__device__ __forceinline__ TV<W> tv_self(int self, double val, int s0) {
-  TV<W> r;
+template <int W, int C>
+__device__ __forceinline__ TV<W, C> tv_self(int self, double val, int s0) {
+  TV<W, C> r;
   r.val = val;
 #pragma unroll
-  for (int c = 0; c < TRK_C; ++c) r.f[c] = (s0 + c == self) ? 1.0 : 0.0;
+  for (int c = 0; c < C; ++c) r.f[c] = (s0 + c == self) ? 1.0 : 0.0;
   r.mask = tm_bit<W>(self);
-  r.win = tm_window<W>(r.mask, s0);
+  r.win = tm_window<W, C>(r.mask, s0);
   return r;
 }
-template <int W>
-__device__ __forceinline__ TV<W> tv_from(const TV<W> &pool, double val) {  // flux_from_*
-  TV<W> r = pool;
+template <int W, int C>
+__device__ __forceinline__ TV<W, C> tv_from(const TV<W, C> &pool, double val) {  // flux_from_*
+  TV<W, C> r = pool;
   r.val = val;
   return r;
 }
-template <int W>
-__device__ __forceinline__ TV<W> tv_add(const TV<W> &a, const TV<W> &b) {  // operator+
-  TV<W> r;
+template <int W, int C>
+__device__ __forceinline__ TV<W, C> tv_add(const TV<W, C> &a, const TV<W, C> &b) {  // operator+
+  TV<W, C> r;
   r.val = a.val + b.val;
   r.mask = tm_or<W>(a.mask, b.mask);
   r.win = a.win | b.win;
@@ -98,21 +100,21 @@ __device__ __forceinline__ TV<W> tv_add(const TV<W> &a, const TV<W> &b) {  // op
   const double inv = hx_recip(r.val);
   const double wa = a.val * inv, wb = b.val * inv;  // (the same for every column: computed once a stash)
 #pragma unroll
-  for (int c = 0; c < TRK_C; ++c) r.f[c] = a.f[c] * wa + b.f[c] * wb;
+  for (int c = 0; c < C; ++c) r.f[c] = a.f[c] * wa + b.f[c] * wb;
   if (__builtin_expect(__any(r.val == 0.0), 0)) {  // a zero total: equal shares, :243-251
     const double share = 1.0 / (double)tm_count<W>(r.mask);
 #pragma unroll
-    for (int c = 0; c < TRK_C; ++c) {
+    for (int c = 0; c < C; ++c) {
       const double v = (r.win >> c & 1u) ? share : 0.0;
       r.f[c] = (r.val == 0.0) ? v : r.f[c];
     }
   }
   return r;
 }
-template <int W>
-__device__ __forceinline__ TV<W> tv_sub(TV<W> a, const TV<W> &b) { a.val = a.val - b.val; return a; }
-template <int W>
-__device__ __forceinline__ TV<W> tv_mul(TV<W> a, double k) { a.val = a.val * k; return a; }
+template <int W, int C>
+__device__ __forceinline__ TV<W, C> tv_sub(TV<W, C> a, const TV<W, C> &b) { a.val = a.val - b.val; return a; }
+template <int W, int C>
+__device__ __forceinline__ TV<W, C> tv_mul(TV<W, C> a, double k) { a.val = a.val * k; return a; }
 
 // what the stash hands over: values it has computed anyway (the per-biome ones are read from the
 // member where they are used -- the stash calls this BEFORE it writes the new pools)
@@ -132,7 +134,7 @@ struct TrkStashIn {
 // this year's -- is one contiguous piece of HBM (2 x 62 KB for one biome), not TP x TP rows that
 // lie npad doubles apart (a TLB miss and a DRAM page for every row), and every address is a
 // wave-uniform base plus the lane's 32-bit offset.
-template <int W>
+template <int W, int C>
 struct TrkIo {
   hx_gd blk_f, blk_v;            // the block's slot of LAST year; this year's follows it
   unsigned src_f, dst_f, prv_f;  // the lane's offsets from blk_f: read / written by this stash, last year
@@ -140,29 +142,29 @@ struct TrkIo {
   int TP, s0;
   bool last;  // last chunk: the masks are stored
 
-  __device__ __forceinline__ TV<W> load_from(unsigned off_f, unsigned off_v, int p, double val, int s0) const {
-    TV<W> r;
+  __device__ __forceinline__ TV<W, C> load_from(unsigned off_f, unsigned off_v, int p, double val, int s0) const {
+    TV<W, C> r;
     r.val = val;
     hx_gd row = blk_f + (size_t)(p * TP + s0) * 64;  // (uniform)
     // (columns past the last pool read the next row's first entries -- finite numbers, the record
     //  is padded by a row group at its end -- and are never stored)
 #pragma unroll
-    for (int c = 0; c < TRK_C; ++c) r.f[c] = row[off_f + c * 64];
+    for (int c = 0; c < C; ++c) r.f[c] = row[off_f + c * 64];
     hx_gd mrow = blk_v + (size_t)(TP + p) * 64;
 #pragma unroll
     for (int i = 0; i < W; ++i)  // (the looped kernels carry two words; the record has the high
       r.mask.w[i] = (i == 0 || TP > 64)  // ones only when there are more than 64 pools)
           ? (unsigned long long)__double_as_longlong(mrow[off_v + (unsigned)(i * TP * 64)]) : 0ull;
-    r.win = tm_window<W>(r.mask, s0);
+    r.win = tm_window<W, C>(r.mask, s0);
     return r;
   }
   // (s: the first column of the chunk -- the current one, or the next one's for a prefetch)
-  __device__ __forceinline__ TV<W> load(int p, double val, int s) const { return load_from(src_f, src_v, p, val, s); }
-  __device__ __forceinline__ TV<W> load_prev(int p, int s) const { return load_from(prv_f, prv_v, p, 0.0, s); }
-  __device__ __forceinline__ void store(int p, const TV<W> &t) const {
+  __device__ __forceinline__ TV<W, C> load(int p, double val, int s) const { return load_from(src_f, src_v, p, val, s); }
+  __device__ __forceinline__ TV<W, C> load_prev(int p, int s) const { return load_from(prv_f, prv_v, p, 0.0, s); }
+  __device__ __forceinline__ void store(int p, const TV<W, C> &t) const {
     hx_gd row = blk_f + (size_t)(p * TP + s0) * 64;
 #pragma unroll
-    for (int c = 0; c < TRK_C; ++c)
+    for (int c = 0; c < C; ++c)
       if (s0 + c < TP) row[dst_f + c * 64] = t.f[c];
     if (last) {
       hx_gd mrow = blk_v + (size_t)(TP + p) * 64;
@@ -193,14 +195,15 @@ __device__ void track_start(const Member<B> &m) {
 template <int B>
 __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkStashIn &in) {
   constexpr int W = (B == HX_DYN) ? 2 : (hx_trk_pools(B) > 64 ? 2 : 1);
-  using T = TV<W>;
+  constexpr int C = trk_c<B>();
+  using T = TV<W, C>;
   const HxBuffers &buf = *m.bufp;
   const int nb = nbio<B>(m);
   const int TP = hx_trk_pools(nb), O0 = 2 + 5 * nb;
   const int vrows = hx_trk_vrows(nb);
   const int k = m.iy - m.trk_iy;
   const bool first = m.nstash == 1;  // this lane's first stash of the year: from last year's matrix
-  TrkIo<W> io;
+  TrkIo<W, C> io;
   io.TP = TP;
   io.blk_f = HX_GD(buf.track_out_f) + ((size_t)blockIdx.x * buf.trk_slots + k) * (size_t)(TP * TP) * 64;
   io.blk_v = HX_GD(buf.track_out_v) + ((size_t)blockIdx.x * buf.trk_slots + k) * (size_t)vrows * 64;
@@ -222,10 +225,10 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
     return r;
   };
 #pragma unroll 1
-  for (int s0 = 0; s0 < TP; s0 += TRK_C) {
+  for (int s0 = 0; s0 < TP; s0 += C) {
     HX_STAMP(m, 20);  // tracking: set-up, everything that does not depend on the column
     io.s0 = s0;
-    io.last = s0 + TRK_C >= TP;
+    io.last = s0 + C >= TP;
     T atm, earth;
     Land5 cur;
     // ---------------- ocean: oceanbox.cpp:240-257, 262-271, 297-303 ----------------
@@ -235,7 +238,7 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         box[b] = io.load(O0 + b, in.pre[b], s0);
-        addn[b] = tv_self<W>(O0 + b, 0.0, s0);
+        addn[b] = tv_self<W, C>(O0 + b, 0.0, s0);
       }
       const T atm_copy = io.load_prev(TKP_ATM, s0);  // OceanComponent::atmosphere_cpool
       // (everything else the land part starts with is requested now: the stores below may alias
@@ -248,28 +251,28 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
       constexpr int from_[7] = {0, 1, 1, 2, 2, 2, 3}, to_[7] = {3, 0, 2, 1, 0, 3, 2};
 #pragma unroll
       for (int i = 0; i < 7; ++i)
-        addn[to_[i]] = tv_add<W>(addn[to_[i]], tv_from<W>(box[from_[i]], in.closs[i]));
+        addn[to_[i]] = tv_add<W, C>(addn[to_[i]], tv_from<W, C>(box[from_[i]], in.closs[i]));
       T ao[2], oa[2];
       const double af[2] = {in.aH, in.aL};
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        ao[b] = tv_from<W>(atm_copy, (af[b] > 0) ? af[b] : 0.0);
-        oa[b] = tv_from<W>(box[b], (af[b] > 0) ? 0.0 : -af[b]);
+        ao[b] = tv_from<W, C>(atm_copy, (af[b] > 0) ? af[b] : 0.0);
+        oa[b] = tv_from<W, C>(box[b], (af[b] > 0) ? 0.0 : -af[b]);
       }
-      oa_flux = tv_add<W>(oa[1], oa[0]);  // get_oaflux: LL + HL
-      ao_flux = tv_add<W>(ao[1], ao[0]);
+      oa_flux = tv_add<W, C>(oa[1], oa[0]);  // get_oaflux: LL + HL
+      ao_flux = tv_add<W, C>(ao[1], ao[0]);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        T c = tv_add<W>(box[b], addn[b]);
-        if (b < 2) { c = tv_add<W>(c, ao[b]); c = tv_sub<W>(c, oa[b]); }
-        else c = tv_add<W>(c, tv_from<W>(atm_copy, 0.0));
+        T c = tv_add<W, C>(box[b], addn[b]);
+        if (b < 2) { c = tv_add<W, C>(c, ao[b]); c = tv_sub<W, C>(c, oa[b]); }
+        else c = tv_add<W, C>(c, tv_from<W, C>(atm_copy, 0.0));
         io.store(O0 + b, c);
       }
     }
 
     HX_STAMP(m, 21);  // tracking: ocean boxes of a chunk (with the chunk's loads)
     // ---------------- land: simpleNbox-runtime.cpp:289-540 ----------------
-    const T ccs_flux = tv_from<W>(atm, m.daccs);
+    const T ccs_flux = tv_from<W, C>(atm, m.daccs);
     auto biome = [&](int b, const Land5 &pools) {
       T veg = pools.veg, det = pools.det, soil = pools.soil, pf = pools.pf, tp = pools.tp;
       const double rfda = m_rh_fda(m, b), rfsa = m_rh_fsa(m, b), rco2 = m_rh_tp_co2(m, lk, b),
@@ -278,31 +281,31 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
       const double wt = (B == 1) ? 1.0 : hx_div_cr(m_npp(m, lk, b) + ((rfda + rfsa) + rco2), in.npp_rh, in.inv_nr);
       const double veg_frac = veg.val / in.total, det_frac = det.val / in.total,
                    soil_frac = soil.val / in.total;
-      const T luc_fva = tv_mul<W>(tv_from<W>(veg, m.luc_e * veg_frac), yf);
-      const T luc_fda = tv_mul<W>(tv_from<W>(det, m.luc_e * det_frac), yf);
-      const T luc_fsa = tv_mul<W>(tv_from<W>(soil, m.luc_e * soil_frac), yf);
-      const T luc_fav = tv_mul<W>(tv_from<W>(atm, m.luc_u), yf);
+      const T luc_fva = tv_mul<W, C>(tv_from<W, C>(veg, m.luc_e * veg_frac), yf);
+      const T luc_fda = tv_mul<W, C>(tv_from<W, C>(det, m.luc_e * det_frac), yf);
+      const T luc_fsa = tv_mul<W, C>(tv_from<W, C>(soil, m.luc_e * soil_frac), yf);
+      const T luc_fav = tv_mul<W, C>(tv_from<W, C>(atm, m.luc_u), yf);
       const double npp_biome = in.npp_total * wt;
       const double fv = lk.f_nppv[b], fd = lk.f_nppd[b], fl = lk.f_litterd[b];
-      const T npp_fav = tv_mul<W>(tv_from<W>(atm, npp_biome * fv), yf);
-      const T npp_fad = tv_mul<W>(tv_from<W>(atm, npp_biome * fd), yf);
-      const T npp_fas = tv_mul<W>(tv_from<W>(atm, npp_biome * (1 - fv - fd)), yf);
+      const T npp_fav = tv_mul<W, C>(tv_from<W, C>(atm, npp_biome * fv), yf);
+      const T npp_fad = tv_mul<W, C>(tv_from<W, C>(atm, npp_biome * fd), yf);
+      const T npp_fas = tv_mul<W, C>(tv_from<W, C>(atm, npp_biome * (1 - fv - fd)), yf);
       const double rh_co2_adj = rco2 * in.rh_adj, rh_ch4_adj = rch4 * in.rh_adj;
-      const T rh_fda_flux = tv_mul<W>(tv_from<W>(det, rfda * in.rh_adj), yf);
-      const T rh_fsa_flux = tv_mul<W>(tv_from<W>(soil, rfsa * in.rh_adj), yf);
-      const T rh_fpa_co2 = tv_mul<W>(tv_from<W>(tp, rh_co2_adj), yf);
-      const T rh_fpa_ch4 = tv_mul<W>(tv_from<W>(tp, rh_ch4_adj), yf);
-      atm = tv_add<W>(tv_add<W>(tv_sub<W>(tv_add<W>(atm, luc_fva), luc_fav), luc_fda), luc_fsa);
-      veg = tv_sub<W>(tv_add<W>(veg, luc_fav), luc_fva);
-      soil = tv_sub<W>(soil, luc_fsa);  // (the reference's detritus line has no effect, :458)
-      veg = tv_add<W>(veg, npp_fav);
-      det = tv_add<W>(det, npp_fad);
-      soil = tv_add<W>(soil, npp_fas);
-      atm = tv_sub<W>(tv_sub<W>(tv_sub<W>(atm, npp_fav), npp_fad), npp_fas);
-      atm = tv_add<W>(tv_add<W>(tv_add<W>(atm, rh_fda_flux), rh_fsa_flux), rh_fpa_co2);
-      det = tv_sub<W>(det, rh_fda_flux);
-      soil = tv_sub<W>(soil, rh_fsa_flux);
-      tp = tv_sub<W>(tv_sub<W>(tp, rh_fpa_co2), rh_fpa_ch4);
+      const T rh_fda_flux = tv_mul<W, C>(tv_from<W, C>(det, rfda * in.rh_adj), yf);
+      const T rh_fsa_flux = tv_mul<W, C>(tv_from<W, C>(soil, rfsa * in.rh_adj), yf);
+      const T rh_fpa_co2 = tv_mul<W, C>(tv_from<W, C>(tp, rh_co2_adj), yf);
+      const T rh_fpa_ch4 = tv_mul<W, C>(tv_from<W, C>(tp, rh_ch4_adj), yf);
+      atm = tv_add<W, C>(tv_add<W, C>(tv_sub<W, C>(tv_add<W, C>(atm, luc_fva), luc_fav), luc_fda), luc_fsa);
+      veg = tv_sub<W, C>(tv_add<W, C>(veg, luc_fav), luc_fva);
+      soil = tv_sub<W, C>(soil, luc_fsa);  // (the reference's detritus line has no effect, :458)
+      veg = tv_add<W, C>(veg, npp_fav);
+      det = tv_add<W, C>(det, npp_fad);
+      soil = tv_add<W, C>(soil, npp_fas);
+      atm = tv_sub<W, C>(tv_sub<W, C>(tv_sub<W, C>(atm, npp_fav), npp_fad), npp_fas);
+      atm = tv_add<W, C>(tv_add<W, C>(tv_add<W, C>(atm, rh_fda_flux), rh_fsa_flux), rh_fpa_co2);
+      det = tv_sub<W, C>(det, rh_fda_flux);
+      soil = tv_sub<W, C>(soil, rh_fsa_flux);
+      tp = tv_sub<W, C>(tv_sub<W, C>(tp, rh_fpa_co2), rh_fpa_ch4);
       {  // compute_pf_thaw_refreeze :744-772 on the pools as they are now
         double x = pf.val * m.f_new_thaw[b], y = 0.0;
         if (x < 0) {
@@ -311,20 +314,20 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
           const double remaining = tp.val - rh_co2_adj - rh_ch4_adj;
           y = (remaining < want) ? remaining : want;
         }
-        const T pf_thaw = tv_mul<W>(tv_from<W>(pf, x), yf);
-        const T pf_refreeze_tp = tv_mul<W>(tv_from<W>(tp, y), yf);
-        const T pf_refreeze_soil = tv_mul<W>(tv_from<W>(soil, 0.0), yf);
-        pf = tv_add<W>(tv_add<W>(tv_sub<W>(pf, pf_thaw), pf_refreeze_tp), pf_refreeze_soil);
-        tp = tv_sub<W>(tv_add<W>(tp, pf_thaw), pf_refreeze_tp);
-        soil = tv_sub<W>(soil, pf_refreeze_soil);
+        const T pf_thaw = tv_mul<W, C>(tv_from<W, C>(pf, x), yf);
+        const T pf_refreeze_tp = tv_mul<W, C>(tv_from<W, C>(tp, y), yf);
+        const T pf_refreeze_soil = tv_mul<W, C>(tv_from<W, C>(soil, 0.0), yf);
+        pf = tv_add<W, C>(tv_add<W, C>(tv_sub<W, C>(pf, pf_thaw), pf_refreeze_tp), pf_refreeze_soil);
+        tp = tv_sub<W, C>(tv_add<W, C>(tp, pf_thaw), pf_refreeze_tp);
+        soil = tv_sub<W, C>(soil, pf_refreeze_soil);
       }
-      const T litter = tv_mul<W>(veg, 0.035 * yf);
-      det = tv_add<W>(det, tv_mul<W>(litter, fl));
-      soil = tv_add<W>(soil, tv_mul<W>(litter, 1 - fl));
-      veg = tv_sub<W>(veg, litter);
-      const T detsoil = tv_mul<W>(det, 0.6 * yf);
-      soil = tv_add<W>(soil, detsoil);
-      det = tv_sub<W>(det, detsoil);
+      const T litter = tv_mul<W, C>(veg, 0.035 * yf);
+      det = tv_add<W, C>(det, tv_mul<W, C>(litter, fl));
+      soil = tv_add<W, C>(soil, tv_mul<W, C>(litter, 1 - fl));
+      veg = tv_sub<W, C>(veg, litter);
+      const T detsoil = tv_mul<W, C>(det, 0.6 * yf);
+      soil = tv_add<W, C>(soil, detsoil);
+      det = tv_sub<W, C>(det, detsoil);
       io.store(2 + 5 * b + 0, veg); io.store(2 + 5 * b + 1, det); io.store(2 + 5 * b + 2, soil);
       io.store(2 + 5 * b + 3, pf); io.store(2 + 5 * b + 4, tp);
     };
@@ -344,10 +347,10 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
         if (b + 1 < B) cur = nxb;
       }
     }
-    const T ffi_flux = tv_from<W>(earth, m.ffi);
-    earth = tv_add<W>(tv_sub<W>(earth, ffi_flux), ccs_flux);
-    atm = tv_sub<W>(tv_add<W>(atm, ffi_flux), ccs_flux);
-    atm = tv_sub<W>(tv_add<W>(atm, oa_flux), ao_flux);
+    const T ffi_flux = tv_from<W, C>(earth, m.ffi);
+    earth = tv_add<W, C>(tv_sub<W, C>(earth, ffi_flux), ccs_flux);
+    atm = tv_sub<W, C>(tv_add<W, C>(atm, ffi_flux), ccs_flux);
+    atm = tv_sub<W, C>(tv_add<W, C>(atm, oa_flux), ao_flux);
     io.store(TKP_EARTH, earth);
     io.store(TKP_ATM, atm);
     HX_STAMP(m, 22);  // tracking: land pools of a chunk
