@@ -143,6 +143,9 @@ def _declare(lib):
         "hx_set_lane_calibration": [P, c.c_int],
         "hx_lanes_calibrated": [P, c.POINTER(c.c_int)],
         "hx_enable_history": [P, c.c_int],
+        "hx_enable_spinup_record": [P, c.c_int],
+        "hx_spinup_record": [P, c.c_int, c.POINTER(c.POINTER(c.c_char_p)), c.POINTER(c.c_int), dp, c.c_int,
+                             c.POINTER(c.c_int)],
         "hx_tracking_pools": [P, c.POINTER(c.POINTER(c.c_char_p)), c.POINTER(c.c_int)],
         "hx_tracking_data": [P, c.c_int, c.c_int, c.c_int, dp, dp, c.POINTER(c.c_ulonglong)],
         "hx_var_info": [P, c.c_char_p, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p)],
@@ -180,7 +183,7 @@ def _declare(lib):
 
 ABI_SYMBOLS = ["hx_backend", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_setvar",
                "hx_getvar", "hx_split_biome", "hx_split_biome_of", "hx_create_biome", "hx_delete_biome", "hx_rename_biome", "hx_set_outputs", "hx_output_capabilities",
-               "hx_set_member_sorting", "hx_lane_of_member", "hx_enable_history", "hx_setvar_dated", "hx_halocarbons", "hx_run_name", "hx_tracking_pools", "hx_tracking_data", "hx_var_info", "hx_biomes", "hx_setvar_dated_members", "hx_unit_csys", "hx_unit_doeclim_kernel", "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
+               "hx_set_member_sorting", "hx_lane_of_member", "hx_enable_history", "hx_enable_spinup_record", "hx_spinup_record", "hx_setvar_dated", "hx_halocarbons", "hx_run_name", "hx_tracking_pools", "hx_tracking_data", "hx_var_info", "hx_biomes", "hx_setvar_dated_members", "hx_unit_csys", "hx_unit_doeclim_kernel", "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
                "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_state_row", "hx_dates", "hx_sizes",
                "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream", "hx_set_pair_kernel_limit",
                "hx_last_run_kernel", "hx_component_output", "hx_newcore_devices", "hx_shards",

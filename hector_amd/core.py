@@ -155,6 +155,26 @@ class Core:
         self._ck(self._lib.hx_halocarbons(self._h, ctypes.byref(names), ctypes.byref(n)))
         return [names[i].decode() for i in range(n.value)]
 
+    def enable_spinup_record(self, on=True):
+        """Keep what the reference's output stream sees after every spinup step (its spinup = 1
+        rows, csv_outputstream_visitor.cpp:86-95): the carbon-cycle variables."""
+        self._ck(self._lib.hx_enable_spinup_record(self._h, 1 if on else 0))
+        return self
+
+    def spinup_record(self, member=0):
+        """-> dict capability -> values[steps] (steps 1 .. spinup_steps(member))"""
+        names = ctypes.POINTER(ctypes.c_char_p)()
+        nv = ctypes.c_int()
+        self._ck(self._lib.hx_spinup_record(self._h, int(member), ctypes.byref(names), ctypes.byref(nv),
+                                            None, 0, None))
+        mx = self.spinup_steps(member)
+        vals = np.zeros((max(mx, 1), nv.value))
+        steps = ctypes.c_int()
+        self._ck(self._lib.hx_spinup_record(self._h, int(member), None, None,
+                                            vals.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), max(mx, 1),
+                                            ctypes.byref(steps)))
+        return {names[i].decode(): vals[:steps.value, i].copy() for i in range(nv.value)}
+
     def enable_history(self, on=True):
         self._ck(self._lib.hx_enable_history(self._h, 1 if on else 0))
         return self

@@ -463,6 +463,7 @@ void EnsembleCore::free_device() {
   fr(d_hist_status_);
   fr(d_gas_par_); fr(d_gas_ser_); d_gas_par_ = d_gas_ser_ = nullptr;
   fr(d_cost_); d_cost_ = nullptr; cost_from_iy_ = -1;
+  fr(d_spin_rec_); d_spin_rec_ = nullptr;
   d_hist_ = nullptr; d_hist_status_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
   fr(d_diag_); fr(d_slr_); d_diag_ = d_slr_ = nullptr; diag_cap_ = 0; slr_valid_to_ = -1;
@@ -514,6 +515,17 @@ void EnsembleCore::alloc_device() {
     check(hipMalloc(&d_hist_, sizeof(double) * ns * np * HX_NSTATE(B_)), "hipMalloc state history");
     check(hipMalloc(&d_hist_status_, sizeof(unsigned) * ns * np), "hipMalloc status history");
   }
+  if (spin_record_) {
+    const size_t bytes = sizeof(double) * (size_t)kc_.max_spinup * HXSR_N * np;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b)
+      throw std::runtime_error("spinup record: " + std::to_string(kc_.max_spinup) + " steps x " +
+                               std::to_string((int)HXSR_N) + " variables x " + std::to_string(npad_) +
+                               " members need " + std::to_string(bytes >> 20) + " MiB of device memory, " +
+                               std::to_string(free_b >> 20) + " MiB are free");
+    check(hipMalloc(&d_spin_rec_, bytes), "hipMalloc spinup record");
+    check(hipMemsetAsync(d_spin_rec_, 0, bytes, stream_), "zero");
+  }
   hist_valid_to_ = 0;
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
@@ -561,6 +573,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   b.nbiome = B_;
   b.cost = d_cost_;
+  b.spin_rec = d_spin_rec_;
   return b;
 }
 
@@ -932,6 +945,38 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
   layout_dirty_ = true;
   need_spinup_ = true;
   last_iy_ = 0;
+}
+
+void EnsembleCore::enable_spinup_record(bool on) {
+  if (on == spin_record_) return;
+  spin_record_ = on;
+  layout_dirty_ = true;
+  need_spinup_ = true;
+  last_iy_ = 0;
+}
+
+const std::vector<std::string> &EnsembleCore::spinup_record_vars() {
+  // capability names, in the order of the HXSR_* rows
+  static const std::vector<std::string> v = {
+      "NBP", "NPP", "RH", "rh_det", "rh_soil", "atmos_co2", "atmos_c_residual", "veg_c", "detritus_c",
+      "soil_c", "permafrost_c", "thawedp_c", "earth_c", "HL_ocean_uptake", "LL_ocean_uptake",
+      "DO_ocean_c", "HL_ocean_c", "IO_ocean_c", "LL_ocean_c", "HL_downwelling", "ocean_uptake"};
+  static_assert(HXSR_N == 21, "spinup_record_vars lists the HXSR_* rows");
+  return v;
+}
+
+int EnsembleCore::spinup_record(int member, double *values, int max_steps) {
+  if (!spin_record_) throw std::runtime_error("the spinup record is off (hx_enable_spinup_record first)");
+  if (member < 0 || member >= n_) throw std::runtime_error("spinup_record: bad member index");
+  const int steps = spinup_steps(member);  // (prepares: runs the spinup if it is due)
+  if (steps > max_steps) throw std::runtime_error("spinup_record: room for " + std::to_string(max_steps) +
+                                                  " steps, the spinup took " + std::to_string(steps));
+  // a shared spinup (no member differs in a parameter the spinup sees) ran on the first wavefront
+  const size_t lane = spin_uniform_ ? 0 : (size_t)lane_of_member_[(size_t)member];
+  if (steps > 0)
+    check(hipMemcpy2D(values, sizeof(double), d_spin_rec_ + lane, (size_t)npad_ * sizeof(double),
+                      sizeof(double), (size_t)steps * HXSR_N, hipMemcpyDeviceToHost), "spinup record");
+  return steps;
 }
 
 void EnsembleCore::enable_history(bool on) {
@@ -1438,6 +1483,7 @@ void EnsembleCore::prepare() {
         if (!row_uniform_[HXP_NGLOBAL + b * HXPB_N + d.row]) uniform = false;
     } else if (!row_uniform_[d.row]) uniform = false;
   }
+  spin_uniform_ = uniform;
   check(hipEventRecord(ev0_, stream_), "event");
   check(hx_launch_spinup(B_, d_args_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
   check(hx_launch_alk(d_args_, uniform ? 1 : npad_, stream_), "alkalinity tuning");

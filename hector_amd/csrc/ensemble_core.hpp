@@ -77,6 +77,12 @@ class EnsembleCore {
   // keep every year's component state in HBM (272 B per member-year for one biome) so that
   // reset(date) can go back to any computed year, like the reference's tseries records
   void enable_history(bool on);
+  // keep what the reference's output stream sees after every spinup step (its "spinup = 1" rows,
+  // csv_outputstream_visitor.cpp:86-95): the carbon-cycle variables, max_spinup x 21 x 8 B per member
+  void enable_spinup_record(bool on);
+  static const std::vector<std::string> &spinup_record_vars();
+  // values[step * nvars + v] for steps 1..spinup_steps(member); returns the step count
+  int spinup_record(int member, double *values, int max_steps);
   // SETDATA with dates for a scenario input series (emissions, SV, RF_albedo...): the same
   // new values for every member.  Like R/messages.R:107-140 the core becomes dirty from
   // min(year) - 1; the next run() resets there (needs the history) or to startDate.
@@ -197,6 +203,8 @@ class EnsembleCore {
   unsigned *d_hist_status_ = nullptr;  // [ns][npad] status bits of every year (with d_hist_)
   void remap_biome_outputs(const std::vector<int> &old_of_new);
   bool history_ = false, shared_dirty_ = false;
+  bool spin_record_ = false, spin_uniform_ = false;
+  double *d_spin_rec_ = nullptr;
   int hist_valid_to_ = 0;   // history slabs 1..hist_valid_to_ are valid
   int dirty_from_iy_ = -1;  // pending auto-reset target (R wrapper's reset_date)
   int *d_lane_of_member_ = nullptr;

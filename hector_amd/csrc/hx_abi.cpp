@@ -248,6 +248,20 @@ int hx_run_name(hx_core *core, const char **name) {
   HX_TRY({ rn = core->core->run_name(); if (name) *name = rn.c_str(); })
 }
 int hx_enable_history(hx_core *core, int on) { HX_TRY(core->core->enable_history(on != 0)) }
+int hx_enable_spinup_record(hx_core *core, int on) { HX_TRY(core->core->enable_spinup_record(on != 0)) }
+int hx_spinup_record(hx_core *core, int member, const char *const **names, int *nvars, double *values,
+                     int max_steps, int *steps) {
+  static const std::vector<const char *> cnames = [] {
+    std::vector<const char *> v;
+    for (const std::string &s : hx::EnsembleCore::spinup_record_vars()) v.push_back(s.c_str());
+    return v;
+  }();
+  if (names) *names = cnames.data();
+  if (nvars) *nvars = (int)cnames.size();
+  if (!values) return 0;  // (the variable list alone)
+  if (!steps) return fail("hx_spinup_record: null argument");
+  HX_TRY(*steps = core->core->spinup_record(member, values, max_steps))
+}
 int hx_setvar_dated(hx_core *core, const char *capability, const int *years, const double *values,
                     int n, const char *units) {
   if (!capability || !years || !values || n < 1) return fail("hx_setvar_dated: bad arguments");

@@ -101,6 +101,7 @@ struct Member {
   int iy;                 // year index being integrated
   int trk_iy;             // first tracked year index (tracking kernels)
   int nb;                 // biome count (looped kernels)
+  double *spin_row;       // spinup kernel: this lane's column of the current step's record, or null
   double (*trk_rec)[64];  // CON == 3: hand-over slots to the tracking companion wavefront
   int *trk_cmd;
 };

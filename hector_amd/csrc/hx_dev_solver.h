@@ -292,6 +292,13 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
 #pragma unroll
   for (int b = 0; b < NB; ++b) pf_t += m.pf[b];
+  [[maybe_unused]] double sp_rd = 0, sp_rs = 0, sp_rc = 0;  // spinup record: final_rh_detritus / _soil, thawed part
+  if constexpr (SPIN) {
+    if (m.spin_row) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { sp_rd += m_rh_fda(m, b); sp_rs += m_rh_fsa(m, b); sp_rc += m_rh_tp_co2(m, lk, b); }
+    }
+  }
   double alf = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
   const double npp_rh = npp_t + rh_t;
   double tpf = c5;
@@ -378,6 +385,16 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     const double residual = m.atmos - match;
     m.cDO = residual + m.cDO;
     m.atmos = m.atmos - residual;
+    if (m.spin_row) {  // the output stream's view of this spinup step (hx_enable_spinup_record)
+      hx_gd r = HX_GD(m.spin_row);
+      const size_t np = (size_t)m.npad;
+      r[HXSR_NBP * np] = alf;
+      r[HXSR_NPP * np] = npp_t;   // (final_npp: the weights sum to one)
+      r[HXSR_RH * np] = (sp_rd + sp_rs) + sp_rc;   // (no CH4 from thawed permafrost in the spinup)
+      r[HXSR_RH_DET * np] = sp_rd; r[HXSR_RH_SOIL * np] = sp_rs;
+      r[HXSR_CA_RESIDUAL * np] = residual;
+      r[HXSR_HL_UPTAKE * np] += aH; r[HXSR_LL_UPTAKE * np] += aL; r[HXSR_HL_DO * np] += lHD;
+    }
   } else if constexpr (CON) {
     // user-supplied [CO2] at this date: same transfer (:567-603); only whole dates exist
     if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {

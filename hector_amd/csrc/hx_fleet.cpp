@@ -176,6 +176,12 @@ bool Fleet::lanes_calibrated() const {
   return true;
 }
 void Fleet::enable_history(bool on) { HX_EACH(enable_history(on)) }
+void Fleet::enable_spinup_record(bool on) { HX_EACH(enable_spinup_record(on)) }
+int Fleet::spinup_record(int member, double *values, int max_steps) {
+  Shard &s = shards_[(size_t)shard_of_member(member)];
+  use(s);
+  return s.core->spinup_record(member - s.offset, values, max_steps);
+}
 void Fleet::set_pair_kernel_limit(int m) { HX_EACH(set_pair_kernel_limit(m)) }
 void Fleet::setvar_dated(const std::string &cap, const int *years, const double *values, int n,
                          const char *units) {

@@ -69,6 +69,8 @@ class Fleet {
   void set_lane_calibration(bool on);
   bool lanes_calibrated() const;
   void enable_history(bool on);
+  void enable_spinup_record(bool on);
+  int spinup_record(int member, double *values, int max_steps);
   void setvar_dated(const std::string &capability, const int *years, const double *values, int n,
                     const char *units);
   void setvar_dated_members(const std::string &capability, const int *years, const double *values,

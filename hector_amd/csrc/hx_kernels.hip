@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   m.pco2H = m.pco2L = 0; m.annualflux_sum = 0; m.nbp = 0; m.nsteps = 0;
   m.kH.Tr = m.kL.Tr = 0; m.kH.g = m.kL.g = 0;
   m.chem_fresh = false;
+  m.spin_row = nullptr;
 
   bool spun = (kc.max_spinup <= 1);
   int steps = 0;
@@ -363,6 +364,13 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
       for (int b = 0; b < nbio<B>(m); ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
                                      op += m.pf[b]; ot += m.thawed[b]; }
       m.nstash = 0; m.nsteps = 0;
+      m.annualflux_sum = 0;
+      if (buf.spin_rec) {
+        m.spin_row = buf.spin_rec + ((size_t)(step - 1) * HXSR_N * buf.npad + mem);
+        hx_gd r = HX_GD(m.spin_row);
+        r[(size_t)HXSR_HL_UPTAKE * buf.npad] = 0.0; r[(size_t)HXSR_LL_UPTAKE * buf.npad] = 0.0;
+        r[(size_t)HXSR_HL_DO * buf.npad] = 0.0;
+      }
       solve_year<B, true>(m, kc, (double)(step - 1), (double)step, YearCon{});
       double nv = 0, nd = 0, nso = 0, np = 0, nt = 0;
 #pragma unroll
@@ -376,6 +384,16 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
       mx = fmax(mx, fabs(m.earth - oE));
       steps = step;
       spun = (mx < kc.eps_spinup) || (m.status != 0);
+      if (m.spin_row) {  // the pools as recorded after the step (record_state)
+        hx_gd r = HX_GD(m.spin_row);
+        const size_t npd = (size_t)buf.npad;
+        r[HXSR_ATMOS_C * npd] = m.atmos; r[HXSR_VEG_C * npd] = nv; r[HXSR_DET_C * npd] = nd;
+        r[HXSR_SOIL_C * npd] = nso; r[HXSR_PERMAFROST_C * npd] = np; r[HXSR_THAWED_C * npd] = nt;
+        r[HXSR_EARTH_C * npd] = m.earth;
+        r[HXSR_C_DO * npd] = m.cDO; r[HXSR_C_HL * npd] = m.cHL; r[HXSR_C_IO * npd] = m.cIO;
+        r[HXSR_C_LL * npd] = m.cLL;
+        r[HXSR_OCEAN_UPTAKE * npd] = m.annualflux_sum;
+      }
     }
   }
   if (!spun) m.status |= HX_ERR_SPINUP;

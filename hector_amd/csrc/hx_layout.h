@@ -217,7 +217,16 @@ struct HxBuffers {
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
   double *cost;          // [npad] what the launches since the last reset cost each lane (4 per dopri5
                          // step + 5 per stash): the host orders the lanes by it (EnsembleCore::assign_lanes)
+  // optional (hx_enable_spinup_record): what the reference's output stream sees after every spinup
+  // step -- its "spinup = 1" rows (csv_outputstream_visitor.cpp:86-95) -- [max_spinup][HXSR_N][npad]
+  double *spin_rec;
 };
+// rows of HxBuffers::spin_rec: the carbon-cycle variables of the stream, which are the ones that
+// move during the spinup
+enum { HXSR_NBP = 0, HXSR_NPP, HXSR_RH, HXSR_RH_DET, HXSR_RH_SOIL, HXSR_ATMOS_C, HXSR_CA_RESIDUAL,
+       HXSR_VEG_C, HXSR_DET_C, HXSR_SOIL_C, HXSR_PERMAFROST_C, HXSR_THAWED_C, HXSR_EARTH_C,
+       HXSR_HL_UPTAKE, HXSR_LL_UPTAKE, HXSR_C_DO, HXSR_C_HL, HXSR_C_IO, HXSR_C_LL, HXSR_HL_DO,
+       HXSR_OCEAN_UPTAKE, HXSR_N };
 
 // ---- diagnostics derived on the device from recorded outputs (hx_diag_kernel) ----
 enum HxDiagKind {

@@ -6,8 +6,9 @@
 //   year,run_name,spinup,component,variable,value,units
 //
 // One row per (year, variable).  Differences from the reference, by design of the ensemble
-// path: only post-spinup years are written (spinup = 0; the reference also streams its ~500
-// spinup steps); with --members N > 1 the run_name column is "<run_name>.<member>"; values are
+// path: the spinup = 1 rows (one set per spinup step, the step number in the year column) hold the
+// carbon-cycle variables of simpleNbox and the ocean only -- the rest does not run in the spinup
+// (--no-spinup-rows leaves them out; off beyond 4 096 members); with --members N > 1 the run_name column is "<run_name>.<member>"; values are
 // printed with 6 significant digits like the reference (forcings with 4,
 // csv_outputstream_visitor.cpp:129) unless --precision is given.
 // Talks to libhector_amd.so through the C ABI only.
@@ -69,6 +70,7 @@ std::vector<double> parse_values(const std::string &txt) {
 static int run_main(int argc, char **argv) {
   std::string scenario, outdir = "output/";
   int members = 1, device = 0, precision = 0, runto = -1;
+  bool spinup_rows = true;  // the stream's spinup = 1 rows (one set per spinup step)
   std::vector<int> devices;  // --devices 0,1,...: the members sharded over several GPUs
   std::vector<std::pair<std::string, std::string>> params;
   for (int i = 1; i < argc; ++i) {
@@ -83,6 +85,7 @@ static int run_main(int argc, char **argv) {
     else if (a == "--output-dir") { outdir = next(); if (outdir.back() != '/') outdir += '/'; }
     else if (a == "--precision") precision = std::atoi(next().c_str());
     else if (a == "--run-to") runto = std::atoi(next().c_str());
+    else if (a == "--no-spinup-rows") spinup_rows = false;
     else if (a == "--set") {  // --set S=2.5,3.0,4.1   one value, or one per member
       const std::string kv = next();
       const size_t eq = kv.find('=');
@@ -91,6 +94,7 @@ static int run_main(int argc, char **argv) {
     } else if (a == "-h" || a == "--help") {
       std::printf("Usage: hector-amd <config file name> [--members N] [--set cap=v[,v...]]...\n"
                   "       [--run-to year] [--output-dir dir] [--precision digits] [--device i]\n"
+                  "       [--no-spinup-rows]\n"
                   "       [--devices i,j,...]   (the members in contiguous blocks over several GPUs)\n");
       return 0;
     } else if (scenario.empty()) scenario = a;
@@ -138,6 +142,10 @@ static int run_main(int argc, char **argv) {
     for (auto &w : wanted) ptr.push_back(w.c_str());
     ck(hx_set_outputs(core, (int)ptr.size(), ptr.data()));
   }
+  // the spinup as the stream sees it (csv_outputstream_visitor.cpp:86-95): 336 KB of HBM per
+  // member -- for the ensembles a stream file makes sense for
+  if (members > 4096) spinup_rows = false;
+  if (spinup_rows) ck(hx_enable_spinup_record(core, 1));
   ck(hx_run(core, (double)runto));
   ck(hx_sync(core));
 
@@ -201,8 +209,60 @@ static int run_main(int argc, char **argv) {
     ck(hx_var_info(core, v, &c, &u));
     info[v] = Info{c, u};
   }
+  // spinup = 1 rows: after every spinup step the visitor prints the model as it stands, the step
+  // number in the year column.  Written here: the carbon-cycle variables of simpleNbox and the
+  // ocean (the ones that move; hx_spinup_record).  Temperature, gases and forcing do not run in
+  // the spinup and the ocean chemistry is off (spinup_chem = 0): what the reference prints for
+  // them there is initial or undefined state and is left out.
+  std::vector<double> sp;
+  const char *const *sp_names = nullptr;
+  int sp_nv = 0, max_spin = 0;
+  if (spinup_rows) {
+    ck(hx_spinup_record(core, 0, &sp_names, &sp_nv, nullptr, 0, nullptr));
+    for (int mbr = 0; mbr < members; ++mbr) {
+      int st = 0;
+      ck(hx_spinup_steps(core, mbr, &st));
+      if (st > max_spin) max_spin = st;
+    }
+    sp.resize((size_t)(max_spin > 0 ? max_spin : 1) * sp_nv);
+  }
+  auto sp_row = [&](int step, const std::string &run, const char *comp, const std::string &var,
+                    double v, const char *units) {
+    auto it = comp_out.find(comp);
+    if (it == comp_out.end()) {
+      int en = 1;
+      ck(hx_component_output(core, comp, &en));
+      it = comp_out.emplace(comp, en != 0).first;
+    }
+    if (it->second)
+      std::fprintf(out, "%d,%s,1,%s,%s,%.*g,%s\n", step, run.c_str(), comp, var.c_str(), p_def, v, units);
+  };
   for (int mbr = 0; mbr < members; ++mbr) {
     const std::string run = members > 1 ? rn + "." + std::to_string(mbr) : rn;
+    if (spinup_rows && max_spin > 0) {
+      int steps = 0;
+      ck(hx_spinup_record(core, mbr, nullptr, nullptr, sp.data(), max_spin, &steps));
+      std::map<std::string, int> col;
+      for (int v = 0; v < sp_nv; ++v) col[sp_names[v]] = v;
+      static const char *const land[] = {"NBP", "NPP", "RH", "rh_det", "rh_soil", "rh_ch4", "CO2_concentration",
+                                         "atmos_co2", "atmos_c_residual", "veg_c", "detritus_c", "soil_c",
+                                         "permafrost_c", "thawedp_c", "f_frozen", "earth_c"};
+      static const char *const sea[] = {"HL_ocean_uptake", "LL_ocean_uptake", "DO_ocean_c", "HL_ocean_c",
+                                        "IO_ocean_c", "LL_ocean_c", "HL_downwelling", "ocean_uptake", "ocean_c"};
+      for (int st = 1; st <= steps; ++st) {
+        const double *r = sp.data() + (size_t)(st - 1) * sp_nv;
+        auto val = [&](const std::string &v) {
+          if (v == "rh_ch4") return r[col["RH"]];                 // (the stream's alias, :151)
+          if (v == "CO2_concentration") return r[col["atmos_co2"]] * (1.0 / 2.13);
+          if (v == "f_frozen") return 1.0;                        // (no thaw in the spinup)
+          if (v == "ocean_c")
+            return r[col["DO_ocean_c"]] + r[col["IO_ocean_c"]] + r[col["LL_ocean_c"]] + r[col["HL_ocean_c"]];
+          return r[col[v]];
+        };
+        for (const char *v : land) sp_row(st, run, "simpleNbox", v, val(v), info[v].units.c_str());
+        for (const char *v : sea) sp_row(st, run, "ocean", v, val(v), info[v].units.c_str());
+      }
+    }
     for (int y = y0; y <= runto; ++y) {
       const size_t o = (size_t)(y - y0) * members + mbr;
       if (y >= base) {

@@ -120,6 +120,19 @@ int hx_setvar_dated_members(hx_core *core, const char *capability, const int *ye
  * what the reference's per-component tseries records provide (src/simpleNbox.cpp:708-840,
  * src/ocean_component.cpp:767-846).  272 B per member-year (one biome); default off. */
 int hx_enable_history(hx_core *core, int on);
+
+/* The spinup as the reference's output stream sees it: CSVOutputStreamVisitor is visited after
+ * every spinup step with spinup = 1 (src/core.cpp:402-408, src/csv_outputstream_visitor.cpp:86-95,
+ * the year column holds the step number).  hx_enable_spinup_record(core, 1) before the first run
+ * keeps the carbon-cycle variables of those rows -- the ones that move during the spinup: NBP, NPP,
+ * RH, rh_det, rh_soil, atmos_co2, atmos_c_residual, the land pools, earth_c, the ocean boxes'
+ * carbon and the air-sea / HL->DO fluxes -- at max_spinup x 21 x 8 B of HBM per member.
+ * hx_spinup_record: *names / *nvars = the capability names (values == NULL: only that);
+ * values[(step-1) * nvars + v] for steps 1 .. *steps of `member`.  hector-amd writes them as the
+ * spinup = 1 rows of outputstream_<run_name>.csv. */
+int hx_enable_spinup_record(hx_core *core, int on);
+int hx_spinup_record(hx_core *core, int member, const char *const **names, int *nvars, double *values,
+                     int max_steps, int *steps);
 /* fetchvars(core, NA, var) for parameters: GETDATA without a date. out[n_members] */
 int hx_getvar(hx_core *core, const char *capability, double *out);
 

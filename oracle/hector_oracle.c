@@ -215,6 +215,7 @@ void hxo_scenario_free(hxo_scenario *s) {
 }
 int hxo_scenario_start(const hxo_scenario *s) { return s->start; }
 int hxo_scenario_end(const hxo_scenario *s) { return s->end; }
+int hxo_scenario_max_spinup(const hxo_scenario *s) { return s->max_spinup; }
 
 void hxo_params_default(const hxo_scenario *s, hxo_params *p) {
   memset(p, 0, sizeof *p);
@@ -1871,8 +1872,7 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
 /* ------------------------------------------------------------------ */
 /* driver                                                              */
 /* ------------------------------------------------------------------ */
-static void record_outputs(member_t *m, int iy, double *out) {
-  const int ns = m->ns;
+static void record_outputs_stride(member_t *m, int iy, double *out, int ns) {
 #define O(V) out[(V) * ns + iy]
   O(HXO_CO2) = m->atmos_c * PGC_TO_PPMVCO2;
   O(HXO_ATMOS_C) = m->atmos_c;
@@ -1932,6 +1932,8 @@ static void record_outputs(member_t *m, int iy, double *out) {
 #undef O
 }
 
+static void record_outputs(member_t *m, int iy, double *out) { record_outputs_stride(m, iy, out, m->ns); }
+
 /* prepareToRun of every component (core.cpp:372-376) */
 static void member_prepare(member_t *m, const hxo_scenario *s, const hxo_params *p,
                            double *buf) {
@@ -1974,8 +1976,11 @@ static void member_prepare(member_t *m, const hxo_scenario *s, const hxo_params 
   m->tas_land = 0.0; m->sst_now = 0.0;
 }
 
-/* Core::run_spinup core.cpp:394-420; returns the number of steps */
-static int member_spinup(member_t *m) {
+/* Core::run_spinup core.cpp:394-420; returns the number of steps.  spin_out (may be NULL):
+ * [variable][max_spinup] -- the state after every step as the output-stream visitor would see it
+ * (CSVOutputStreamVisitor is visited after every spinup step with spinup = 1, core.cpp:402-408,
+ * csv_outputstream_visitor.cpp:86-95), row step-1. */
+static int member_spinup_rec(member_t *m, double *spin_out) {
   const hxo_scenario *s = m->sc;
   int step = 0, spunup = 0;
   if (s->do_spinup) {
@@ -2003,12 +2008,15 @@ static int member_spinup(member_t *m) {
       spunup = (max_dcdt < s->eps_spinup);
       if (spunup) m->t = s->start;
       snb_record_state(m);
+      if (spin_out) record_outputs_stride(m, step - 1, spin_out, s->max_spinup);
     }
     if (!spunup) m->err |= HXO_ERR_SPINUP;
     m->core_in_spinup = 0;
   }
   return step;
 }
+
+static int member_spinup(member_t *m) { return member_spinup_rec(m, NULL); }
 
 /* slrComponent::run + compute_slr  src/slr_component.cpp:116-232 (Vermeer & Rahmstorf 2009).
  * tgav is recorded from startDate+1; nothing is computed before the end of the reference
@@ -2180,6 +2188,19 @@ int hxo_run_member_tracking(const hxo_scenario *s, const hxo_params *p, int run_
   int step = member_spinup(m);
   if (spinup_steps) *spinup_steps = step;
   member_main(m, run_to, out);
+  free(buf);
+  return m->err;
+}
+
+/* The spinup alone, with what the output stream sees after every step (spinup = 1 rows):
+ * spin_out [HXO_NVAR][s->max_spinup], row step-1; returns the error mask, *steps the step count. */
+int hxo_run_member_spinup(const hxo_scenario *s, const hxo_params *p, double *spin_out, int *steps) {
+  member_t M, *m = &M;
+  memset(spin_out, 0, sizeof(double) * (size_t)HXO_NVAR * (size_t)s->max_spinup);
+  double *buf = (double *)malloc(sizeof(double) * (size_t)s->ns * 8);
+  member_prepare(m, s, p, buf);
+  const int step = member_spinup_rec(m, spin_out);
+  if (steps) *steps = step;
   free(buf);
   return m->err;
 }

@@ -112,6 +112,7 @@ hxo_scenario *hxo_scenario_load(const char *path);
 void hxo_scenario_free(hxo_scenario *);
 int hxo_scenario_start(const hxo_scenario *);
 int hxo_scenario_end(const hxo_scenario *);
+int hxo_scenario_max_spinup(const hxo_scenario *);
 
 /* Fill *p with the scenario's own (INI) values, one "global" biome. */
 void hxo_params_default(const hxo_scenario *, hxo_params *p);
@@ -143,6 +144,11 @@ void hxo_set_rounding_noise(double rel);
 int hxo_run_member_tracking(const hxo_scenario *, const hxo_params *, int run_to,
                             int tracking_date, double *out, int *spinup_steps, double *trk_f,
                             double *trk_v);
+
+/* The spinup alone (Core::run_spinup, core.cpp:394-420) with the state the output-stream visitor
+ * sees after every step (its spinup = 1 rows, csv_outputstream_visitor.cpp:86-95):
+ * spin_out[HXO_NVAR][max_spinup], row step-1.  *steps (may be NULL) = number of steps. */
+int hxo_run_member_spinup(const hxo_scenario *s, const hxo_params *p, double *spin_out, int *steps);
 
 /* Run members [0,n) whose parameters differ from *base only in S and q10_rh[0]
  * (the BASELINE config 2-4 ensemble); writes co2[n*ns], tgav[n*ns] (may be

@@ -98,6 +98,20 @@ class Oracle:
                                       out.ctypes.data, ctypes.byref(steps))
         return {v: out[i] for i, v in enumerate(VARS)}, err, steps.value
 
+    def run_spinup(self, p=None):
+        """The spinup alone -> (dict var -> [steps]: what the output stream sees after every
+        spinup step, its spinup = 1 rows; err; steps)"""
+        p = p or self.default_params()
+        self.lib.hxo_scenario_max_spinup.argtypes = [ctypes.c_void_p]
+        mx = self.lib.hxo_scenario_max_spinup(self.sc)
+        out = np.zeros((len(VARS), mx))
+        steps = ctypes.c_int(0)
+        fn = self.lib.hxo_run_member_spinup
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        err = fn(self.sc, ctypes.byref(p), out.ctypes.data, ctypes.byref(steps))
+        return {v: out[i, :steps.value] for i, v in enumerate(VARS)}, err, steps.value
+
     def run_tracking(self, p, tracking_date, run_to=None):
         """-> (values[ns, TP], fractions[ns, TP, TP], pool names, err); see hector_oracle.h"""
         p = p or self.default_params()

@@ -31,8 +31,8 @@ def read_stream(path):
 def check_stream_against_golden(rows, golden, run_name):
     by = {}
     for r in rows:
-        assert r["spinup"] == "0"
-        if r["run_name"] == run_name:
+        assert r["spinup"] in ("0", "1")
+        if r["run_name"] == run_name and r["spinup"] == "0":
             by.setdefault(r["variable"], {})[int(r["year"])] = float(r["value"])
     for gv, sv in GOLDEN_TO_STREAM.items():
         ref = golden[gv]
@@ -59,6 +59,23 @@ def test_cli_writes_the_reference_output_stream(emul_lib, golden, tmp_path):
                  ("N2O", "N2O_concentration", "ppbv N2O")]:
         assert want in comps, want
     assert min(by["RF_tot"]) == 1750 and min(by["slr"]) == 1746 and min(by["sl_rc"]) == 1990
+    # the spinup = 1 rows (csv_outputstream_visitor.cpp:86-95): the step number in the year
+    # column, one set of carbon-cycle rows per spinup step, ahead of the run years
+    spin = [r for r in rows if r["spinup"] == "1"]
+    assert rows.index(spin[-1]) < rows.index(next(r for r in rows if r["spinup"] == "0"))
+    steps = sorted({int(r["year"]) for r in spin})
+    assert steps == list(range(1, 499)) and len(spin) == 498 * 25
+    last = {r["variable"]: float(r["value"]) for r in spin if r["year"] == "498"}
+    assert last["CO2_concentration"] == pytest.approx(277.15, rel=1e-6)     # pinned to C0
+    assert last["veg_c"] == pytest.approx(golden["veg_c"][0], rel=2e-6) if "veg_c" in golden else True
+    assert last["atmos_co2"] == pytest.approx(golden["atmos_co2"][0], rel=2e-6)
+    assert last["ocean_c"] == pytest.approx(golden["ocean_c"][0], rel=2e-6)
+    assert last["permafrost_c"] == pytest.approx(golden["permafrost_c"][0], rel=2e-6)
+    assert {r["component"] for r in spin} == {"simpleNbox", "ocean"}
+    r = subprocess.run([EMUL_CLI, SCENARIO, "--output-dir", str(tmp_path), "--no-spinup-rows",
+                        "--run-to", "1750"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert all(x["spinup"] == "0" for x in read_stream(tmp_path / "outputstream_ssp245.csv"))
 
 
 def test_cli_ensemble_members_and_errors(emul_lib, golden, tmp_path):
