@@ -14,3 +14,5 @@ mkdir -p gpurun_out
 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -4 gpurun_out/${TAG}_pytest_gpu.log
 bash tools/prof/collect.sh $TAG "65536 1" "65536 4" "1024 1" "32768 1" "131072 1" > gpurun_out/collect_${TAG}.log 2>&1; tail -c 150 gpurun_out/collect_${TAG}.log
 python tools/prof/time_variants.py prod=hector_amd/lib/libhector_amd.so --configs=65536x1,65536x4,1024x1,32768x1,131072x1,262144x1 2>&1 | grep -v "^$\|amdgpu.ids" | tee gpurun_out/${TAG}_sizes.txt
+python tools/prof/tracking_times.py 2>&1 | grep "^|" | tee gpurun_out/${TAG}_tracking.md
+python bench.py --steps 20 --warmup 3 2>/dev/null | grep "^{" | tail -1 > gpurun_out/${TAG}_bench_default_line.json
