@@ -358,14 +358,15 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
 }
 
 // ===========================================================================================
-// One biome: the companion wavefront (hx_run_kernel<1, HF, KERPM, 3>, 128 threads a block).
+// One biome: the companion wavefronts (hx_run_kernel<1, HF, KERPM, 3>, 192 threads a block).
 //
-// The eleven pools' maps -- 121 fractions, 11 masks -- fit the register file of a wavefront that
-// does nothing else.  Wave 0 runs the model and, at every stash, hands the values the maps move
-// with (36 doubles a lane) over through LDS; wave 1 keeps the whole matrix in registers for the
-// launch, mixes while wave 0 is already integrating the next segment, and writes a year's matrix
-// to the record once, at the year's end.  Nothing of the matrix is re-read from HBM, the model
-// wavefront's registers hold no tracking state, and the two overlap.
+// The eleven pools' maps -- 121 fractions, 11 masks -- fit the register files of two wavefronts that
+// do nothing else (source columns 0-5 and 6-10: every mixing operation acts on each column
+// separately).  Wave 0 runs the model and, at every stash, hands the values the maps move with
+// (36 doubles a lane) over through LDS; waves 1 and 2 keep their half of the matrix in registers
+// for the launch, mix while wave 0 is already integrating the next segment, and write a year's
+// matrix to the record once, at the year's end.  Nothing of the matrix is re-read from HBM, the
+// model wavefront's registers hold no tracking state, and the three overlap.
 // ===========================================================================================
 enum { TRKR_YF = 0, TRKR_PRE = 1, TRKR_CLOSS = 5, TRKR_AH = 12, TRKR_AL, TRKR_NPP, TRKR_RHADJ, TRKR_TOTAL,
        TRKR_ATMOS, TRKR_EARTH, TRKR_DACCS, TRKR_FFI, TRKR_LUCE, TRKR_LUCU,
@@ -374,17 +375,25 @@ enum { TRKR_YF = 0, TRKR_PRE = 1, TRKR_CLOSS = 5, TRKR_AH = 12, TRKR_AL, TRKR_NP
        TRKR_ACTIVE, TRKR_N };
 enum { TRKC_STASH = 1, TRKC_YEAR = 2, TRKC_DONE = 3 };
 
-template <int TP>
-struct TVR {  // a pool or a flux with its whole map, in registers
+// The companions' additions are kept in program order: left alone, the scheduler starts every
+// reciprocal and weight of a stash as early as it can (they depend on the handed-over values only)
+// and ~100 more doubles are live than the maps need -- into AGPRs and scratch again.
+#ifdef HX_HOST_EMULATION
+#define HX_TRK_ORDER()
+#else
+#define HX_TRK_ORDER() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <int NC>
+struct TVR {  // a pool or a flux with columns c0 .. c0 + NC - 1 of its map, in registers
   double val;
-  double f[TP];
-  unsigned long long mask;
+  double f[NC];
+  unsigned long long mask;  // (the whole map's names)
 };
-template <int TP> __device__ __forceinline__ TVR<TP> tvr_self(int self, double val) {
+template <int TP> __device__ __forceinline__ TVR<TP> tvr_self(int self, double val, int c0) {
   TVR<TP> r;
   r.val = val;
 #pragma unroll
-  for (int s = 0; s < TP; ++s) r.f[s] = (s == self) ? 1.0 : 0.0;
+  for (int s = 0; s < TP; ++s) r.f[s] = (c0 + s == self) ? 1.0 : 0.0;
   r.mask = 1ull << self;
   return r;
 }
@@ -393,7 +402,8 @@ template <int TP> __device__ __forceinline__ TVR<TP> tvr_from(const TVR<TP> &poo
   r.val = val;
   return r;
 }
-template <int TP> __device__ __forceinline__ TVR<TP> tvr_add(const TVR<TP> &a, const TVR<TP> &b) {
+template <int TP> __device__ __forceinline__ TVR<TP> tvr_add(const TVR<TP> &a, const TVR<TP> &b, int c0) {
+  HX_TRK_ORDER();
   TVR<TP> r;
   r.val = a.val + b.val;
   r.mask = a.mask | b.mask;
@@ -405,7 +415,7 @@ template <int TP> __device__ __forceinline__ TVR<TP> tvr_add(const TVR<TP> &a, c
     const double share = 1.0 / (double)__popcll(r.mask);
 #pragma unroll
     for (int s = 0; s < TP; ++s) {
-      const double v = (r.mask >> s & 1ull) ? share : 0.0;
+      const double v = (r.mask >> (c0 + s) & 1ull) ? share : 0.0;
       r.f[s] = (r.val == 0.0) ? v : r.f[s];
     }
   }
@@ -413,7 +423,7 @@ template <int TP> __device__ __forceinline__ TVR<TP> tvr_add(const TVR<TP> &a, c
 }
 // the same with a structurally empty left side (a fresh sum of inflows: value 0, the pool's own
 // name in the map): the flux's fractions as they are instead of times value / value
-template <int TP> __device__ __forceinline__ TVR<TP> tvr_add_to_empty(int self, const TVR<TP> &b, double bval) {
+template <int TP> __device__ __forceinline__ TVR<TP> tvr_add_to_empty(int self, const TVR<TP> &b, double bval, int c0) {
   TVR<TP> r = b;
   r.val = 0.0 + bval;
   r.mask = b.mask | 1ull << self;
@@ -421,20 +431,20 @@ template <int TP> __device__ __forceinline__ TVR<TP> tvr_add_to_empty(int self, 
     const double share = 1.0 / (double)__popcll(r.mask);
 #pragma unroll
     for (int s = 0; s < TP; ++s) {
-      const double v = (r.mask >> s & 1ull) ? share : 0.0;
+      const double v = (r.mask >> (c0 + s) & 1ull) ? share : 0.0;
       r.f[s] = (r.val == 0.0) ? v : r.f[s];
     }
   }
   return r;
 }
 // ... and with a flux of value 0 (the reference adds a few of those: only the names arrive)
-template <int TP> __device__ __forceinline__ TVR<TP> tvr_add_names(TVR<TP> a, unsigned long long names) {
+template <int TP> __device__ __forceinline__ TVR<TP> tvr_add_names(TVR<TP> a, unsigned long long names, int c0) {
   a.mask |= names;
   if (__builtin_expect(__any(a.val == 0.0), 0)) {
     const double share = 1.0 / (double)__popcll(a.mask);
 #pragma unroll
     for (int s = 0; s < TP; ++s) {
-      const double v = (a.mask >> s & 1ull) ? share : 0.0;
+      const double v = (a.mask >> (c0 + s) & 1ull) ? share : 0.0;
       a.f[s] = (a.val == 0.0) ? v : a.f[s];
     }
   }
@@ -468,7 +478,7 @@ __device__ __forceinline__ void track_post_stash(const Member<B> &m, const LandK
   r[TRKR_RFDA][l] = m_rh_fda(m, 0); r[TRKR_RFSA][l] = m_rh_fsa(m, 0);
   r[TRKR_RCO2][l] = m_rh_tp_co2(m, lk, 0); r[TRKR_RCH4][l] = m_rh_tp_ch4(m, lk, 0);
   r[TRKR_FV][l] = lk.f_nppv[0]; r[TRKR_FD][l] = lk.f_nppd[0]; r[TRKR_FL][l] = lk.f_litterd[0];
-  r[TRKR_ACTIVE][l] = 1.0;
+  r[TRKR_ACTIVE][l] = (double)(ev + 1);  // (this lane takes part in event ev: both companions read it)
   m.trk_cmd[(ev & 1) * 2] = TRKC_STASH;
   m.trk_cmd[4] = ev + 1;
   __syncthreads();
@@ -481,26 +491,31 @@ __device__ __forceinline__ void track_post(int *cmd, int what, int iy) {
   __syncthreads();
 }
 
-// wave 1
-__device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, int lane,
+// waves 1 and 2: columns c0 .. c0 + TRK_NC - 1 of every map (sources 0-5 and 6-10).  Half the
+// matrix each -- 66 fractions, not 121: with the whole matrix on one wavefront the maps spilled into
+// AGPRs and every addition paid ~40 register moves for its 22 multiply-adds
+constexpr int TRK_NC = 6, TRK_WAVES = 2;
+__device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, int lane, int c0,
                                 double (*rec)[64], int *cmd) {
   constexpr int TP = hx_trk_pools(1), O0 = 2 + 5;
-  using T = TVR<TP>;
+  constexpr int NC = TRK_NC;
+  using T = TVR<NC>;
   const HxBuffers &buf = args->buf;
   const int trk_iy = args->kc.trk_iy;
   hx_gd rf = HX_GD(buf.track_out_f) + ((size_t)blockIdx.x * buf.trk_slots * (size_t)(TP * TP) * 64 + lane);
   hx_gd rv = HX_GD(buf.track_out_v) + ((size_t)blockIdx.x * buf.trk_slots * (size_t)hx_trk_vrows(1) * 64 + lane);
-  T P[TP];
+  T P[TP];  // (rows: every pool; columns: this wavefront's)
   // start_tracking(): every pool 100 % itself -- or, when a run resumes past the tracking date
   // (run() again, reset(date)), the maps of the end of last year from the record
   const bool resume = iy_from + 1 > trk_iy;
   const int slot0 = resume ? iy_from - trk_iy + 1 : 0;
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    P[p] = tvr_self<TP>(p, 0.0);
+    P[p] = tvr_self<NC>(p, 0.0, c0);
     if (resume) {
 #pragma unroll
-      for (int s = 0; s < TP; ++s) P[p].f[s] = rf[((size_t)slot0 * TP * TP + p * TP + s) * 64];
+      for (int s = 0; s < NC; ++s)  // (past the last source: the next row's first entries, never stored)
+        P[p].f[s] = rf[((size_t)slot0 * TP * TP + p * TP + c0 + s) * 64];
       P[p].mask = (unsigned long long)__double_as_longlong(rv[((size_t)slot0 * hx_trk_vrows(1) + TP + p) * 64]);
     }
   }
@@ -517,8 +532,9 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
 #pragma unroll
       for (int p = 0; p < TP; ++p) {
 #pragma unroll
-        for (int s = 0; s < TP; ++s) of[(size_t)(p * TP + s) * 64] = P[p].f[s];
-        ov[(size_t)(TP + p) * 64] = __longlong_as_double((long long)P[p].mask);
+        for (int s = 0; s < NC; ++s)
+          if (c0 + s < TP) of[(size_t)(p * TP + c0 + s) * 64] = P[p].f[s];
+        if (c0 == 0) ov[(size_t)(TP + p) * 64] = __longlong_as_double((long long)P[p].mask);
       }
       atm_copy = P[TKP_ATM];
       continue;
@@ -526,8 +542,7 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
     // ---- a stash: the values stay in their LDS slots (wave 0 writes the other set next) ----
     double (*in_)[64] = rec + (ev & 1) * TRKR_N;
 #define in(i) in_[(i)][lane]
-    const bool active = in(TRKR_ACTIVE) != 0.0;
-    in(TRKR_ACTIVE) = 0.0;
+    const bool active = in(TRKR_ACTIVE) == (double)(ev + 1);
     if (active) {
       const double yf = in(TRKR_YF);
       // ---------------- ocean: oceanbox.cpp:240-257, 262-271, 297-303 ----------------
@@ -537,24 +552,24 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
       T addn[4];  // (each box's first inflow is transfers 0..3, its second 4..6)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        addn[to_[i]] = tvr_add_to_empty<TP>(O0 + to_[i], P[O0 + from_[i]], in(TRKR_CLOSS + i));
+        addn[to_[i]] = tvr_add_to_empty<NC>(O0 + to_[i], P[O0 + from_[i]], in(TRKR_CLOSS + i), c0);
 #pragma unroll
       for (int i = 4; i < 7; ++i)
-        addn[to_[i]] = tvr_add<TP>(addn[to_[i]], tvr_from<TP>(P[O0 + from_[i]], in(TRKR_CLOSS + i)));
+        addn[to_[i]] = tvr_add<NC>(addn[to_[i]], tvr_from<NC>(P[O0 + from_[i]], in(TRKR_CLOSS + i)), c0);
       T ao[2], oa[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const double af = in(TRKR_AH + b);
-        ao[b] = tvr_from<TP>(atm_copy, (af > 0) ? af : 0.0);
-        oa[b] = tvr_from<TP>(P[O0 + b], (af > 0) ? 0.0 : -af);
+        ao[b] = tvr_from<NC>(atm_copy, (af > 0) ? af : 0.0);
+        oa[b] = tvr_from<NC>(P[O0 + b], (af > 0) ? 0.0 : -af);
       }
-      const T oa_flux = tvr_add<TP>(oa[1], oa[0]);  // get_oaflux: LL + HL
-      const T ao_flux = tvr_add<TP>(ao[1], ao[0]);
+      const T oa_flux = tvr_add<NC>(oa[1], oa[0], c0);  // get_oaflux: LL + HL
+      const T ao_flux = tvr_add<NC>(ao[1], ao[0], c0);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        T c = tvr_add<TP>(P[O0 + b], addn[b]);
-        if (b < 2) { c = tvr_add<TP>(c, ao[b]); c = tvr_sub<TP>(c, oa[b]); }
-        else c = tvr_add_names<TP>(c, atm_copy.mask);
+        T c = tvr_add<NC>(P[O0 + b], addn[b], c0);
+        if (b < 2) { c = tvr_add<NC>(c, ao[b], c0); c = tvr_sub<NC>(c, oa[b]); }
+        else c = tvr_add_names<NC>(c, atm_copy.mask, c0);
         P[O0 + b] = c;
       }
       // ---------------- land: simpleNbox-runtime.cpp:289-540 ----------------
@@ -562,35 +577,35 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
       atm.val = in(TRKR_ATMOS); P[TKP_EARTH].val = in(TRKR_EARTH);
       veg.val = in(TRKR_VEG); det.val = in(TRKR_DET); soil.val = in(TRKR_SOIL); pf.val = in(TRKR_PF);
       tp.val = in(TRKR_TP);
-      const T ffi_flux = tvr_from<TP>(P[TKP_EARTH], in(TRKR_FFI));
-      const T ccs_flux = tvr_from<TP>(atm, in(TRKR_DACCS));
+      const T ffi_flux = tvr_from<NC>(P[TKP_EARTH], in(TRKR_FFI));
+      const T ccs_flux = tvr_from<NC>(atm, in(TRKR_DACCS));
       const double total = in(TRKR_TOTAL), luc_e = in(TRKR_LUCE), rh_adj = in(TRKR_RHADJ);
       const double veg_frac = veg.val / total, det_frac = det.val / total, soil_frac = soil.val / total;
-      const T luc_fva = tvr_mul<TP>(tvr_from<TP>(veg, luc_e * veg_frac), yf);
-      const T luc_fda = tvr_mul<TP>(tvr_from<TP>(det, luc_e * det_frac), yf);
-      const T luc_fsa = tvr_mul<TP>(tvr_from<TP>(soil, luc_e * soil_frac), yf);
-      const T luc_fav = tvr_mul<TP>(tvr_from<TP>(atm, in(TRKR_LUCU)), yf);
+      const T luc_fva = tvr_mul<NC>(tvr_from<NC>(veg, luc_e * veg_frac), yf);
+      const T luc_fda = tvr_mul<NC>(tvr_from<NC>(det, luc_e * det_frac), yf);
+      const T luc_fsa = tvr_mul<NC>(tvr_from<NC>(soil, luc_e * soil_frac), yf);
+      const T luc_fav = tvr_mul<NC>(tvr_from<NC>(atm, in(TRKR_LUCU)), yf);
       const double npp_biome = in(TRKR_NPP) * 1.0;
       const double fv = in(TRKR_FV), fd = in(TRKR_FD), fl = in(TRKR_FL);
-      const T npp_fav = tvr_mul<TP>(tvr_from<TP>(atm, npp_biome * fv), yf);
-      const T npp_fad = tvr_mul<TP>(tvr_from<TP>(atm, npp_biome * fd), yf);
-      const T npp_fas = tvr_mul<TP>(tvr_from<TP>(atm, npp_biome * (1 - fv - fd)), yf);
+      const T npp_fav = tvr_mul<NC>(tvr_from<NC>(atm, npp_biome * fv), yf);
+      const T npp_fad = tvr_mul<NC>(tvr_from<NC>(atm, npp_biome * fd), yf);
+      const T npp_fas = tvr_mul<NC>(tvr_from<NC>(atm, npp_biome * (1 - fv - fd)), yf);
       const double rh_co2_adj = in(TRKR_RCO2) * rh_adj, rh_ch4_adj = in(TRKR_RCH4) * rh_adj;
-      const T rh_fda_flux = tvr_mul<TP>(tvr_from<TP>(det, in(TRKR_RFDA) * rh_adj), yf);
-      const T rh_fsa_flux = tvr_mul<TP>(tvr_from<TP>(soil, in(TRKR_RFSA) * rh_adj), yf);
-      const T rh_fpa_co2 = tvr_mul<TP>(tvr_from<TP>(tp, rh_co2_adj), yf);
-      const T rh_fpa_ch4 = tvr_mul<TP>(tvr_from<TP>(tp, rh_ch4_adj), yf);
-      atm = tvr_add<TP>(tvr_add<TP>(tvr_sub<TP>(tvr_add<TP>(atm, luc_fva), luc_fav), luc_fda), luc_fsa);
-      veg = tvr_sub<TP>(tvr_add<TP>(veg, luc_fav), luc_fva);
-      soil = tvr_sub<TP>(soil, luc_fsa);  // (the reference's detritus line has no effect, :458)
-      veg = tvr_add<TP>(veg, npp_fav);
-      det = tvr_add<TP>(det, npp_fad);
-      soil = tvr_add<TP>(soil, npp_fas);
-      atm = tvr_sub<TP>(tvr_sub<TP>(tvr_sub<TP>(atm, npp_fav), npp_fad), npp_fas);
-      atm = tvr_add<TP>(tvr_add<TP>(tvr_add<TP>(atm, rh_fda_flux), rh_fsa_flux), rh_fpa_co2);
-      det = tvr_sub<TP>(det, rh_fda_flux);
-      soil = tvr_sub<TP>(soil, rh_fsa_flux);
-      tp = tvr_sub<TP>(tvr_sub<TP>(tp, rh_fpa_co2), rh_fpa_ch4);
+      const T rh_fda_flux = tvr_mul<NC>(tvr_from<NC>(det, in(TRKR_RFDA) * rh_adj), yf);
+      const T rh_fsa_flux = tvr_mul<NC>(tvr_from<NC>(soil, in(TRKR_RFSA) * rh_adj), yf);
+      const T rh_fpa_co2 = tvr_mul<NC>(tvr_from<NC>(tp, rh_co2_adj), yf);
+      const T rh_fpa_ch4 = tvr_mul<NC>(tvr_from<NC>(tp, rh_ch4_adj), yf);
+      atm = tvr_add<NC>(tvr_add<NC>(tvr_sub<NC>(tvr_add<NC>(atm, luc_fva, c0), luc_fav), luc_fda, c0), luc_fsa, c0);
+      veg = tvr_sub<NC>(tvr_add<NC>(veg, luc_fav, c0), luc_fva);
+      soil = tvr_sub<NC>(soil, luc_fsa);  // (the reference's detritus line has no effect, :458)
+      veg = tvr_add<NC>(veg, npp_fav, c0);
+      det = tvr_add<NC>(det, npp_fad, c0);
+      soil = tvr_add<NC>(soil, npp_fas, c0);
+      atm = tvr_sub<NC>(tvr_sub<NC>(tvr_sub<NC>(atm, npp_fav), npp_fad), npp_fas);
+      atm = tvr_add<NC>(tvr_add<NC>(tvr_add<NC>(atm, rh_fda_flux, c0), rh_fsa_flux, c0), rh_fpa_co2, c0);
+      det = tvr_sub<NC>(det, rh_fda_flux);
+      soil = tvr_sub<NC>(soil, rh_fsa_flux);
+      tp = tvr_sub<NC>(tvr_sub<NC>(tp, rh_fpa_co2), rh_fpa_ch4);
       {  // compute_pf_thaw_refreeze :744-772 on the pools as they are now
         double x = pf.val * in(TRKR_FNT), y = 0.0;
         if (x < 0) {
@@ -599,22 +614,22 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
           const double remaining = tp.val - rh_co2_adj - rh_ch4_adj;
           y = (remaining < want) ? remaining : want;
         }
-        const T pf_thaw = tvr_mul<TP>(tvr_from<TP>(pf, x), yf);
-        const T pf_refreeze_tp = tvr_mul<TP>(tvr_from<TP>(tp, y), yf);
+        const T pf_thaw = tvr_mul<NC>(tvr_from<NC>(pf, x), yf);
+        const T pf_refreeze_tp = tvr_mul<NC>(tvr_from<NC>(tp, y), yf);
         // (pf_refreeze_soil: a flux of 0 from the soil)
-        pf = tvr_add_names<TP>(tvr_add<TP>(tvr_sub<TP>(pf, pf_thaw), pf_refreeze_tp), soil.mask);
-        tp = tvr_sub<TP>(tvr_add<TP>(tp, pf_thaw), pf_refreeze_tp);
+        pf = tvr_add_names<NC>(tvr_add<NC>(tvr_sub<NC>(pf, pf_thaw), pf_refreeze_tp, c0), soil.mask, c0);
+        tp = tvr_sub<NC>(tvr_add<NC>(tp, pf_thaw, c0), pf_refreeze_tp);
       }
-      const T litter = tvr_mul<TP>(veg, 0.035 * yf);
-      det = tvr_add<TP>(det, tvr_mul<TP>(litter, fl));
-      soil = tvr_add<TP>(soil, tvr_mul<TP>(litter, 1 - fl));
-      veg = tvr_sub<TP>(veg, litter);
-      const T detsoil = tvr_mul<TP>(det, 0.6 * yf);
-      soil = tvr_add<TP>(soil, detsoil);
-      det = tvr_sub<TP>(det, detsoil);
-      P[TKP_EARTH] = tvr_add<TP>(tvr_sub<TP>(P[TKP_EARTH], ffi_flux), ccs_flux);
-      atm = tvr_sub<TP>(tvr_add<TP>(atm, ffi_flux), ccs_flux);
-      atm = tvr_sub<TP>(tvr_add<TP>(atm, oa_flux), ao_flux);
+      const T litter = tvr_mul<NC>(veg, 0.035 * yf);
+      det = tvr_add<NC>(det, tvr_mul<NC>(litter, fl), c0);
+      soil = tvr_add<NC>(soil, tvr_mul<NC>(litter, 1 - fl), c0);
+      veg = tvr_sub<NC>(veg, litter);
+      const T detsoil = tvr_mul<NC>(det, 0.6 * yf);
+      soil = tvr_add<NC>(soil, detsoil, c0);
+      det = tvr_sub<NC>(det, detsoil);
+      P[TKP_EARTH] = tvr_add<NC>(tvr_sub<NC>(P[TKP_EARTH], ffi_flux), ccs_flux, c0);
+      atm = tvr_sub<NC>(tvr_add<NC>(atm, ffi_flux, c0), ccs_flux);
+      atm = tvr_sub<NC>(tvr_add<NC>(atm, oa_flux, c0), ao_flux);
     }
 #undef in
   }

@@ -456,9 +456,9 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // a land-ocean warming ratio, or diagnostics beyond HXO_SST_LO are recorded.  A separate
 // instantiation, so that plain runs carry none of it.
 // CON = 2: ... with carbon tracking inside the stash (hx_dev_track.h); CON = 3 (one biome): ...
-// with carbon tracking on a companion wavefront -- 128 threads a block, wave 1 only tracks.
+// with carbon tracking on two companion wavefronts -- 192 threads a block, waves 1 and 2 only track.
 template <int B, bool HF, bool KERPM, int CON>
-__global__ __launch_bounds__(CON == 3 ? 128 : 64) void hx_run_kernel(const HxArgs *__restrict__ args,
+__global__ __launch_bounds__(CON == 3 ? 64 * (1 + TRK_WAVES) : 64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                                      int iy_from, int iy_to) {
   static_assert(CON != 3 || B == 1, "the tracking companion holds the maps of one biome");
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
@@ -475,10 +475,12 @@ __global__ __launch_bounds__(CON == 3 ? 128 : 64) void hx_run_kernel(const HxArg
     __shared__ int s_cmd[5];                  // {what, year} of each set; wave 0's event counter
     s_trk_rec = s_rec; s_trk_cmd = s_cmd;
     if (threadIdx.x >= 64) {
-      s_rec[TRKR_ACTIVE][lane] = 0.0; s_rec[TRKR_N + TRKR_ACTIVE][lane] = 0.0;
-      s_cmd[4] = 0;
+      if (threadIdx.x < 128) {
+        s_rec[TRKR_ACTIVE][lane] = 0.0; s_rec[TRKR_N + TRKR_ACTIVE][lane] = 0.0;
+        s_cmd[4] = 0;
+      }
       __syncthreads();
-      track_companion(args, iy_from, lane, s_trk_rec, s_trk_cmd);
+      track_companion(args, iy_from, lane, ((int)(threadIdx.x >> 6) - 1) * TRK_NC, s_trk_rec, s_trk_cmd);
       return;
     }
     __syncthreads();  // (the companion has cleared the hand-over flags)
@@ -1501,7 +1503,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 #ifdef HX_MINIMAL_TRACK  // ... and the carbon-tracking ones
   if constexpr (B == 1) {
     if (con == 2 && !getenv("HECTOR_AMD_TRACK_INLINE")) {
-      hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(128), lds, st, d_args, iy_from, iy_to);
+      hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(64 * (1 + TRK_WAVES)), lds, st, d_args, iy_from, iy_to);
       return;
     }
   }
@@ -1517,8 +1519,8 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   if constexpr (B == 1) {    // one biome: the maps live on a companion wavefront
     static const bool inline_maps = getenv("HECTOR_AMD_TRACK_INLINE") != nullptr;
     if (con == 2 && !inline_maps) {
-      if (kpm) hipLaunchKernelGGL((hx_run_kernel<1, true, true, 3>), dim3(blocks), dim3(128), lds, st, d_args, iy_from, iy_to);
-      else hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(128), lds, st, d_args, iy_from, iy_to);
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<1, true, true, 3>), dim3(blocks), dim3(64 * (1 + TRK_WAVES)), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(64 * (1 + TRK_WAVES)), lds, st, d_args, iy_from, iy_to);
       return;
     }
   }
