@@ -369,10 +369,15 @@ __device__ void track_stash(const Member<B> &m, const LandK<B> &lk, const TrkSta
 // model wavefront's registers hold no tracking state, and the three overlap.
 // ===========================================================================================
 enum { TRKR_YF = 0, TRKR_PRE = 1, TRKR_CLOSS = 5, TRKR_AH = 12, TRKR_AL, TRKR_NPP, TRKR_RHADJ, TRKR_TOTAL,
-       TRKR_ATMOS, TRKR_EARTH, TRKR_DACCS, TRKR_FFI, TRKR_LUCE, TRKR_LUCU,
-       TRKR_VEG, TRKR_DET, TRKR_SOIL, TRKR_PF, TRKR_TP, TRKR_FNT,
-       TRKR_RFDA, TRKR_RFSA, TRKR_RCO2, TRKR_RCH4, TRKR_FV, TRKR_FD, TRKR_FL,
-       TRKR_ACTIVE, TRKR_N };
+       TRKR_ATMOS, TRKR_EARTH, TRKR_DACCS, TRKR_FFI, TRKR_LUCE, TRKR_LUCU, TRKR_ACTIVE, TRKR_B0 };
+// ... and per biome
+enum { TRKB_VEG = 0, TRKB_DET, TRKB_SOIL, TRKB_PF, TRKB_TP, TRKB_FNT, TRKB_RFDA, TRKB_RFSA, TRKB_RCO2,
+       TRKB_RCH4, TRKB_FV, TRKB_FD, TRKB_FL, TRKB_WT, TRKB_N };
+constexpr int trkr_n(int B) { return TRKR_B0 + TRKB_N * B; }  // hand-over slots of one set
+// companions of a block and source columns each: 11 pools 2 x 6, 16 pools 3 x 6, 21 pools 3 x 7,
+// 26 pools 3 x 9 (a block is at most four wavefronts of 512 registers: the CU's register file)
+template <int B> constexpr int trk_waves() { return B == 1 ? 2 : 3; }
+template <int B> constexpr int trk_nc() { return (hx_trk_pools(B) + trk_waves<B>() - 1) / trk_waves<B>(); }
 enum { TRKC_STASH = 1, TRKC_YEAR = 2, TRKC_DONE = 3 };
 
 // The companions' additions are kept in program order: left alone, the scheduler starts every
@@ -462,7 +467,7 @@ template <int B>
 __device__ __forceinline__ void track_post_stash(const Member<B> &m, const LandK<B> &lk,
                                                  const TrkStashIn &in) {
   const int ev = m.trk_cmd[4];
-  double (*r)[64] = m.trk_rec + (ev & 1) * TRKR_N;
+  double (*r)[64] = m.trk_rec + (ev & 1) * trkr_n(B);
   const int l = m.lane;
   r[TRKR_YF][l] = in.yf;
 #pragma unroll
@@ -473,12 +478,19 @@ __device__ __forceinline__ void track_post_stash(const Member<B> &m, const LandK
   r[TRKR_NPP][l] = in.npp_total; r[TRKR_RHADJ][l] = in.rh_adj; r[TRKR_TOTAL][l] = in.total;
   r[TRKR_ATMOS][l] = m.atmos; r[TRKR_EARTH][l] = m.earth; r[TRKR_DACCS][l] = m.daccs;
   r[TRKR_FFI][l] = m.ffi; r[TRKR_LUCE][l] = m.luc_e; r[TRKR_LUCU][l] = m.luc_u;
-  r[TRKR_VEG][l] = m.veg[0]; r[TRKR_DET][l] = m.det[0]; r[TRKR_SOIL][l] = m.soil[0];
-  r[TRKR_PF][l] = m.pf[0]; r[TRKR_TP][l] = m.thawed[0]; r[TRKR_FNT][l] = m.f_new_thaw[0];
-  r[TRKR_RFDA][l] = m_rh_fda(m, 0); r[TRKR_RFSA][l] = m_rh_fsa(m, 0);
-  r[TRKR_RCO2][l] = m_rh_tp_co2(m, lk, 0); r[TRKR_RCH4][l] = m_rh_tp_ch4(m, lk, 0);
-  r[TRKR_FV][l] = lk.f_nppv[0]; r[TRKR_FD][l] = lk.f_nppd[0]; r[TRKR_FL][l] = lk.f_litterd[0];
-  r[TRKR_ACTIVE][l] = (double)(ev + 1);  // (this lane takes part in event ev: both companions read it)
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    double (*rb)[64] = r + TRKR_B0 + TRKB_N * b;
+    const double rfda = m_rh_fda(m, b), rfsa = m_rh_fsa(m, b), rco2 = m_rh_tp_co2(m, lk, b);
+    rb[TRKB_VEG][l] = m.veg[b]; rb[TRKB_DET][l] = m.det[b]; rb[TRKB_SOIL][l] = m.soil[b];
+    rb[TRKB_PF][l] = m.pf[b]; rb[TRKB_TP][l] = m.thawed[b]; rb[TRKB_FNT][l] = m.f_new_thaw[b];
+    rb[TRKB_RFDA][l] = rfda; rb[TRKB_RFSA][l] = rfsa; rb[TRKB_RCO2][l] = rco2;
+    rb[TRKB_RCH4][l] = m_rh_tp_ch4(m, lk, b);
+    rb[TRKB_FV][l] = lk.f_nppv[b]; rb[TRKB_FD][l] = lk.f_nppd[b]; rb[TRKB_FL][l] = lk.f_litterd[b];
+    // the biome's weight, as SimpleNbox::stashCValues computes it
+    rb[TRKB_WT][l] = (B == 1) ? 1.0 : hx_div_cr(m_npp(m, lk, b) + ((rfda + rfsa) + rco2), in.npp_rh, in.inv_nr);
+  }
+  r[TRKR_ACTIVE][l] = (double)(ev + 1);  // (this lane takes part in event ev: every companion reads it)
   m.trk_cmd[(ev & 1) * 2] = TRKC_STASH;
   m.trk_cmd[4] = ev + 1;
   __syncthreads();
@@ -491,19 +503,19 @@ __device__ __forceinline__ void track_post(int *cmd, int what, int iy) {
   __syncthreads();
 }
 
-// waves 1 and 2: columns c0 .. c0 + TRK_NC - 1 of every map (sources 0-5 and 6-10).  Half the
-// matrix each -- 66 fractions, not 121: with the whole matrix on one wavefront the maps spilled into
-// AGPRs and every addition paid ~40 register moves for its 22 multiply-adds
-constexpr int TRK_NC = 6, TRK_WAVES = 2;
+// waves 1 .. trk_waves<B>(): columns c0 .. c0 + trk_nc<B>() - 1 of every map (one biome: sources 0-5
+// and 6-10 -- 66 fractions each, not 121: with the whole matrix on one wavefront the maps spilled
+// into AGPRs and every addition paid ~40 register moves for its 22 multiply-adds)
+template <int B>
 __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, int lane, int c0,
                                 double (*rec)[64], int *cmd) {
-  constexpr int TP = hx_trk_pools(1), O0 = 2 + 5;
-  constexpr int NC = TRK_NC;
+  constexpr int TP = hx_trk_pools(B), O0 = 2 + 5 * B;
+  constexpr int NC = trk_nc<B>();
   using T = TVR<NC>;
   const HxBuffers &buf = args->buf;
   const int trk_iy = args->kc.trk_iy;
   hx_gd rf = HX_GD(buf.track_out_f) + ((size_t)blockIdx.x * buf.trk_slots * (size_t)(TP * TP) * 64 + lane);
-  hx_gd rv = HX_GD(buf.track_out_v) + ((size_t)blockIdx.x * buf.trk_slots * (size_t)hx_trk_vrows(1) * 64 + lane);
+  hx_gd rv = HX_GD(buf.track_out_v) + ((size_t)blockIdx.x * buf.trk_slots * (size_t)hx_trk_vrows(B) * 64 + lane);
   T P[TP];  // (rows: every pool; columns: this wavefront's)
   // start_tracking(): every pool 100 % itself -- or, when a run resumes past the tracking date
   // (run() again, reset(date)), the maps of the end of last year from the record
@@ -516,7 +528,7 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
 #pragma unroll
       for (int s = 0; s < NC; ++s)  // (past the last source: the next row's first entries, never stored)
         P[p].f[s] = rf[((size_t)slot0 * TP * TP + p * TP + c0 + s) * 64];
-      P[p].mask = (unsigned long long)__double_as_longlong(rv[((size_t)slot0 * hx_trk_vrows(1) + TP + p) * 64]);
+      P[p].mask = (unsigned long long)__double_as_longlong(rv[((size_t)slot0 * hx_trk_vrows(B) + TP + p) * 64]);
     }
   }
   T atm_copy = P[TKP_ATM];  // OceanComponent::atmosphere_cpool: the atmosphere as of SimpleNbox::run
@@ -528,7 +540,7 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
       // CSVFluxPoolVisitor: the year's maps (the pool values are written by wave 0)
       const size_t slot = (size_t)(iy - trk_iy) + 1;
       hx_gd of = rf + slot * (size_t)(TP * TP) * 64;
-      hx_gd ov = rv + slot * (size_t)hx_trk_vrows(1) * 64;
+      hx_gd ov = rv + slot * (size_t)hx_trk_vrows(B) * 64;
 #pragma unroll
       for (int p = 0; p < TP; ++p) {
 #pragma unroll
@@ -540,7 +552,7 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
       continue;
     }
     // ---- a stash: the values stay in their LDS slots (wave 0 writes the other set next) ----
-    double (*in_)[64] = rec + (ev & 1) * TRKR_N;
+    double (*in_)[64] = rec + (ev & 1) * trkr_n(B);
 #define in(i) in_[(i)][lane]
     const bool active = in(TRKR_ACTIVE) == (double)(ev + 1);
     if (active) {
@@ -573,26 +585,30 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
         P[O0 + b] = c;
       }
       // ---------------- land: simpleNbox-runtime.cpp:289-540 ----------------
-      T &atm = P[TKP_ATM], &veg = P[2], &det = P[3], &soil = P[4], &pf = P[5], &tp = P[6];
+      T &atm = P[TKP_ATM];
       atm.val = in(TRKR_ATMOS); P[TKP_EARTH].val = in(TRKR_EARTH);
-      veg.val = in(TRKR_VEG); det.val = in(TRKR_DET); soil.val = in(TRKR_SOIL); pf.val = in(TRKR_PF);
-      tp.val = in(TRKR_TP);
       const T ffi_flux = tvr_from<NC>(P[TKP_EARTH], in(TRKR_FFI));
       const T ccs_flux = tvr_from<NC>(atm, in(TRKR_DACCS));
       const double total = in(TRKR_TOTAL), luc_e = in(TRKR_LUCE), rh_adj = in(TRKR_RHADJ);
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+#define inb(i) in_[TRKR_B0 + TRKB_N * b + (i)][lane]
+      T &veg = P[2 + 5 * b], &det = P[3 + 5 * b], &soil = P[4 + 5 * b], &pf = P[5 + 5 * b], &tp = P[6 + 5 * b];
+      veg.val = inb(TRKB_VEG); det.val = inb(TRKB_DET); soil.val = inb(TRKB_SOIL); pf.val = inb(TRKB_PF);
+      tp.val = inb(TRKB_TP);
       const double veg_frac = veg.val / total, det_frac = det.val / total, soil_frac = soil.val / total;
       const T luc_fva = tvr_mul<NC>(tvr_from<NC>(veg, luc_e * veg_frac), yf);
       const T luc_fda = tvr_mul<NC>(tvr_from<NC>(det, luc_e * det_frac), yf);
       const T luc_fsa = tvr_mul<NC>(tvr_from<NC>(soil, luc_e * soil_frac), yf);
       const T luc_fav = tvr_mul<NC>(tvr_from<NC>(atm, in(TRKR_LUCU)), yf);
-      const double npp_biome = in(TRKR_NPP) * 1.0;
-      const double fv = in(TRKR_FV), fd = in(TRKR_FD), fl = in(TRKR_FL);
+      const double npp_biome = in(TRKR_NPP) * inb(TRKB_WT);
+      const double fv = inb(TRKB_FV), fd = inb(TRKB_FD), fl = inb(TRKB_FL);
       const T npp_fav = tvr_mul<NC>(tvr_from<NC>(atm, npp_biome * fv), yf);
       const T npp_fad = tvr_mul<NC>(tvr_from<NC>(atm, npp_biome * fd), yf);
       const T npp_fas = tvr_mul<NC>(tvr_from<NC>(atm, npp_biome * (1 - fv - fd)), yf);
-      const double rh_co2_adj = in(TRKR_RCO2) * rh_adj, rh_ch4_adj = in(TRKR_RCH4) * rh_adj;
-      const T rh_fda_flux = tvr_mul<NC>(tvr_from<NC>(det, in(TRKR_RFDA) * rh_adj), yf);
-      const T rh_fsa_flux = tvr_mul<NC>(tvr_from<NC>(soil, in(TRKR_RFSA) * rh_adj), yf);
+      const double rh_co2_adj = inb(TRKB_RCO2) * rh_adj, rh_ch4_adj = inb(TRKB_RCH4) * rh_adj;
+      const T rh_fda_flux = tvr_mul<NC>(tvr_from<NC>(det, inb(TRKB_RFDA) * rh_adj), yf);
+      const T rh_fsa_flux = tvr_mul<NC>(tvr_from<NC>(soil, inb(TRKB_RFSA) * rh_adj), yf);
       const T rh_fpa_co2 = tvr_mul<NC>(tvr_from<NC>(tp, rh_co2_adj), yf);
       const T rh_fpa_ch4 = tvr_mul<NC>(tvr_from<NC>(tp, rh_ch4_adj), yf);
       atm = tvr_add<NC>(tvr_add<NC>(tvr_sub<NC>(tvr_add<NC>(atm, luc_fva, c0), luc_fav), luc_fda, c0), luc_fsa, c0);
@@ -607,7 +623,7 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
       soil = tvr_sub<NC>(soil, rh_fsa_flux);
       tp = tvr_sub<NC>(tvr_sub<NC>(tp, rh_fpa_co2), rh_fpa_ch4);
       {  // compute_pf_thaw_refreeze :744-772 on the pools as they are now
-        double x = pf.val * in(TRKR_FNT), y = 0.0;
+        double x = pf.val * inb(TRKB_FNT), y = 0.0;
         if (x < 0) {
           const double want = -x;
           x = 0.0;
@@ -627,6 +643,8 @@ __device__ void track_companion(const HxArgs *__restrict__ args, int iy_from, in
       const T detsoil = tvr_mul<NC>(det, 0.6 * yf);
       soil = tvr_add<NC>(soil, detsoil, c0);
       det = tvr_sub<NC>(det, detsoil);
+#undef inb
+      }
       P[TKP_EARTH] = tvr_add<NC>(tvr_sub<NC>(P[TKP_EARTH], ffi_flux), ccs_flux, c0);
       atm = tvr_sub<NC>(tvr_add<NC>(atm, ffi_flux, c0), ccs_flux);
       atm = tvr_sub<NC>(tvr_add<NC>(atm, oa_flux, c0), ao_flux);

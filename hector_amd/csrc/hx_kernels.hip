@@ -458,9 +458,9 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // CON = 2: ... with carbon tracking inside the stash (hx_dev_track.h); CON = 3 (one biome): ...
 // with carbon tracking on two companion wavefronts -- 192 threads a block, waves 1 and 2 only track.
 template <int B, bool HF, bool KERPM, int CON>
-__global__ __launch_bounds__(CON == 3 ? 64 * (1 + TRK_WAVES) : 64) void hx_run_kernel(const HxArgs *__restrict__ args,
+__global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 : B)>()) : 64) void hx_run_kernel(const HxArgs *__restrict__ args,
                                                                      int iy_from, int iy_to) {
-  static_assert(CON != 3 || B == 1, "the tracking companion holds the maps of one biome");
+  static_assert(CON != 3 || (B >= 1 && B <= 4), "tracking companions: the unrolled kernels");
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
   // (multi-biome kernels need that LDS for the per-biome arrays and re-read the block's SSTs
   // from the output array instead)
@@ -471,16 +471,16 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + TRK_WAVES) : 64) void hx_run_k
   [[maybe_unused]] double (*s_trk_rec)[64] = nullptr;
   [[maybe_unused]] int *s_trk_cmd = nullptr;
   if constexpr (CON == 3) {
-    __shared__ double s_rec[2 * TRKR_N][64];  // two sets of hand-over slots
+    __shared__ double s_rec[2 * trkr_n(B)][64];  // two sets of hand-over slots
     __shared__ int s_cmd[5];                  // {what, year} of each set; wave 0's event counter
     s_trk_rec = s_rec; s_trk_cmd = s_cmd;
     if (threadIdx.x >= 64) {
       if (threadIdx.x < 128) {
-        s_rec[TRKR_ACTIVE][lane] = 0.0; s_rec[TRKR_N + TRKR_ACTIVE][lane] = 0.0;
+        s_rec[TRKR_ACTIVE][lane] = 0.0; s_rec[trkr_n(B) + TRKR_ACTIVE][lane] = 0.0;
         s_cmd[4] = 0;
       }
       __syncthreads();
-      track_companion(args, iy_from, lane, ((int)(threadIdx.x >> 6) - 1) * TRK_NC, s_trk_rec, s_trk_cmd);
+      track_companion<B>(args, iy_from, lane, ((int)(threadIdx.x >> 6) - 1) * trk_nc<B>(), s_trk_rec, s_trk_cmd);
       return;
     }
     __syncthreads();  // (the companion has cleared the hand-over flags)
@@ -1478,6 +1478,14 @@ hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) 
   return hipGetLastError();
 }
 
+// biome counts whose carbon tracking runs on companion wavefronts (tools/prof/tracking_times.py)
+// (8 192 members tracked 1750-2300: one biome 11.4 ms on companions against 29.9 ms inside the
+//  stash, two biomes 23.5 / 32.1 ms, three 70.9 / 60.3 ms, four 215 / 82 ms -- their 147 and 234
+//  fractions a wavefront spill; a block of four 512-register wavefronts owns a CU, so two biomes
+//  take the companions only while every block gets a CU of its own: 32 768 members 49.8 / 41.3 ms)
+#ifndef HX_TRK_COMPANION_MAXB
+#define HX_TRK_COMPANION_MAXB 2
+#endif
 template <int B>
 static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st, int nb = B) {
@@ -1503,7 +1511,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 #ifdef HX_MINIMAL_TRACK  // ... and the carbon-tracking ones
   if constexpr (B == 1) {
     if (con == 2 && !getenv("HECTOR_AMD_TRACK_INLINE")) {
-      hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(64 * (1 + TRK_WAVES)), lds, st, d_args, iy_from, iy_to);
+      hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(64 * (1 + trk_waves<1>())), lds, st, d_args, iy_from, iy_to);
       return;
     }
   }
@@ -1516,11 +1524,18 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   return;
 #endif
 #ifndef HX_HOST_EMULATION   // (the host build runs a block's threads one after the other)
-  if constexpr (B == 1) {    // one biome: the maps live on a companion wavefront
+  if constexpr (B >= 1 && B <= HX_TRK_COMPANION_MAXB) {  // the maps live on companion wavefronts
     static const bool inline_maps = getenv("HECTOR_AMD_TRACK_INLINE") != nullptr;
-    if (con == 2 && !inline_maps) {
-      if (kpm) hipLaunchKernelGGL((hx_run_kernel<1, true, true, 3>), dim3(blocks), dim3(64 * (1 + TRK_WAVES)), lds, st, d_args, iy_from, iy_to);
-      else hipLaunchKernelGGL((hx_run_kernel<1, true, false, 3>), dim3(blocks), dim3(64 * (1 + TRK_WAVES)), lds, st, d_args, iy_from, iy_to);
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+      return n;
+    }();
+    if (con == 2 && !inline_maps && (B == 1 || blocks <= cus)) {
+      constexpr int threads = 64 * (1 + trk_waves<B>());
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<B, true, true, 3>), dim3(blocks), dim3(threads), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<B, true, false, 3>), dim3(blocks), dim3(threads), lds, st, d_args, iy_from, iy_to);
       return;
     }
   }

@@ -183,3 +183,61 @@ def test_tracking_refuses_carbon_constraints(emul_lib, tmp_path):
     c.setvar("trackingDate", [1770])
     with pytest.raises(hector_amd.HectorAmdError, match="constraint"):
         c.run(1850)
+
+
+TRACK_BOTH_WAYS = """
+import sys, numpy as np, hector_amd
+from hector_amd import ensemble
+out = {}
+for nb in (1, 2):
+    n = 200
+    S, q = ensemble.ecs_q10(n, offset=5)
+    c = hector_amd.Core(hector_amd.DEFAULT_SCENARIO, n, device=0)
+    if nb > 1:
+        c.split_biome(["a", "b"], fveg_c=[0.3, 0.7])
+        c.setvar("a.q10_rh", q)
+    else:
+        c.setvar("q10_rh", q)
+    c.setvar("S", S, "degC").setvar("trackingDate", [1800.0])
+    c.run(1900)
+    c.run(2000)           # resumes past the tracking date: the maps come back from the record
+    assert (c.status() == 0).all()
+    for i in (0, 63, 64, 199):
+        v, f, held = c.tracking_data(i, (1800, 2000), masks=True)
+        out["v%d_%d" % (nb, i)] = v; out["f%d_%d" % (nb, i)] = f; out["m%d_%d" % (nb, i)] = held
+    c.reset(1850); c.run(1950)   # reset(date) into the tracked span needs the history: refused or redone
+np.savez(sys.argv[1], **out)
+"""
+
+
+@pytest.mark.gpu
+def test_companion_wavefronts_and_inline_maps_agree_on_gpu(tmp_path):
+    """One and two biomes track on companion wavefronts (hx_run_kernel<B,HF,KERPM,3>: the maps in
+    the registers of wavefronts that do nothing else), HECTOR_AMD_TRACK_INLINE=1 keeps the maps
+    in the record and mixes inside the stash (what 3-16 biomes and big two-biome ensembles do):
+    the same pools bit for bit, the same names in every map, fractions to rounding."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = {}
+    for mode in ("companions", "inline"):
+        env = dict(os.environ)
+        env.pop("HECTOR_AMD_TRACK_INLINE", None)
+        if mode == "inline":
+            env["HECTOR_AMD_TRACK_INLINE"] = "1"
+        path = str(tmp_path / (mode + ".npz"))
+        script = TRACK_BOTH_WAYS.replace("c.reset(1850); c.run(1950)", "pass")
+        r = subprocess.run([sys.executable, "-c", script, path], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[mode] = np.load(path)
+    a, b = res["companions"], res["inline"]
+    for k in a.files:
+        if k.startswith("v"):
+            assert np.array_equal(a[k], b[k]), k
+        elif k.startswith("m"):
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert np.abs(a[k] - b[k]).max() < 1e-12, k
+            assert np.abs(a[k].sum(axis=2) - 1.0).max() < 1e-12
