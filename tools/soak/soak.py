@@ -171,13 +171,17 @@ def tracking(gpu, argv):
     for rd in range(int(os.environ.get("ROUNDS", "12"))):
         name = ["ssp119", "ssp245", "ssp585"][rng.integers(3)]
         path = os.path.join(R, "hector_amd", "data", name + ".hxs")
-        B = int(rng.choice([1, 2, 4])); n = 3
+        B = int(rng.choice([1, 1, 2, 2, 3, 4, 5, 8, 12])); n = 3   # (5+: looped kernels; 12: two mask words)
         T0 = int(rng.integers(1750, 2050)); END = int(rng.integers(T0 + 5, 2301))
         c = hector_amd.Core(path, n, **kw); c.enable_history(True)
         if B > 1:
             c.split_biome(["b%d" % b for b in range(B)])
         c.setvar("trackingDate", [T0])
         S = rng.uniform(2, 5, n); q10 = rng.uniform(1.2, 2.8, (B, n)); wf = rng.uniform(0.8, 1.6, (B, n))
+        no_pf = B <= 4 and rng.uniform() < 0.3   # no permafrost: pools of zero, maps shared equally
+        if no_pf:
+            for b in range(B):
+                c.setvar(("b%d." % b if B > 1 else "") + "permafrost_c", [0.0])
         c.setvar("S", S, "degC")
         for b in range(B):
             pre = "b%d." % b if B > 1 else ""
@@ -195,6 +199,8 @@ def tracking(gpu, argv):
             p.S = S[i]
             for b in range(B):
                 p.q10_rh[b] = q10[b][i]; p.warmingfactor[b] = wf[b][i]
+                if no_pf:
+                    p.permafrost_c[b] = 0.0
             ov, of, _, err = o.run_tracking(p, T0, END); assert err == 0
             gv, gf = c.tracking_data(i, (T0, END))
             k0, k1 = T0 - 1745, END - 1745 + 1
