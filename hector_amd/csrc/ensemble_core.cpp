@@ -1,6 +1,9 @@
 // ensemble_core.cpp -- see ensemble_core.hpp.
 #include "ensemble_core.hpp"
 
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -436,7 +439,7 @@ void EnsembleCore::build_shared() {
   k.M0f = has(ch4_con, 0) ? ch4_con[0] : k.M0;
   k.sqrtM0 = std::sqrt(k.M0f);
   k.inv_h2o_span = 1.0 / (1831 - k.M0f);
-  if (k.M0f != M0f_old) need_spinup_ = true;  // the post-spinup state holds CH4(startDate)
+  if (k.M0f != M0f_old) { need_spinup_ = true; spin_valid_ = false; }  // the post-spinup state holds CH4(startDate)
   k.con_mask = (any(co2_con) ? HXC_CO2 : 0) | (any(nbp_con) ? HXC_NBP : 0) |
                (any(tas_con) ? HXC_TAS : 0) | (any(ftot_con) ? HXC_FTOT : 0) |
                (any(ch4_con) ? HXC_CH4 : 0);
@@ -506,7 +509,8 @@ void EnsembleCore::alloc_device() {
   // DOECLIM kernel table, zero-padded by HX_KPAD (= 32) entries in front and 64 behind (the
   // history pass runs up to three slices of four years past the end)
   check(hipMalloc(&d_ker_, sizeof(double) * (ns + 96) * np), "hipMalloc ker");
-  check(hipMalloc(&d_status_, sizeof(unsigned) * np * 2), "hipMalloc status");
+  // status: live | post-spinup snapshot (with the derive-time flags) | the spinup's own result
+  check(hipMalloc(&d_status_, sizeof(unsigned) * np * 3), "hipMalloc status");
   check(hipMalloc(&d_spin_steps_, sizeof(int) * np), "hipMalloc spin");
   check(hipMalloc(&d_args_, sizeof(HxArgs)), "hipMalloc args");
   check(hipMalloc(&d_derived_, sizeof(double) * np * HX_NDERIVED(B_)), "hipMalloc derived");
@@ -540,7 +544,8 @@ void EnsembleCore::alloc_device() {
                        hipMemcpyHostToDevice, stream_), "upload shared");
   layout_dirty_ = false;
   params_dirty_ = true;
-  need_spinup_ = true;
+  rows_all_dirty_ = true;   // fresh buffers: every row of the parameter table is sent again
+  need_spinup_ = true; spin_valid_ = false;
 }
 
 HxBuffers EnsembleCore::buffers() const {
@@ -682,7 +687,7 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
       gas_dirty_ = true;
       shared_dirty_ = true;
       last_iy_ = 0;
-      need_spinup_ = true;
+      need_spinup_ = true; spin_valid_ = false;
       return;
     }
   }
@@ -702,6 +707,8 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
   }
   row_uniform_[row] = uniform;
   params_dirty_ = true;
+  if (row_dirty_.size() == params_.size()) row_dirty_[(size_t)row] = 1; else rows_all_dirty_ = true;
+  if (d.spinup) spin_valid_ = false;  // (any other parameter leaves the post-spinup state as it is)
   lane_cost_.clear();  // measured with other parameters: back to the parameter key
   // R/messages.R:107-140: a parameter change invalidates the run from date 0
   last_iy_ = 0;
@@ -711,7 +718,6 @@ void EnsembleCore::setvar(const std::string &capability, const double *values, i
     for (double v : r) if (v != 0.0) any = true;
     if (any != out_enabled_[HXO_SST_LO]) { out_enabled_[HXO_SST_LO] = any; layout_dirty_ = true; }
   }
-  (void)d;
 }
 
 void EnsembleCore::getvar(const std::string &capability, double *out) const {
@@ -818,7 +824,7 @@ void EnsembleCore::split_biome_of(const std::string &old_biome,
   biome_names_ = nn;
   layout_dirty_ = true;
   params_dirty_ = true;
-  need_spinup_ = true;
+  need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 
@@ -856,7 +862,7 @@ void EnsembleCore::create_biome(const std::string &biome) {
   }
   ++B_;
   biome_names_.push_back(biome);
-  layout_dirty_ = params_dirty_ = need_spinup_ = true;
+  layout_dirty_ = params_dirty_ = need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 
@@ -875,7 +881,7 @@ void EnsembleCore::delete_biome(const std::string &biome) {
     remap_biome_outputs(old_of_new);
   }
   --B_;
-  layout_dirty_ = params_dirty_ = need_spinup_ = true;
+  layout_dirty_ = params_dirty_ = need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 
@@ -943,7 +949,7 @@ void EnsembleCore::set_outputs(const std::vector<std::string> &caps) {
   if (!changed) return;
   for (int v = 0; v < HXO_NVAR; ++v) out_enabled_[v] = want[v];
   layout_dirty_ = true;
-  need_spinup_ = true;
+  need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 
@@ -951,7 +957,7 @@ void EnsembleCore::enable_spinup_record(bool on) {
   if (on == spin_record_) return;
   spin_record_ = on;
   layout_dirty_ = true;
-  need_spinup_ = true;
+  need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 
@@ -983,7 +989,7 @@ void EnsembleCore::enable_history(bool on) {
   if (on == history_) return;
   history_ = on;
   layout_dirty_ = true;
-  need_spinup_ = true;
+  need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 
@@ -1296,6 +1302,22 @@ void EnsembleCore::run_gas_kernel() {
   upload_args();
 }
 
+// HECTOR_AMD_TIMING=1: wall time of prepare()'s stages on stderr (tools/prof/e2e_times.py)
+namespace {
+struct StageClock {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  StageClock() : on(std::getenv("HECTOR_AMD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char *what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[hector_amd timing] %-28s %8.3f ms\n", what,
+                 std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+}  // namespace
+
 void EnsembleCore::lane_of_member(int *out) {
   prepare();
   std::memcpy(out, lane_of_member_.data(), sizeof(int) * (size_t)n_);
@@ -1315,6 +1337,42 @@ void EnsembleCore::set_member_sorting(bool on) {
 // varying parameters (quantile bins of the first, sorted by the second inside a
 // bin).  On the ECS/Q10 ensemble this brings the wave-max stash count from 2.69 to
 // 2.06 per year (member mean 2.00) and steps from 4.63 to 3.62 (mean 3.52).
+// A stable sort of `order` by a double key (ascending, or descending with ties kept in order),
+// as std::stable_sort with `key[a] < key[b]` gives it, in linear time: least-significant-digit
+// radix passes over the order-preserving integer image of the keys (11 bits a pass; a pass whose
+// digit is the same for every key is skipped).  Sorting 65 536 members with std::stable_sort and
+// an indirect comparison took 8 ms per parameter upload -- as long as the year loop itself.
+namespace {
+void radix_stable_sort(std::vector<int> &order, size_t from, size_t to, const std::vector<double> &key,
+                       bool descending) {
+  const size_t n = to - from;
+  if (n < 2) return;
+  struct Item { uint64_t k; int idx; };
+  std::vector<Item> a(n), b(n);
+  for (size_t i = 0; i < n; ++i) {
+    const int idx = order[from + i];
+    const double v = key[(size_t)idx] + 0.0;  // (-0.0 compares equal to 0.0: one image for both)
+    uint64_t u;
+    std::memcpy(&u, &v, sizeof u);
+    u ^= (u >> 63) ? ~uint64_t(0) : (uint64_t(1) << 63);  // ascending doubles -> ascending integers
+    a[i] = Item{descending ? ~u : u, idx};
+  }
+  constexpr int BITS = 11, NPASS = 6, RAD = 1 << BITS;
+  std::vector<uint32_t> hist((size_t)NPASS * RAD, 0);
+  for (size_t i = 0; i < n; ++i)
+    for (int p = 0; p < NPASS; ++p) ++hist[(size_t)p * RAD + ((a[i].k >> (p * BITS)) & (RAD - 1))];
+  for (int p = 0; p < NPASS; ++p) {
+    uint32_t *h = hist.data() + (size_t)p * RAD;
+    if (h[(a[0].k >> (p * BITS)) & (RAD - 1)] == n) continue;  // every key has this digit
+    uint32_t sum = 0;
+    for (int d = 0; d < RAD; ++d) { const uint32_t c = h[d]; h[d] = sum; sum += c; }
+    for (size_t i = 0; i < n; ++i) b[h[(a[i].k >> (p * BITS)) & (RAD - 1)]++] = a[i];
+    a.swap(b);
+  }
+  for (size_t i = 0; i < n; ++i) order[from + i] = a[i].idx;
+}
+}  // namespace
+
 void EnsembleCore::assign_lanes() {
   member_of_lane_.resize((size_t)npad_);
   lane_of_member_.resize((size_t)n_);
@@ -1324,8 +1382,7 @@ void EnsembleCore::assign_lanes() {
   for (int r = 0; r < HX_NPARAM(B_); ++r)
     if (!row_uniform_[r]) varying.push_back(r);
   if (sort_members_ && n_ > HX_WAVE && !varying.empty()) {
-    const std::vector<double> &p = params_[varying[0]];
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p[a] < p[b]; });
+    radix_stable_sort(order, 0, (size_t)n_, params_[varying[0]], false);
     if (varying.size() > 1) {
       // second key: the second perturbed parameter, or -- with more than two -- the sum of
       // the standardised remaining ones (per-biome Q10s and warming factors act together)
@@ -1343,15 +1400,13 @@ void EnsembleCore::assign_lanes() {
       nbins = std::max(1, nbins);
       const int per = (n_ + nbins - 1) / nbins;
       for (int b0 = 0; b0 < n_; b0 += per)
-        std::stable_sort(order.begin() + b0, order.begin() + std::min(n_, b0 + per),
-                         [&](int a, int b) { return q[a] < q[b]; });
+        radix_stable_sort(order, (size_t)b0, (size_t)std::min(n_, b0 + per), q, false);
     }
   }
   if (sort_members_ && n_ > HX_WAVE && (int)lane_cost_.size() == n_) {
     // measured cost, costliest first (ties keep the parameter order): wavefronts of members that
     // really take the same number of steps and stashes, the expensive ones dispatched first
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return lane_cost_[(size_t)a] > lane_cost_[(size_t)b]; });
+    radix_stable_sort(order, 0, (size_t)n_, lane_cost_, true);
   }
   for (int l = 0; l < npad_; ++l) member_of_lane_[(size_t)l] = order[(size_t)std::min(l, n_ - 1)];
   for (int l = 0; l < n_; ++l) lane_of_member_[(size_t)order[(size_t)l]] = l;
@@ -1388,27 +1443,55 @@ void EnsembleCore::maybe_calibrate_lanes() {
 
 void EnsembleCore::upload_params() {
   const size_t np = (size_t)npad_;
+  StageClock clk;
   assign_lanes();
-  std::vector<double> flat(np * HX_NPARAM(B_));
-  for (int r = 0; r < HX_NPARAM(B_); ++r)
-    for (size_t l = 0; l < np; ++l) flat[(size_t)r * np + l] = params_[r][(size_t)member_of_lane_[l]];
-  check(hipMemcpyAsync(d_lane_of_member_, lane_of_member_.data(), sizeof(int) * (size_t)n_,
-                       hipMemcpyHostToDevice, stream_), "upload lane map");
-  check(hipMemcpyAsync(d_params_, flat.data(), sizeof(double) * flat.size(),
-                       hipMemcpyHostToDevice, stream_), "upload params");
+  clk.lap("  assign_lanes");
+  // Only what moved goes to the device: a row that was set since the last upload, and -- when
+  // the lane order changed -- the rows that differ between members (a uniform row reads the same
+  // in every order).  The calibration loop (new values of two or three parameters for every
+  // member, reset, run) sends those rows instead of the whole table.
+  const int nrows = HX_NPARAM(B_);
+  const bool all = rows_all_dirty_ || (int)row_dirty_.size() != nrows;
+  const bool order_changed = all || uploaded_order_ != member_of_lane_;
+  std::vector<int> send;
+  for (int r = 0; r < nrows; ++r)
+    if (all || row_dirty_[(size_t)r] || (order_changed && !row_uniform_[(size_t)r])) send.push_back(r);
+  std::vector<double> flat(np * send.size());
+  for (size_t k = 0; k < send.size(); ++k) {
+    const std::vector<double> &row = params_[(size_t)send[k]];
+    double *dst = flat.data() + k * np;
+    if (row_uniform_[(size_t)send[k]]) std::fill(dst, dst + np, row[0]);
+    else for (size_t l = 0; l < np; ++l) dst[l] = row[(size_t)member_of_lane_[l]];
+  }
+  clk.lap("  flatten rows");
+  if (order_changed)
+    check(hipMemcpyAsync(d_lane_of_member_, lane_of_member_.data(), sizeof(int) * (size_t)n_,
+                         hipMemcpyHostToDevice, stream_), "upload lane map");
+  for (size_t k = 0; k < send.size();) {  // runs of adjacent rows travel together
+    size_t e = k + 1;
+    while (e < send.size() && send[e] == send[e - 1] + 1) ++e;
+    check(hipMemcpyAsync(d_params_ + (size_t)send[k] * np, flat.data() + k * np,
+                         sizeof(double) * np * (e - k), hipMemcpyHostToDevice, stream_), "upload params");
+    k = e;
+  }
   {
-    std::vector<double> u((size_t)HX_NPARAM(B_));
-    for (int r = 0; r < HX_NPARAM(B_); ++r) u[(size_t)r] = params_[r][0];
+    std::vector<double> u((size_t)nrows);
+    for (int r = 0; r < nrows; ++r) u[(size_t)r] = params_[(size_t)r][0];
     check(hipMemcpyAsync(d_uparams_, u.data(), sizeof(double) * u.size(), hipMemcpyHostToDevice,
                          stream_), "upload uniform params");
     check(hipStreamSynchronize(stream_), "sync uniform params");
   }
   check(hipStreamSynchronize(stream_), "sync params");
+  clk.lap("  H2D params (waited)");
+  row_dirty_.assign((size_t)nrows, 0);
+  rows_all_dirty_ = false;
+  order_changed_ = order_changed;
+  uploaded_order_ = member_of_lane_;
   // DOECLIM convolution kernel: one shared table when every member has the same
   // diffusivity (wave-uniform scalar loads in the run kernel), else Ker[ns][npad]
   ker_per_member_ = !row_uniform_[HXP_DIFF];
-  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 96) * np, stream_),
-        "zero ker");
+  check(hipMemsetAsync(d_ker_, 0, sizeof(double) * ((size_t)scen_.ns() + 96) * (ker_per_member_ ? np : 1),
+                       stream_), "zero ker");
   check(hx_launch_doeclim_kernel(d_params_ + (size_t)HXP_DIFF * np, d_ker_, scen_.ns(),
                                  ker_per_member_ ? npad_ : 1, ker_per_member_ ? npad_ : 1,
                                  stream_), "doeclim kernel table");
@@ -1454,7 +1537,8 @@ void EnsembleCore::check_parameters() const {
 
 void EnsembleCore::prepare() {
   check(hipSetDevice(device_), "hipSetDevice");
-  if (layout_dirty_) alloc_device();
+  StageClock clk;
+  if (layout_dirty_) { alloc_device(); clk.lap("alloc_device"); }
   if (shared_dirty_) {  // dated inputs changed: rebuild the per-year table
     build_shared();
     check(hipMemcpyAsync(d_shared_, shared_.data(), sizeof(double) * shared_.size(),
@@ -1465,12 +1549,16 @@ void EnsembleCore::prepare() {
   }
   if (params_dirty_) {
     check_parameters();
+    clk.lap("check_parameters");
     upload_params();
-    for (int k = 0; k < HXM_N; ++k) if (!member_series_[k].empty()) mseries_dirty_ = true;  // lanes may have moved
+    clk.lap("upload_params");
+    if (order_changed_)
+      for (int k = 0; k < HXM_N; ++k) if (!member_series_[k].empty()) mseries_dirty_ = true;  // lanes have moved
     gas_dirty_ = true;
   }
   if (gas_dirty_ || (!gas_member_.empty() && !d_mseries_[HXM_N2O])) run_gas_kernel();
   if (mseries_dirty_) upload_member_series();
+  clk.lap("gas kernel / member series");
   if (!need_spinup_) return;
   // Spinup is independent of every parameter that is not in the spinup set
   // (SURVEY 3f): if those rows are uniform, spin up one prototype wavefront and
@@ -1483,31 +1571,55 @@ void EnsembleCore::prepare() {
         if (!row_uniform_[HXP_NGLOBAL + b * HXPB_N + d.row]) uniform = false;
     } else if (!row_uniform_[d.row]) uniform = false;
   }
+  const size_t np = (size_t)npad_;
+  // A shared spinup whose inputs have not changed since it ran -- the parameters set in between
+  // are ones the spinup does not see (kParams: spinup = false; the calibration loop's S, Q10,
+  // beta, diffusivity ...) -- is not run again: every lane's post-spinup state, step count and
+  // year-0 outputs are the prototype's, whatever the lane order, and still on the device.  Only
+  // the members' own derive-time flags are applied anew.  (last_spinup_ms() then reports 0.)
+  const bool reuse = spin_valid_ && uniform && spin_uniform_ && !std::getenv("HECTOR_AMD_ALWAYS_SPINUP");
   spin_uniform_ = uniform;
-  check(hipEventRecord(ev0_, stream_), "event");
-  check(hx_launch_spinup(B_, d_args_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
-  check(hx_launch_alk(d_args_, uniform ? 1 : npad_, stream_), "alkalinity tuning");
-  if (uniform) {
-    check(hx_launch_broadcast(d_state_, HX_NSTATE(B_), npad_, stream_), "broadcast state");
-    check(hx_launch_broadcast_u32(d_status_, npad_, stream_), "broadcast status");
-    check(hx_launch_broadcast_u32(reinterpret_cast<unsigned *>(d_spin_steps_), npad_, stream_),
-          "broadcast steps");
-    for (int v = 0; v < HXO_NVAR; ++v)
-      if (d_out_[v]) check(hx_launch_broadcast(d_out_[v], 1, npad_, stream_), "broadcast out");
+  if (reuse) {
+    check(hipMemcpyAsync(d_state_, d_state_ + np * HX_NSTATE(B_), sizeof(double) * np * HX_NSTATE(B_),
+                         hipMemcpyDeviceToDevice, stream_), "restore state");
+    check(hipMemcpyAsync(d_status_, d_status_ + 2 * np, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
+                         stream_), "restore status");
+  } else {
+    check(hipEventRecord(ev0_, stream_), "event");
+    check(hx_launch_spinup(B_, d_args_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
+    check(hx_launch_alk(d_args_, uniform ? 1 : npad_, stream_), "alkalinity tuning");
+    if (uniform) {
+      check(hx_launch_broadcast(d_state_, HX_NSTATE(B_), npad_, stream_), "broadcast state");
+      check(hx_launch_broadcast_u32(d_status_, npad_, stream_), "broadcast status");
+      check(hx_launch_broadcast_u32(reinterpret_cast<unsigned *>(d_spin_steps_), npad_, stream_),
+            "broadcast steps");
+      for (int v = 0; v < HXO_NVAR; ++v)
+        if (d_out_[v]) check(hx_launch_broadcast(d_out_[v], 1, npad_, stream_), "broadcast out");
+    }
+    // the spinup's own status, before the members' derive-time flags: what a later reuse starts from
+    check(hipMemcpyAsync(d_status_ + 2 * np, d_status_, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
+                         stream_), "keep spinup status");
   }
   check(hx_launch_or_flags(d_status_, d_derived_ + (size_t)HXD_FLAG * npad_, npad_, stream_),
         "derive flags");
   // snapshot of the post-spinup state for reset(startDate)
-  const size_t np = (size_t)npad_;
-  check(hipMemcpyAsync(d_state_ + np * HX_NSTATE(B_), d_state_, sizeof(double) * np * HX_NSTATE(B_),
-                       hipMemcpyDeviceToDevice, stream_), "snapshot state");
+  if (!reuse)
+    check(hipMemcpyAsync(d_state_ + np * HX_NSTATE(B_), d_state_, sizeof(double) * np * HX_NSTATE(B_),
+                         hipMemcpyDeviceToDevice, stream_), "snapshot state");
   check(hipMemcpyAsync(d_status_ + np, d_status_, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
                        stream_), "snapshot status");
-  check(hipEventRecord(ev1_, stream_), "event");
-  check(hipEventSynchronize(ev1_), "spinup sync");
-  float ms = 0;
-  check(hipEventElapsedTime(&ms, ev0_, ev1_), "elapsed");
-  spin_ms_ = ms;
+  if (reuse) {
+    spin_ms_ = 0.0;
+    clk.lap("post-spinup state reused");
+  } else {
+    check(hipEventRecord(ev1_, stream_), "event");
+    check(hipEventSynchronize(ev1_), "spinup sync");
+    float ms = 0;
+    check(hipEventElapsedTime(&ms, ev0_, ev1_), "elapsed");
+    spin_ms_ = ms;
+    clk.lap("spinup + snapshot (waited)");
+  }
+  spin_valid_ = uniform;
   need_spinup_ = false;
   last_iy_ = 0;
   hist_valid_to_ = 0;
@@ -1516,7 +1628,7 @@ void EnsembleCore::prepare() {
 
 void EnsembleCore::reset(double date) {
   if (date < scen_.start) {  // core.cpp:511-549: rerun spinup
-    need_spinup_ = true;
+    need_spinup_ = true; spin_valid_ = false;
     last_iy_ = 0;
     dirty_from_iy_ = -1;
     return;
@@ -1861,7 +1973,7 @@ void EnsembleCore::set_tracking_date(int year) {
   tracking_year_ = year;
   if (trk_iy() == before) return;
   layout_dirty_ = true;
-  need_spinup_ = true;
+  need_spinup_ = true; spin_valid_ = false;
   last_iy_ = 0;
 }
 

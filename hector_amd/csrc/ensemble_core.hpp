@@ -160,6 +160,14 @@ class EnsembleCore {
   void maybe_calibrate_lanes();
   void assign_lanes();
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
+  // What the device holds of the parameter table: the rows set since the last upload and the lane
+  // order of that upload (upload_params() sends only what moved).
+  std::vector<char> row_dirty_;
+  bool rows_all_dirty_ = true, order_changed_ = true;
+  std::vector<int> uploaded_order_;
+  // The post-spinup snapshot on the device belongs to the current spinup inputs (a shared spinup
+  // is then not repeated when only parameters it does not see were set: prepare()).
+  bool spin_valid_ = false;
   int last_iy_ = 0;
   HxConst kc_{};
   std::vector<double> member_series_[HXM_N];  // host [ns][n_], member order; empty = shared
