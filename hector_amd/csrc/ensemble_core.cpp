@@ -1,6 +1,7 @@
 // ensemble_core.cpp -- see ensemble_core.hpp.
 #include "ensemble_core.hpp"
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -1419,7 +1420,7 @@ void EnsembleCore::maybe_calibrate_lanes() {
 #ifndef HX_HOST_EMULATION
   {  // With no more wavefronts than SIMDs every wavefront has a SIMD to itself from start to end
     // and the launch lasts as long as its costliest one under any order: nothing to gain.
-    static int simds[64] = {};
+    static std::atomic<int> simds[64] = {};   // (shards of a Fleet prepare on their own threads)
     if (device_ < 64 && !simds[device_]) {
       hipDeviceProp_t prop;
       check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
@@ -2102,9 +2103,25 @@ void EnsembleCore::check_component_enabled(const std::string &capability_in) con
                              " (component [" + sec + "] is disabled)");
 }
 
+// row_pitch: doubles between the rows (years) of out_host; 0 or n_members = contiguous.  A shard
+// of a Fleet writes its block of members straight into the whole ensemble's [year][member] array.
 void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1,
-                             double *out_host) {
+                             double *out_host, size_t row_pitch) {
   check_component_enabled(capability);
+  if (row_pitch == (size_t)n_) row_pitch = 0;
+  if (row_pitch) {
+    static const char *const whole[] = {"pH", "PCO2", "DIC", "CO3", "ML_ocean_c"};
+    bool on_host = fetch_host(capability, year0, year1, nullptr);
+    for (const char *w : whole) if (capability == w) on_host = true;
+    if (on_host) {  // answered or combined on the host: through a contiguous block
+      const size_t ny = (size_t)(year1 - year0 + 1);
+      std::vector<double> part(ny * (size_t)n_);
+      fetchvars(capability, year0, year1, part.data(), 0);
+      for (size_t y = 0; y < ny; ++y)
+        std::memcpy(out_host + y * row_pitch, part.data() + y * (size_t)n_, sizeof(double) * (size_t)n_);
+      return;
+    }
+  }
   if (fetch_host(capability, year0, year1, out_host)) return;
   {  // whole-surface values: area-weighted low/high latitude (ocean_component.cpp:466-503)
     static const char *const combos[][3] = {{"pH", "LL_pH", "HL_pH"}, {"PCO2", "LL_PCO2", "HL_PCO2"},
@@ -2156,8 +2173,12 @@ void EnsembleCore::fetchvars(const std::string &capability, int year0, int year1
     src = d_out_[v] + (size_t)iy0 * npad_;
   }
   check(hx_launch_gather(src, d_lane_of_member_, d_gather_, n_, npad_, ny, stream_), "gather");
-  check(hipMemcpyAsync(out_host, d_gather_, sizeof(double) * need, hipMemcpyDeviceToHost, stream_),
-        "fetch");
+  if (row_pitch)
+    check(hipMemcpy2DAsync(out_host, sizeof(double) * row_pitch, d_gather_, sizeof(double) * (size_t)n_,
+                           sizeof(double) * (size_t)n_, (size_t)ny, hipMemcpyDeviceToHost, stream_), "fetch");
+  else
+    check(hipMemcpyAsync(out_host, d_gather_, sizeof(double) * need, hipMemcpyDeviceToHost, stream_),
+          "fetch");
   check(hipStreamSynchronize(stream_), "fetch sync");
 }
 

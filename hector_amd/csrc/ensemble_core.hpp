@@ -101,7 +101,8 @@ class EnsembleCore {
   void run(double runtodate);   // Core::run; < 0 => endDate.  Asynchronous.
   void sync();                  // wait for the stream
   // GETDATA with dates: out[(year - year0) * n + member]
-  void fetchvars(const std::string &capability, int year0, int year1, double *out_host);
+  void fetchvars(const std::string &capability, int year0, int year1, double *out_host,
+                 size_t row_pitch = 0);
   bool host_output(const std::string &capability);
   // Carbon tracking (Core::trackingDate, get_tracking_data): origins of every pool's carbon from
   // `year` on.  year <= 0 or beyond endDate switches it off.

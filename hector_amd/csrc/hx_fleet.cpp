@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 
 #ifndef HX_HOST_EMULATION
 #include <dlfcn.h>
@@ -143,6 +145,31 @@ int Fleet::shard_of_member(int member) const {
 
 #define HX_EACH(call) for (Shard &s : shards_) { use(s); s.core->call; }
 
+// The verbs that do real host work or wait for a device -- run() (lane order, parameter upload,
+// spinup), reset(), sync(), fetchvars() -- take the shards side by side, one host thread per
+// shard: done one after the other, GPU k would start k x (host preparation + spinup) late, and
+// eight device-to-host copies would share one PCIe link's worth of time.  The first error in shard
+// order is the call's error.  (The host-emulation build runs a "kernel" on the calling thread with
+// its LDS in globals: shards stay sequential there.)
+template <class F>
+void Fleet::each_parallel(F &&fn) {
+#ifndef HX_HOST_EMULATION
+  if (shards_.size() > 1 && !std::getenv("HECTOR_AMD_FLEET_SEQUENTIAL")) {
+    std::vector<std::exception_ptr> err(shards_.size());
+    std::vector<std::thread> th;
+    auto body = [&](size_t k) {
+      try { use(shards_[k]); fn(shards_[k]); } catch (...) { err[k] = std::current_exception(); }
+    };
+    for (size_t k = 1; k < shards_.size(); ++k) th.emplace_back(body, k);
+    body(0);
+    for (std::thread &t : th) t.join();
+    for (std::exception_ptr &e : err) if (e) std::rethrow_exception(e);
+    return;
+  }
+#endif
+  for (Shard &s : shards_) { use(s); fn(s); }
+}
+
 void Fleet::setvar(const std::string &cap, const double *values, int nvalues, const char *units) {
   if (shards_.size() == 1) { shards_[0].core->setvar(cap, values, nvalues, units); return; }
   if (nvalues != 1 && nvalues != n_)
@@ -203,23 +230,16 @@ void Fleet::setvar_dated_members(const std::string &cap, const int *years, const
 void Fleet::lane_of_member(int *out) {
   for (Shard &s : shards_) { use(s); s.core->lane_of_member(out + s.offset); }
 }
-void Fleet::reset(double date) { HX_EACH(reset(date)) }
-void Fleet::run(double runtodate) { HX_EACH(run(runtodate)) }
-void Fleet::sync() { HX_EACH(sync()) }
+void Fleet::reset(double date) { each_parallel([&](Shard &s) { s.core->reset(date); }); }
+void Fleet::run(double runtodate) { each_parallel([&](Shard &s) { s.core->run(runtodate); }); }
+void Fleet::sync() { each_parallel([&](Shard &s) { s.core->sync(); }); }
 
 void Fleet::fetchvars(const std::string &cap, int year0, int year1, double *out_host) {
   if (shards_.size() == 1) { shards_[0].core->fetchvars(cap, year0, year1, out_host); return; }
   const int ny = year1 - year0 + 1;
   if (ny < 1) throw std::runtime_error("fetchvars: year1 < year0");
-  std::vector<double> part;
-  for (Shard &s : shards_) {
-    use(s);
-    part.resize((size_t)ny * (size_t)s.count);
-    s.core->fetchvars(cap, year0, year1, part.data());
-    for (int y = 0; y < ny; ++y)
-      std::memcpy(out_host + (size_t)y * n_ + s.offset, part.data() + (size_t)y * s.count,
-                  sizeof(double) * (size_t)s.count);
-  }
+  // every shard copies its block of members straight into its columns of out_host
+  each_parallel([&](Shard &s) { s.core->fetchvars(cap, year0, year1, out_host + s.offset, (size_t)n_); });
 }
 
 const double *Fleet::device_var(const std::string &cap, int *npad, int shard_index) {

@@ -115,6 +115,7 @@ class Fleet {
     void *comm = nullptr;                                                // ncclComm_t
   };
   void use(const Shard &s) const;
+  template <class F> void each_parallel(F &&fn);  // fn(shard) on every shard, one host thread each
   void ensure_comm();
   void ensure_stats_buffers(size_t block_doubles);
   void free_stats_buffers();

@@ -81,6 +81,11 @@ inline hipError_t hipMemcpy2D(void *d, size_t dp, const void *s, size_t sp, size
   return hipSuccess;
 }
 
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h,
+                                   hipMemcpyKind k, hipStream_t) {
+  return hipMemcpy2D(d, dp, s, sp, w, h, k);
+}
+
 template <class K, class... A>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
   gridDim = {grid.x, grid.y, grid.z};

@@ -39,14 +39,16 @@ def test_every_routed_verb_equals_the_single_core(emul_lib, tmp_path):
     years = np.arange(1760, 1770)
     ffi = 0.1 + 0.01 * np.arange(years.size * N).reshape(years.size, N)
     for c in (one, many):
-        c.set_outputs(["CO2_concentration", "global_tas", "RF_tot"])
+        c.set_outputs(["CO2_concentration", "global_tas", "RF_tot", "HL_pH", "LL_pH"])
         c.setvar("S", S, "degC").setvar("q10_rh", q10).setvar("beta", [0.5])
         c.enable_history(True)
         c.setvar_dated_members("ffi_emissions", years, ffi)
         c.run(RUN_TO)
     np.testing.assert_array_equal(many.getvar("S"), S)
     np.testing.assert_array_equal(many.getvar("beta"), np.full(N, 0.5))
-    for v in ("CO2_concentration", "global_tas", "RF_tot", "ffi_emissions"):
+    # (on the device; a per-member input; combined on the host from two arrays; answered on the
+    #  host from the scenario: each shard writes its columns of the whole ensemble's array)
+    for v in ("CO2_concentration", "global_tas", "RF_tot", "ffi_emissions", "pH", "luc_emissions", "RF_SO2"):
         a, b = one.fetchvars(v, (1745, RUN_TO)), many.fetchvars(v, (1745, RUN_TO))
         np.testing.assert_array_equal(a, b, err_msg=v)
     np.testing.assert_array_equal(one.status(), many.status())
