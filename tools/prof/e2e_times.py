@@ -59,6 +59,17 @@ def job(n, out_bufs=None):
         core.run(2300)
         core.ensemble_stats(["CO2_concentration", "global_tas"], (1745, 2300))
     t["setvar x2 + reset + run + stats (mean of %d)" % k] = (time.perf_counter() - c0) / k
+    # ... with a parameter the spinup sees (npp_flux0 per member): every member spins up again
+    c0 = time.perf_counter()
+    for _ in range(k):
+        core.setvar("S", S * rng.uniform(0.99, 1.01, n), "degC")
+        core.setvar("npp_flux0", rng.uniform(48.0, 60.0, n), "Pg C/yr")
+        core.reset(1745)
+        core.run(2300)
+        core.ensemble_stats(["CO2_concentration", "global_tas"], (1745, 2300))
+    t["... with npp_flux0 per member (mean of %d)" % k] = (time.perf_counter() - c0) / k
+    t["  of it: spinup kernel (all members)"] = core.last_spinup_ms() * 1e-3
+    t["  of it: year-loop kernel (3 rows vary)"] = core.last_run_ms() * 1e-3
     c0 = time.perf_counter()
     core.shutdown()
     t["shutdown"] = time.perf_counter() - c0
