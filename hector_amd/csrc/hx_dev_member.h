@@ -40,12 +40,18 @@ constexpr int HX_NBIOME_ARR = 9;
 // reference creates any number of biomes (simpleNbox.cpp:864-1124); 1-4 have unrolled kernels.
 constexpr int HX_DYN = 0;
 template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : B; }
+// Five to eight biomes have unrolled kernels too (round 3: the looped kernel waits out a memory
+// latency per biome and loop -- 22.8 ms against 10.9 for four biomes at 8 192 members; unrolled,
+// five biomes take 12.1 ms, eight 16.8); like the looped ones they keep the 21 DOECLIM /
+// ocean-exchange constants OUT of the park: 14 + 10 B slots, 32 KB and 37 KB for five and six
+// biomes (four wavefronts a CU), 42 KB and 47 KB for seven and eight (three).
+template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || B > 4; }
 // The looped kernels size their park for the core's biome count at launch (dynamic LDS) and do
 // NOT park the 21 DOECLIM / ocean-exchange constants (read from the derived table where they are
 // used: three loads a year against a model year of ~100k cycles): 14 + 10 nb slots -- 33 KB for
 // five biomes, 49 KB for eight -- so that up to four wavefronts share a CU where the fixed
 // 97.5 KB allowed one.
-template <int B> constexpr int pk_ff0() { return B == HX_DYN ? (int)PK_D0 : (int)PK_FFROZEN0; }
+template <int B> constexpr int pk_ff0() { return hx_lean_park<B>() ? (int)PK_D0 : (int)PK_FFROZEN0; }
 template <int B> constexpr int hx_npark() {
   return pk_ff0<B>() + hx_bmax<B>() + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * hx_bmax<B>());
 }
@@ -113,7 +119,7 @@ template <int B> __device__ __forceinline__ int nbio(const Member<B> &m) {
 // a member's DOECLIM / ocean-exchange constant (row HXD_A0.. / HXD_KLH.. of the derived table):
 // from the park, or -- looped kernels -- from the table itself
 template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, int row) {
-  if constexpr (B == HX_DYN) return m.der[(size_t)row * m.npad];
+  if constexpr (hx_lean_park<B>()) return m.der[(size_t)row * m.npad];
   else return PKM(m, row >= HXD_KLH && row < HXD_KLH + 7 ? PK_K0 + (row - HXD_KLH) : PK_D0 + (row - HXD_A0));
 }
 
@@ -219,7 +225,7 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   // constants -> park
   PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
   PKM(m, PK_VOL) = ldp(buf, HXP_VOL, mem);
-  if constexpr (B != HX_DYN) {
+  if constexpr (!hx_lean_park<B>()) {
 #pragma unroll
     for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
 #pragma unroll

@@ -1451,16 +1451,28 @@ static void hx_allow_dynamic_lds(const void *kernel, size_t bytes) {
 #endif
 }
 
+// biome counts from this one on take the looped kernels (default: 9; HECTOR_AMD_LOOPED_BIOMES_FROM=5
+// sends 5-8 there as well -- the tests hold the unrolled and the looped kernels against each other)
+static int hx_looped_from() {   // (read at every launch: a test switches it between two cores)
+  const char *e = getenv("HECTOR_AMD_LOOPED_BIOMES_FROM");
+  const int x = e ? atoi(e) : 9;
+  return x < 5 ? 5 : x;
+}
+
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st) {
   const int blocks = (nmem_launch + 63) / 64;
-  switch (B) {
+  switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
     case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
 #ifndef HX_MINIMAL_BUILD
     case 2: hipLaunchKernelGGL(hx_spinup_kernel<2>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
 #endif
     case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 5: hipLaunchKernelGGL(hx_spinup_kernel<5>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 6: hipLaunchKernelGGL(hx_spinup_kernel<6>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 7: hipLaunchKernelGGL(hx_spinup_kernel<7>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+    case 8: hipLaunchKernelGGL(hx_spinup_kernel<8>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     default:
       if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
       {
@@ -1540,6 +1552,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     }
   }
 #endif
+  if constexpr (B <= 4) {  // (HX_DYN = 0 included; hx_launch_run sends 5 and 6 biomes with tracking there)
   if (con == 2 && kpm) {
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
     return;
@@ -1547,6 +1560,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   if (con == 2) {
     hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
     return;
+  }
   }
   if (con && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
@@ -1583,13 +1597,23 @@ hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, boo
 }
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st) {
-  switch (B) {
+  switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
     case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
 #ifndef HX_MINIMAL_BUILD
     case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
 #endif
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+    // five to eight biomes: unrolled like 1-4 (lean park, hx_dev_member.h); carbon tracking on the
+    // looped kernels' 8-column chunks
+    case 5: if (con != 2) { launch_run_b<5>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+            launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+    case 6: if (con != 2) { launch_run_b<6>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+            launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+    case 7: if (con != 2) { launch_run_b<7>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+            launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+    case 8: if (con != 2) { launch_run_b<8>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+            launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
     default:
       if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
       launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B);

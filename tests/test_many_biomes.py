@@ -77,9 +77,52 @@ def identical_split_equals_global(lib, nb=7, **kw):
         assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(a).max()), v
 
 
-def test_many_biomes_vs_oracle(emul_lib, oracle):
-    many_biome_checks(emul_lib, oracle, counts=(5, 11), n=2, run_to=2100, allow_emulation=True)
+def unrolled_equals_looped(lib, monkeypatch, n, run_to, tol=1e-11, **kw):
+    """Five to eight biomes run unrolled kernels (round 3), nine to sixteen the looped ones;
+    HECTOR_AMD_LOOPED_BIOMES_FROM=5 sends 5-8 to the looped kernels too: the same ensemble on
+    both -- plain, with the heat-flux output and per-member diffusivity, and with a constraint
+    (the extended kernels) -- must agree to rounding: the sums over biomes run in the same order,
+    only the compiler's contraction of multiply-adds differs (1e-11 on the host build to 1900;
+    on the GPU to 2300 the last bits grow to ~1e-10, the same size as against the oracle)."""
+    for nb in (5, 6, 7, 8):
+        res = []
+        for looped in (False, True):
+            if looped:
+                monkeypatch.setenv("HECTOR_AMD_LOOPED_BIOMES_FROM", "5")
+            else:
+                monkeypatch.delenv("HECTOR_AMD_LOOPED_BIOMES_FROM", raising=False)
+            r = np.random.default_rng(nb)
+            c = hector_amd.Core(SCENARIO, n, lib_path=lib, **kw)
+            names = ["k%d" % i for i in range(nb)]
+            fr = r.random(nb) + 0.3; fr /= fr.sum()
+            hector_amd.split_biome(c, "global", names, fveg_c=fr, fdetritus_c=fr, fsoil_c=fr,
+                                   fpermafrost_c=fr, fnpp_flux0=fr)
+            c.setvar("S", 2.0 + 3.0 * ensemble.uniform01(np.arange(n), 3, seed=nb), "degC")
+            c.setvar("diff", 1.5 + 1.5 * ensemble.uniform01(np.arange(n), 4, seed=nb), "cm2/s")
+            for i, b in enumerate(names):
+                c.setvar(b + ".q10_rh", 1.2 + 1.6 * ensemble.uniform01(np.arange(n), 5 + i, seed=nb))
+                c.setvar(b + ".warmingfactor", 0.8 + 0.2 * i)
+            outs = ["CO2_concentration", "global_tas", "heatflux", "permafrost_c", names[-1] + ".soil_c", "NPP"]
+            c.set_outputs(outs)
+            c.run(run_to)
+            got = [c.fetchvars(v, (Y0, run_to)) for v in outs]
+            # ... and the constrained kernels: global tas pinned from 1850 on
+            yrs = np.arange(1850, run_to + 1)
+            c.setvar_dated("tas_constrain", yrs, 0.01 * (yrs - 1850), "degC")
+            c.reset(Y0); c.run(run_to)
+            got += [c.fetchvars(v, (Y0, run_to)) for v in outs]
+            assert (c.status() == 0).all()
+            res.append(got)
+            c.shutdown()
+        monkeypatch.delenv("HECTOR_AMD_LOOPED_BIOMES_FROM", raising=False)
+        for a, b in zip(*res):
+            assert np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), nb
+
+
+def test_many_biomes_vs_oracle(emul_lib, oracle, monkeypatch):
+    many_biome_checks(emul_lib, oracle, counts=(5, 8, 11), n=2, run_to=2100, allow_emulation=True)
     identical_split_equals_global(emul_lib, allow_emulation=True)
+    unrolled_equals_looped(emul_lib, monkeypatch, 3, 1900, allow_emulation=True)
 
 
 def test_many_biomes_api(emul_lib):
@@ -100,5 +143,10 @@ def test_many_biomes_api(emul_lib):
 
 @pytest.mark.gpu
 def test_many_biomes_vs_oracle_on_gpu(hip_lib, oracle):
-    many_biome_checks(hip_lib, oracle, counts=(5, 8, 11, 16), n=6, device=0)
+    many_biome_checks(hip_lib, oracle, counts=(5, 6, 8, 9, 16), n=6, device=0)
     identical_split_equals_global(hip_lib, device=0)
+
+
+@pytest.mark.gpu
+def test_unrolled_and_looped_kernels_agree_on_gpu(hip_lib, monkeypatch):
+    unrolled_equals_looped(hip_lib, monkeypatch, 200, 2300, tol=2e-8, device=0)

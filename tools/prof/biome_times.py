@@ -13,11 +13,13 @@ from hector_amd import ensemble  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-    counts = [int(x) for x in sys.argv[2:]] or [4, 5, 8, 16]
+    args = [a for a in sys.argv[1:] if not a.startswith("--lib=")]
+    lib = [a[6:] for a in sys.argv[1:] if a.startswith("--lib=")]   # an experiment build (gpuwork/)
+    n = int(args[0]) if args else 65536
+    counts = [int(x) for x in args[1:]] or [4, 5, 8, 16]
     S = 1.5 + 4.5 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 0)
     for nb in counts:
-        c = hector_amd.Core(n_members=n, device=0)
+        c = hector_amd.Core(n_members=n, device=0, **({"lib_path": os.path.abspath(lib[0])} if lib else {}))
         names = ["b%d" % i for i in range(nb)]
         if nb > 1:
             c.split_biome(names)

@@ -36,7 +36,17 @@ def main():
         k.setdefault("lib_path", lib)
         return orig(*a, **k)
     hector_amd.Core = core_with_lib
-    c = bench.make_core(n, biomes, 0, 0)
+    if biomes in (1, 4):
+        c = bench.make_core(n, biomes, 0, 0)
+    else:   # any other count: the ensemble of tools/prof/biome_times.py (S, per-biome Q10, warming factors)
+        from hector_amd import ensemble
+        c = hector_amd.Core(n_members=n, device=0)
+        names = ["b%d" % i for i in range(biomes)]
+        c.split_biome(names)
+        c.setvar("S", 1.5 + 4.5 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 0), "degC")
+        for b, nm in enumerate(names):
+            c.setvar(nm + ".q10_rh", 1.0 + 2.0 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 10 + b))
+            c.setvar(nm + ".warmingfactor", np.full(n, 1.0 + 0.5 * (b % 4)))
     c.run(2300)
     ms = c.last_run_ms()
     t = c.fetchvars("global_tas", (1745, 1745 + 23))      # [24][members]: per-wave values
