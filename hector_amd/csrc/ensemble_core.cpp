@@ -467,6 +467,7 @@ void EnsembleCore::free_device() {
   fr(d_hist_status_);
   fr(d_gas_par_); fr(d_gas_ser_); d_gas_par_ = d_gas_ser_ = nullptr;
   fr(d_cost_); d_cost_ = nullptr; cost_from_iy_ = -1;
+  fr(d_bscratch_); d_bscratch_ = nullptr;
   fr(d_spin_rec_); d_spin_rec_ = nullptr;
   d_hist_ = nullptr; d_hist_status_ = nullptr;
   for (int k = 0; k < HXM_N; ++k) { fr(d_mseries_[k]); d_mseries_[k] = nullptr; if (!member_series_[k].empty()) mseries_dirty_ = true; }
@@ -535,6 +536,8 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
   check(hipMalloc(&d_cost_, sizeof(double) * np), "hipMalloc lane cost");
+  check(hipMalloc(&d_bscratch_, sizeof(double) * np * (size_t)B_), "hipMalloc biome scratch");
+  check(hipMemsetAsync(d_bscratch_, 0, sizeof(double) * np * (size_t)B_, stream_), "zero");
   cost_from_iy_ = -1;
   for (int v = 0; v < HXO_NVAR; ++v)
     if (out_enabled_[v]) {
@@ -580,6 +583,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.nbiome = B_;
   b.cost = d_cost_;
   b.spin_rec = d_spin_rec_;
+  b.bscratch = d_bscratch_;
   return b;
 }
 

@@ -157,6 +157,7 @@ class EnsembleCore {
   bool sort_members_ = true, calibrate_lanes_ = true;
   std::vector<double> lane_cost_;  // [n_] measured cost per member (empty: parameter key)
   double *d_cost_ = nullptr;
+  double *d_bscratch_ = nullptr;  // [nbiome][npad] f_new_thaw of the seven- and eight-biome kernels
   int cost_from_iy_ = -1;         // d_cost_ covers the years cost_from_iy_+1..last_iy_ (-1: nothing)
   void maybe_calibrate_lanes();
   void assign_lanes();

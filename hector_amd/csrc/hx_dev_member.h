@@ -44,7 +44,8 @@ template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : B; }
 // latency per biome and loop -- 22.8 ms against 10.9 for four biomes at 8 192 members; unrolled,
 // five biomes take 12.1 ms, eight 16.8); like the looped ones they keep the 21 DOECLIM /
 // ocean-exchange constants OUT of the park: 14 + 10 B slots, 32 KB and 37 KB for five and six
-// biomes (four wavefronts a CU), 42 KB and 47 KB for seven and eight (three).
+// biomes, 35 KB and 39 KB for seven and eight with two more values per biome left in HBM
+// (hx_slim_park): four wavefronts a CU for all of them.
 template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || B > 4; }
 // The looped kernels size their park for the core's biome count at launch (dynamic LDS) and do
 // NOT park the 21 DOECLIM / ocean-exchange constants (read from the derived table where they are
@@ -52,11 +53,18 @@ template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || B > 4; }
 // five biomes, 49 KB for eight -- so that up to four wavefronts share a CU where the fixed
 // 97.5 KB allowed one.
 template <int B> constexpr int pk_ff0() { return hx_lean_park<B>() ? (int)PK_D0 : (int)PK_FFROZEN0; }
+// Seven and eight biomes: the two per-biome values that are touched least -- f_frozen (read and
+// written once a year; it IS a row of the state table) and f_new_thaw (written once a year, read
+// by the three or so flow computations) -- stay in HBM: 14 + 8 B slots = 35 / 39 KB, four
+// wavefronts a CU where 42 / 47 KB allowed three (65 536 members then take one round, not two).
+template <int B> constexpr bool hx_slim_park() { return B == 7 || B == 8; }
+template <int B> constexpr int hx_npark_arr() { return hx_slim_park<B>() ? HX_NBIOME_ARR - 1 : HX_NBIOME_ARR; }
+template <int B> constexpr int hx_nff() { return hx_slim_park<B>() ? 0 : hx_bmax<B>(); }  // parked f_frozen slots
 template <int B> constexpr int hx_npark() {
-  return pk_ff0<B>() + hx_bmax<B>() + (B == 1 ? (int)PKB_N : HX_NBIOME_ARR * hx_bmax<B>());
+  return pk_ff0<B>() + hx_nff<B>() + (B == 1 ? (int)PKB_N : hx_npark_arr<B>() * hx_bmax<B>());
 }
 __host__ __device__ inline int hx_npark_dyn(int nb) { return PK_D0 + nb + HX_NBIOME_ARR * nb; }
-template <int B> constexpr int hx_pkb1() { return pk_ff0<B>() + hx_bmax<B>(); }
+template <int B> constexpr int hx_pkb1() { return pk_ff0<B>() + hx_nff<B>(); }
 
 // Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
 // registers, 36 doubles for B = 4 on top of the solver's working set overflow 256 VGPRs +
@@ -74,6 +82,15 @@ struct RegArr1 {
 };
 template <int B> struct BiomeArr { using type = ParkArr; };
 template <> struct BiomeArr<1> { using type = RegArr1; };
+// a per-biome array in HBM: element b of this lane at base[b * stride]
+struct GlobArr {
+  hx_gd base;
+  size_t stride;
+  __device__ __forceinline__ double HX_GLOBAL &operator[](int b) const { return base[(size_t)b * stride]; }
+};
+template <int B> struct BiomeArrThaw { using type = typename BiomeArr<B>::type; };
+template <> struct BiomeArrThaw<7> { using type = GlobArr; };
+template <> struct BiomeArrThaw<8> { using type = GlobArr; };
 
 // What stays in registers through the carbon-cycle solver of one year.
 template <int B>
@@ -88,7 +105,9 @@ struct Member {
   double alkH, alkL, hH, hL;
   unsigned status;
   // per-year
-  typename BiomeArr<B>::type co2fert, tempfertd, f_new_thaw;
+  typename BiomeArr<B>::type co2fert, tempfertd;
+  typename BiomeArrThaw<B>::type f_new_thaw;
+  GlobArr ffz;   // slim park: f_frozen of this lane in the state table
   double luc_e, luc_u, ffi, daccs, npp_luc_adjust;
   ChemK kH, kL;
   double pco2H, pco2L;
@@ -116,6 +135,15 @@ template <int B> __device__ __forceinline__ int nbio(const Member<B> &m) {
   if constexpr (B == HX_DYN) return m.nb; else return B;
 }
 #define PKM(m, slot) ((m).pk[(slot)][(m).lane])
+// f_frozen of biome b: a park slot, or (slim park) the state table's row itself
+template <int B> __device__ __forceinline__ double ffrozen_of(const Member<B> &m, int b) {
+  if constexpr (hx_slim_park<B>()) return m.ffz[b];
+  else return PKM(m, pk_ff0<B>() + b);
+}
+template <int B> __device__ __forceinline__ void set_ffrozen(const Member<B> &m, int b, double v) {
+  if constexpr (hx_slim_park<B>()) m.ffz[b] = v;
+  else PKM(m, pk_ff0<B>() + b) = v;
+}
 // a member's DOECLIM / ocean-exchange constant (row HXD_A0.. / HXD_KLH.. of the derived table):
 // from the park, or -- looped kernels -- from the table itself
 template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, int row) {
@@ -212,13 +240,24 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   m.nb = buf.nbiome;
   if constexpr (B != 1) {
     const int bm = (B == HX_DYN) ? buf.nbiome : hx_bmax<B>();   // slots per array
-    const int o = pk_ff0<B>() + bm;
+    const int o = pk_ff0<B>() + (hx_slim_park<B>() ? 0 : bm);
+    if constexpr (hx_slim_park<B>()) {
+      ParkArr *arr[HX_NBIOME_ARR - 1] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
+                                         &m.co2fert, &m.tempfertd};
+#pragma unroll
+      for (int k = 0; k < HX_NBIOME_ARR - 1; ++k) { arr[k]->base = park + o + k * bm; arr[k]->lane = lane; }
+      m.f_new_thaw.base = HX_GD(buf.bscratch) + mem;
+      m.f_new_thaw.stride = (size_t)buf.npad;
+      m.ffz.base = HX_GD(buf.state) + (size_t)(HXS_NGLOBAL + HXSB_F_FROZEN) * buf.npad + mem;
+      m.ffz.stride = (size_t)HXSB_N * buf.npad;
+    } else {
     ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
                                    &m.co2fert, &m.tempfertd, &m.f_new_thaw};
 #pragma unroll
     for (int k = 0; k < HX_NBIOME_ARR; ++k) {
       arr[k]->base = park + o + k * bm;
       arr[k]->lane = lane;
+    }
     }
   }
   m.C0 = ldp(buf, HXP_C0, mem);
@@ -316,9 +355,10 @@ __device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
   sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
   sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
   if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
+  if (hx_slim_park<B>() && !base) return;  // (the live table's rows are where f_frozen lives)
 #pragma unroll
   for (int b = 0; b < nbio<B>(m); ++b)
-    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, PKM(m, pk_ff0<B>() + b));
+    sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, ffrozen_of<B>(m, b));
 }
 
 }  // namespace

@@ -504,9 +504,11 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
     PKM(m, PK_BASE_CO2) = lds_(buf, HXS_BASE_CO2, mem);
     PKM(m, PK_LN_CH4) = hx_log(lds_(buf, HXS_CH4, mem));
     PKM(m, PK_LN_CO2R) = hx_log(hx_div(m.atmos * PGC2PPM, m.C0));
+    if constexpr (!hx_slim_park<B>()) {
 #pragma unroll
     for (int b = 0; b < nbio<B>(m); ++b)
       PKM(m, pk_ff0<B>() + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
+    }
   }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
       if constexpr (B != HX_DYN) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        s_ffrozen[b] = PKM(m, pk_ff0<B>() + b);
+        s_ffrozen[b] = ffrozen_of<B>(m, b);
         if constexpr (B == 1) {
           constexpr int o = hx_pkb1<B>();
           p_beta[b] = PKM(m, o + PKB_BETA); p_wf[b] = PKM(m, o + PKB_WF);
@@ -727,8 +729,8 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
                                       ldp(buf, pr + HXPB_PF_SIGMA, mem) * 1.4142135623730951);
               ff = 1 - erfc(-d) / 2;
             }
-            m.f_new_thaw[b] = PKM(m, pk_ff0<B>() + b) - ff;
-            PKM(m, pk_ff0<B>() + b) = ff;
+            m.f_new_thaw[b] = ffrozen_of<B>(m, b) - ff;
+            set_ffrozen<B>(m, b, ff);
           }
           const double Trm = (iy > 1) ? (twin * wf) * 0.005 : 0.0;
           const double tfs = hx_exp(lnq10 * (Trm * 0.1));
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
             ff = 1 - erfc(-d) / 2;
           }
           m.f_new_thaw[b] = s_ffrozen[b] - ff;
-          PKM(m, pk_ff0<B>() + b) = ff;
+          set_ffrozen<B>(m, b, ff);
         }
         const double tfs = ex[14 + 2 * b];  // exp(ln q10 * Trm / 10), Trm = 200-year mean
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
           putb(HXOB_VEG, m.veg[b]); putb(HXOB_DET, m.det[b]); putb(HXOB_SOIL, m.soil[b]);
           putb(HXOB_PF, m.pf[b]); putb(HXOB_THAWED, m.thawed[b]);
           putb(HXOB_RH_CH4, m_rh_tp_ch4(m, lkb, b));
-          putb(HXOB_F_FROZEN, PKM(m, pk_ff0<B>() + b));
+          putb(HXOB_F_FROZEN, ffrozen_of<B>(m, b));
           putb(HXOB_TEMPFERTD, m.tempfertd[b]); putb(HXOB_TEMPFERTS, m.tempferts[b]);
         }
       }
@@ -1029,7 +1031,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
         for (int b = 0; b < nbio<B>(m); ++b) { rch4 += m_rh_tp_ch4(m, lk, b); ptot += m.pf[b]; }
         if (ptot > 0.0) {
 #pragma unroll
-          for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * PKM(m, pk_ff0<B>() + b);
+          for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * ffrozen_of<B>(m, b);
         } else ff = 1.0;
         if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rch4);
         if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);

@@ -152,7 +152,7 @@ int hx_split_biome_of(hx_core *core, const char *old_biome, int n_biomes,
  * SimpleNbox::createBiome / deleteBiome / renameBiome, src/simpleNbox.cpp:864-1060).  A created
  * biome has empty pools and npp_flux0 = 0 and the other parameters of the most recent biome
  * (set them with hx_setvar("<biome>.veg_c", ...), like R's create_biome does); at most 16 biomes
- * (1-4 run fully unrolled kernels, 5-16 kernels that loop over the biomes).
+ * (1-8 run fully unrolled kernels, 9-16 kernels that loop over the biomes).
  * All three invalidate the run (spinup again), like any parameter change. */
 int hx_create_biome(hx_core *core, const char *biome);
 int hx_delete_biome(hx_core *core, const char *biome);
