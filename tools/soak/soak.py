@@ -52,6 +52,20 @@ def biomes(gpu, argv):
         print("seed", seed, _fmt(w), "%.0fs" % (time.time() - t0), flush=True)
 
 
+def biomes_many(gpu, argv):
+    """5-9 biomes (the unrolled five- to eight-biome kernels, the looped kernel for nine),
+    per-member pool splits, every per-biome parameter."""
+    import test_random_sweep as T
+    for seed in range(int(argv[0]) if argv else 2):
+        if gpu:
+            w = T.sweep_biomes(HIP, 512, seed=100 + seed, scenarios=("ssp245", "ssp585", "ssp119"),
+                               check_every=8, counts=(5, 6, 7, 8, 9), device=0)
+        else:
+            w = T.sweep_biomes(EMUL, 4, seed=100 + seed, scenarios=("ssp245",), counts=(5, 6, 7, 8, 9),
+                               allow_emulation=True)
+        print("biomes_many seed %d: %s" % (seed, _fmt(w)), flush=True)
+
+
 def mixed(gpu, argv):
     """scenario x biomes x one random constraint window x land-ocean warming ratio."""
     import test_random_sweep as T
@@ -281,7 +295,7 @@ def million(gpu, argv):
     print("ill-conditioned members:", rep["ill_conditioned_members"])
 
 
-HARNESSES = {"all_parameters": all_parameters, "biomes": biomes, "mixed": mixed, "workflows": workflows,
+HARNESSES = {"all_parameters": all_parameters, "biomes": biomes, "biomes_many": biomes_many, "mixed": mixed, "workflows": workflows,
              "diagnostics": diagnostics, "shared_parameters": shared_parameters, "tracking": tracking,
              "million": million}
 
