@@ -56,7 +56,7 @@ def biomes_many(gpu, argv):
     """5-9 biomes (the unrolled five- to eight-biome kernels, the looped kernel for nine),
     per-member pool splits, every per-biome parameter."""
     import test_random_sweep as T
-    for seed in range(int(argv[0]) if argv else 2):
+    for seed in range(2):
         if gpu:
             w = T.sweep_biomes(HIP, 512, seed=100 + seed, scenarios=("ssp245", "ssp585", "ssp119"),
                                check_every=8, counts=(5, 6, 7, 8, 9), device=0)
