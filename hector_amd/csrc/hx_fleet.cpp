@@ -160,8 +160,13 @@ void Fleet::each_parallel(F &&fn) {
     auto body = [&](size_t k) {
       try { use(shards_[k]); fn(shards_[k]); } catch (...) { err[k] = std::current_exception(); }
     };
-    for (size_t k = 1; k < shards_.size(); ++k) th.emplace_back(body, k);
+    size_t started = 1;
+    try {
+      for (; started < shards_.size(); ++started) th.emplace_back(body, started);
+    } catch (...) {  // no more threads to be had: the remaining shards on this one
+    }
     body(0);
+    for (size_t k = started; k < shards_.size(); ++k) body(k);
     for (std::thread &t : th) t.join();
     for (std::exception_ptr &e : err) if (e) std::rethrow_exception(e);
     return;

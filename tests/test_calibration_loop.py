@@ -99,6 +99,53 @@ def test_calibration_loop_equals_fresh_cores(emul_lib):
     _loop_equals_fresh(emul_lib, 200, 1800)
 
 
+# every parameter the spinup is said not to see (kParams: spinup = false), with a range for it
+NOT_SEEN_BY_SPINUP = {
+    "S": (1.5, 6.0), "diff": (0.6, 3.0), "qco2": (3.4, 4.1), "aero_scalar": (0.3, 1.7),
+    "vol_scalar": (0.5, 1.5), "lo_warming_ratio": (1.2, 1.9), "beta": (0.2, 0.9), "q10_rh": (1.1, 3.0),
+    "warmingfactor": (0.8, 1.6), "rh_ch4_frac": (0.01, 0.04), "pf_mu": (1.4, 1.9),
+    "pf_sigma": (0.8, 1.1), "fpf_static": (0.6, 0.85),
+}
+
+
+def test_the_spinup_really_does_not_see_those_parameters(emul_lib):
+    """The reuse of a shared spinup rests on the table of which parameters the spinup reads.  If one
+    marked `spinup = false` did enter it, a core that spun up under OTHER values of it would differ
+    from a fresh one: all thirteen at once, per member, then one at a time (uniform values)."""
+    n, run_to = 70, 1790
+    rng = np.random.default_rng(11)
+    new = {k: rng.uniform(lo, hi, n) for k, (lo, hi) in NOT_SEEN_BY_SPINUP.items()}
+    a = _core(n, emul_lib)
+    a.setvar("lo_warming_ratio", 1.5)         # (its first non-zero value adds an output array: new buffers)
+    _results(a, run_to)                       # spun up under the scenario's defaults
+    for k, v in new.items():
+        a.setvar(k, v)
+    a.reset(1745)
+    ra = _results(a, run_to)
+    assert a.last_spinup_ms() == 0.0
+    f = _core(n, emul_lib)
+    for k, v in new.items():
+        f.setvar(k, v)
+    rf = _results(f, run_to)
+    for x, y in zip(ra[:3], rf[:3]):
+        assert np.array_equal(x, y)
+    assert ra[3] == rf[3]
+    a.shutdown(); f.shutdown()
+    for k, (lo, hi) in NOT_SEEN_BY_SPINUP.items():
+        a = _core(4, emul_lib)
+        a.setvar("lo_warming_ratio", 1.5)
+        _results(a, 1760)
+        a.setvar(k, hi)
+        a.reset(1745)
+        ra = _results(a, 1760)
+        assert a.last_spinup_ms() == 0.0, k
+        f = _core(4, emul_lib)
+        f.setvar("lo_warming_ratio", 1.5).setvar(k, hi)
+        rf = _results(f, 1760)
+        assert np.array_equal(ra[0], rf[0]) and np.array_equal(ra[1], rf[1]) and ra[3] == rf[3], k
+        a.shutdown(); f.shutdown()
+
+
 def _reference_order(rows, n, wave=64):
     """The lane order as DESIGN.md 4 states it, with numpy's stable sorts: by the first varying
     parameter; then, inside sqrt(n / 64) bins of that order, by the second (more than two: the
