@@ -184,6 +184,38 @@ def test_config5_every_member_vs_oracle(hip_lib, oracle):
                           "warmingfactor 1, 1.5, 2, 2.5 (hector_amd/ensemble.py biome4)"})
 
 
+@pytest.mark.parametrize("nb", [6, 8])
+def test_unrolled_many_biome_kernels_every_member_vs_oracle(hip_lib, oracle, nb):
+    """The unrolled kernels of five to eight biomes (round 3; six: the lean park, eight: the slim
+    one with f_frozen / f_new_thaw in HBM): 16 384 members, every one against the oracle -- S,
+    a Q10 per biome, warming factors 1 ... 2.5 -- with identical stash schedules."""
+    n = 16384
+    idx = np.arange(n, dtype=np.uint64)
+    S = 1.5 + 4.5 * ensemble.uniform01(idx, 0)
+    q10s = [1.0 + 2.0 * ensemble.uniform01(idx, 10 + b) for b in range(nb)]
+    wfs = [1.0 + 0.5 * (b % 4) for b in range(nb)]
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    names = ["b%d" % b for b in range(nb)]
+    c.split_biome(names)
+    c.setvar("S", S, "degC")
+    for b, nm in enumerate(names):
+        c.setvar(nm + ".q10_rh", q10s[b]).setvar(nm + ".warmingfactor", wfs[b])
+    c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+    c.run(2300)
+    assert (c.status() == 0).all()
+
+    def mp(i):
+        p = oracle.default_params()
+        oracle.split_equal(p, nb)
+        p.S = S[i]
+        for b in range(nb):
+            p.q10_rh[b] = q10s[b][i]; p.warmingfactor[b] = wfs[b]
+        return p
+    _compare("unrolled_16384x%d" % nb, c, oracle, mp, np.arange(n), n,
+             {"ensemble": "%d equal biomes, S ~ U(1.5, 6), q10_rh ~ U(1, 3) per biome, warmingfactor "
+                          "1, 1.5, 2, 2.5 repeating (tools/prof/biome_times.py)" % nb})
+
+
 def test_config4_million_member_grid_sample_vs_oracle(hip_lib, oracle):
     """configs[3]'s 1 048 576 members on one GPU (the 8-GPU job shards exactly this grid): 65 536
     members spread evenly over it (every 16th, among them member 394 646, the one member of the
