@@ -306,8 +306,8 @@ def setup_native_collective(core, dist, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--members", type=int, default=65536, help="members per GPU")
     ap.add_argument("--biomes", type=int, default=1, choices=[1, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
