@@ -344,8 +344,16 @@ class Core:
         self._ck(self._lib.hx_set_pair_kernel_limit(self._h, int(max_members)))
         return self
 
+    def set_two_wave_from(self, min_members):
+        """Ensembles of at least min_members members (one biome, shared diffusivity, no
+        constraints / heat-flux outputs) run on the flavour of the kernel built for two resident
+        wavefronts per SIMD (include/hector_amd.h); < 0: the default (more wavefronts than the
+        GPU has SIMDs), 0: never."""
+        self._ck(self._lib.hx_set_two_wave_from(self._h, int(min_members)))
+        return self
+
     def last_run_kernel(self):
-        """'run' or 'pair': the kernel the last run() launched."""
+        """'run', 'run2' or 'pair': the kernel the last run() launched."""
         s = ctypes.c_char_p()
         self._ck(self._lib.hx_last_run_kernel(self._h, ctypes.byref(s)))
         return s.value.decode()

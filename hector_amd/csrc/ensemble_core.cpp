@@ -19,7 +19,7 @@ int hx_pair_available();
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
                               int iy_to, hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st);
+                         int iy_from, int iy_to, hipStream_t st, bool two_wave);
 int hx_doeclim_block_years();
 void hx_fill_chem_table_host(double *t);
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
@@ -153,6 +153,14 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   check(hipSetDevice(device_), "hipSetDevice");
   check(hipStreamCreate(&stream_), "hipStreamCreate");
   if (const char *e2 = std::getenv("HECTOR_AMD_PAIR_MAX_MEMBERS")) pair_max_members_ = std::atoi(e2);
+  if (const char *e3 = std::getenv("HECTOR_AMD_TWO_WAVE_FROM")) two_wave_from_ = std::atoi(e3);
+#ifndef HX_HOST_EMULATION
+  {
+    hipDeviceProp_t prop;
+    check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+    simds_ = 4 * prop.multiProcessorCount;
+  }
+#endif
   try {  // a constructor that throws gets no destructor: release the stream and events here
     check(hipEventCreate(&ev0_), "hipEventCreate");
     check(hipEventCreate(&ev1_), "hipEventCreate");
@@ -1424,13 +1432,7 @@ void EnsembleCore::maybe_calibrate_lanes() {
 #ifndef HX_HOST_EMULATION
   {  // With no more wavefronts than SIMDs every wavefront has a SIMD to itself from start to end
     // and the launch lasts as long as its costliest one under any order: nothing to gain.
-    static std::atomic<int> simds[64] = {};   // (shards of a Fleet prepare on their own threads)
-    if (device_ < 64 && !simds[device_]) {
-      hipDeviceProp_t prop;
-      check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
-      simds[device_] = 4 * prop.multiProcessorCount;
-    }
-    if (device_ < 64 && npad_ / HX_WAVE <= simds[device_] && !std::getenv("HECTOR_AMD_CALIBRATE_ALWAYS")) return;
+    if (npad_ / HX_WAVE <= simds_ && !std::getenv("HECTOR_AMD_CALIBRATE_ALWAYS")) return;
   }
 #endif
   sync();
@@ -1717,12 +1719,16 @@ void EnsembleCore::run(double runtodate) {
       if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) pair = false;
     }
   last_run_pair_ = pair;
+  // more wavefronts than SIMDs: the one-biome kernel built for two resident wavefronts per SIMD
+  const int w2_from = two_wave_from_ < 0 ? simds_ * HX_WAVE + 1 : two_wave_from_;
+  const bool w2 = !pair && B_ == 1 && con == 0 && !hf && !ker_per_member_ && w2_from > 0 && n_ >= w2_from;
+  last_run_w2_ = w2;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,
                              stream_), "run kernel (pair)");
   else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
-                      stream_),
+                      stream_, w2),
         "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;

@@ -132,7 +132,11 @@ class EnsembleCore {
   // "output=0" in a component's section: the output stream leaves its rows out (core.cpp:257-262)
   bool component_output_enabled(const std::string &section) const { return scen_.scalar(section, "output", 1.0) > 0; }
   void set_pair_kernel_limit(int max_members) { pair_max_members_ = max_members < 0 ? 0 : max_members; }
-  const char *last_run_kernel() const { return last_run_pair_ ? "pair" : "run"; }
+  // Ensembles of at least min_members take the one-biome kernel built for two resident
+  // wavefronts per SIMD (hx_run_kernel<HX_B1W2>): < 0 the default -- more wavefronts than the
+  // device has SIMDs --, 0 never
+  void set_two_wave_from(int min_members) { two_wave_from_ = min_members; }
+  const char *last_run_kernel() const { return last_run_pair_ ? "pair" : last_run_w2_ ? "run2" : "run"; }
   double last_spinup_ms() const { return spin_ms_; }
   hipStream_t stream() const { return stream_; }
 
@@ -229,6 +233,9 @@ class EnsembleCore {
   bool run_timed_ = false;
   int pair_max_members_ = 32768;  // ensembles up to this size use the two-wavefront kernel (0: never)
   bool last_run_pair_ = false;
+  int two_wave_from_ = -1;        // see set_two_wave_from()
+  bool last_run_w2_ = false;
+  int simds_ = 1024;              // SIMDs of this core's device (4 per compute unit)
   mutable double run_ms_ = 0, spin_ms_ = 0;
 };
 

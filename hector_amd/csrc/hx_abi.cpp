@@ -324,6 +324,9 @@ int hx_component_output(hx_core *core, const char *component, int *enabled) {
 int hx_set_pair_kernel_limit(hx_core *core, int max_members) {
   HX_TRY(core->core->set_pair_kernel_limit(max_members))
 }
+int hx_set_two_wave_from(hx_core *core, int min_members) {
+  HX_TRY(core->core->set_two_wave_from(min_members))
+}
 int hx_last_run_kernel(hx_core *core, const char **name) { HX_TRY(*name = core->core->last_run_kernel()) }
 
 }  // extern "C"

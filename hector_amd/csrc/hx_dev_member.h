@@ -39,20 +39,39 @@ constexpr int HX_NBIOME_ARR = 9;
 // HX_BDYN), every per-biome loop runs to it, the per-biome arrays are sized for HX_BDYN.  The
 // reference creates any number of biomes (simpleNbox.cpp:864-1124); 1-4 have unrolled kernels.
 constexpr int HX_DYN = 0;
-template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : B; }
+// Template tag of the one-biome kernel built for TWO resident wavefronts per SIMD (hx_run_kernel
+// <HX_B1W2, ...>: at most 256 registers and 20 KB of LDS a wavefront).  Ensembles of more
+// wavefronts than the GPU has SIMDs take it: the second wavefront fills the issue slots that a
+// dependent fp64 chain leaves empty.  Same model code as B = 1; what differs
+// is where a member's values live between their uses:
+//  * the LDS park holds 11 year-level slots and f_frozen; its other 28 slots take what only the
+//    carbonate solve of a stash needs (both boxes' constants, surface-box carbon, [H+], pCO2)
+//    while the dopri5 step loop runs (w2_park_out / w2_park_in): 56 registers;
+//  * constants (DOECLIM matrices, ocean exchange, biome parameters, aerosol scalings, the
+//    alkalinities) are read from the parameter / derived / state tables where they are used, the
+//    block's SSTs from the output array, and nothing is requested a phase ahead (what waits in
+//    registers through the solver is what the second wavefront is there to hide instead).
+constexpr int HX_B1W2 = 101;
+template <int B> constexpr bool hx_w2() { return B == HX_B1W2; }
+// compile-time biome count of the unrolled kernels (0: the looped ones)
+template <int B> constexpr int hx_nbc() { return B == HX_B1W2 ? 1 : B; }
+template <int B> constexpr bool hx_one() { return hx_nbc<B>() == 1; }
+template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : hx_nbc<B>(); }
 // Five to eight biomes have unrolled kernels too (round 3: the looped kernel waits out a memory
 // latency per biome and loop -- 22.8 ms against 10.9 for four biomes at 8 192 members; unrolled,
 // five biomes take 12.1 ms, eight 16.8); like the looped ones they keep the 21 DOECLIM /
 // ocean-exchange constants OUT of the park: 14 + 10 B slots, 32 KB and 37 KB for five and six
 // biomes, 35 KB and 39 KB for seven and eight with two more values per biome left in HBM
 // (hx_slim_park): four wavefronts a CU for all of them.
-template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || B > 4; }
+template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || hx_nbc<B>() > 4 || hx_w2<B>(); }
 // The looped kernels size their park for the core's biome count at launch (dynamic LDS) and do
 // NOT park the 21 DOECLIM / ocean-exchange constants (read from the derived table where they are
 // used: three loads a year against a model year of ~100k cycles): 14 + 10 nb slots -- 33 KB for
 // five biomes, 49 KB for eight -- so that up to four wavefronts share a CU where the fixed
 // 97.5 KB allowed one.
-template <int B> constexpr int pk_ff0() { return hx_lean_park<B>() ? (int)PK_D0 : (int)PK_FFROZEN0; }
+template <int B> constexpr int pk_ff0() {
+  return hx_w2<B>() ? (int)PK_AERO : hx_lean_park<B>() ? (int)PK_D0 : (int)PK_FFROZEN0;
+}
 // Seven and eight biomes: the two per-biome values that are touched least -- f_frozen (read and
 // written once a year; it IS a row of the state table) and f_new_thaw (written once a year, read
 // by the three or so flow computations) -- stay in HBM: 14 + 8 B slots = 35 / 39 KB, four
@@ -60,7 +79,13 @@ template <int B> constexpr int pk_ff0() { return hx_lean_park<B>() ? (int)PK_D0 
 template <int B> constexpr bool hx_slim_park() { return B == 7 || B == 8; }
 template <int B> constexpr int hx_npark_arr() { return hx_slim_park<B>() ? HX_NBIOME_ARR - 1 : HX_NBIOME_ARR; }
 template <int B> constexpr int hx_nff() { return hx_slim_park<B>() ? 0 : hx_bmax<B>(); }  // parked f_frozen slots
+// two-wavefront flavour: what the step loop does not touch waits in these slots (w2_park_out)
+// (27 slots behind f_frozen, and PK_EOS: the two-wavefront flavour reads end_of_spinup_vegc from
+// its state row once a year)
+constexpr int PK_W2_0 = PK_AERO + 1, PK_W2_N = 28;
+constexpr int w2_slot(int i) { return i == PK_W2_N - 1 ? (int)PK_EOS : PK_W2_0 + i; }
 template <int B> constexpr int hx_npark() {
+  if (hx_w2<B>()) return PK_W2_0 + PK_W2_N - 1;   // 40 slots = 20 KB: eight wavefronts a CU
   return pk_ff0<B>() + hx_nff<B>() + (B == 1 ? (int)PKB_N : hx_npark_arr<B>() * hx_bmax<B>());
 }
 __host__ __device__ inline int hx_npark_dyn(int nb) { return PK_D0 + nb + HX_NBIOME_ARR * nb; }
@@ -82,6 +107,7 @@ struct RegArr1 {
 };
 template <int B> struct BiomeArr { using type = ParkArr; };
 template <> struct BiomeArr<1> { using type = RegArr1; };
+template <> struct BiomeArr<HX_B1W2> { using type = RegArr1; };
 // a per-biome array in HBM: element b of this lane at base[b * stride]
 struct GlobArr {
   hx_gd base;
@@ -119,6 +145,7 @@ struct Member {
   hx_gcd par;  // params + mem   (row stride npad)
   hx_gcd der;  // derived + mem
   int npad;
+  unsigned moff;     // two-wavefront flavour: this lane's byte offset within a table row (8 mem)
   double (*pk)[64];  // LDS park
   int lane;
   hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
@@ -132,7 +159,7 @@ struct Member {
 };
 // trip count of the per-biome loops
 template <int B> __device__ __forceinline__ int nbio(const Member<B> &m) {
-  if constexpr (B == HX_DYN) return m.nb; else return B;
+  if constexpr (B == HX_DYN) return m.nb; else return hx_nbc<B>();
 }
 #define PKM(m, slot) ((m).pk[(slot)][(m).lane])
 // f_frozen of biome b: a park slot, or (slim park) the state table's row itself
@@ -146,15 +173,46 @@ template <int B> __device__ __forceinline__ void set_ffrozen(const Member<B> &m,
 }
 // a member's DOECLIM / ocean-exchange constant (row HXD_A0.. / HXD_KLH.. of the derived table):
 // from the park, or -- looped kernels -- from the table itself
+// (two-wavefront flavour) Row offsets row * npad * 8 are scalar products of a launch constant;
+// left alone the optimiser computes all ~40 of them ahead of the year loop and the register
+// allocator then keeps them in the lanes of a spill VGPR (a v_readlane where each is used: a
+// vector-ALU slot).  Passing npad through an empty asm at the head of a region makes the products
+// that region's own: one s_mul_i32 each, on the scalar unit, next to the other wavefront's
+// vector instructions.  (Only where the wavefront's control flow is uniform.)
+#ifndef HX_HOST_EMULATION
+#define HX_W2_LOCAL(m) asm volatile("" : "+s"((m).npad))
+#else
+#define HX_W2_LOCAL(m)
+#endif
+// (two-wavefront flavour) element of row `row` of a [rows][npad] table for this lane: a
+// wave-uniform row address plus the lane's 32-bit byte offset -- the form global_load takes an
+// SGPR base and one VGPR for, no 64-bit vector address arithmetic.  Tables of up to 4 GB.
+// the same for a row whose (wave-uniform, 64-bit) address the caller has: any table size
+__device__ __forceinline__ double hx_ldm(hx_gcd row, unsigned moff) {
+  return *(hx_gcd)((const char HX_GLOBAL *)row + moff);
+}
+__device__ __forceinline__ void hx_stm(hx_gd row, unsigned moff, double v) {
+  *(hx_gd)((char HX_GLOBAL *)row + moff) = v;
+}
+__device__ __forceinline__ double w2_ld(const double *tbl, int npad, int row, unsigned moff) {
+  const char HX_GLOBAL *r = (const char HX_GLOBAL *)HX_GCD(tbl) + (size_t)((unsigned)row * ((unsigned)npad * 8u));
+  return *(hx_gcd)(r + moff);
+}
+__device__ __forceinline__ void w2_st(double *tbl, int npad, int row, unsigned moff, double v) {
+  char HX_GLOBAL *r = (char HX_GLOBAL *)HX_GD(tbl) + (size_t)((unsigned)row * ((unsigned)npad * 8u));
+  *(hx_gd)(r + moff) = v;
+}
 template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, int row) {
-  if constexpr (hx_lean_park<B>()) return m.der[(size_t)row * m.npad];
+  if constexpr (hx_w2<B>()) return w2_ld(m.bufp->derived, m.npad, row, m.moff);
+  else if constexpr (hx_lean_park<B>()) return m.der[(size_t)row * m.npad];
   else return PKM(m, row >= HXD_KLH && row < HXD_KLH + 7 ? PK_K0 + (row - HXD_KLH) : PK_D0 + (row - HXD_A0));
 }
 
 // biome constants of the land model, fetched where they are used
 template <int B>
 struct LandK {
-  double npp0[B], f_nppv[B], f_nppd[B], f_litterd[B], rh_ch4_frac[B], fpf_static[B];
+  static constexpr int N = hx_nbc<B>();
+  double npp0[N], f_nppv[N], f_nppd[N], f_litterd[N], rh_ch4_frac[N], fpf_static[N];
 };
 // looped kernels: a column of the parameter table read where it is used (scalar load from the
 // uniform table when every member shares the biome constants, else the member's row)
@@ -180,6 +238,24 @@ __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
     k.f_nppd = c; k.f_nppd.col = HXPB_F_NPPD; k.f_litterd = c; k.f_litterd.col = HXPB_F_LITTERD;
     k.rh_ch4_frac = c; k.rh_ch4_frac.col = HXPB_RH_CH4_FRAC;
     k.fpf_static = c; k.fpf_static.col = HXPB_FPF_STATIC;
+  } else if constexpr (hx_w2<B>()) {
+    // the biome's constants where they live: scalar loads when every member shares them (the
+    // usual case: ensembles perturb Q10, beta, warming factors), else the member's rows
+    const int r = HXP_NGLOBAL;
+    if (m.upar) {
+      hx_ccd u = m.upar + r;
+      k.npp0[0] = u[HXPB_NPP0]; k.f_nppv[0] = u[HXPB_F_NPPV]; k.f_nppd[0] = u[HXPB_F_NPPD];
+      k.f_litterd[0] = u[HXPB_F_LITTERD]; k.rh_ch4_frac[0] = u[HXPB_RH_CH4_FRAC];
+      k.fpf_static[0] = u[HXPB_FPF_STATIC];
+    } else {
+      const double *p = m.bufp->params;
+      k.npp0[0] = w2_ld(p, m.npad, r + HXPB_NPP0, m.moff);
+      k.f_nppv[0] = w2_ld(p, m.npad, r + HXPB_F_NPPV, m.moff);
+      k.f_nppd[0] = w2_ld(p, m.npad, r + HXPB_F_NPPD, m.moff);
+      k.f_litterd[0] = w2_ld(p, m.npad, r + HXPB_F_LITTERD, m.moff);
+      k.rh_ch4_frac[0] = w2_ld(p, m.npad, r + HXPB_RH_CH4_FRAC, m.moff);
+      k.fpf_static[0] = w2_ld(p, m.npad, r + HXPB_FPF_STATIC, m.moff);
+    }
   } else if constexpr (B == 1) {
     constexpr int o = hx_pkb1<B>();
     k.npp0[0] = PKM(m, o + PKB_NPP0); k.f_nppv[0] = PKM(m, o + PKB_F_NPPV);
@@ -190,7 +266,7 @@ __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
       // every member has the same biome constants (the usual case: ensembles perturb Q10, beta,
       // warming factors): wave-uniform scalar loads instead of 6 B vector loads from HBM
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < hx_nbc<B>(); ++b) {
         hx_ccd r = m.upar + (HXP_NGLOBAL + b * HXPB_N);
         k.npp0[b] = r[HXPB_NPP0]; k.f_nppv[b] = r[HXPB_F_NPPV]; k.f_nppd[b] = r[HXPB_F_NPPD];
         k.f_litterd[b] = r[HXPB_F_LITTERD]; k.rh_ch4_frac[b] = r[HXPB_RH_CH4_FRAC];
@@ -199,7 +275,7 @@ __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
       return;
     }
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < hx_nbc<B>(); ++b) {
       hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
       k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
       k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
@@ -234,11 +310,12 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   m.par = HX_GCD(buf.params) + mem;
   m.der = HX_GCD(buf.derived) + mem;
   m.npad = buf.npad;
+  m.moff = (unsigned)mem * 8u;
   m.pk = park;
   m.lane = lane;
   m.upar = (B != 1 && buf.uni_landk) ? HX_CCD(buf.uparams) : nullptr;
   m.nb = buf.nbiome;
-  if constexpr (B != 1) {
+  if constexpr (!hx_one<B>()) {
     const int bm = (B == HX_DYN) ? buf.nbiome : hx_bmax<B>();   // slots per array
     const int o = pk_ff0<B>() + (hx_slim_park<B>() ? 0 : bm);
     if constexpr (hx_slim_park<B>()) {
@@ -262,8 +339,10 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   }
   m.C0 = ldp(buf, HXP_C0, mem);
   // constants -> park
+  if constexpr (!hx_w2<B>()) {
   PKM(m, PK_AERO) = ldp(buf, HXP_AERO, mem);
   PKM(m, PK_VOL) = ldp(buf, HXP_VOL, mem);
+  }
   if constexpr (!hx_lean_park<B>()) {
 #pragma unroll
     for (int k = 0; k < 14; ++k) PKM(m, PK_D0 + k) = ldd(buf, HXD_A0 + k, mem);
@@ -288,6 +367,39 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
 }
 
 // solver-resident state <-> HBM state table
+// The parked chemistry (HX_B1W2): while the dopri5 step loop runs, what only a stash touches --
+// both surface boxes' carbonate constants, their carbon, [H+] and pCO2 -- waits in LDS.
+template <int B>
+__device__ __forceinline__ void w2_park_out(const Member<B> &m) {
+  const ChemK *k[2] = {&m.kH, &m.kL};
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int o = 11 * b;
+    PKM(m, w2_slot(o + 0)) = k[b]->A2; PKM(m, w2_slot(o + 1)) = k[b]->A1; PKM(m, w2_slot(o + 2)) = k[b]->C4;
+    PKM(m, w2_slot(o + 3)) = k[b]->C3; PKM(m, w2_slot(o + 4)) = k[b]->C2; PKM(m, w2_slot(o + 5)) = k[b]->C1;
+    PKM(m, w2_slot(o + 6)) = k[b]->C0; PKM(m, w2_slot(o + 7)) = k[b]->K1; PKM(m, w2_slot(o + 8)) = k[b]->K1K2;
+    PKM(m, w2_slot(o + 9)) = k[b]->rKh; PKM(m, w2_slot(o + 10)) = k[b]->g;
+  }
+  PKM(m, w2_slot(22)) = m.cHL; PKM(m, w2_slot(23)) = m.cLL; PKM(m, w2_slot(24)) = m.hH;
+  PKM(m, w2_slot(25)) = m.hL; PKM(m, w2_slot(26)) = m.pco2H; PKM(m, w2_slot(27)) = m.pco2L;
+  HX_FENCE();
+}
+template <int B>
+__device__ __forceinline__ void w2_park_in(Member<B> &m) {
+  HX_FENCE();
+  ChemK *k[2] = {&m.kH, &m.kL};
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int o = 11 * b;
+    k[b]->A2 = PKM(m, w2_slot(o + 0)); k[b]->A1 = PKM(m, w2_slot(o + 1)); k[b]->C4 = PKM(m, w2_slot(o + 2));
+    k[b]->C3 = PKM(m, w2_slot(o + 3)); k[b]->C2 = PKM(m, w2_slot(o + 4)); k[b]->C1 = PKM(m, w2_slot(o + 5));
+    k[b]->C0 = PKM(m, w2_slot(o + 6)); k[b]->K1 = PKM(m, w2_slot(o + 7)); k[b]->K1K2 = PKM(m, w2_slot(o + 8));
+    k[b]->rKh = PKM(m, w2_slot(o + 9)); k[b]->g = PKM(m, w2_slot(o + 10));
+  }
+  m.cHL = PKM(m, w2_slot(22)); m.cLL = PKM(m, w2_slot(23)); m.hH = PKM(m, w2_slot(24));
+  m.hL = PKM(m, w2_slot(25)); m.pco2H = PKM(m, w2_slot(26)); m.pco2L = PKM(m, w2_slot(27));
+}
+
 template <int B>
 __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member<B> &m) {
   m.cHL = lds_(buf, HXS_C_HL, mem); m.cLL = lds_(buf, HXS_C_LL, mem);
@@ -300,7 +412,9 @@ __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member
   m.ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
   m.lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
   m.sdt = lds_(buf, HXS_SOLVER_DT, mem);
-  m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem);
+  // (two-wavefront flavour: the alkalinities never change during a run and only the year start
+  // needs them: read from their rows there instead of held in registers through the year)
+  if constexpr (!hx_w2<B>()) { m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem); }
   m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
 #pragma unroll
   for (int b = 0; b < nbio<B>(m); ++b) {
@@ -329,7 +443,14 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf_, int mem,
   sts_(buf, HXS_TS_TIMEOUT, mem, (double)m.ts_timeout);
   sts_(buf, HXS_LASTFLUX_ANN, mem, m.lastflux_ann);
   sts_(buf, HXS_SOLVER_DT, mem, m.sdt);
+  if constexpr (hx_w2<B>()) {   // (not held in registers: the live rows are the values)
+    if (base) {
+      sts_(buf, HXS_ALK_HL, mem, lds_(buf_, HXS_ALK_HL, mem));
+      sts_(buf, HXS_ALK_LL, mem, lds_(buf_, HXS_ALK_LL, mem));
+    }
+  } else {
   sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
+  }
   sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
 #pragma unroll
   for (int b = 0; b < nbio<B>(m); ++b) {
@@ -354,7 +475,11 @@ __device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
   sts_(buf, HXS_F_PREV, mem, PKM(m, PK_F_PREV));
   sts_(buf, HXS_BASE_TOT, mem, PKM(m, PK_BASE_TOT));
   sts_(buf, HXS_BASE_CO2, mem, PKM(m, PK_BASE_CO2));
+  if constexpr (hx_w2<B>()) {  // (PK_EOS is a parking slot there; the live row is the value)
+    if (base) sts_(buf, HXS_EOS_VEGC, mem, lds_(buf_, HXS_EOS_VEGC, mem));
+  } else {
   if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
+  }
   if (hx_slim_park<B>() && !base) return;  // (the live table's rows are where f_frozen lives)
 #pragma unroll
   for (int b = 0; b < nbio<B>(m); ++b)

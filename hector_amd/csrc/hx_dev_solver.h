@@ -349,10 +349,10 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const double wt = (B == 1) ? 1.0
+    const double wt = hx_one<B>() ? 1.0
         : hx_div_cr(m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b)),
                     npp_rh, inv_nr);
-    const double wt_pf = (B == 1) ? ((pf_t > 0) ? 1.0 : 0.0) : hx_div_cr(m.pf[b], pf_t, inv_pf);
+    const double wt_pf = hx_one<B>() ? ((pf_t > 0) ? 1.0 : 0.0) : hx_div_cr(m.pf[b], pf_t, inv_pf);
     if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
       const double a = m_rh_fda(m, b) * rh_adj, bb = m_rh_fsa(m, b) * rh_adj;
       const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
@@ -517,6 +517,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 
   Interval K, K2s;
   Interval &K2 = CON ? K2s : K;
+  if constexpr (hx_w2<B>()) HX_W2_LOCAL(m);
   {
     LandK<B> lk;
     load_landk<B>(m, lk);
@@ -525,7 +526,16 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   HX_STAMP(m, 5);   // interval constants of the year's first segment
   // getCValues  simpleNbox-runtime.cpp:247-258
   double y[NP], l4, l5, l7;
-  auto load_pools = [&]() {
+  auto load_pools = [&](bool in_loop) {
+    if constexpr (hx_w2<B>()) {
+      // inside the step loop (a retry) the surface boxes' carbon is in its parking slots
+      if (in_loop) {
+        y[0] = m.atmos; y[1] = m.veg[0]; y[2] = m.det[0]; y[3] = m.soil[0];
+        y[4] = m.cDO + m.cIO + PKM(m, w2_slot(23)) + PKM(m, w2_slot(22));
+        l4 = m.pf[0]; l5 = m.thawed[0]; l7 = m.earth;
+        return;
+      }
+    }
     double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll
     for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
@@ -534,7 +544,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     l4 = p; l5 = th; l7 = m.earth;
     if constexpr (CON) y[5] = th;
   };
-  load_pools();
+  load_pools(false);
   m.ode_start = t0;
   double t = t0;   // time reached by accepted steps
   int retry = 0;
@@ -554,6 +564,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt);
     int fails = 0;
     bool stepping = seg;
+    if constexpr (hx_w2<B>()) w2_park_out<B>(m);
     // One pass = one dopri5 attempt of every stepping lane.  The attempt itself is straight-line
     // code that ALL lanes execute (a lane that has reached its target computes on stale values
     // and discards the result: ~2 % of the lanes, against the predication and register shuffling
@@ -582,7 +593,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
           need = stepping && ((t + dtl) - m.ode_start) > m.max_ts;
         }
-        if (reload) { load_pools(); rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); }
+        if (reload) { load_pools(true); rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); }
       }
       double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
       // the land-use loss rates of the attempt's stage times (see rhs): five independent
@@ -667,6 +678,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       }
       HX_STAMP(m, 6);   // dopri5 attempts (+ retries)
     }
+    if constexpr (hx_w2<B>()) w2_park_in<B>(m);
     HX_STAMP(m, 10);
     HX_COUNT(m, 17);    // segments
     if (seg && alive) {

@@ -215,6 +215,7 @@ int Fleet::spinup_record(int member, double *values, int max_steps) {
   return s.core->spinup_record(member - s.offset, values, max_steps);
 }
 void Fleet::set_pair_kernel_limit(int m) { HX_EACH(set_pair_kernel_limit(m)) }
+void Fleet::set_two_wave_from(int m) { HX_EACH(set_two_wave_from(m)) }   // (members of a shard)
 void Fleet::setvar_dated(const std::string &cap, const int *years, const double *values, int n,
                          const char *units) {
   HX_EACH(setvar_dated(cap, years, values, n, units))

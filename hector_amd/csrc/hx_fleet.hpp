@@ -91,6 +91,7 @@ class Fleet {
   double last_spinup_ms();
   hipStream_t stream(int shard_index = 0) const { return shards_[(size_t)shard_index].core->stream(); }
   void set_pair_kernel_limit(int max_members);
+  void set_two_wave_from(int min_members);
 
   // ---- the collective -----------------------------------------------------------------------
   // Join a communicator of n_procs * n_shards() ranks; this process's shards are ranks

@@ -44,6 +44,14 @@
 #define HX_DBLK 32  // DOECLIM block length = years per run-kernel launch
 #define HX_KPAD 32  // zero entries in front of the Ker table (the host pads 64 behind it)
 
+// hx_run_kernel<HX_B1W2, ...> is compiled for two resident wavefronts per SIMD (hx_dev_member.h);
+// every other instantiation keeps the compiler's default bounds
+#ifndef HX_HOST_EMULATION
+#define HX_WAVES_PER_SIMD(B) __attribute__((amdgpu_waves_per_eu(hx_w2<B>() ? 2 : 1, hx_w2<B>() ? 2 : 8)))
+#else
+#define HX_WAVES_PER_SIMD(B)
+#endif
+
 #include "hx_dev_const.h"
 #include "hx_dev_clock.h"
 #include "hx_dev_math.h"
@@ -210,7 +218,9 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
 // (Inlined: as a real call like doeclim_pass_dev it is as fast, but hx_run_kernel<2,0,0,0> built
 // with ROCm 7.2's compiler then faults on the device -- one instantiation of 32, found by the
 // test suite; nothing in the source distinguishes it.)
-template <bool HF>
+// ACCV: the accumulators in VGPRs ("v" pin) -- the two-wavefront flavour: a kernel that names
+// AGPRs gets its 256 registers split 128 + 128 by the compiler, one that does not gets 256 VGPRs.
+template <bool HF, bool ACCV = false>
 __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
                                                             const double *ker, double *part,
                                                             double *part2, int ns, int npad,
@@ -218,6 +228,11 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
   // (hist_end: history years i < hist_end enter the sums; the run kernel passes blk0, the
   // small-ensemble kernel blk0 - 1 and adds the last year itself)
   typedef double d4 __attribute__((ext_vector_type(4)));
+#ifndef HX_HOST_EMULATION
+  // (two-wavefront flavour: the lane's part of the addresses below is computed HERE, not ahead of
+  // the year loop where the optimiser would hoist it and keep six more registers live for good)
+  if constexpr (ACCV) asm volatile("" : "+v"(mem));
+#endif
   const int lane = mem & 63, q = lane >> 4, c = lane & 15;
   const size_t np = (size_t)npad;
   hx_gcd hist = HX_GCD(sst_hist) + (mem - lane) + c;  // member 16 g + c of this wavefront
@@ -261,7 +276,11 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
   // 1024 cycles of matrix pipe).  Without it the code was only correct for instruction orders
   // that happened to keep an accumulator's reuse 7 MFMAs apart.
   auto pin = [&]() {
-    if constexpr (HF)
+    if constexpr (ACCV && !HF)
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+                   : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                     "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
+    else if constexpr (HF)
       asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
                    : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]),
                      "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]),
@@ -458,9 +477,10 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // CON = 2: ... with carbon tracking inside the stash (hx_dev_track.h); CON = 3 (one biome): ...
 // with carbon tracking on two companion wavefronts -- 192 threads a block, waves 1 and 2 only track.
 template <int B, bool HF, bool KERPM, int CON>
-__global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 : B)>()) : 64) void hx_run_kernel(const HxArgs *__restrict__ args,
-                                                                     int iy_from, int iy_to) {
+__global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 : B)>()) : 64) HX_WAVES_PER_SIMD(B)
+void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   static_assert(CON != 3 || (B >= 1 && B <= 4), "tracking companions: the unrolled kernels");
+  static_assert(!hx_w2<B>() || CON == 0, "two-wavefront flavour: the plain kernel");
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
   // (multi-biome kernels need that LDS for the per-biome arrays and re-read the block's SSTs
   // from the output array instead)
@@ -488,6 +508,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
   __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
   double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
+  if constexpr (CON || hx_w2<B>()) m.bufp = &args->buf;
   bind_member<B>(args->buf, mem, m, s_park, lane);
 #ifdef HX_PHASE_CLOCK
   for (int k = 0; k < HX_NCLK; ++k) hx_s_clk[k] = 0;
@@ -497,7 +518,8 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
   {  // year-level state -> park
     const HxBuffers &buf = args->buf;
     PKM(m, PK_CH4) = lds_(buf, HXS_CH4, mem); PKM(m, PK_SST) = lds_(buf, HXS_SST, mem);
-    PKM(m, PK_EOS) = lds_(buf, HXS_EOS_VEGC, mem); PKM(m, PK_TLAND) = lds_(buf, HXS_TLAND, mem);
+    if constexpr (!hx_w2<B>()) PKM(m, PK_EOS) = lds_(buf, HXS_EOS_VEGC, mem);
+    PKM(m, PK_TLAND) = lds_(buf, HXS_TLAND, mem);
     PKM(m, PK_TWIN) = lds_(buf, HXS_TWIN, mem); PKM(m, PK_TL_M1) = lds_(buf, HXS_TL_M1, mem);
     PKM(m, PK_TL_M2) = lds_(buf, HXS_TL_M2, mem); PKM(m, PK_F_PREV) = lds_(buf, HXS_F_PREV, mem);
     PKM(m, PK_BASE_TOT) = lds_(buf, HXS_BASE_TOT, mem);
@@ -516,7 +538,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
   // and the block's history partial sum -- and with one wavefront on the SIMD a load's latency is
   // waited out in full: they are requested a phase ahead, before the solver (pf_*).
   double pf_tl_old = 0.0, pf_dpart = 0.0;
-  {
+  if constexpr (!hx_w2<B>()) {
     const int iold0 = iy_from + 1 - 203;
     pf_tl_old = HX_GCD(args->buf.out[HXO_TLAND])[(size_t)(iold0 >= 1 ? iold0 : 0) * args->buf.npad + mem];
   }
@@ -530,8 +552,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
     ya[4] = shn[HXSH_CH4N]; ya[5] = shn[HXSH_O3_NOX]; ya[6] = shn[HXSH_O3_CO]; ya[7] = shn[HXSH_O3_NMVOC];
     ya[8] = shn[HXSH_FFI]; ya[9] = shn[HXSH_DACCS]; ya[10] = shn[HXSH_LUC_E]; ya[11] = shn[HXSH_LUC_U];
   };
-  load_year_a(iy_from + 1);
-  if constexpr (CON) m.bufp = &args->buf;
+  if constexpr (!hx_w2<B>()) load_year_a(iy_from + 1);
   if constexpr (CON >= 2) m.trk_iy = args->kc.trk_iy;
   if constexpr (CON == 3) { m.trk_rec = s_trk_rec; m.trk_cmd = s_trk_cmd; }
   int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
@@ -553,7 +574,15 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
       }
       const double prev_ch4 = PKM(m, PK_CH4);
       double sst = PKM(m, PK_SST);
-      const double eos = PKM(m, PK_EOS);
+      double eos;
+      if constexpr (hx_w2<B>()) {   // values that live in the tables (hx_dev_member.h)
+        HX_W2_LOCAL(m);
+        eos = w2_ld(buf.state, m.npad, HXS_EOS_VEGC, m.moff);
+        m.alkH = w2_ld(buf.state, m.npad, HXS_ALK_HL, m.moff);
+        m.alkL = w2_ld(buf.state, m.npad, HXS_ALK_LL, m.moff);
+      } else {
+        eos = PKM(m, PK_EOS);
+      }
       double tland = PKM(m, PK_TLAND);
       if constexpr (CON) {
         // land-ocean warming ratio: the carbon cycle and the ocean see temperatures derived
@@ -569,16 +598,36 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
       double twin = PKM(m, PK_TWIN);
       const double tl_m2 = PKM(m, PK_TL_M2);
       const int iold = iy - 203;
+      if constexpr (hx_w2<B>()) {
+        // (two resident wavefronts hide a load's latency: nothing is requested a phase ahead, so
+        // nothing waits in registers through the solver)
+        load_year_a(iy);
+        pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold >= 1 ? iold : 0) * buf.npad, m.moff);
+      }
       const double tl_old = pf_tl_old;
-      constexpr int SB = (B == HX_DYN) ? 1 : B;  // (the looped kernels read these where they use them)
+      constexpr int NB = hx_nbc<B>();
+      constexpr int SB = (B == HX_DYN) ? 1 : NB;  // (the looped kernels read these where they use them)
       double p_beta[SB], p_wf[SB], p_lnq10[SB], p_mu[SB], p_sigma[SB], s_ffrozen[SB];
       LandK<B> lk;
       if constexpr (B == HX_DYN) load_landk<B>(m, lk);
       if constexpr (B != HX_DYN) {
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < NB; ++b) {
         s_ffrozen[b] = ffrozen_of<B>(m, b);
-        if constexpr (B == 1) {
+        if constexpr (hx_w2<B>()) {
+          const int pr = HXP_NGLOBAL;
+          p_wf[b] = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
+          if (buf.uni_bio) {
+            hx_ccd u = HX_CCD(buf.uparams) + pr;
+            p_beta[b] = u[HXPB_BETA]; p_mu[b] = u[HXPB_PF_MU]; p_sigma[b] = u[HXPB_PF_SIGMA];
+          } else {
+            p_beta[b] = w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff);
+            p_mu[b] = w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
+            p_sigma[b] = w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
+          }
+          p_lnq10[b] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL, m.moff);
+          load_landk<B>(m, lk);
+        } else if constexpr (B == 1) {
           constexpr int o = hx_pkb1<B>();
           p_beta[b] = PKM(m, o + PKB_BETA); p_wf[b] = PKM(m, o + PKB_WF);
           p_mu[b] = PKM(m, o + PKB_MU); p_sigma[b] = PKM(m, o + PKB_SIGMA);
@@ -629,15 +678,15 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
       // exponent, the biomes' temperatures
       const double TcH = sst + 18 + (-16.4), TcL = sst + 18 + 2.9;
       double Tb[SB];
-      double lg[2 + B];
+      double lg[2 + NB];
       lg[0] = TcH + 273.15; lg[1] = TcL + 273.15;
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < NB; ++b) {
         Tb[b] = tland * p_wf[b];
         lg[2 + b] = (Tb[b] > 0) ? Tb[b] : 1.0;  // ln(Tb) of the permafrost curve, if Tb > 0
       }
-      hx_log_batch<2 + B>(lg, kc.mtab);
-      double ex[13 + 2 * B];
+      hx_log_batch<2 + NB>(lg, kc.mtab);
+      double ex[13 + 2 * NB];
       // (literals here: as data -- HxConst::ctab, -DHX_CHEM_TABLE -- the 39 constants arrive in
       // one sweep of scalar loads, 78 SGPRs at once, and 73 of the kernel's SGPRs spill)
 #ifdef HX_CHEM_TABLE
@@ -649,12 +698,12 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
 #endif
       ex[12] = -toh;
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < NB; ++b) {
         const double Trm = (iy > 1) ? (twin * p_wf[b]) * 0.005 : 0.0;
         ex[13 + 2 * b] = p_lnq10[b] * (Tb[b] * 0.1);
         ex[14 + 2 * b] = p_lnq10[b] * (Trm * 0.1);
       }
-      hx_exp_chunks<13 + 2 * B>(ex, kc.mtab);
+      hx_exp_chunks<13 + 2 * NB>(ex, kc.mtab);
       const double tau_oh = kc.TOH0 * ex[12];
       if constexpr (CON) {
       if (buf.out[HXO_TAU_OH]) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
@@ -739,7 +788,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
         }
       }
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
+      for (int b = 0; b < NB; ++b) {
         m.co2fert[b] = 1 + p_beta[b] * lnc;
         m.tempfertd[b] = ex[13 + 2 * b];  // exp(ln q10 * Tb / 10)
         m.f_new_thaw[b] = 0.0;
@@ -761,7 +810,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
     HX_STAMP(m, 4);     // slow parameters
     // ======================= phase B: carbon-cycle solver ====================
     {
-      {  // next year's window entry, this year's history partial sum (see pf_* above)
+      if constexpr (!hx_w2<B>()) {  // next year's window entry, this year's history partial sum (see pf_* above)
         const HxBuffers &buf = args->buf;
         const int iold1 = iy + 1 - 203;
         pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
@@ -806,7 +855,7 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
         blk0 = iy;
 #if HX_HAS_MFMA
         if constexpr (!KERPM)
-          doeclim_pass_mfma<HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+          doeclim_pass_mfma<HF, hx_w2<B>()>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                 const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem, blk0);
         else
 #endif
@@ -816,12 +865,26 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
         pf_dpart = HX_GCD(buf.dpart)[mem];
         HX_STAMP(m, 11);  // DOECLIM history pass (once per HX_DBLK years)
       }
+      constexpr bool TALL = hx_w2<B>();
+      if constexpr (hx_w2<B>()) {  // what the other kernels request ahead of the solver
+        pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(iy - blk0) * buf.npad, m.moff);
+        yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
+        ch4 = PKM(m, PK_CH4);
+        o3 = ((5 * PKM(m, PK_LN_CH4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
+      }
       // every HBM value this phase needs, issued back to back
       const double tland = PKM(m, PK_TLAND), sst = PKM(m, PK_SST);
       const double f_prev = PKM(m, PK_F_PREV);
       const double base_tot = PKM(m, PK_BASE_TOT), base_co2 = PKM(m, PK_BASE_CO2);
       const double tl_m1 = PKM(m, PK_TL_M1);
-      const double p_aero = PKM(m, PK_AERO), p_vol = PKM(m, PK_VOL);
+      double p_aero, p_vol;
+      if constexpr (hx_w2<B>()) {
+        HX_W2_LOCAL(m);
+        p_aero = w2_ld(buf.params, m.npad, HXP_AERO, m.moff); p_vol = w2_ld(buf.params, m.npad, HXP_VOL, m.moff);
+        m.C0 = w2_ld(buf.params, m.npad, HXP_C0, m.moff);
+      } else {
+        p_aero = PKM(m, PK_AERO); p_vol = PKM(m, PK_VOL);
+      }
 #define HXDK(row) dconst<B>(m, (row))
       const double dA0 = HXDK(HXD_A0), dA1 = HXDK(HXD_A1), dA2 = HXDK(HXD_A2), dA3 = HXDK(HXD_A3),
                    dIB0 = HXDK(HXD_IB0), dIB1 = HXDK(HXD_IB1), dIB2 = HXDK(HXD_IB2),
@@ -898,6 +961,37 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
         // latency per chunk instead of per entry); entries from this year on enter as 0 * Ker,
         // which leaves the sums bit for bit what the entry-by-entry loop gives
         const int nchunk = (jb + 7) >> 3;
+        if constexpr (TALL) {
+          // Kernels without the LDS tile read the block's SSTs back from the output array: the
+          // two-wavefront flavour requests the whole block at once (chunk after chunk each would
+          // wait out its own trip to L2 / HBM); rows from this year on hold stale values of an
+          // earlier run and enter as 0 * Ker, like the tail of a chunk.
+          double Tall[HX_DBLK];
+          hx_gcd srow = HX_GCD(buf.out[HXO_SST]) + (size_t)blk0 * buf.npad;   // (wave-uniform)
+#pragma unroll
+          for (int r = 0; r < HX_DBLK; ++r) {
+            const int i = blk0 + r;
+            Tall[r] = hx_ldm(srow + (size_t)((i < ns ? i : ns - 1) - blk0) * buf.npad, m.moff);
+          }
+#pragma unroll
+          for (int c = 0; c < HX_DBLK / 8; ++c) {
+            if (c < nchunk) {
+              const int i0 = blk0 + 8 * c;
+              double K[8], K2[8];
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                K[r] = ldk(kq + i0 + r);
+                K2[r] = want_hf ? ldk(kq + i0 + r + 1) : 0.0;
+              }
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const double t = (i0 + r < iy) ? Tall[8 * c + r] : 0.0;
+                dpast += t * K[r];
+                if (want_hf) hint += t * K2[r];
+              }
+            }
+          }
+        } else
         for (int c = 0; c < nchunk; ++c) {
           const int i0 = blk0 + 8 * c;
           double T[8], K[8], K2[8];
@@ -966,11 +1060,19 @@ __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 
       PKM(m, PK_SST) = sst_new;
       // ---- outputs ----
       const size_t o = (size_t)iy * buf.npad + mem;
+      if constexpr (hx_w2<B>()) {  // (wave-uniform row address + the lane's 32-bit offset)
+        const size_t orow = (size_t)iy * buf.npad;
+        hx_stm(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
+        hx_stm(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
+        if (buf.out[HXO_CO2]) hx_stm(HX_GD(buf.out[HXO_CO2]) + orow, m.moff, co2c);
+        if (buf.out[HXO_TGAV]) hx_stm(HX_GD(buf.out[HXO_TGAV]) + orow, m.moff, tgav);
+      } else {
       sto_(buf, HXO_SST, o, sst_new);
       sto_(buf, HXO_TLAND, o, tl_rep);
       if constexpr (CON) { if (buf.out[HXO_SST_LO]) sto_(buf, HXO_SST_LO, o, sst_rep); }
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
+      }
       if (buf.out_rare) {  // (one test instead of ~25 pointer loads and branches a year)
       if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);
       if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);
@@ -1464,6 +1566,11 @@ static int hx_looped_from() {   // (read at every launch: a test switches it bet
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
                             hipStream_t st) {
   const int blocks = (nmem_launch + 63) / 64;
+#ifdef HX_W2_ONLY
+  if (B != 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, d_args, d_steps);
+  return hipGetLastError();
+#else
   switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
     case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
 #ifndef HX_MINIMAL_BUILD
@@ -1484,6 +1591,7 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
       }
   }
   return hipGetLastError();
+#endif
 }
 
 hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) {
@@ -1502,7 +1610,7 @@ hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) 
 #endif
 template <int B>
 static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st, int nb = B) {
+                         int iy_from, int iy_to, hipStream_t st, int nb = B, bool two_wave = false) {
   const int blocks = npad / 64;
   const size_t lds = (B == HX_DYN) ? hx_dyn_lds_bytes(nb) : 0;
   if constexpr (B == HX_DYN) {
@@ -1519,6 +1627,13 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
                           static_cast<const void *>(nullptr)})
       if (k)
       hx_allow_dynamic_lds(k, lds);
+  }
+  if constexpr (B == 1) {
+    // the flavour built for two resident wavefronts per SIMD (EnsembleCore::run decides)
+    if (two_wave && !con && !hf && !kpm) {
+      hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
   }
 #ifdef HX_MINIMAL_BUILD  // experiment builds (tools/prof): the plain kernel only
   (void)hf; (void)kpm; (void)con;
@@ -1537,6 +1652,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   return;
 #endif
+#ifndef HX_W2_ONLY   // (HX_W2_ONLY, with HX_MINIMAL_BUILD: nothing but the plain one-biome kernels)
 #ifndef HX_HOST_EMULATION   // (the host build runs a block's threads one after the other)
   if constexpr (B >= 1 && B <= HX_TRK_COMPANION_MAXB) {  // the maps live on companion wavefronts
     static const bool inline_maps = getenv("HECTOR_AMD_TRACK_INLINE") != nullptr;
@@ -1576,16 +1692,20 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     hipLaunchKernelGGL((hx_run_kernel<B, false, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else
     hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+#endif
 }
-#if HX_HAS_MFMA
+#if HX_HAS_MFMA && !defined(HX_W2_ONLY)
+#define HX_HAS_PAIR 1
 #include "hx_dev_pair.h"
+#else
+#define HX_HAS_PAIR 0
 #endif
 // the small-ensemble kernel (two wavefronts per 64 members, hx_dev_pair.h): one biome, no
 // constraints, the outputs listed in EnsembleCore::run; kpm: per-member DOECLIM kernel tables
-int hx_pair_available() { return HX_HAS_MFMA; }
+int hx_pair_available() { return HX_HAS_PAIR; }
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
                               int iy_to, hipStream_t st) {
-#if HX_HAS_MFMA
+#if HX_HAS_PAIR
   const dim3 g(npad / 64), b(128);
   if (kpm && heatflux) hipLaunchKernelGGL((hx_pair_kernel<true, true>), g, b, 0, st, d_args, iy_from, iy_to);
   else if (kpm) hipLaunchKernelGGL((hx_pair_kernel<true, false>), g, b, 0, st, d_args, iy_from, iy_to);
@@ -1598,9 +1718,14 @@ hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, boo
 #endif
 }
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st) {
+                         int iy_from, int iy_to, hipStream_t st, bool two_wave) {
+#ifdef HX_W2_ONLY
+  if (B != 1) return hipErrorInvalidValue;
+  launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave);
+  return hipGetLastError();
+#else
   switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
-    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave); break;
 #ifndef HX_MINIMAL_BUILD
     case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
     case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
@@ -1621,6 +1746,7 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
       launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B);
   }
   return hipGetLastError();
+#endif
 }
 
 int hx_doeclim_block_years() { return HX_DBLK; }

@@ -294,6 +294,16 @@ int hx_stream_shard(hx_core *core, int shard, void **stream);
  * per two SIMDs; 0 = never; the environment variable HECTOR_AMD_PAIR_MAX_MEMBERS sets the default of
  * new cores).  hx_last_run_kernel: "run" or "pair", whichever the last hx_run took. */
 int hx_set_pair_kernel_limit(hx_core *core, int max_members);
+/* Large ensembles -- more wavefronts of 64 members than the GPU has SIMDs (65 536 members on an
+ * MI355X), e.g. BASELINE configs[3]'s 131 072 members per GPU -- are run by a flavour of the
+ * one-biome kernel compiled for TWO resident wavefronts per SIMD (at most 256 registers and 20 KB
+ * of LDS a wavefront; hx_dev_member.h, HX_B1W2): the second wavefront issues into the slots a
+ * dependent fp64 chain of the first leaves empty.  Same model code, same decisions; it serves what
+ * the plain kernel serves (one biome, shared diffusivity, no constraints / heat-flux outputs).
+ * hx_set_two_wave_from: ensembles of at least min_members members use it (< 0: the default, one
+ * more wavefront than the device has SIMDs; 0: never; the environment variable
+ * HECTOR_AMD_TWO_WAVE_FROM sets the default of new cores).  hx_last_run_kernel then says "run2". */
+int hx_set_two_wave_from(hx_core *core, int min_members);
 
 /* Core::outputEnabled (src/core.cpp:257-262, 688-695): 0 if the scenario's section of that component
  * says output=0 -- the output stream visitor then leaves the component's rows out

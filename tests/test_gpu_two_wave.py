@@ -1,0 +1,146 @@
+"""The two-wavefronts-per-SIMD flavour of the one-biome run kernel (hx_run_kernel<HX_B1W2>,
+hector_amd/csrc/hx_dev_member.h) on the MI355X.
+
+Ensembles of more wavefronts than the GPU has SIMDs take it by default (`hx_set_two_wave_from`);
+the tests force it on smaller ones too.  Same criterion as the other parity tests: the HIP path
+against the CPU oracle, tolerance 2e-8 (north star 1e-6), identical stash schedules; against the
+plain kernel the decisions must be identical and the trajectories agree to rounding (the two are
+separate instantiations whose multiply-add pairs the compiler contracts independently)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hector_amd
+from hector_amd import ensemble
+from conftest import ROOT, SCENARIO
+
+pytestmark = pytest.mark.gpu
+
+REL_CO2 = 2e-8
+ABS_T = 2e-8
+OUTS = ["CO2_concentration", "global_tas", "timesteps", "solver_steps", "RF_tot", "atmos_co2",
+        "ocean_c", "veg_c", "detritus_c", "soil_c", "permafrost_c", "thawedp_c", "earth_c", "NBP",
+        "ocean_uptake", "HL_pH", "LL_pH", "CH4_concentration", "O3_concentration", "sst", "land_tas"]
+
+
+def _core(hip_lib, n, two_wave, outs=OUTS):
+    S, q10 = ensemble.ecs_q10(n)
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    assert c.backend == "hip"
+    c.set_pair_kernel_limit(0)
+    c.set_two_wave_from(1 if two_wave else 0)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    c.set_outputs(outs)
+    return c, S, q10
+
+
+def test_two_wave_kernel_vs_plain_kernel_and_oracle(hip_lib, oracle):
+    n = 4096
+    a, S, q10 = _core(hip_lib, n, True)
+    b, _, _ = _core(hip_lib, n, False)
+    a.run(2300); b.run(2300)
+    assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run"
+    assert (a.status() == 0).all() and (b.status() == 0).all()
+    worst = {}
+    for v in OUTS:
+        x, y = a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))
+        if v in ("timesteps", "solver_steps"):
+            assert np.array_equal(x, y), v     # the same decisions, member by member
+            continue
+        scale = np.maximum(np.abs(y), 1.0)
+        worst[v] = float((np.abs(x - y) / scale).max())
+        assert worst[v] < 1e-9, (v, worst[v])
+    print("two-wave against plain kernel, worst scaled differences:", json.dumps(worst))
+    # ... and against the oracle, a sample of the members
+    idx = np.arange(0, n, 32)
+    oco2, otg, err = oracle.run_ecs_q10(S[idx], q10[idx])
+    assert err == 0
+    co2 = a.fetchvars("CO2_concentration", (1745, 2300))[:, idx].T
+    tg = a.fetchvars("global_tas", (1745, 2300))[:, idx].T
+    assert (np.abs(co2 - oco2) / oco2).max() < REL_CO2
+    assert np.abs(tg - otg).max() < ABS_T
+    a.shutdown(); b.shutdown()
+
+
+def test_two_wave_kernel_in_pieces_equals_one_launch(hip_lib):
+    n = 1024
+    a, _, _ = _core(hip_lib, n, True, ["CO2_concentration", "global_tas", "timesteps"])
+    b, _, _ = _core(hip_lib, n, True, ["CO2_concentration", "global_tas", "timesteps"])
+    a.run(2300)
+    for y in (1760, 1761, 1850, 1999, 2100, 2300):   # block starts move with the launches
+        b.run(y)
+    assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run2"
+    for v in ("CO2_concentration", "global_tas", "timesteps"):
+        assert np.array_equal(a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))), v
+    # reset(startDate) + run reproduces the run
+    ref = a.fetchvars("CO2_concentration", (1745, 2300))
+    a.reset(1745); a.run(2300)
+    assert np.array_equal(ref, a.fetchvars("CO2_concentration", (1745, 2300)))
+    a.shutdown(); b.shutdown()
+
+
+def test_two_wave_kernel_with_state_history_and_kernel_changes(hip_lib):
+    """reset(date) from the state history the two-wave kernel writes, and a run that changes
+    kernels between launches (the state table is the interface)."""
+    n = 512
+    outs = ["CO2_concentration", "global_tas"]
+    a, _, _ = _core(hip_lib, n, True, outs)
+    a.enable_history()
+    a.run(2300)
+    ref = {v: a.fetchvars(v, (1745, 2300)) for v in outs}
+    a.reset(1900); a.run(2300)
+    for v in outs:
+        assert np.array_equal(ref[v], a.fetchvars(v, (1745, 2300))), v
+    # plain kernel to 1900, two-wave kernel from there: agrees with the plain kernel throughout
+    b, _, _ = _core(hip_lib, n, False, outs)
+    b.run(1900)
+    assert b.last_run_kernel() == "run"
+    b.set_two_wave_from(1)
+    b.run(2300)
+    assert b.last_run_kernel() == "run2"
+    c, _, _ = _core(hip_lib, n, False, outs)
+    c.run(2300)
+    for v in outs:
+        x, y = b.fetchvars(v, (1745, 2300)), c.fetchvars(v, (1745, 2300))
+        assert (np.abs(x - y) / np.maximum(np.abs(y), 1.0)).max() < 1e-9, v
+    a.shutdown(); b.shutdown(); c.shutdown()
+
+
+def test_two_wave_kernel_is_the_default_beyond_one_wavefront_per_simd(hip_lib):
+    n = 65536 + 64
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    S, q10 = ensemble.ecs_q10(n)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    c.set_outputs(["CO2_concentration"])
+    c.run(1760)
+    assert c.last_run_kernel() == "run2"
+    c.shutdown()
+    c = hector_amd.Core(SCENARIO, 65536, device=0, lib_path=hip_lib)
+    c.set_outputs(["CO2_concentration"])
+    c.run(1760)
+    assert c.last_run_kernel() == "run"
+    c.shutdown()
+
+
+def test_config4_share_of_one_gpu_every_member_vs_oracle(hip_lib, oracle):
+    """131 072 members -- what one GPU holds of BASELINE configs[3]'s 1 048 576 over eight -- on the
+    two-wave kernel, EVERY member against the oracle."""
+    from test_gpu_fullsize import _compare
+    n = 131072
+    S, q10 = ensemble.ecs_q10(n)
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    c.set_outputs(["CO2_concentration", "global_tas", "timesteps"])
+    c.run(2300)
+    assert c.last_run_kernel() == "run2"
+    assert (c.status() == 0).all()
+
+    def mp(i):
+        p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        return p
+    _compare("config4_share_131072x1_two_wave", c, oracle, mp, np.arange(n), n,
+             {"ensemble": "S ~ U(1.5, 6), q10_rh ~ U(1, 3), seed 20260928 (hector_amd/ensemble.py)",
+              "kernel": c.last_run_kernel()})
+    c.shutdown()
