@@ -20,8 +20,14 @@ resident in HBM before the timed region; spinup and upload are excluded, as
 SURVEY.md 8(d) defines the metric.  Weak scaling: per-GPU members fixed.
 
 N = 1 workload: BASELINE.json configs[2] -- 65 536-member perturbed ECS/Q10
-ensemble on one MI355X (the 1 048 576-member / 8-GPU configs[3] is the same
-kernel at 131 072 members per GPU: pass --members 131072).
+ensemble on one MI355X.  N > 1 workload: BASELINE.json configs[3]'s shape -- 131 072 members
+on every GPU, the named 1 048 576 members at N = 8 -- as the line's `value`, and
+configs[2]-per-GPU (65 536 members on every GPU: the N = 1 workload, weak-scaled) timed after it
+in the same job as `other_configs[0]`.  (--members M: M per GPU at any N, nothing else.)
+A multi-GPU line is only valid if every member of the ensemble is in the gathered statistics,
+the collective spans as many ranks as the job has GPUs and it travelled over RCCL: the line says
+so (`members_in_statistics`, `collective_world_size`, `collective_backend`) and the process
+exits 3 with an `invalid` list in the line otherwise.
 
 Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
   roofline      -- the BINDING bound: executed fp64 flop/s against the 78.6 TFLOP/s fp64
@@ -190,7 +196,9 @@ def roofline_object(members, biomes, kernel_ms, kernel="run"):
     yard = alg_bytes / secs / 1e9
     r = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VECTOR_PEAK / 1e12,
          "unit": "TFLOP/s", "frac": None, "traffic": None,
-         "kernel": "hx_pair_kernel" if kernel == "pair" else "hx_run_kernel<%d>" % biomes,
+         "kernel": ("hx_pair_kernel" if kernel == "pair" else
+                    "hx_run_kernel<HX_B1W2> (two resident wavefronts per SIMD)" if kernel == "run2" else
+                    "hx_run_kernel<%d>" % biomes),
          "kernel_ms": kernel_ms,
          "kernel_source_hash": kernel_source_hash()}
     if entry is not None:
@@ -284,23 +292,183 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def setup_native_collective(core, dist, world, rank):
+COMM_INIT_TIMEOUT_S = 120.0
+
+
+def setup_native_collective(core, dist, world, rank, timeout_s=COMM_INIT_TIMEOUT_S):
     """One RCCL communicator inside libhector_amd.so over all ranks (hx_comm_init_rank): rank 0's
-    unique id travels through torch.distributed's store.  -> (ok, message); every rank agrees."""
+    unique id travels through torch.distributed's store.  The call is bounded: it runs on a helper
+    thread (ctypes releases the GIL) and a rank whose ncclCommInitRank has not returned after
+    timeout_s reports failure instead of hanging the job.  -> (ok, message); every rank agrees."""
+    import threading
     import torch
     import hector_amd
     from hector_amd import core as core_mod
     ids = [core_mod.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
-    ok, msg = 1, ""
-    try:
-        core.comm_init_rank(world, rank, ids[0])
-    except hector_amd.HectorAmdError as e:
-        ok, msg = 0, str(e)
+    res = {}
+
+    def work():
+        try:
+            core.comm_init_rank(world, rank, ids[0])
+            res["ok"] = True
+        except hector_amd.HectorAmdError as e:
+            res["ok"], res["msg"] = False, str(e)
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        ok, msg = 0, "hx_comm_init_rank did not return within %.0f s" % timeout_s
+    else:
+        ok, msg = (1, "") if res.get("ok") else (0, res.get("msg", "unknown error"))
     flag = torch.tensor([ok], dtype=torch.int32,
                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(flag.item()), msg
+
+
+def runtime_versions():
+    """HIP runtime / driver this process runs on, next to the compiler that built the kernels: a
+    library built by one ROCm and run under another's runtime works today; the line records the
+    pairing so that a change of either shows in the figures' provenance."""
+    import ctypes
+    v = {"compiler": compiler_id()}
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        for name, key in (("hipRuntimeGetVersion", "hip_runtime"), ("hipDriverGetVersion", "hip_driver")):
+            x = ctypes.c_int(0)
+            if getattr(hip, name)(ctypes.byref(x)) == 0:
+                v[key] = x.value
+    except OSError:
+        pass
+    try:
+        import torch
+        v["torch"] = torch.__version__
+        v["torch_hip"] = torch.version.hip
+    except Exception:
+        pass
+    try:
+        import hector_amd
+        v["library_built_with_hip"] = hector_amd.build_info()
+    except Exception:
+        pass
+    return v
+
+
+def run_workload(args, ctx, n, steps, warmup):
+    """One weak-scaling workload: n members on every GPU, `steps` timed steps between barriers.
+    -> dict of this rank's view (elapsed and kernel time already the maximum over ranks)."""
+    import numpy as np
+    import torch
+    from hector_amd.distributed import allreduce_stats
+    dist, world, rank, dev = ctx["dist"], ctx["world"], ctx["rank"], ctx["dev"]
+    use_dist, shards = ctx["use_dist"], ctx["shards"]
+    offset = rank * n  # weak scaling: contiguous member blocks, SURVEY.md 8(e)
+    if args.single_process:
+        devices = list(range(args.gpus)) if args.dist_backend == "nccl" else [0] * args.gpus
+        core = make_core(n * shards, args.biomes, 0, 0, devices=devices)
+    else:
+        core = make_core(n, args.biomes, offset, ctx["local_rank"])
+    start, end = core.strtdate, core.enddate
+    nyr = end - start + 1
+    stats = torch.zeros((2, nyr, 5), dtype=torch.float64, device=dev)
+
+    # Who combines the statistics across GPUs.  native: the library's own communicator,
+    # ncclAllGather on the core's stream.  torch: one all-reduce by torch.distributed on torch's
+    # stream, ordered against the core's stream through an ExternalStream.
+    collective, fallback = None, None
+    if use_dist:
+        collective = args.collective if args.dist_backend == "nccl" else "torch"
+        if collective == "native":
+            ok, msg = setup_native_collective(core, dist, world, rank)
+            if not ok:
+                sys.stderr.write("bench.py: rank %d: the library's RCCL communicator could not be "
+                                 "created (%s); falling back to torch.distributed's\n" % (rank, msg))
+                collective, fallback = "torch", msg
+    elif shards > 1:
+        collective = "native"
+    core_stream = torch.cuda.ExternalStream(core.stream(), device=dev) if collective == "torch" else None
+
+    def step():
+        core.reset(start)
+        core.run(end, wait=False)
+        if collective == "torch":
+            core.stats_device("CO2_concentration", start, end, stats[0].data_ptr())
+            core.stats_device("global_tas", start, end, stats[1].data_ptr())
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(core_stream)      # statistics written before they are reduced
+            allreduce_stats(stats, dist, force=True)
+            core_stream.wait_stream(cur)      # ... and reduced before the next step overwrites them
+        else:   # local reductions (+ the one all-gather when there are several ranks)
+            core.ensemble_stats(STAT_VARS, (start, end), d_out=stats.data_ptr(), host=False)
+        return core.last_run_ms()
+
+    core.status()  # upload + spinup + alkalinity tuning, outside every timed region
+    # Lane calibration, also outside: one complete pass lets the core measure what every member's
+    # solver costs; the reset adopts the lane order by measured cost (hx_set_lane_calibration:
+    # wavefronts of like members, the costliest dispatched first) and spins up again.  (Every
+    # hx_run_kernel dispatch a profiler sees is a full 555-year one.)
+    core.run(end)
+    core.reset(start)
+    core.status()
+    spin_ms = core.last_spinup_ms()
+    for _ in range(warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kern_ms = []
+    for _ in range(steps):
+        kern_ms.append(step())
+    core.sync()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+    r = {"n": n, "steps": steps, "warmup": warmup,
+         "elapsed": float(t.item()),
+         "kernel_ms": float(km.item()),   # slowest rank's (and slowest shard's) mean kernel time
+         "bad": int((core.status() != 0).sum()),
+         "stats_host": stats.cpu().numpy(),
+         "which_kernel": core.last_run_kernel(),
+         "calibrated": core.lanes_calibrated(),
+         "spin_ms": spin_ms, "collective": collective, "native_fallback": fallback}
+    r["comm_world"], _, r["comm_backend"] = core.comm_info()
+    core.shutdown()
+    return r
+
+
+def collective_facts(args, ctx, r):
+    """-> (backend string, world size of the collective that combined the statistics)."""
+    if r["collective"] == "native":
+        return "RCCL ncclAllGather issued by libhector_amd.so (%s)" % r["comm_backend"], r["comm_world"]
+    if r["collective"] == "torch":
+        return (("RCCL all-reduce through torch.distributed (nccl)" if args.dist_backend == "nccl"
+                 else "torch.distributed %s (rehearsal, not RCCL)" % args.dist_backend), ctx["world"])
+    return None, 1
+
+
+def workload_name(n, n_gpus, biomes):
+    if biomes == 4:
+        return ("%d-member perturbed 4-biome ECS/Q10/warmingfactor ensemble per GPU, SSP2-4.5 1745-2300 "
+                "(BASELINE configs[4])" % n)
+    if n == 131072:
+        which = ("BASELINE configs[3]: 1 048 576 members over 8 GPUs" if n_gpus == 8 else
+                 "BASELINE configs[3]'s shape, 131 072 members per GPU: %d members over %d GPU%s, "
+                 "1 048 576 at 8" % (n * n_gpus, n_gpus, "" if n_gpus == 1 else "s"))
+    elif n == 65536:
+        which = "BASELINE configs[2] on every GPU" if n_gpus > 1 else "BASELINE configs[2]"
+    elif n == 1024:
+        which = "BASELINE configs[1]"
+    else:
+        which = "the kernel of BASELINE configs[2], another ensemble size"
+    return "%d-member perturbed ECS/Q10 ensemble per GPU, SSP2-4.5 1745-2300 (%s)" % (n, which)
 
 
 def main():
@@ -308,7 +476,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--members", type=int, default=65536, help="members per GPU")
+    ap.add_argument("--members", type=int, default=None,
+                    help="members per GPU (default: 65 536 = BASELINE configs[2] on one GPU; "
+                         "131 072 = configs[3]'s share of one GPU when --gpus > 1)")
     ap.add_argument("--biomes", type=int, default=1, choices=[1, 4])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -337,7 +507,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from hector_amd.distributed import allreduce_stats, finalize
+    from hector_amd.distributed import finalize
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -359,104 +529,44 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # RCCL's complaints on stderr, whoever issues the call
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
-    n = args.members
     shards = args.gpus if args.single_process else 1   # GPUs this process drives
     n_gpus = world * shards
-    offset = rank * n  # weak scaling: contiguous member blocks, SURVEY.md 8(e)
-    if args.single_process:
-        devices = list(range(args.gpus)) if args.dist_backend == "nccl" else [0] * args.gpus
-        core = make_core(n * shards, args.biomes, 0, 0, devices=devices)
-    else:
-        core = make_core(n, args.biomes, offset, local_rank)
-    start, end = core.strtdate, core.enddate
-    nyr = end - start + 1
-    stats = torch.zeros((2, nyr, 5), dtype=torch.float64, device=dev)
+    ctx = {"dist": dist, "world": world, "rank": rank, "local_rank": local_rank, "dev": dev,
+           "use_dist": use_dist, "shards": shards}
+    # The headline workload.  One GPU: BASELINE configs[2] (65 536 members).  Several GPUs: configs[3]'s
+    # shape -- 131 072 members on every GPU, 1 048 576 at N = 8 -- with configs[2]-per-GPU (the N = 1
+    # line's workload, weak-scaled) timed after it and reported in other_configs.
+    n = args.members if args.members else (65536 if n_gpus == 1 else 131072)
+    r = run_workload(args, ctx, n, args.steps, args.warmup)
+    second = None
+    if n_gpus > 1 and not args.members and not args.no_other_configs:
+        second = run_workload(args, ctx, 65536, max(5, args.steps // 2), 1)
 
-    # Who combines the statistics across GPUs.  native: the library's own communicator,
-    # ncclAllGather on the core's stream.  torch: one all-reduce by torch.distributed on torch's
-    # stream, ordered against the core's stream through an ExternalStream.
-    collective = None
-    if use_dist:
-        collective = args.collective if args.dist_backend == "nccl" else "torch"
-        if collective == "native":
-            ok, msg = setup_native_collective(core, dist, world, rank)
-            if not ok:
-                sys.stderr.write("bench.py: rank %d: the library's RCCL communicator could not be "
-                                 "created (%s); falling back to torch.distributed's\n" % (rank, msg))
-                collective = "torch"
-    elif shards > 1:
-        collective = "native"
-    core_stream = torch.cuda.ExternalStream(core.stream(), device=dev) if collective == "torch" else None
-
-    def step():
-        core.reset(start)
-        core.run(end, wait=False)
-        if collective == "torch":
-            core.stats_device("CO2_concentration", start, end, stats[0].data_ptr())
-            core.stats_device("global_tas", start, end, stats[1].data_ptr())
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(core_stream)      # statistics written before they are reduced
-            allreduce_stats(stats, dist, force=True)
-            core_stream.wait_stream(cur)      # ... and reduced before the next step overwrites them
-        else:   # local reductions (+ the one all-gather when there are several ranks)
-            core.ensemble_stats(STAT_VARS, (start, end), d_out=stats.data_ptr(), host=False)
-        return core.last_run_ms()
-
-    core.status()  # upload + spinup + alkalinity tuning, outside every timed region
-    # Lane calibration, also outside: one complete pass lets the core measure what every member's
-    # solver costs; the reset adopts the lane order by measured cost (hx_set_lane_calibration:
-    # wavefronts of like members, the costliest dispatched first) and spins up again.  (Every
-    # hx_run_kernel dispatch a profiler sees is a full 555-year one.)
-    core.run(end)
-    core.reset(start)
-    core.status()
-    spin_ms = core.last_spinup_ms()
-    for _ in range(args.warmup):
-        step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kern_ms = []
-    for _ in range(args.steps):
-        kern_ms.append(step())
-    core.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    kernel_ms = float(km.item())   # slowest rank's (and slowest shard's) mean kernel time
-    bad = int((core.status() != 0).sum())
-    stats_host = stats.cpu().numpy()
-    which_kernel = core.last_run_kernel()
-    calibrated = core.lanes_calibrated()
-    comm_world, _, comm_backend = core.comm_info()
-    core.shutdown()
-
+    failures = []
     if rank == 0:
-        total_members = n * n_gpus
+        def summary(r):
+            total_members = r["n"] * n_gpus
+            mean, std, mn, mx = finalize(r["stats_host"])
+            backend, cworld = collective_facts(args, ctx, r)
+            in_stats = int(r["stats_host"][0, -1, 0])
+            # what a multi-GPU line must show to count (exit status below)
+            if in_stats != total_members:
+                failures.append("%d members in the statistics, %d in the ensemble" % (in_stats, total_members))
+            if n_gpus > 1:
+                if cworld != n_gpus:
+                    failures.append("the collective spans %s ranks, the job %d GPUs" % (cworld, n_gpus))
+                if args.dist_backend == "nccl" and "RCCL" not in (backend or ""):
+                    failures.append("the statistics did not travel over RCCL (%s)" % backend)
+            return total_members, mean, backend, cworld, in_stats
+        total_members, mean, backend, cworld, in_stats = summary(r)
+        elapsed, kernel_ms = r["elapsed"], r["kernel_ms"]
         value = total_members * YEARS * args.steps / elapsed
-        mean, std, mn, mx = finalize(stats_host)
-        if collective == "native":
-            backend = "RCCL ncclAllGather issued by libhector_amd.so (%s)" % comm_backend
-            cworld = comm_world
-        elif collective == "torch":
-            backend = ("RCCL all-reduce through torch.distributed (nccl)" if args.dist_backend == "nccl"
-                       else "torch.distributed %s (rehearsal, not RCCL)" % args.dist_backend)
-            cworld = world
-        else:
-            backend, cworld = None, 1
         out = {
             "metric": "ensemble-member simulated years/sec",
             "value": value,
@@ -471,11 +581,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%d-member perturbed %s ensemble per GPU, SSP2-4.5 1745-2300 "
-                            "(BASELINE configs[%d]); reference dopri5 adaptive solver + "
-                            "stash/retry logic; spinup and upload excluded" %
-                            (n, "ECS/Q10" if args.biomes == 1 else "4-biome ECS/Q10/warmingfactor",
-                             2 if args.biomes == 1 else 4),
+                "workload": workload_name(n, n_gpus, args.biomes) +
+                            "; reference dopri5 adaptive solver + stash/retry logic; spinup and upload excluded",
                 "members_per_gpu": n, "global_members": total_members, "years_per_member": YEARS,
                 "biomes": args.biomes,
                 "parallelism": "member-sharded x%d (%s), one statistics collective per step" %
@@ -483,14 +590,29 @@ def main():
                                 else "one process per GPU"),
                 "collective_backend": backend,
                 "collective_world_size": cworld,
-                "spinup_ms_excluded": spin_ms, "members_with_model_errors": bad,
-                "lanes_ordered_by": "measured cost" if calibrated else "parameter key",
-                "members_in_statistics": int(stats_host[0, -1, 0]),
+                "native_collective_fallback": r["native_fallback"],
+                "rehearsal_not_rccl": bool(use_dist and args.dist_backend != "nccl"),
+                "spinup_ms_excluded": r["spin_ms"], "members_with_model_errors": r["bad"],
+                "lanes_ordered_by": "measured cost" if r["calibrated"] else "parameter key",
+                "members_in_statistics": in_stats,
                 "co2_2300_mean_ppm": float(mean[0, -1]), "tgav_2300_mean_K": float(mean[1, -1]),
+                "versions": runtime_versions(),
             },
             # per-rank maximum of the mean kernel time when N > 1
-            "roofline": roofline_object(n, args.biomes, kernel_ms, which_kernel),
+            "roofline": roofline_object(n, args.biomes, kernel_ms, r["which_kernel"]),
         }
+        if second is not None:
+            tm2, mean2, backend2, cworld2, in2 = summary(second)
+            rf2 = roofline_object(second["n"], args.biomes, second["kernel_ms"], second["which_kernel"])
+            out["other_configs"] = [{
+                "workload": workload_name(second["n"], n_gpus, args.biomes),
+                "members_per_gpu": second["n"], "global_members": tm2, "n_gpus": n_gpus,
+                "steps": second["steps"], "ms_per_step": second["elapsed"] / second["steps"] * 1e3,
+                "value": tm2 * YEARS * second["steps"] / second["elapsed"], "unit": "member-years/s",
+                "scaling": "weak", "kernel": rf2["kernel"], "kernel_ms": second["kernel_ms"],
+                "collective_backend": backend2, "collective_world_size": cworld2,
+                "members_in_statistics": in2, "members_with_model_errors": second["bad"],
+                "fp64_valu_frac": rf2["frac"], "pmc_profile_stale": rf2.get("pmc_profile_stale")}]
         if n_gpus == 1 and not args.no_other_configs:
             others = []
             for (m2, b2) in ((1024, 1), (32768, 1), (131072, 1), (65536, 4)):
@@ -512,10 +634,15 @@ def main():
                               "by the survey with a Boost shim: 600-1 030 member-years/s/core (BASELINE.md "
                               "2), i.e. the oracle is ~100-200x the reference per core",
             }
+        if failures:
+            out["invalid"] = failures
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()
+    if failures:
+        sys.stderr.write("bench.py: INVALID multi-GPU line: " + "; ".join(failures) + "\n")
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -9,3 +9,9 @@ from .core import (Core, newcore, run, reset, shutdown, setvar, fetchvars,  # no
 from . import capabilities  # noqa: F401
 
 __version__ = "0.1.0"
+
+
+def build_info(lib_path=None):
+    """hx_build_info(): the HIP the native library was built with and the runtime it runs on."""
+    from . import _lib
+    return _lib.load(lib_path).hx_build_info().decode()

@@ -118,6 +118,7 @@ def _declare(lib):
     P = c.c_void_p
     dp = c.POINTER(c.c_double)
     lib.hx_backend.restype = c.c_char_p
+    lib.hx_build_info.restype = c.c_char_p
     lib.hx_last_error.restype = c.c_char_p
     sig = {
         "hx_newcore": [c.c_char_p, c.c_int, c.c_int, c.POINTER(P)],
@@ -182,7 +183,7 @@ def _declare(lib):
         fn.restype = c.c_int
 
 
-ABI_SYMBOLS = ["hx_backend", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_setvar",
+ABI_SYMBOLS = ["hx_backend", "hx_build_info", "hx_last_error", "hx_newcore", "hx_shutdown", "hx_setvar",
                "hx_getvar", "hx_split_biome", "hx_split_biome_of", "hx_create_biome", "hx_delete_biome", "hx_rename_biome", "hx_set_outputs", "hx_output_capabilities",
                "hx_set_member_sorting", "hx_lane_of_member", "hx_enable_history", "hx_enable_spinup_record", "hx_spinup_record", "hx_setvar_dated", "hx_halocarbons", "hx_run_name", "hx_tracking_pools", "hx_tracking_data", "hx_var_info", "hx_biomes", "hx_setvar_dated_members", "hx_unit_csys", "hx_unit_doeclim_kernel", "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
                "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_state_row", "hx_dates", "hx_sizes",

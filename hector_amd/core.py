@@ -346,7 +346,7 @@ class Core:
 
     def set_two_wave_from(self, min_members):
         """Ensembles of at least min_members members (one biome, shared diffusivity, no
-        constraints / heat-flux outputs) run on the flavour of the kernel built for two resident
+        constraints) run on the flavour of the kernel built for two resident
         wavefronts per SIMD (include/hector_amd.h); < 0: the default (more wavefronts than the
         GPU has SIMDs), 0: never."""
         self._ck(self._lib.hx_set_two_wave_from(self._h, int(min_members)))

@@ -492,7 +492,7 @@ void EnsembleCore::alloc_device() {
   free_device();
   const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
-  check(hipMalloc(&d_uparams_, sizeof(double) * HX_NPARAM(B_)), "hipMalloc uniform params");
+  check(hipMalloc(&d_uparams_, sizeof(double) * (HX_NPARAM(B_) + HX_NDERIVED(B_))), "hipMalloc uniform params");
   if (trk_iy() >= 0) {  // carbon tracking: the yearly record of the origin matrices from the tracking
     // date on (the kernels update the current year's matrix in place, hx_dev_track.h)
     const size_t TP = (size_t)(2 + 5 * B_ + 4), nyt = ns - (size_t)trk_iy();
@@ -570,6 +570,11 @@ HxBuffers EnsembleCore::buffers() const {
   b.hist = d_hist_; b.hist_status = d_hist_status_;
   for (int k = 0; k < HXM_N; ++k) b.mseries[k] = d_mseries_[k];
   b.uparams = d_uparams_;
+  b.uderived = d_uparams_ ? d_uparams_ + HX_NPARAM(B_) : nullptr;
+  b.uni_k = (row_uniform_[HXP_TT] && row_uniform_[HXP_TU] && row_uniform_[HXP_TWI] && row_uniform_[HXP_TID]) ? 1 : 0;
+  b.uni_avc = (row_uniform_[HXP_AERO] && row_uniform_[HXP_VOL] && row_uniform_[HXP_C0]) ? 1 : 0;
+  b.uni_wf = 1;
+  for (int bb = 0; bb < B_; ++bb) if (!row_uniform_[HXP_NGLOBAL + bb * HXPB_N + HXPB_WF]) b.uni_wf = 0;
   b.track_out_f = d_track_out_f_; b.track_out_v = d_track_out_v_;
   b.trk_slots = trk_iy() >= 0 ? scen_.ns() - trk_iy() + 1 : 0;
   b.uni_landk = b.uni_bio = 1;
@@ -1504,6 +1509,11 @@ void EnsembleCore::upload_params() {
                                  stream_), "doeclim kernel table");
   check(hx_launch_derive(d_params_, d_derived_, d_ker_, ker_per_member_ ? 1 : 0, scen_.ns(), B_,
                          npad_, stream_), "derive kernel");
+  // lane 0's derived constants behind the uniform parameter values (HxBuffers::uderived): rows
+  // that are the same for every member are read through scalar loads
+  check(hipMemcpy2DAsync(d_uparams_ + HX_NPARAM(B_), sizeof(double), d_derived_, sizeof(double) * np,
+                         sizeof(double), (size_t)HX_NDERIVED(B_), hipMemcpyDeviceToDevice, stream_),
+        "uniform derived constants");
   {
     bool lo_any = false;
     for (double v : params_[HXP_LO_RATIO]) if (v != 0.0) lo_any = true;
@@ -1721,7 +1731,7 @@ void EnsembleCore::run(double runtodate) {
   last_run_pair_ = pair;
   // more wavefronts than SIMDs: the one-biome kernel built for two resident wavefronts per SIMD
   const int w2_from = two_wave_from_ < 0 ? simds_ * HX_WAVE + 1 : two_wave_from_;
-  const bool w2 = !pair && B_ == 1 && con == 0 && !hf && !ker_per_member_ && w2_from > 0 && n_ >= w2_from;
+  const bool w2 = !pair && B_ == 1 && con == 0 && !ker_per_member_ && w2_from > 0 && n_ >= w2_from;
   last_run_w2_ = w2;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,

@@ -2,6 +2,8 @@
 // Thin: argument checks, exception -> return code + hx_last_error().
 #include <cstring>
 #include <stdexcept>
+#include <mutex>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -34,9 +36,48 @@ int fail(const char *msg) { g_err = msg; return 1; }
   try { body; return 0; } catch (const std::exception &e) { return fail(e); }  \
   catch (...) { return fail("unknown error"); }
 
+// The HIP the library was built with (hipcc's HIP_VERSION_*) and the runtime it finds itself on
+// may differ: torch's wheel bundles its own libamdhip64, an R host links the system's.  A pairing
+// across a MAJOR version is reported once, on stderr, by the first call of hx_backend() -- which
+// every loader makes first -- and in hx_build_info()'s string.
+namespace {
+std::string build_info_string() {
+  char b[256];
+#ifndef HX_HOST_EMULATION
+  int rt = 0, drv = 0;
+  (void)hipRuntimeGetVersion(&rt);
+  (void)hipDriverGetVersion(&drv);
+  std::snprintf(b, sizeof b, "built with HIP %d.%d.%d (%s), gfx950; runtime %d, driver %d",
+                HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, __VERSION__, rt, drv);
+#else
+  std::snprintf(b, sizeof b, "host emulation (%s)", __VERSION__);
+#endif
+  return b;
+}
+void check_runtime_pairing_once() {
+#ifndef HX_HOST_EMULATION
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int rt = 0;
+    if (hipRuntimeGetVersion(&rt) != hipSuccess || rt <= 0) return;
+    const int rt_major = rt / 10000000;   // HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+    if (rt_major != HIP_VERSION_MAJOR)
+      std::fprintf(stderr, "hector_amd: WARNING: libhector_amd.so was built with HIP %d.%d.%d and runs on HIP "
+                           "runtime %d (major version %d): kernels compiled by one major release are not "
+                           "guaranteed to load on another -- rebuild with the matching hipcc (make -C "
+                           "hector_amd/csrc)\n",
+                   HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt, rt_major);
+  });
+#endif
+}
+}  // namespace
 extern "C" {
 
-const char *hx_backend(void) { return HX_BACKEND_NAME; }
+const char *hx_backend(void) { check_runtime_pairing_once(); return HX_BACKEND_NAME; }
+const char *hx_build_info(void) {
+  static const std::string info = build_info_string();
+  return info.c_str();
+}
 const char *hx_last_error(void) { return g_err.c_str(); }
 
 int hx_newcore(const char *scenario, int n_members, int device, hx_core **out) {

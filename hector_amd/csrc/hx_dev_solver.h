@@ -202,9 +202,18 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
                                       Interval &K2, const YearCon &yc, bool more) {
   LandK<B> lk;
   load_landk<B>(m, lk);
-  const double kHD = dconst<B>(m, HXD_KHD), kLH = dconst<B>(m, HXD_KLH), kLI = dconst<B>(m, HXD_KLI),
-               kIL = dconst<B>(m, HXD_KIL), kIH = dconst<B>(m, HXD_KIH), kID = dconst<B>(m, HXD_KID),
-               kDI = dconst<B>(m, HXD_KDI);
+  double kHD, kLH, kLI, kIL, kIH, kID, kDI;
+  bool k_uniform = false;
+  if constexpr (hx_w2<B>()) k_uniform = m.bufp->uni_k != 0;
+  if (k_uniform) {   // (two-wavefront flavour: scalar loads when every member shares them)
+    hx_ccd u = HX_CCD(m.bufp->uderived);
+    kHD = u[HXD_KHD]; kLH = u[HXD_KLH]; kLI = u[HXD_KLI]; kIL = u[HXD_KIL]; kIH = u[HXD_KIH];
+    kID = u[HXD_KID]; kDI = u[HXD_KDI];
+  } else {
+    kHD = dconst<B>(m, HXD_KHD); kLH = dconst<B>(m, HXD_KLH); kLI = dconst<B>(m, HXD_KLI);
+    kIL = dconst<B>(m, HXD_KIL); kIH = dconst<B>(m, HXD_KIH); kID = dconst<B>(m, HXD_KID);
+    kDI = dconst<B>(m, HXD_KDI);
+  }
   const double yf = t - m.ode_start;
   m.nstash++;
   const bool in_partial_year = (t != floor(t));

@@ -35,6 +35,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -68,6 +69,7 @@ Rccl &rccl() {
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
   r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
   r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
   r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
@@ -80,6 +82,27 @@ void nccl_ck(ncclResult_t e, const char *what) {
   if (e != ncclSuccess)
     throw std::runtime_error(std::string("RCCL error in ") + what + ": " + rccl().GetErrorString(e));
 }
+// ncclGroupStart ... ncclGroupEnd around the per-shard calls of one process.  The group is ALWAYS
+// closed: an exception between the two would otherwise leave RCCL's thread-local group open, and
+// the library shares the process's RCCL with the host (PyTorch's copy when there is one) -- its
+// next collective would be queued into our dangling group and never run.  end() is the checked
+// close of the normal path (the calls' results -- communicator handles, queued kernels -- exist
+// only after it); the destructor closes what an unwinding exception left open, result ignored.
+struct RcclGroup {
+  Rccl &r;
+  bool open = false;
+  RcclGroup(Rccl &rc, bool grouped) : r(rc) {
+    if (grouped) { nccl_ck(r.GroupStart(), "ncclGroupStart"); open = true; }
+  }
+  void end() {
+    if (!open) return;
+    open = false;
+    nccl_ck(r.GroupEnd(), "ncclGroupEnd");
+  }
+  ~RcclGroup() { if (open) (void)r.GroupEnd(); }
+  RcclGroup(const RcclGroup &) = delete;
+  RcclGroup &operator=(const RcclGroup &) = delete;
+};
 #endif
 
 bool rehearsal_allowed() {
@@ -143,7 +166,28 @@ int Fleet::shard_of_member(int member) const {
   return 0;
 }
 
-#define HX_EACH(call) for (Shard &s : shards_) { use(s); s.core->call; }
+void Fleet::check_poison() const {
+  if (!poisoned_.empty()) throw std::runtime_error(poisoned_);
+}
+void Fleet::poison(size_t shard, const char *call, const char *why) {
+  poisoned_ = "hector_amd: this sharded core is inconsistent and refuses further calls: " +
+              std::string(call) + " failed on shard " + std::to_string(shard) + " of " +
+              std::to_string(shards_.size()) + " (" + why + ") after it had been applied to the "
+              "shards before it; shut the core down and create it again";
+}
+
+// a routed call, shard after shard; a failure after the first shard leaves the shards different
+#define HX_EACH(call)                                                              \
+  {                                                                                \
+    check_poison();                                                                \
+    size_t k_ = 0;                                                                 \
+    try {                                                                          \
+      for (; k_ < shards_.size(); ++k_) { Shard &s = shards_[k_]; use(s); s.core->call; } \
+    } catch (const std::exception &e_) {                                           \
+      if (k_ > 0) poison(k_, #call, e_.what());                                    \
+      throw;                                                                       \
+    }                                                                              \
+  }
 
 // The verbs that do real host work or wait for a device -- run() (lane order, parameter upload,
 // spinup), reset(), sync(), fetchvars() -- take the shards side by side, one host thread per
@@ -153,6 +197,7 @@ int Fleet::shard_of_member(int member) const {
 // its LDS in globals: shards stay sequential there.)
 template <class F>
 void Fleet::each_parallel(F &&fn) {
+  check_poison();
 #ifndef HX_HOST_EMULATION
   if (shards_.size() > 1 && !std::getenv("HECTOR_AMD_FLEET_SEQUENTIAL")) {
     std::vector<std::exception_ptr> err(shards_.size());
@@ -168,21 +213,46 @@ void Fleet::each_parallel(F &&fn) {
     body(0);
     for (size_t k = started; k < shards_.size(); ++k) body(k);
     for (std::thread &t : th) t.join();
-    for (std::exception_ptr &e : err) if (e) std::rethrow_exception(e);
+    size_t failed = 0, first = shards_.size();
+    for (size_t k = 0; k < err.size(); ++k) if (err[k]) { ++failed; if (first == shards_.size()) first = k; }
+    if (failed) {
+      if (failed < shards_.size()) {   // some shards went through, some did not
+        try { std::rethrow_exception(err[first]); }
+        catch (const std::exception &e) { poison(first, "a parallel call (run / reset / sync / fetchvars)", e.what()); }
+        catch (...) { poison(first, "a parallel call", "unknown error"); }
+      }
+      std::rethrow_exception(err[first]);
+    }
     return;
   }
 #endif
-  for (Shard &s : shards_) { use(s); fn(s); }
+  {
+    size_t k = 0;
+    try {
+      for (; k < shards_.size(); ++k) { use(shards_[k]); fn(shards_[k]); }
+    } catch (const std::exception &e) {
+      if (k > 0) poison(k, "a sharded call (run / reset / sync / fetchvars)", e.what());
+      throw;
+    }
+  }
 }
 
 void Fleet::setvar(const std::string &cap, const double *values, int nvalues, const char *units) {
   if (shards_.size() == 1) { shards_[0].core->setvar(cap, values, nvalues, units); return; }
   if (nvalues != 1 && nvalues != n_)
     throw std::runtime_error("setvar: expected 1 or n_members values");
-  for (Shard &s : shards_) {
-    use(s);
-    if (nvalues == 1) s.core->setvar(cap, values, 1, units);
-    else s.core->setvar(cap, values + s.offset, s.count, units);
+  check_poison();
+  size_t k = 0;
+  try {
+    for (; k < shards_.size(); ++k) {
+      Shard &s = shards_[k];
+      use(s);
+      if (nvalues == 1) s.core->setvar(cap, values, 1, units);
+      else s.core->setvar(cap, values + s.offset, s.count, units);
+    }
+  } catch (const std::exception &e) {
+    if (k > 0) poison(k, "setvar", e.what());
+    throw;
   }
 }
 void Fleet::getvar(const std::string &cap, double *out) {
@@ -335,20 +405,27 @@ void Fleet::comm_init_rank(int n_procs, int proc_rank, const char *id_bytes) {
   const int L = n_shards();
   world_ = n_procs * L;
   first_rank_ = proc_rank * L;
+  // (inside a group ncclCommInitRank writes the handle when the group ends: the slots it writes to
+  // must outlive the calls, hence one array for all shards)
+  std::vector<ncclComm_t> comms((size_t)L, nullptr);
   try {
-    if (L > 1) nccl_ck(r.GroupStart(), "ncclGroupStart");
-    for (int s = 0; s < L; ++s) {
-      hip_ck(hipSetDevice(shards_[(size_t)s].device), "hipSetDevice");
-      ncclComm_t c = nullptr;
-      nccl_ck(r.CommInitRank(&c, world_, id, first_rank_ + s), "ncclCommInitRank");
-      shards_[(size_t)s].comm = c;
+    {
+      RcclGroup group(r, L > 1);
+      for (int s = 0; s < L; ++s) {
+        hip_ck(hipSetDevice(shards_[(size_t)s].device), "hipSetDevice");
+        nccl_ck(r.CommInitRank(&comms[(size_t)s], world_, id, first_rank_ + s), "ncclCommInitRank");
+      }
+      group.end();
     }
-    if (L > 1) nccl_ck(r.GroupEnd(), "ncclGroupEnd");
-    // (inside a group the handles are filled in by ncclGroupEnd)
     for (int s = 0; s < L; ++s)
-      if (!shards_[(size_t)s].comm) throw std::runtime_error("ncclCommInitRank returned no communicator");
+      if (!comms[(size_t)s]) throw std::runtime_error("ncclCommInitRank returned no communicator");
+    for (int s = 0; s < L; ++s) shards_[(size_t)s].comm = comms[(size_t)s];
     free_stats_buffers();  // sized for the old world
   } catch (...) {
+    // communicators that did come to life are torn down, not leaked (abort: their peers may never
+    // have arrived, a destroy could wait for them)
+    for (int s = 0; s < L; ++s)
+      if (comms[(size_t)s]) { (void)hipSetDevice(shards_[(size_t)s].device); (void)r.CommAbort(comms[(size_t)s]); }
     for (Shard &s : shards_) s.comm = nullptr;
     world_ = 1; first_rank_ = 0;
     throw;
@@ -422,13 +499,13 @@ void Fleet::ensemble_stats(const std::vector<std::string> &caps, int year0, int 
   } else {
 #ifndef HX_HOST_EMULATION
     Rccl &r = rccl();
-    if (shards_.size() > 1) nccl_ck(r.GroupStart(), "ncclGroupStart");
+    RcclGroup group(r, shards_.size() > 1);
     for (Shard &s : shards_) {
       use(s);
       nccl_ck(r.AllGather(s.d_local, s.d_slots, blk, ncclDouble, (ncclComm_t)s.comm, s.core->stream()),
               "ncclAllGather");
     }
-    if (shards_.size() > 1) nccl_ck(r.GroupEnd(), "ncclGroupEnd");
+    group.end();
 #endif
   }
   // 3. combined in rank order on every rank: bit-identical everywhere

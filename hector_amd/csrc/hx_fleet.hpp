@@ -126,6 +126,12 @@ class Fleet {
   bool comm_ready_ = false;
   int world_ = 1, first_rank_ = 0;
   size_t stats_cap_ = 0;  // doubles per block the staging buffers hold
+  // A routed call that failed on some shards after it went through on others has left the
+  // shards with different biome lists, parameters or dates: from then on every call fails with
+  // this message (which shard, which call, why) instead of mixing them silently.
+  std::string poisoned_;
+  void check_poison() const;
+  void poison(size_t shard, const char *call, const char *why);
 };
 
 }  // namespace hx

@@ -276,7 +276,13 @@ __device__ __forceinline__ void doeclim_pass_mfma(const double *sst_hist,
   // 1024 cycles of matrix pipe).  Without it the code was only correct for instruction orders
   // that happened to keep an accumulator's reuse 7 MFMAs apart.
   auto pin = [&]() {
-    if constexpr (ACCV && !HF)
+    if constexpr (ACCV && HF)
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
+                   : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                     "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),
+                     "+v"(acc2[0][0]), "+v"(acc2[0][1]), "+v"(acc2[0][2]), "+v"(acc2[0][3]),
+                     "+v"(acc2[1][0]), "+v"(acc2[1][1]), "+v"(acc2[1][2]), "+v"(acc2[1][3]));
+    else if constexpr (ACCV)
       asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"
                    : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
                      "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));
@@ -616,7 +622,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         s_ffrozen[b] = ffrozen_of<B>(m, b);
         if constexpr (hx_w2<B>()) {
           const int pr = HXP_NGLOBAL;
-          p_wf[b] = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
+          if (buf.uni_wf) p_wf[b] = HX_CCD(buf.uparams)[pr + HXPB_WF];
+          else p_wf[b] = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
           if (buf.uni_bio) {
             hx_ccd u = HX_CCD(buf.uparams) + pr;
             p_beta[b] = u[HXPB_BETA]; p_mu[b] = u[HXPB_PF_MU]; p_sigma[b] = u[HXPB_PF_SIGMA];
@@ -866,6 +873,16 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         HX_STAMP(m, 11);  // DOECLIM history pass (once per HX_DBLK years)
       }
       constexpr bool TALL = hx_w2<B>();
+#ifndef HX_W2_TALL_LATE   // (-DHX_W2_TALL_LATE, experiment builds: requested where they are used)
+      [[maybe_unused]] double Tall[HX_DBLK];
+      if constexpr (TALL) {
+#pragma unroll
+        for (int r = 0; r < HX_DBLK; ++r) {
+          const int i = blk0 + r;
+          Tall[r] = hx_ldm(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
+        }
+      }
+#endif
       if constexpr (hx_w2<B>()) {  // what the other kernels request ahead of the solver
         pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(iy - blk0) * buf.npad, m.moff);
         yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
@@ -880,8 +897,13 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       double p_aero, p_vol;
       if constexpr (hx_w2<B>()) {
         HX_W2_LOCAL(m);
-        p_aero = w2_ld(buf.params, m.npad, HXP_AERO, m.moff); p_vol = w2_ld(buf.params, m.npad, HXP_VOL, m.moff);
-        m.C0 = w2_ld(buf.params, m.npad, HXP_C0, m.moff);
+        if (buf.uni_avc) {   // (scalar loads when every member shares them)
+          hx_ccd u = HX_CCD(buf.uparams);
+          p_aero = u[HXP_AERO]; p_vol = u[HXP_VOL]; m.C0 = u[HXP_C0];
+        } else {
+          p_aero = w2_ld(buf.params, m.npad, HXP_AERO, m.moff); p_vol = w2_ld(buf.params, m.npad, HXP_VOL, m.moff);
+          m.C0 = w2_ld(buf.params, m.npad, HXP_C0, m.moff);
+        }
       } else {
         p_aero = PKM(m, PK_AERO); p_vol = PKM(m, PK_VOL);
       }
@@ -964,15 +986,18 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         if constexpr (TALL) {
           // Kernels without the LDS tile read the block's SSTs back from the output array: the
           // two-wavefront flavour requests the whole block at once (chunk after chunk each would
-          // wait out its own trip to L2 / HBM); rows from this year on hold stale values of an
-          // earlier run and enter as 0 * Ker, like the tail of a chunk.
+          // wait out its own trip to L2 / HBM).  Rows from this year on (stale values of an
+          // earlier run) are replaced by row 0, the SST anomaly of startDate = 0 for every member,
+          // like in the history pass: the row choice is scalar arithmetic, the terms enter as
+          // 0 * Ker with no select on the vector side.
+#ifdef HX_W2_TALL_LATE
           double Tall[HX_DBLK];
-          hx_gcd srow = HX_GCD(buf.out[HXO_SST]) + (size_t)blk0 * buf.npad;   // (wave-uniform)
 #pragma unroll
           for (int r = 0; r < HX_DBLK; ++r) {
             const int i = blk0 + r;
-            Tall[r] = hx_ldm(srow + (size_t)((i < ns ? i : ns - 1) - blk0) * buf.npad, m.moff);
+            Tall[r] = hx_ldm(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
           }
+#endif
 #pragma unroll
           for (int c = 0; c < HX_DBLK / 8; ++c) {
             if (c < nchunk) {
@@ -985,9 +1010,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
               }
 #pragma unroll
               for (int r = 0; r < 8; ++r) {
-                const double t = (i0 + r < iy) ? Tall[8 * c + r] : 0.0;
-                dpast += t * K[r];
-                if (want_hf) hint += t * K2[r];
+                dpast += Tall[8 * c + r] * K[r];
+                if (want_hf) hint += Tall[8 * c + r] * K2[r];
               }
             }
           }
@@ -1630,8 +1654,11 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   }
   if constexpr (B == 1) {
     // the flavour built for two resident wavefronts per SIMD (EnsembleCore::run decides)
-    if (two_wave && !con && !hf && !kpm) {
-      hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    // (shared diffusivity only: the per-member history pass, two sweeps of 16 accumulators over a
+    //  32-entry kernel window, does not fit 256 registers -- 77 to 120 of them spill)
+    if (two_wave && !con && !kpm) {
+      if (hf) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       return;
     }
   }

@@ -204,6 +204,11 @@ struct HxBuffers {
   const double *mseries[HXM_N];  // per-member series (row iy as in the shared table) or nullptr
   const double *uparams;   // [HX_NPARAM(B)] one value per parameter row (member 0): rows that are
   int uni_landk, uni_bio;  // uniform over members are read through scalar loads (multi-biome kernels)
+  // two-wavefront flavour (HX_B1W2): lane 0's derived constants [HX_NDERIVED(B)], and which groups
+  // of rows every member shares -- the ocean exchange coefficients (HXD_KLH..HXD_KDI), aerosol /
+  // volcanic scaling and C0, the biomes' warming factors
+  const double *uderived;
+  int uni_k, uni_avc, uni_wf;
   // carbon tracking (CON == 2 kernels): the yearly record of every member's origin matrix; the
   // current year's matrix is updated in place by every stash (hx_dev_track.h)
   // both tiled by wavefront, [npad/64][trk_slots][rows][64]: slot 0 the identity of the tracking

@@ -35,6 +35,10 @@ typedef struct hx_core hx_core; /* opaque; replaces the int index of Core::mkcor
 /* "hip" for the product library.  (A test-only host-emulation build reports
  * "host-emulation"; the Python loader refuses it outside tests.) */
 const char *hx_backend(void);
+/* "built with HIP x.y.z (<compiler>), gfx950; runtime <hipRuntimeGetVersion>, driver
+ * <hipDriverGetVersion>": the toolchain pairing behind a run's figures.  hx_backend()'s first call
+ * warns on stderr when the runtime's major version is not the build's. */
+const char *hx_build_info(void);
 const char *hx_last_error(void);
 
 /* newcore(inifile, ...)  R/hector.R:81-87, src/rcpp_hector.cpp:31-86.
@@ -299,7 +303,7 @@ int hx_set_pair_kernel_limit(hx_core *core, int max_members);
  * one-biome kernel compiled for TWO resident wavefronts per SIMD (at most 256 registers and 20 KB
  * of LDS a wavefront; hx_dev_member.h, HX_B1W2): the second wavefront issues into the slots a
  * dependent fp64 chain of the first leaves empty.  Same model code, same decisions; it serves what
- * the plain kernel serves (one biome, shared diffusivity, no constraints / heat-flux outputs).
+ * the plain kernel serves with a shared diffusivity (one biome, no constraints or diagnostics of the extended kernel).
  * hx_set_two_wave_from: ensembles of at least min_members members use it (< 0: the default, one
  * more wavefront than the device has SIMDs; 0: never; the environment variable
  * HECTOR_AMD_TWO_WAVE_FROM sets the default of new cores).  hx_last_run_kernel then says "run2". */

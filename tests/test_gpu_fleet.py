@@ -199,3 +199,81 @@ def test_c_host_example_on_the_gpu(hip_lib, tmp_path):
                            timeout=600, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "global_tas 2100: members 4096 " in r.stdout and "members with model errors: 0" in r.stdout
+
+
+def test_sharded_core_over_every_visible_device_equals_one_core(hip_lib):
+    """hx_newcore_devices over range(hipGetDeviceCount()): on a one-GPU box this repeats the
+    one-device list; on any box with more it is the first execution of the fleet on distinct
+    devices -- per-shard host threads, ncclCommInitRank of several ranks inside one group, the
+    grouped all-gather, strided fetchvars into one host array -- against ONE core over the same
+    members, bit for bit, and the gathered statistics against a host reduction."""
+    import torch
+    nd = torch.cuda.device_count()
+    n = 3000 * nd + 7   # ragged blocks
+    S, q10 = ensemble.ecs_q10(n)
+    one = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    many = hector_amd.Core(SCENARIO, n, devices=list(range(nd)), lib_path=hip_lib)
+    devs, offs = many.shards()
+    assert devs == list(range(nd)) and offs[0] == 0 and offs[-1] == n
+    for c in (one, many):
+        c.set_pair_kernel_limit(0)
+        c.setvar("S", S, "degC").setvar("q10_rh", q10)
+        c.run(2300, wait=False)
+    for v in VARS:
+        np.testing.assert_array_equal(one.fetchvars(v, (1745, 2300)), many.fetchvars(v, (1745, 2300)))
+    assert (many.status() == 0).all()
+    st = many.ensemble_stats(VARS, (1745, 2300))
+    _check_stats(st, one, 1745, 2300)
+    world, first, backend = many.comm_info()
+    if nd > 1:
+        assert world == nd and first == 0 and backend.startswith("rccl "), (world, backend)
+    one.shutdown(); many.shutdown()
+
+
+def test_bench_two_ranks_over_rccl_on_two_gpus():
+    """One process per GPU, world size 2, the library's own communicator (ncclCommInitRank with
+    world > 1) and ONE ncclAllGather per step: needs two devices (skipped on the builder's box,
+    run by whoever has them -- the driver's 8-GPU node takes the same path at --gpus 8)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r, out = _bench(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out["n_gpus"] == 2 and out["config"]["collective_world_size"] == 2
+    assert "RCCL ncclAllGather issued by libhector_amd.so" in out["config"]["collective_backend"]
+    assert out["config"]["global_members"] == 4096 and out["config"]["members_in_statistics"] == 4096
+    assert out["config"]["native_collective_fallback"] is None
+    # the gathered statistics are those of one core over the same 4096 members
+    S, q10 = ensemble.ecs_q10(4096)
+    c = hector_amd.Core(SCENARIO, 4096, device=0)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)").run(2300)
+    tg = c.fetchvars("global_tas", (2300, 2300))[0]
+    assert abs(out["config"]["tgav_2300_mean_K"] - tg.mean()) < 1e-9
+    c.shutdown()
+
+
+def test_bench_multi_gpu_default_times_the_named_configurations():
+    """`bench.py --gpus N` without --members: the line's value is BASELINE configs[3]'s shape
+    (131 072 members per GPU, 1 048 576 at N = 8) and other_configs[0] the N = 1 workload
+    weak-scaled (65 536 per GPU), both checked for complete statistics.  Two gloo ranks on this
+    box's one GPU (rehearsal: the line says so)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_PORT"] = str(29800 + os.getpid() % 90)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and "invalid" not in out
+    cfg = out["config"]
+    assert cfg["members_per_gpu"] == 131072 and cfg["global_members"] == 262144
+    assert cfg["members_in_statistics"] == 262144 and cfg["collective_world_size"] == 2
+    assert "configs[3]" in cfg["workload"] and cfg["rehearsal_not_rccl"] is True
+    assert out["roofline"]["kernel"].startswith("hx_run_kernel<HX_B1W2")
+    o = out["other_configs"][0]
+    assert o["members_per_gpu"] == 65536 and o["global_members"] == 131072
+    assert o["members_in_statistics"] == 131072 and "configs[2]" in o["workload"]
+    assert "hip_runtime" in cfg["versions"] and "compiler" in cfg["versions"]
