@@ -359,14 +359,15 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
       c.alive = status == 0;
       PSTAMP(4);
-      while (__any(c.alive && c.t < tnew)) {
+      // (bottom-tested, like solve_year's loops: the vote may not be duplicated into a loop header)
+      for (bool go_seg = __any(c.alive && c.t < tnew); go_seg; go_seg = __any(c.alive && c.t < tnew)) {
         const bool seg = c.alive && c.t < tnew;
         c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = false; c.fails = 0;
         c.stepping = seg;
         // (as in solve_year: the fresh stepper's first RHS ahead of the loop, the attempt as
         // straight-line code for every lane, retries behind a uniform rare branch)
         rhs(y, dxdt, 0);
-        while (__any(c.stepping)) {
+        for (bool go_ = __any(c.stepping); go_; go_ = __any(c.stepping)) {
           double xn[2], dn[2], en[2], ed[2];
           if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
             if (c.stepping && pair_retry(c, status)) { load_pools(); rhs(y, dxdt, 0); }
@@ -713,14 +714,15 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       const bool want_flux = buf.stash_diag != 0;
       if (iy < iy_to) prefetch(iy + 1);
       PSTAMP(4);
-      while (__any(c.alive && c.t < tnew)) {
+      // (bottom-tested, like solve_year's loops: the vote may not be duplicated into a loop header)
+      for (bool go_seg = __any(c.alive && c.t < tnew); go_seg; go_seg = __any(c.alive && c.t < tnew)) {
         const bool seg = c.alive && c.t < tnew;
         c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = false; c.fails = 0;
         c.stepping = seg;
         double y0c = 0, y4c = 0;  // the ocean side's atmosphere / ocean totals after the last accepted step
         auto first_rhs = [&]() { rrs[0] = hx_div1(luc_e, y[0] + y[1] + y[2]); rhs(y, dxdt, 0); };
         first_rhs();  // (the fresh stepper's first RHS, ahead of the loop: see the ocean side)
-        while (__any(c.stepping)) {
+        for (bool go_ = __any(c.stepping); go_; go_ = __any(c.stepping)) {
           double xn[3], dn[3], en[3], ed[3];
           if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
             if (c.stepping && pair_retry(c, status)) { load_pools(); first_rhs(); }

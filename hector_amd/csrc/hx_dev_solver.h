@@ -478,7 +478,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   // is two s_mov_b32, and with machine LICM off -- see the Makefile -- they are materialised where
   // they are used), 12 % of the pass's instructions; five s_load_dwordx8/x16 a pass instead.
   // (-DHX_TAB_LITERALS: the old form, for experiment builds.)
-  const double *const T = kc.tab;
+  const double *T = kc.tab;
 #define b21 T[0]
 #define f2 T[1]
 #define b31 T[2]
@@ -562,7 +562,11 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   // pool, runaway CO2) can drive the step size towards zero -- a lane that never finishes its
   // year would hang the whole launch.
   bool alive = m.status == 0;
+#ifndef HX_TOP_TESTED_LOOPS   // (bottom-tested like the step loop below, for the same reason)
+  for (bool go_seg = __any(alive && t < tnew); go_seg; go_seg = __any(alive && t < tnew)) {
+#else
   while (__any(alive && t < tnew)) {
+#endif
     const bool seg = alive && t < tnew;
     // fresh integrate_adaptive call: by-value dt, fresh controlled stepper
     const double t_start = t;
@@ -579,9 +583,26 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     // and discards the result: ~2 % of the lanes, against the predication and register shuffling
     // of a divergent region around 330 instructions); per-lane control is the clip of dt, the
     // rare retry block, and ONE masked region at the end where an accepted step is committed.
+#ifndef HX_TOP_TESTED_LOOPS
+    // (the wavefront's vote at the BOTTOM of the loop: with `while (__any(stepping))` the vote is
+    // the loop header, which the compiler may not duplicate (a convergent operation), so the loop
+    // stays top-tested and every value that leaves it -- t, dt, the pools, their derivatives -- is
+    // copied to its exit register at the top of EVERY pass)
+    for (bool go_ = __any(stepping); go_; go_ = __any(stepping)) {
+#else
     while (__any(stepping)) {
+#endif
       HX_STAMP(m, 10);
       HX_COUNT(m, 16);  // step-loop iterations
+#if !defined(HX_TAB_LITERALS) && !defined(HX_HOST_EMULATION) && !defined(HX_TOP_TESTED_LOOPS)
+      {  // The tableau is read HERE, in every pass: an offset the optimiser cannot see through keeps
+        // it from requesting all 30 entries ahead of the (bottom-tested) loop, where 60 scalar
+        // registers held across the loop mean as many spilled ones around it.
+        int toff = 0;
+        asm volatile("" : "+s"(toff));
+        T = kc.tab + toff;
+      }
+#endif
       if (stepping && ((t + dtl) - t_target) > EPS) dtl = t_target - t;
       // Every dopri5 stage time is <= t+dtl, and the model refuses any RHS
       // evaluation beyond max_timestep (ocean_component.cpp:621-625), so the
