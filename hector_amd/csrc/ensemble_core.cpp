@@ -228,7 +228,8 @@ void EnsembleCore::init_from_scenario() {
     }
     if (!biomes.empty()) {
       if ((int)biomes.size() > HX_BDYN)
-        throw std::runtime_error("at most " + std::to_string(HX_BDYN) + " biomes are supported");
+        throw std::runtime_error("at most " + std::to_string(HX_BDYN) + " biomes are supported"
+                                 " (the reference creates any number, simpleNbox.cpp:864-1124; here the per-biome pools of a member live in one wavefront's share of the LDS and the per-biome outputs in a table sized at build time: HX_BDYN in hx_layout.h)");
       B_ = (int)biomes.size();
       biome_names_ = biomes;
       const std::vector<std::vector<double>> global = params_;
@@ -257,11 +258,28 @@ void EnsembleCore::init_from_scenario() {
   // forcing component copes with missing halocarbons, aerosols, volcanic SO2 and ozone
   // (forcing_component.cpp:392-484); sea-level rise has no dependants.  The components of the
   // year loop itself cannot be taken out of this integrator.
-  for (const char *sec : {"simpleNbox", "ocean", "temperature", "forcing", "carbon-cycle-solver",
-                          "CH4", "N2O", "OH"})
+  for (const char *sec : {"simpleNbox", "ocean", "temperature", "forcing", "carbon-cycle-solver"})
     if (component_disabled(sec))
       throw std::runtime_error(std::string("[") + sec + "] enabled=0 is not supported: the component "
-                               "is part of the GPU year loop");
+                               "is part of the GPU year loop (the reference's run fails on the "
+                               "capability it no longer finds, core.cpp:743)");
+  // The gas components: N2O has no dependants but the forcing component, which then skips the
+  // major greenhouse gases altogether (CO2, N2O, CH4, stratospheric H2O:
+  // forcing_component.cpp:315-389 asks for all three concentrations or none).  CH4 can only go
+  // together with the two components that ask for its concentration every year (OH:
+  // oh_component.cpp:150, ozone: o3_component.cpp:134), OH only with CH4 (ch4_component.cpp:164
+  // asks for the OH lifetime): the reference aborts its first year otherwise (core.cpp:743).
+  {
+    const bool no_ch4 = component_disabled("CH4"), no_oh = component_disabled("OH"),
+               no_o3 = component_disabled("ozone");
+    if (no_ch4 && !(no_oh && no_o3))
+      throw std::runtime_error("[CH4] enabled=0: [" + std::string(no_oh ? "ozone" : "OH") +
+                               "] requests the CH4 concentration every year (Capability "
+                               "CH4_concentration not found, core.cpp:743): disable [OH] and [ozone] too");
+    if (no_oh && !no_ch4)
+      throw std::runtime_error("[OH] enabled=0: [CH4] requests the OH lifetime every year "
+                               "(Capability TAU_OH not found, core.cpp:743): disable [CH4] (and [ozone]) too");
+  }
   if (s.scalar("ocean", "spinup_chem", 0) != 0)
     // With spinup_chem = 1 the reference never tunes -- never even sets -- the surface boxes'
     // alkalinity (oceanbox::chem_equilibrate runs only "if (!spinup_chem ...)",
@@ -459,6 +477,12 @@ void EnsembleCore::build_shared() {
   k.N0 = N0f; k.sqrtN0 = std::sqrt(N0f);
   k.delta_co2 = s.scalar("forcing", "delta_co2"); k.delta_ch4 = s.scalar("forcing", "delta_ch4");
   k.delta_n2o = s.scalar("forcing", "delta_n2o");
+  if (component_disabled("CH4") || component_disabled("N2O")) {
+    // the forcing component leaves out CO2, N2O, CH4 and stratospheric H2O (see the constructor):
+    // sarf * (-1) + sarf = 0 exactly, and (CH4 - M0) * 0 = 0
+    k.delta_co2 = k.delta_ch4 = k.delta_n2o = -1.0;
+    k.inv_h2o_span = 0.0;
+  }
   k.o3_rf = component_disabled("ozone") ? 0.0 : 0.042;
   hx_fill_tableau(k.tab);
   hx_fill_math_table(k.mtab);
@@ -776,7 +800,8 @@ void EnsembleCore::split_biome_of(const std::string &old_biome,
   const int nb = (int)names.size(), ob = biome_index(old_biome);
   if (ob < 0) throw std::runtime_error("Biome '" + old_biome + "' missing from biome list.");
   if (nb < 1 || B_ - 1 + nb > HX_BDYN)
-    throw std::runtime_error("split_biome: at most " + std::to_string(HX_BDYN) + " biomes supported");
+    throw std::runtime_error("split_biome: at most " + std::to_string(HX_BDYN) + " biomes supported"
+                             " (the reference creates any number, simpleNbox.cpp:864-1124; here the per-biome pools of a member live in one wavefront's share of the LDS and the per-biome outputs in a table sized at build time: HX_BDYN in hx_layout.h)");
   for (int a = 0; a < nb; ++a) {
     if (names[(size_t)a].empty() || names[(size_t)a].find('.') != std::string::npos)
       throw std::runtime_error("split_biome: bad biome name '" + names[(size_t)a] + "'");
@@ -870,7 +895,8 @@ void EnsembleCore::create_biome(const std::string &biome) {
   if (biome.empty() || biome.find('.') != std::string::npos)
     throw std::runtime_error("create_biome: bad biome name '" + biome + "'");
   if (B_ >= HX_BDYN)
-    throw std::runtime_error("create_biome: at most " + std::to_string(HX_BDYN) + " biomes supported");
+    throw std::runtime_error("create_biome: at most " + std::to_string(HX_BDYN) + " biomes supported"
+                             " (the reference creates any number, simpleNbox.cpp:864-1124; here the per-biome pools of a member live in one wavefront's share of the LDS and the per-biome outputs in a table sized at build time: HX_BDYN in hx_layout.h)");
   const int last = HXP_NGLOBAL + (B_ - 1) * HXPB_N;
   for (int k = 0; k < HXPB_N; ++k) {
     const bool pool = k == HXPB_VEG0 || k == HXPB_DET0 || k == HXPB_SOIL0 || k == HXPB_PF0 ||
@@ -2112,6 +2138,12 @@ void EnsembleCore::check_component_enabled(const std::string &capability_in) con
     for (const char *s : {"bc", "oc", "so2", "nh3"}) if (component_disabled(s)) sec = s;
   } else if (cap == "RF_vol" && so2_off) sec = "so2";
   else if ((cap == "O3_concentration" || cap == "RF_O3_trop") && component_disabled("ozone")) sec = "ozone";
+  else if ((cap == "CH4_concentration" || cap == "RF_CH4" || cap == "RF_H2O_strat") && component_disabled("CH4")) sec = "CH4";
+  else if ((cap == "N2O_concentration" || cap == "RF_N2O") && component_disabled("N2O")) sec = "N2O";
+  else if ((cap == "RF_CH4" || cap == "RF_H2O_strat" || cap == "RF_N2O") &&
+           (component_disabled("N2O") || component_disabled("CH4")))
+    sec = component_disabled("N2O") ? "N2O" : "CH4";   // (not computed: forcing_component.cpp:315-317)
+  else if (cap == "TAU_OH" && component_disabled("OH")) sec = "OH";
   else if ((cap == "slr" || cap == "sl_rc" || cap == "slr_no_ice" || cap == "sl_rc_no_ice") &&
            component_disabled("slr")) sec = "slr";
   else

@@ -32,6 +32,11 @@ struct hxo_scenario {
   /* components switched off with "enabled=0" (core.cpp:251-256): the forcing component then
    * finds no such capability and leaves the forcing out (forcing_component.cpp:392-484) */
   int off_bc, off_oc, off_so2, off_nh3, off_ozone;
+  /* [N2O] or [CH4] (with [OH] and [ozone], which ask for the CH4 concentration at run time:
+   * oh_component.cpp:150, o3_component.cpp:134) disabled: the forcing component finds
+   * D_CH4_CONC / D_N2O_CONC missing and skips the major greenhouse gases altogether -- CO2, N2O,
+   * CH4 and stratospheric H2O (forcing_component.cpp:315-389) */
+  int off_n2o, off_ch4;
   double C0, npp_flux0, veg_c, detritus_c, soil_c, permafrost_c;
   double f_nppv, f_nppd, f_litterd, beta, q10_rh;
   double eps_abs, eps_rel, dt, eps_spinup;
@@ -90,6 +95,9 @@ static void set_scalar(hxo_scenario *s, const char *sec, const char *key,
     else if (!strcmp(sec, "so2")) s->off_so2 = off;
     else if (!strcmp(sec, "nh3")) s->off_nh3 = off;
     else if (!strcmp(sec, "ozone")) s->off_ozone = off;
+    else if (!strcmp(sec, "N2O")) s->off_n2o = off;
+    else if (!strcmp(sec, "CH4")) s->off_ch4 = off;
+    else if (!strcmp(sec, "OH")) { /* (runs only together with CH4 off; nothing else reads it) */ }
     else { hxo_halo *hh = find_halo(s, sec, 1); if (hh) hh->disabled = off; }
     return;
   }
@@ -1809,17 +1817,23 @@ static void year_forcing(member_t *m, int year, double CO2_conc) {
   else alpha_prime = d1;
   double sarf_co2 = (alpha_prime + n2o_alpha) * log(CO2_conc / C0);
   double fco2 = (sarf_co2 * s->delta_co2) + sarf_co2;
-  f[nf].name = "RF_CO2"; f[nf++].v = fco2;
+  const int major = !(s->off_ch4 || s->off_n2o);  /* :315-317 checkCapability of all three */
+  if (!major) fco2 = 0.0;
+  if (major) { f[nf].name = "RF_CO2"; f[nf++].v = fco2; }
   double sarf_n2o = (a2 * sqrt(CO2_conc) + b2 * sqrt(Na) + c2 * sqrt(Ma) + d2) *
                     (sqrt(Na) - sqrt(N0));
   double fn2o = (s->delta_n2o * sarf_n2o) + sarf_n2o;
-  f[nf].name = "RF_N2O"; f[nf++].v = fn2o;
+  if (!major) fn2o = 0.0;
+  if (major) { f[nf].name = "RF_N2O"; f[nf++].v = fn2o; }
   double sarf_ch4 = (a3 * sqrt(Ma) + b3 * sqrt(Na) + d3) * (sqrt(Ma) - sqrt(M0));
   double fch4 = (s->delta_ch4 * sarf_ch4) + sarf_ch4;
-  f[nf].name = "RF_CH4"; f[nf++].v = fch4;
+  if (!major) fch4 = 0.0;
+  if (major) { f[nf].name = "RF_CH4"; f[nf++].v = fch4; }
   const double Ma_base = 1831, stratH2O_base = 0.0485;
+  if (major) {
   f[nf].name = "RF_H2O_strat";
   f[nf++].v = stratH2O_base * ((Ma - M0) / (Ma_base - M0));
+  }
   if (!s->off_ozone) { f[nf].name = "RF_O3_trop"; f[nf++].v = 0.042 * m->o3; }  /* :392 */
   for (int h = 0; h < s->nhalo; h++) {
     if (s->halo[h].disabled) continue;  /* :413-419 checkCapability */

@@ -16,6 +16,11 @@ CASES = {
     "aerosol_bc": [("bc", "enabled")],
     "so2": [("so2", "enabled")],
     "slr_and_cf4": [("slr", "enabled"), ("CF4_halocarbon", "enabled")],
+    # the gas components of the year loop: without N2O -- or without CH4, which takes OH and ozone
+    # with it -- the forcing component skips CO2, N2O, CH4 and stratospheric H2O altogether
+    # (forcing_component.cpp:315-389)
+    "n2o": [("N2O", "enabled")],
+    "ch4_oh_ozone": [("CH4", "enabled"), ("OH", "enabled"), ("ozone", "enabled")],
 }
 
 
@@ -44,16 +49,31 @@ def disabled_component_checks(lib, tmp_path, **kw):
             assert np.abs(c.fetchvars("RF_tot", (Y0, Y1))[:, 0] - rf0).max() > 1e-3, name  # it matters
         # the disabled component's variables are gone, like an unregistered capability
         gone = {"ozone": "RF_O3_trop", "two_halocarbons": "RF_CFC12", "aerosol_bc": "RF_SO2",
-                "so2": "RF_vol", "slr_and_cf4": "CF4_concentration"}[name]
+                "so2": "RF_vol", "slr_and_cf4": "CF4_concentration", "n2o": "N2O_concentration",
+                "ch4_oh_ozone": "CH4_concentration"}[name]
         with pytest.raises(hector_amd.HectorAmdError, match="disabled"):
             c.fetchvars(gone, (1800, 1810))
         if name == "slr_and_cf4":
             with pytest.raises(hector_amd.HectorAmdError, match="disabled"):
                 c.fetchvars("slr", (2000, 2010))
             assert np.isfinite(c.fetchvars("RF_CFC11", (1800, 1810))).all()
-    for sec in ("temperature", "CH4", "simpleNbox"):
+        if name in ("n2o", "ch4_oh_ozone"):
+            for v in ("RF_CH4", "RF_N2O", "RF_H2O_strat"):
+                with pytest.raises(hector_amd.HectorAmdError, match="disabled"):
+                    c.fetchvars(v, (1800, 1810))
+            c.set_outputs(["RF_CO2"]); c.reset(Y0); c.run(1800)
+            assert (c.fetchvars("RF_CO2", (Y0, 1800)) == 0.0).all()
+    for sec in ("temperature", "forcing", "simpleNbox"):
         path = edited_pack(tmp_path / ("no_%s.hxs" % sec), None, None, [], [], scalars={(sec, "enabled"): 0.0})
         with pytest.raises(hector_amd.HectorAmdError, match="not supported"):
+            hector_amd.Core(path, 1, lib_path=lib, **kw)
+    # a gas component whose dependants stay: the reference aborts its first year on the missing
+    # capability (core.cpp:743); here the core is refused with the same finding
+    for secs, what in ((["CH4"], "CH4_concentration not found"), (["CH4", "OH"], "CH4_concentration not found"),
+                       (["OH"], "TAU_OH not found")):
+        path = edited_pack(tmp_path / ("no_%s.hxs" % "_".join(secs)), None, None, [], [],
+                           scalars={(x, "enabled"): 0.0 for x in secs})
+        with pytest.raises(hector_amd.HectorAmdError, match=what):
             hector_amd.Core(path, 1, lib_path=lib, **kw)
 
 

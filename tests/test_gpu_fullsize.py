@@ -75,12 +75,13 @@ def _fetch_members(core, var, members, years_per_piece=40):
     return out
 
 
-def _compare(tag, core, oracle, make_params, members, total, extra, ill_conditioned_allowed=0):
+def _compare(tag, core, oracle, make_params, members, total, extra, ill_conditioned_members=()):
     """members: indices (into the core's ensemble) to check against the oracle.
-    ill_conditioned_allowed: up to that many members may miss the tolerance IF the oracle's own
-    answer for them moves as far under rounding-sized noise (hxo_set_rounding_noise: a
-    controller decision on a tie, which no implementation pins -- SURVEY.md 7 expected "a tiny
-    flip rate on 1 M members"); each is listed in the report."""
+    ill_conditioned_members: the members -- named by index, not by count -- that may miss the
+    tolerance IF the oracle's own answer for them moves as far under rounding-sized noise
+    (hxo_set_rounding_noise: a controller decision on a tie, which no implementation pins --
+    SURVEY.md 7 expected "a tiny flip rate on 1 M members"); each is listed in the report.  Any
+    other member outside the tolerance fails the test."""
     t0 = time.time()
     oco2, otg, ots, oerr = _oracle_all(oracle, lambda k: make_params(int(members[k])), len(members))
     t_or = time.time() - t0
@@ -105,7 +106,10 @@ def _compare(tag, core, oracle, make_params, members, total, extra, ill_conditio
     bad = np.nonzero((rel.max(1) >= REL_CO2) | (dt.max(1) >= ABS_T) | flips)[0]
     rep["members_outside_the_tolerance"] = int(bad.size)
     rep["north_star_members_over_1e-6"] = int((rel.max(1) > 1e-6).sum())
-    if bad.size and bad.size <= ill_conditioned_allowed:
+    known = set(int(x) for x in ill_conditioned_members)
+    unexpected = [int(members[k]) for k in bad if int(members[k]) not in known]
+    rep["members_outside_the_tolerance_not_on_the_list_of_known_ties"] = unexpected
+    if bad.size and not unexpected:
         from test_random_sweep import self_sensitivity
         rep["ill_conditioned_members"] = []
         for k in bad:
@@ -121,7 +125,7 @@ def _compare(tag, core, oracle, make_params, members, total, extra, ill_conditio
     with open(os.path.join(ROOT, "gpurun_out", "parity_fullsize_%s.json" % tag), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
-    assert bad.size <= ill_conditioned_allowed, rep
+    assert not unexpected, rep
     for m in rep.get("ill_conditioned_members", []):
         # the oracle does not pin this member either: its own answer moves as far
         assert m["rel_dCO2"] < 50.0 * m["oracle_moves_under_1e-13_noise_by"], m
@@ -220,8 +224,10 @@ def test_config4_million_member_grid_sample_vs_oracle(hip_lib, oracle):
     """configs[3]'s 1 048 576 members on one GPU (the 8-GPU job shards exactly this grid): 65 536
     members spread evenly over it (every 16th, among them member 394 646, the one member of the
     million that round 2's every-member pass found outside the tolerance) against the oracle.
-    The statement: at most 2 of them miss 2e-8, and those are members whose last-year stash
-    decision the oracle itself does not pin (it flips under +-1e-13 noise)."""
+    The statement: none of them misses 2e-8 except, possibly, member 394 646 (S = 5.385,
+    Q10 = 1.807) -- whitelisted BY INDEX: its last-year stash decision is a tie of the ocean's
+    timestep controller that the oracle itself does not pin (it flips under +-1e-13 noise, which
+    the test then demonstrates)."""
     n = 1 << 20
     S, q10 = ensemble.ecs_q10(n)
     c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
@@ -236,4 +242,5 @@ def test_config4_million_member_grid_sample_vs_oracle(hip_lib, oracle):
         p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
         return p
     _compare("config4_1048576x1_sample", c, oracle, mp, members, n,
-             {"ensemble": "S ~ U(1.5, 6), q10_rh ~ U(1, 3), seed 20260928"}, ill_conditioned_allowed=2)
+             {"ensemble": "S ~ U(1.5, 6), q10_rh ~ U(1, 3), seed 20260928", "kernel": c.last_run_kernel()},
+             ill_conditioned_members=(394646,))

@@ -95,6 +95,31 @@ def test_lint_sees_a_matrix_result_read_too_early(tmp_path):
     assert _scan_mfma(MFMA_ROUND_ROBIN, tmp_path, "rr.s") == []
 
 
+def test_lint_sees_vgpr_accumulators_too(tmp_path):
+    """The two-wavefront flavour pins its accumulators in VGPRs ("v" operands of the asm pin): the
+    same hazards, with any vector instruction or store as the reader."""
+    early = ("\n_Z6kernelv:\n"
+             "\tv_mfma_f64_16x16x4_f64 v[100:107], v[0:1], v[2:3], v[100:107]\n"
+             "\tv_mfma_f64_16x16x4_f64 v[108:115], v[0:1], v[4:5], v[108:115]\n"
+             "\tv_add_f64 v[40:41], v[108:109], v[40:41]\n"
+             "\ts_endpgm\n.Lfunc_end0:\n")
+    hits = _scan_mfma(early, tmp_path, "vearly.s")
+    assert len(hits) == 1 and "v_add_f64" in hits[0][2], hits
+    pinned = early.replace("\tv_add_f64", "\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_add_f64")
+    assert _scan_mfma(pinned, tmp_path, "vpinned.s") == []
+    store = early.replace("v_add_f64 v[40:41], v[108:109], v[40:41]", "global_store_dwordx2 v50, v[108:109], s[2:3]")
+    assert len(_scan_mfma(store, tmp_path, "vstore.s")) == 1
+    # a result overwritten by a load before anyone reads it is no hazard of THIS kind
+    over = early.replace("\tv_add_f64", "\tglobal_load_dwordx2 v[108:109], v50, s[2:3]\n\tv_add_f64")
+    assert _scan_mfma(over, tmp_path, "vover.s") == []
+    b2b = MFMA_BACK_TO_BACK.replace("a[0:7]", "v[100:107]")
+    assert len(_scan_mfma(b2b, tmp_path, "vb2b.s")) >= 1
+    rr = "\n_Z6kernelv:\n.LBB0_1:\n" + "".join(
+        "\tv_mfma_f64_16x16x4_f64 v[%d:%d], v[0:1], v[2:3], v[%d:%d]\n" % (100 + 8 * k, 107 + 8 * k, 100 + 8 * k, 107 + 8 * k)
+        for k in range(8)) + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n.Lfunc_end0:\n"
+    assert _scan_mfma(rr, tmp_path, "vrr.s") == []
+
+
 def test_assembly_of_the_built_library_is_clean():
     files = glob.glob(os.path.join(ROOT, "hector_amd", "build", "hx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"))
     if not files:
@@ -102,3 +127,8 @@ def test_assembly_of_the_built_library_is_clean():
         pytest.skip("no assembly in hector_amd/build (the library was not built in this tree)")
     assert check_isa.scan(files[0]) == []
     assert check_isa.scan_mfma(files[0]) == []
+    # ... and the lint did look at the two-wavefront flavour's matrix instructions (VGPR form)
+    text = open(files[0], errors="replace").read()
+    k = text.index("_Z13hx_run_kernelILi101ELb0ELb0ELi0EEvPK6HxArgsii:")
+    body = text[k:text.index(".Lfunc_end", k)]
+    assert body.count("v_mfma_f64_16x16x4_f64 v[") >= 32 and "v_mfma_f64_16x16x4_f64 a[" not in body

@@ -20,7 +20,8 @@ hundred lines earlier (the other arm of an if / else that merges two values into
 the branch computed may be copied under the branch's mask: the other lanes got theirs before
 the branch.  A value from outside the branch may not.)  Exit status 1 if there is any.
 
-Second check (scan_mfma): the fp64 matrix-pipe pass keeps its accumulators in AGPRs across the
+Second check (scan_mfma; AGPR accumulators in the one-wavefront kernels, VGPR ones in the
+two-wavefront flavour): the fp64 matrix-pipe pass keeps its accumulators in AGPRs across the
 loop by an `asm` statement that hides the v_mfma results from the compiler's hazard recogniser
 and carries the wait states itself (hx_kernels.hip, doeclim_pass_mfma).  That is only correct
 while the wait really sits between every v_mfma_f64_16x16x4_f64 and the first instruction that
@@ -105,15 +106,29 @@ def scan(path):
     return found
 
 
-MFMA = re.compile(r"^\s*v_mfma_f64_16x16x4_f64\s+a\[(\d+):(\d+)\],\s*\S+,\s*\S+,\s*(a\[(\d+):(\d+)\]|\S+)")
-AREAD = re.compile(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b")
+MFMA = re.compile(r"^\s*v_mfma_f64_16x16x4_f64\s+([av])\[(\d+):(\d+)\],\s*([^,]+),\s*([^,]+),\s*(\S+)")
+REG = re.compile(r"\b([av])\[(\d+):(\d+)\]|\b([av])(\d+)\b")
 MFMA_WAIT = 18   # 8 passes of a 16x16x4 fp64 MFMA: its result may be read 18 wait states later
 MFMA_PASSES = 8  # issue slots a v_mfma_f64_16x16x4_f64 itself occupies
+STORES = ("global_store", "scratch_store", "ds_write", "buffer_store", "flat_store")
+
+
+def _regs(text):
+    """[(file, index)] of every a / v register named in an operand string."""
+    out = []
+    for r in REG.finditer(text):
+        if r.group(1) is not None:
+            out.extend((r.group(1), k) for k in range(int(r.group(2)), int(r.group(3)) + 1))
+        else:
+            out.append((r.group(4), int(r.group(5))))
+    return out
 
 
 def scan_mfma(path):
-    """-> [(kernel, line number, text, wait states seen)]: AGPR reads too close behind the
-    v_mfma that produced them."""
+    """-> [(kernel, line number, text, wait states seen)]: reads of a v_mfma result -- in the AGPRs
+    of the one-wavefront kernels or the VGPRs of the two-wavefront flavour, as SrcC of a later
+    v_mfma, by v_accvgpr_read, a store or any vector instruction -- too close behind the v_mfma that
+    produced it."""
     lines = open(path, errors="replace").read().split("\n")
     found = []
     kernels, cur = [], None
@@ -125,11 +140,11 @@ def scan_mfma(path):
             continue
         if cur is None:
             continue
-        s = l.strip()
+        s = l.split(";")[0].strip()
         if s.startswith(".Lfunc_end"):
             cur = None
             continue
-        if not s or s[0] == ";" or (s[0] == "." and not s.startswith(".LBB")):
+        if not s or (s[0] == "." and not s.startswith(".LBB")):
             continue
         cur[1].append((i + 1, s))
     for name, ins in kernels:
@@ -146,36 +161,34 @@ def scan_mfma(path):
                 if tgt in labels and labels[tgt] < k and any(x.startswith("v_mfma_f64") for _, x in ins[labels[tgt]:k]):
                     stream.extend(ins[labels[tgt]:k + 1])
         clock = 0
-        written = {}   # AGPR index -> clock of the v_mfma that last wrote it
+        written = {}   # (file, index) -> clock of the v_mfma that last wrote it
         for ln, t in stream:
             if t.startswith(".LBB"):
                 continue
             op = t.split()[0]
             m = MFMA.match(t)
-            reads = []
+            body = t[len(op):]
+            reads, writes = [], []
             if m:
-                if m.group(4) is not None:
-                    reads = list(range(int(m.group(4)), int(m.group(5)) + 1))
-            elif op.startswith(("v_accvgpr_read", "v_accvgpr_mov", "global_store", "scratch_store", "ds_write", "buffer_store")):
-                body = t[len(op):]
-                if op.startswith("v_accvgpr"):
-                    body = body.split(",", 1)[1] if "," in body else ""
-                for r in AREAD.finditer(body):
-                    if r.group(1) is not None:
-                        reads.extend(range(int(r.group(1)), int(r.group(2)) + 1))
-                    else:
-                        reads.append(int(r.group(3)))
+                reads = _regs(m.group(4)) + _regs(m.group(5)) + _regs(m.group(6))
+            elif op.startswith(STORES):
+                reads = _regs(body)
+            elif op.startswith(("v_", "global_load", "ds_read", "scratch_load", "buffer_load", "flat_load")):
+                parts = body.split(",", 1)
+                writes = _regs(parts[0])
+                reads = _regs(parts[1]) if len(parts) > 1 else []
+                if op.startswith(("v_cmp", "v_cmpx")):   # (compares write vcc / an SGPR pair)
+                    reads, writes = _regs(body), []
             for a in reads:
                 if a in written and clock - written[a] < MFMA_WAIT:
                     found.append((name, ln, t, clock - written[a]))
                     break
             if m:
-                for a in range(int(m.group(1)), int(m.group(2)) + 1):
-                    written[a] = clock
-            elif op.startswith("v_accvgpr_write"):
-                mm = re.match(r"v_accvgpr_write_b32\s+a(\d+)", t)
-                if mm:
-                    written.pop(int(mm.group(1)), None)
+                for k in range(int(m.group(2)), int(m.group(3)) + 1):
+                    written[(m.group(1), k)] = clock
+            else:
+                for a in writes:
+                    written.pop(a, None)
             n = re.match(r"s_nop\s+(\d+)", t)
             clock += int(n.group(1)) + 1 if n else (MFMA_PASSES if m else 1)
     return found
