@@ -71,40 +71,58 @@ struct Dp5 {
 // one dopri5 attempt on NP variables: candidate xn, its derivative dn, and the error quotients
 // en_i = |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)) of every variable (the divisions side
 // by side here, BEFORE the hand-off: after the barrier an attempt's error is two maxima away)
+// (T: the tableau as data, HxConst::tab in hx_fill_tableau's order, or null for the literals)
 template <int NP, class Rhs>
 __device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double eps_abs,
                                              double eps_rel, const double *y, const double *dxdt,
-                                             double *xn, double *dn, double *en, double *ed) {
+                                             double *xn, double *dn, double *en, double *ed,
+                                             const double *T = nullptr) {
   double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP];
+  struct Tab {
+    const double *T;
+    // stage 2: b21, 1/5 | 3: b31 b32 3/10 | 4: b41 b42 b43 4/5 | 5: b51..b54 8/9 | 6: b61..b65 |
+    // candidate: c1 c3 c4 c5 c6 | error: dc1 dc3 dc4 dc5 dc6 dc7
+    __device__ __forceinline__ double operator()(int i, double lit) const { return T ? T[i] : lit; }
+  } const tb{T};
+  struct {
+    double b21, b31, b32, b41, b42, b43, b51, b52, b53, b54, b61, b62, b63, b64, b65, c1, c3, c4, c5,
+        c6, dc1, dc3, dc4, dc5, dc6, dc7;
+  } const Dp5 = {tb(0, ::Dp5::b21), tb(2, ::Dp5::b31), tb(3, ::Dp5::b32), tb(5, ::Dp5::b41),
+                 tb(6, ::Dp5::b42), tb(7, ::Dp5::b43), tb(9, ::Dp5::b51), tb(10, ::Dp5::b52),
+                 tb(11, ::Dp5::b53), tb(12, ::Dp5::b54), tb(14, ::Dp5::b61), tb(15, ::Dp5::b62),
+                 tb(16, ::Dp5::b63), tb(17, ::Dp5::b64), tb(18, ::Dp5::b65), tb(19, ::Dp5::c1),
+                 tb(20, ::Dp5::c3), tb(21, ::Dp5::c4), tb(22, ::Dp5::c5), tb(23, ::Dp5::c6),
+                 tb(24, ::Dp5::dc1), tb(25, ::Dp5::dc3), tb(26, ::Dp5::dc4), tb(27, ::Dp5::dc5),
+                 tb(28, ::Dp5::dc6), tb(29, ::Dp5::dc7)};
 #pragma unroll
-  for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5::b21 * dxdt[i];
+  for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5.b21 * dxdt[i];
   rhs(xt, k2, 1);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5::b31 * dxdt[i] + dtl * Dp5::b32 * k2[i];
+  for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * Dp5.b31 * dxdt[i] + dtl * Dp5.b32 * k2[i];
   rhs(xt, k3, 2);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
-    xt[i] = y[i] + dtl * Dp5::b41 * dxdt[i] + dtl * Dp5::b42 * k2[i] + dtl * Dp5::b43 * k3[i];
+    xt[i] = y[i] + dtl * Dp5.b41 * dxdt[i] + dtl * Dp5.b42 * k2[i] + dtl * Dp5.b43 * k3[i];
   rhs(xt, k4, 3);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
-    xt[i] = y[i] + dtl * Dp5::b51 * dxdt[i] + dtl * Dp5::b52 * k2[i] + dtl * Dp5::b53 * k3[i] +
-            dtl * Dp5::b54 * k4[i];
+    xt[i] = y[i] + dtl * Dp5.b51 * dxdt[i] + dtl * Dp5.b52 * k2[i] + dtl * Dp5.b53 * k3[i] +
+            dtl * Dp5.b54 * k4[i];
   rhs(xt, k5, 4);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
-    xt[i] = y[i] + dtl * Dp5::b61 * dxdt[i] + dtl * Dp5::b62 * k2[i] + dtl * Dp5::b63 * k3[i] +
-            dtl * Dp5::b64 * k4[i] + dtl * Dp5::b65 * k5[i];
+    xt[i] = y[i] + dtl * Dp5.b61 * dxdt[i] + dtl * Dp5.b62 * k2[i] + dtl * Dp5.b63 * k3[i] +
+            dtl * Dp5.b64 * k4[i] + dtl * Dp5.b65 * k5[i];
   rhs(xt, k6, 5);
 #pragma unroll
   for (int i = 0; i < NP; ++i)
-    xn[i] = y[i] + dtl * Dp5::c1 * dxdt[i] + dtl * Dp5::c3 * k3[i] + dtl * Dp5::c4 * k4[i] +
-            dtl * Dp5::c5 * k5[i] + dtl * Dp5::c6 * k6[i];
+    xn[i] = y[i] + dtl * Dp5.c1 * dxdt[i] + dtl * Dp5.c3 * k3[i] + dtl * Dp5.c4 * k4[i] +
+            dtl * Dp5.c5 * k5[i] + dtl * Dp5.c6 * k6[i];
   rhs(xn, dn, 5);
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const double xe = dtl * Dp5::dc1 * dxdt[i] + dtl * Dp5::dc3 * k3[i] + dtl * Dp5::dc4 * k4[i] +
-                      dtl * Dp5::dc5 * k5[i] + dtl * Dp5::dc6 * k6[i] + dtl * Dp5::dc7 * dn[i];
+    const double xe = dtl * Dp5.dc1 * dxdt[i] + dtl * Dp5.dc3 * k3[i] + dtl * Dp5.dc4 * k4[i] +
+                      dtl * Dp5.dc5 * k5[i] + dtl * Dp5.dc6 * k6[i] + dtl * Dp5.dc7 * dn[i];
     en[i] = hx_div(fabs(xe), eps_abs + eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i])));
   }
   (void)ed;
@@ -373,7 +391,13 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
             if (c.stepping && pair_retry(c, status)) { load_pools(); rhs(y, dxdt, 0); }
           }
           const bool tried = c.stepping;
+#ifndef HX_PAIR_TAB_LITERALS
+          const double *Tp;
+          { int toff = 0; asm volatile("" : "+s"(toff)); Tp = kc.tab + toff; }   // (read in this pass: see solve_year)
+          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed, Tp);
+#else
           pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+#endif
           if (!sums_done) history_sums(iy);
           s_st[par][PS_N0][lane] = en[0];
           s_st[par][PS_N4][lane] = en[1];
@@ -737,7 +761,13 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
             rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
             rrs[5] = hx_div1(luc_e, tot0 + hC);
           }
+#ifndef HX_PAIR_TAB_LITERALS
+          const double *Tp;
+          { int toff = 0; asm volatile("" : "+s"(toff)); Tp = kc.tab + toff; }   // (read in this pass: see solve_year)
+          pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed, Tp);
+#else
           pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+#endif
           const double bn = fmax(fmax(en[0], en[1]), en[2]);  // largest quotient of the three
           s_st[par][PS_NL][lane] = bn;
           PSTAMPF(12);

@@ -1721,7 +1721,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
 #endif
 }
-#if HX_HAS_MFMA && !defined(HX_W2_ONLY)
+#if HX_HAS_MFMA && (!defined(HX_W2_ONLY) || defined(HX_WITH_PAIR))
 #define HX_HAS_PAIR 1
 #include "hx_dev_pair.h"
 #else

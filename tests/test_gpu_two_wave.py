@@ -153,3 +153,26 @@ def test_config4_share_of_one_gpu_every_member_vs_oracle(hip_lib, oracle):
              {"ensemble": "S ~ U(1.5, 6), q10_rh ~ U(1, 3), seed 20260928 (hector_amd/ensemble.py)",
               "kernel": c.last_run_kernel()})
     c.shutdown()
+
+
+def test_two_wave_kernel_heat_flux_instantiation_vs_plain_kernel_and_oracle(hip_lib, oracle):
+    """hx_run_kernel<HX_B1W2, HF>: the second history sum (16 accumulator tiles in VGPRs) behind
+    the `heatflux` output -- against the plain kernel's heat-flux instantiation and the oracle."""
+    n = 2048
+    outs = ["CO2_concentration", "global_tas", "heatflux", "timesteps"]
+    a, S, q10 = _core(hip_lib, n, True, outs)
+    b, _, _ = _core(hip_lib, n, False, outs)
+    a.run(2300); b.run(2300)
+    assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run"
+    assert (a.status() == 0).all()
+    assert np.array_equal(a.fetchvars("timesteps", (1745, 2300)), b.fetchvars("timesteps", (1745, 2300)))
+    for v in ("CO2_concentration", "global_tas", "heatflux"):
+        x, y = a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))
+        assert (np.abs(x - y) / np.maximum(np.abs(y), 1.0)).max() < REL_CO2, v
+    for i in (0, 777, 2047):
+        p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        r, err, _ = oracle.run(p)
+        assert err == 0
+        assert np.abs(a.fetchvars("heatflux", (1745, 2300))[:, i] - r["heatflux"]).max() < ABS_T
+        assert np.abs(a.fetchvars("global_tas", (1745, 2300))[:, i] - r["global_tas"]).max() < ABS_T
+    a.shutdown(); b.shutdown()
