@@ -487,6 +487,7 @@ void EnsembleCore::build_shared() {
   hx_fill_tableau(k.tab);
   hx_fill_math_table(k.mtab);
   hx_fill_chem_table_host(k.ctab);
+  hx_fill_chem_fit(k.kfit);
 }
 
 void EnsembleCore::free_device() {

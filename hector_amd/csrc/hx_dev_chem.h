@@ -326,6 +326,85 @@ inline void hx_fill_chem_table(double *t) {
   for (int i = 0; i < 39; ++i) t[i] = v[i];
   t[39] = 0.0;
 }
+// The six exponentials of BOTH boxes from the fitted polynomials (HxConst::kfit; hx_chem_fit.inc,
+// tools/make_chem_fit.py): a box's temperature stays within a few kelvin of a fixed centre for a
+// whole run (SST anomaly + 18 + deltaT), and over centre +- 8 K each of K0, Kw, 1/Kh, K1, K2, Kb
+// is ONE degree-13 polynomial in t = (Tc - centre) / 8 K to 3.4e-16 relative (truncation < 2e-17;
+// the rest is Horner's rounding, like the ~1 ulp of the exponential it replaces) -- 13
+// multiply-adds instead of an argument polynomial, a logarithm and a 23-instruction exponential:
+// twelve independent chains, coefficient row after coefficient row through scalar loads.
+// e[0..5] = HL's, e[6..11] = LL's, in chem_exponents' order.  The caller checks the interval
+// (chem_fit_applies) for the WHOLE wavefront and takes the formulas themselves otherwise.
+__device__ __forceinline__ bool chem_fit_applies(double TcH, double TcL) {
+  // (written so that a NaN temperature is outside)
+  return fabs(TcH - HX_CHEM_FIT_CENTRE_HL) <= HX_CHEM_FIT_HALF_WIDTH &&
+         fabs(TcL - HX_CHEM_FIT_CENTRE_LL) <= HX_CHEM_FIT_HALF_WIDTH;
+}
+__device__ __forceinline__ void chem_constants_fit(double TcH, double TcL, const double *F, double *e) {
+  const double t[2] = {(TcH - HX_CHEM_FIT_CENTRE_HL) * (1.0 / HX_CHEM_FIT_HALF_WIDTH),
+                       (TcL - HX_CHEM_FIT_CENTRE_LL) * (1.0 / HX_CHEM_FIT_HALF_WIDTH)};
+  double p[12];
+#ifndef HX_HOST_EMULATION
+  // Row after row, twelve chains side by side: the next row's coefficients are requested
+  // (scalar loads) while this row's multiply-adds issue, and a scheduling barrier keeps the
+  // optimiser from asking for all 168 at once (336 scalar registers: it spills 90 of them).
+  // v_fma_f64 takes the coefficient from its SGPR pair as the addend (left to the compiler a
+  // coefficient that is used once becomes two v_mov into the destination of a v_fmac_f64: three
+  // vector instructions per multiply-add).  The wait for a row sits BEHIND the multiply-adds of the
+  // row before it (HX_ROW_ARRIVED: scalar loads return out of order, so a wait is for all of them,
+  // and placed lazily -- in front of the row's first use -- it would also wait out the row
+  // requested just before it).  (HX_CHEM_FIT_GROUP 6: one box at a time, half the scalar registers;
+  // measured slower, profiles/r04_variant_log.md.)
+#ifndef HX_CHEM_FIT_GROUP
+#define HX_CHEM_FIT_GROUP 12
+#endif
+  constexpr int G = HX_CHEM_FIT_GROUP;
+#if HX_CHEM_FIT_GROUP == 6
+#define HX_ROW_ARRIVED(r) asm volatile("" :: "s"(r[0]), "s"(r[1]), "s"(r[2]), "s"(r[3]), "s"(r[4]), "s"(r[5]))
+#else
+#define HX_ROW_ARRIVED(r) asm volatile("" :: "s"(r[0]), "s"(r[1]), "s"(r[2]), "s"(r[3]), "s"(r[4]), "s"(r[5]), \
+                                       "s"(r[6]), "s"(r[7]), "s"(r[8]), "s"(r[9]), "s"(r[10]), "s"(r[11]))
+#endif
+#pragma unroll
+  for (int g0 = 0; g0 < 12; g0 += G) {
+    double cur[G], nxt[G];
+#pragma unroll
+    for (int f = 0; f < G; ++f) { cur[f] = F[g0 + f]; nxt[f] = F[12 + g0 + f]; }
+    HX_ROW_ARRIVED(cur);
+#pragma unroll
+    for (int f = 0; f < G; ++f) asm("v_mov_b64 %0, %1" : "=v"(p[g0 + f]) : "s"(cur[f]));   // (row 0: the leading coefficients)
+    HX_ROW_ARRIVED(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < G; ++f) cur[f] = nxt[f];
+#pragma unroll
+    for (int j = 1; j <= HX_CHEM_FIT_DEGREE; ++j) {
+      if (j < HX_CHEM_FIT_DEGREE) {
+#pragma unroll
+        for (int f = 0; f < G; ++f) nxt[f] = F[(j + 1) * 12 + g0 + f];
+      }
+#pragma unroll
+      for (int f = 0; f < G; ++f)
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p[g0 + f]) : "v"(p[g0 + f]), "v"(t[(g0 + f) / 6]), "s"(cur[f]));
+      if (j < HX_CHEM_FIT_DEGREE) HX_ROW_ARRIVED(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < G; ++f) cur[f] = nxt[f];
+    }
+  }
+#undef HX_ROW_ARRIVED
+#else
+#pragma unroll
+  for (int f = 0; f < 12; ++f) p[f] = F[f];
+#pragma unroll
+  for (int j = 1; j <= HX_CHEM_FIT_DEGREE; ++j) {
+#pragma unroll
+    for (int f = 0; f < 12; ++f) p[f] = fma(p[f], t[f / 6], F[j * 12 + f]);
+  }
+#endif
+#pragma unroll
+  for (int f = 0; f < 12; ++f) e[f] = p[f];
+}
 __device__ __forceinline__ void chem_from_exponentials(double Tc, const double *e, double As,
                                                        ChemK &k) {
   const double Sc = 2073.1 - (125.62 * Tc) + (3.6276 * Tc * Tc) - (0.043219 * Tc * Tc * Tc);

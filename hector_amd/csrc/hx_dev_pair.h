@@ -329,12 +329,29 @@ __global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
       // ---- year start (ocean): equilibrium constants of both boxes; LL's go to the land side ----
       const double TcH = sst + 18 + (-16.4), TcL = sst + 18 + 2.9;
-      double lg[2] = {TcH + 273.15, TcL + 273.15};
-      hx_log_batch<2>(lg);
       double ex[12];
-      chem_exponents(TcH, lg[0], &ex[0]);
-      chem_exponents(TcL, lg[1], &ex[6]);
-      hx_exp_chunks<12>(ex);
+#ifndef HX_NO_CHEM_FIT
+      // (see hx_run_kernel, phase A: the fitted polynomials; the formulas themselves for the lanes
+      // of a wavefront that holds a box temperature outside the fit's interval)
+      const bool fit_in = chem_fit_applies(TcH, TcL);
+      chem_constants_fit(TcH, TcL, kc.kfit, ex);
+      if (__builtin_expect(__any(!fit_in), 0))
+#endif
+      {
+        double lg[2] = {TcH + 273.15, TcL + 273.15}, e12[12];
+        hx_log_batch<2>(lg);
+        chem_exponents(TcH, lg[0], &e12[0]);
+        chem_exponents(TcL, lg[1], &e12[6]);
+        hx_exp_chunks<12>(e12);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+#ifndef HX_NO_CHEM_FIT
+          ex[i] = fit_in ? ex[i] : e12[i];
+#else
+          ex[i] = e12[i];
+#endif
+        }
+      }
       chem_from_exponentials(TcH, &ex[0], O_AsHL, kH);
       chem_from_exponentials(TcL, &ex[6], O_AsLL, kL);
       chem_poly_constants(alkH, kH);

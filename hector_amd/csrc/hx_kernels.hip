@@ -558,7 +558,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
     ya[4] = shn[HXSH_CH4N]; ya[5] = shn[HXSH_O3_NOX]; ya[6] = shn[HXSH_O3_CO]; ya[7] = shn[HXSH_O3_NMVOC];
     ya[8] = shn[HXSH_FFI]; ya[9] = shn[HXSH_DACCS]; ya[10] = shn[HXSH_LUC_E]; ya[11] = shn[HXSH_LUC_U];
   };
+#ifndef HX_NO_SCALAR_PREFETCH
   if constexpr (!hx_w2<B>()) load_year_a(iy_from + 1);
+#endif
   if constexpr (CON >= 2) m.trk_iy = args->kc.trk_iy;
   if constexpr (CON == 3) { m.trk_rec = s_trk_rec; m.trk_cmd = s_trk_cmd; }
   int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
@@ -610,6 +612,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         load_year_a(iy);
         pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold >= 1 ? iold : 0) * buf.npad, m.moff);
       }
+#ifdef HX_NO_SCALAR_PREFETCH
+      else load_year_a(iy);
+#endif
       const double tl_old = pf_tl_old;
       constexpr int NB = hx_nbc<B>();
       constexpr int SB = (B == HX_DYN) ? 1 : NB;  // (the looped kernels read these where they use them)
@@ -692,17 +697,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         Tb[b] = tland * p_wf[b];
         lg[2 + b] = (Tb[b] > 0) ? Tb[b] : 1.0;  // ln(Tb) of the permafrost curve, if Tb > 0
       }
-      hx_log_batch<2 + NB>(lg, kc.mtab);
       double ex[13 + 2 * NB];
-      // (literals here: as data -- HxConst::ctab, -DHX_CHEM_TABLE -- the 39 constants arrive in
-      // one sweep of scalar loads, 78 SGPRs at once, and 73 of the kernel's SGPRs spill)
-#ifdef HX_CHEM_TABLE
-      chem_exponents(TcH, lg[0], &ex[0], kc.ctab);
-      chem_exponents(TcL, lg[1], &ex[6], kc.ctab);
-#else
-      chem_exponents(TcH, lg[0], &ex[0]);
-      chem_exponents(TcL, lg[1], &ex[6]);
-#endif
       ex[12] = -toh;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -710,7 +705,56 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         ex[13 + 2 * b] = p_lnq10[b] * (Tb[b] * 0.1);
         ex[14 + 2 * b] = p_lnq10[b] * (Trm * 0.1);
       }
-      hx_exp_chunks<13 + 2 * NB>(ex, kc.mtab);
+      // The year's other logarithms and exponentials (permafrost curve, OH lifetime, Q10 factors)
+      // in their own batches; the twelve T-only constants of the two boxes from the fitted
+      // polynomials (chem_constants_fit) -- except for a lane whose box temperature has left the
+      // fit's interval (SST anomalies outside -3 ... +13 K): when the wavefront holds such a lane
+      // every lane also evaluates the formulas themselves, and each lane keeps the fit's values if
+      // it is inside and the formulas' if it is not, so that a member's result does not depend on
+      // its neighbours.  (-DHX_NO_CHEM_FIT: the formulas for every lane, experiment builds.)
+      if constexpr (NB > 0) {
+        double lb[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) lb[b] = lg[2 + b];
+        hx_log_batch<(NB > 0 ? NB : 1)>(lb, kc.mtab);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) lg[2 + b] = lb[b];
+      }
+      {
+        double eb[1 + 2 * NB];
+#pragma unroll
+        for (int i = 0; i < 1 + 2 * NB; ++i) eb[i] = ex[12 + i];
+        hx_exp_chunks<1 + 2 * NB>(eb, kc.mtab);
+#pragma unroll
+        for (int i = 0; i < 1 + 2 * NB; ++i) ex[12 + i] = eb[i];
+      }
+#ifndef HX_NO_CHEM_FIT
+      const bool fit_in = chem_fit_applies(TcH, TcL);
+      chem_constants_fit(TcH, TcL, kc.kfit, ex);
+      if (__builtin_expect(__any(!fit_in), 0))
+#endif
+      {
+        double l2[2] = {lg[0], lg[1]}, e12[12];
+        hx_log_batch<2>(l2, kc.mtab);
+      // (literals here: as data -- HxConst::ctab, -DHX_CHEM_TABLE -- the 39 constants arrive in
+      // one sweep of scalar loads, 78 SGPRs at once, and 73 of the kernel's SGPRs spill)
+#ifdef HX_CHEM_TABLE
+        chem_exponents(TcH, l2[0], &e12[0], kc.ctab);
+        chem_exponents(TcL, l2[1], &e12[6], kc.ctab);
+#else
+        chem_exponents(TcH, l2[0], &e12[0]);
+        chem_exponents(TcL, l2[1], &e12[6]);
+#endif
+        hx_exp_chunks<12>(e12, kc.mtab);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+#ifndef HX_NO_CHEM_FIT
+          ex[i] = fit_in ? ex[i] : e12[i];
+#else
+          ex[i] = e12[i];
+#endif
+        }
+      }
       const double tau_oh = kc.TOH0 * ex[12];
       if constexpr (CON) {
       if (buf.out[HXO_TAU_OH]) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
@@ -824,8 +868,12 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         const bool newblk = blk0 < 0 || iy >= blk0 + HX_DBLK;  // (then the pass has not run yet)
         pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iy - blk0) * buf.npad + mem];
         hx_ccd shc = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+#ifndef HX_NO_SCALAR_PREFETCH
         yc4[0] = shc[HXSH_SQRT_N2O]; yc4[1] = shc[HXSH_RF_OTHER]; yc4[2] = shc[HXSH_RF_AERO]; yc4[3] = shc[HXSH_RF_VOL];
         load_year_a(iy + 1);
+#else
+        (void)shc;
+#endif
       }
       const double year = (double)(args->kc.start_year + iy);
       YearCon yc{};
@@ -881,6 +929,11 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           const int i = blk0 + r;
           Tall[r] = hx_ldm(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
         }
+      }
+#endif
+#ifdef HX_NO_SCALAR_PREFETCH
+      if constexpr (!hx_w2<B>()) {
+        yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
       }
 #endif
       if constexpr (hx_w2<B>()) {  // what the other kernels request ahead of the solver

@@ -154,7 +154,16 @@ struct HxConst {
   double mtab[32];
   // ... and the constants of the equilibrium-constant formulas (hx_fill_chem_table, hx_dev_chem.h)
   double ctab[40];
+  // The surface boxes' six T-only equilibrium constants as polynomials in the box temperature
+  // (hx_chem_fit.inc, generated by tools/make_chem_fit.py; chem_constants_fit in hx_dev_chem.h):
+  // [power, descending][box * 6 + {K0, Kw, 1/Kh, K1, K2, Kb}]
+  double kfit[14 * 12];
 };
+#include "hx_chem_fit.inc"
+static_assert(HX_CHEM_FIT_DEGREE == 13, "HxConst::kfit is sized for degree 13");
+inline void hx_fill_chem_fit(double *t) {
+  for (int i = 0; i < (HX_CHEM_FIT_DEGREE + 1) * 12; ++i) t[i] = hx_chem_fit_table[i];
+}
 // [0..11] exp Taylor 1/13! .. 1/2!, [12] log2 e, [13] -ln2_hi, [14] -ln2_lo; [16..22] Lg1..Lg7,
 // [23] ln2_hi, [24] ln2_lo, [25] sqrt(1/2)   (hx_dev_math.h)
 inline void hx_fill_math_table(double *t) {

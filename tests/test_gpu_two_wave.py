@@ -176,3 +176,44 @@ def test_two_wave_kernel_heat_flux_instantiation_vs_plain_kernel_and_oracle(hip_
         assert np.abs(a.fetchvars("heatflux", (1745, 2300))[:, i] - r["heatflux"]).max() < ABS_T
         assert np.abs(a.fetchvars("global_tas", (1745, 2300))[:, i] - r["global_tas"]).max() < ABS_T
     a.shutdown(); b.shutdown()
+
+
+def test_two_wave_kernel_with_rows_that_differ_between_members(hip_lib, oracle):
+    """Every table row the flavour reads through a scalar load when the members share it --
+    biome constants, warming factor, aerosol / volcanic scaling, C0, ocean transports -- perturbed
+    per member here: the member's own rows are read instead.  Against the plain kernel and, for a
+    few members, the oracle."""
+    n = 1024
+    S, q10 = ensemble.ecs_q10(n)
+    rng = np.random.default_rng(11)
+    par = {"beta": 0.3 + 0.4 * rng.random(n), "aero_scalar": 0.5 + rng.random(n),
+           "vol_scalar": 0.5 + rng.random(n), "npp_flux0": 50.0 + 10.0 * rng.random(n),
+           "warmingfactor": 1.0 + 0.5 * rng.random(n), "f_nppv": 0.3 + 0.1 * rng.random(n),
+           "pf_mu": 1.6 + 0.2 * rng.random(n), "tt": 6.5e7 + 1e7 * rng.random(n),
+           "C0": 270.0 + 15.0 * rng.random(n)}
+    outs = ["CO2_concentration", "global_tas", "timesteps"]
+    cores = []
+    for two_wave in (True, False):
+        c, _, _ = _core(hip_lib, n, two_wave, outs)
+        for k, v in par.items():
+            c.setvar(k, v)
+        c.run(2300)
+        assert (c.status() == 0).all()
+        cores.append(c)
+    a, b = cores
+    assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run"
+    assert np.array_equal(a.fetchvars("timesteps", (1745, 2300)), b.fetchvars("timesteps", (1745, 2300)))
+    for v in ("CO2_concentration", "global_tas"):
+        x, y = a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))
+        assert (np.abs(x - y) / np.maximum(np.abs(y), 1.0)).max() < REL_CO2, v
+    for i in (0, 513, 1023):
+        p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]
+        p.beta[0] = par["beta"][i]; p.aero_scalar = par["aero_scalar"][i]; p.vol_scalar = par["vol_scalar"][i]
+        p.npp_flux0[0] = par["npp_flux0"][i]; p.warmingfactor[0] = par["warmingfactor"][i]
+        p.f_nppv[0] = par["f_nppv"][i]; p.pf_mu[0] = par["pf_mu"][i]; p.tt = par["tt"][i]; p.C0 = par["C0"][i]
+        r, err, _ = oracle.run(p)
+        assert err == 0
+        ref = r["CO2_concentration"]
+        assert (np.abs(a.fetchvars("CO2_concentration", (1745, 2300))[:, i] - ref) / ref).max() < REL_CO2
+        assert np.abs(a.fetchvars("global_tas", (1745, 2300))[:, i] - r["global_tas"]).max() < ABS_T
+    a.shutdown(); b.shutdown()
