@@ -52,6 +52,11 @@
 #define HX_WAVES_PER_SIMD(B)
 #endif
 
+// (the fitted equilibrium constants of next year evaluated at the end of phase C: see hx_run_kernel)
+#if !defined(HX_NO_CHEM_FIT) && !defined(HX_FIT_IN_PHASE_A)
+#define HX_FIT_CARRIED 1
+#endif
+
 #include "hx_dev_const.h"
 #include "hx_dev_clock.h"
 #include "hx_dev_math.h"
@@ -564,6 +569,19 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   if constexpr (CON >= 2) m.trk_iy = args->kc.trk_iy;
   if constexpr (CON == 3) { m.trk_rec = s_trk_rec; m.trk_cmd = s_trk_cmd; }
   int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
+#ifdef HX_FIT_CARRIED
+  // Next year's fitted equilibrium constants (chem_constants_fit) are evaluated at the END of
+  // phase C -- the SST they depend on is known there -- and carried to the year start in 24
+  // vector registers: in phase A the two coefficient rows in flight (48 scalar registers) pushed
+  // ~60 long-lived scalars into spill lanes (164 v_readlane / v_writelane a year against 63).
+  // (Plain kernels; with constraints or a land-ocean warming ratio the year start may see another
+  // SST than DOECLIM's, and the extended kernels evaluate the fit there.)
+  [[maybe_unused]] double fitc[12];
+  if constexpr (CON == 0) {
+    const double s0 = PKM(m, PK_SST);
+    chem_constants_fit(s0 + 18 + (-16.4), s0 + 18 + 2.9, args->kc.kfit, fitc);
+  }
+#endif
 
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
@@ -730,6 +748,12 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       }
 #ifndef HX_NO_CHEM_FIT
       const bool fit_in = chem_fit_applies(TcH, TcL);
+#ifdef HX_FIT_CARRIED
+      if constexpr (CON == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ex[i] = fitc[i];
+      } else
+#endif
       chem_constants_fit(TcH, TcL, kc.kfit, ex);
       if (__builtin_expect(__any(!fit_in), 0))
 #endif
@@ -1135,6 +1159,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       PKM(m, PK_TL_M1) = tl_seen;  // for the next year
       PKM(m, PK_TLAND) = tl_new;
       PKM(m, PK_SST) = sst_new;
+#ifdef HX_FIT_CARRIED
+      if constexpr (CON == 0) chem_constants_fit(sst_new + 18 + (-16.4), sst_new + 18 + 2.9, kc.kfit, fitc);
+#endif
       // ---- outputs ----
       const size_t o = (size_t)iy * buf.npad + mem;
       if constexpr (hx_w2<B>()) {  // (wave-uniform row address + the lane's 32-bit offset)
