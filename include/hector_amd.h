@@ -192,6 +192,12 @@ int hx_set_member_sorting(hx_core *core, int on);
  * key until the next complete run).  Only ensembles of more wavefronts than the GPU has SIMDs
  * (65 536 members on an MI355X) are reordered: a smaller one lasts as long as its costliest
  * wavefront under any order.  Default on; results do not depend on it.
+ * Cost to know about: that one hx_reset(startDate) uploads the reordered rows and, unless the
+ * spinup is shared by all members, integrates the spinup again before it returns (it BLOCKS for
+ * hx_last_spinup_ms, which then reports that spinup; 0 when the shared spinup was reused), and a
+ * hx_setvar afterwards falls back to the parameter key -- a calibration loop that changes
+ * parameters every iteration (setvar / reset / run) gains nothing from it and should switch it
+ * off with hx_set_lane_calibration(core, 0).
  * hx_lanes_calibrated: 1 once the measured order is in use. */
 int hx_set_lane_calibration(hx_core *core, int on);
 int hx_lanes_calibrated(hx_core *core, int *yes);
