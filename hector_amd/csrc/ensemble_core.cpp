@@ -19,7 +19,7 @@ int hx_pair_available();
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
                               int iy_to, hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st, bool two_wave);
+                         int iy_from, int iy_to, hipStream_t st, bool two_wave, int cus);
 int hx_doeclim_block_years();
 void hx_fill_chem_table_host(double *t);
 hipError_t hx_launch_broadcast(double *table, int nrows, int npad, hipStream_t st);
@@ -1765,7 +1765,7 @@ void EnsembleCore::run(double runtodate) {
                              stream_), "run kernel (pair)");
   else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
-                      stream_, w2),
+                      stream_, w2, simds_ / 4),
         "run kernel");
   check(hipEventRecord(ev1_, stream_), "event");
   run_timed_ = true;

@@ -645,6 +645,24 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
     pc[b] = (co2st * 1e6) * k[b]->rKh;
   }
 }
+// chem_solve2's interface on the select-based restart of chem_solve_boxes (no divergent region:
+// -DHX_CHEM_SELECT routes the run kernels' solves here, experiment builds -- round 3 measured
+// +16 % on the one-wavefront kernel (70 spilled SGPRs), round 4 re-measured it on the
+// two-wavefront flavour: profiles/r04_variant_log.md)
+__device__ __forceinline__ void chem_solve2_select(const ChemK &kH, const ChemK &kL, double cH, double cL,
+                                                   double alkH, double alkL, double &hH, double &hL,
+                                                   double &pco2H, double &pco2L, unsigned &status) {
+  const ChemK *const k[2] = {&kH, &kL};
+  const double carbon[2] = {cH, cL}, alk[2] = {alkH, alkL}, inv_vol[2] = {1.0 / O_vHL, 1.0 / O_vLL};
+  double h[2] = {hH, hL}, pc[2];
+  chem_solve_boxes<2>(k, carbon, alk, inv_vol, h, pc, status);
+  hH = h[0]; hL = h[1]; pco2H = pc[0]; pco2L = pc[1];
+}
+#ifdef HX_CHEM_SELECT
+#define HX_CHEM_SOLVE2 chem_solve2_select
+#else
+#define HX_CHEM_SOLVE2 chem_solve2
+#endif
 // one box (the small-ensemble kernel gives each of its two wavefronts one)
 __device__ __forceinline__ void chem_solve1(const ChemK &kb, double carbon_, double alk_,
                                             double inv_vol_, double &h_, double &pco2,

@@ -227,7 +227,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     // first stash of a year that is the carbon the year-start solve already used
     // (same T, DIC, alk -> same result), so only later stashes need a new solve
     if (!m.chem_fresh)
-      chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
+      HX_CHEM_SOLVE2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
                   m.status);
     m.chem_fresh = false;
     aH = ((co2 - m.pco2H) * m.kH.g) * yf;

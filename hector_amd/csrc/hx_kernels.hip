@@ -821,7 +821,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       HX_STAMP(m, 2);   // T-only equilibrium constants of both boxes (from the exponentials)
       m.annualflux_sum = 0; m.nstash = 0; m.nsteps = 0;
       // (the alkalinities were tuned once, right after the spinup: hx_alk_kernel)
-      chem_solve2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
+      HX_CHEM_SOLVE2(m.kH, m.kL, m.cHL, m.cLL, m.alkH, m.alkL, m.hH, m.hL, m.pco2H, m.pco2L,
                   m.status);
       m.chem_fresh = true;
       HX_STAMP(m, 3);   // year-start carbonate solve
@@ -1714,7 +1714,8 @@ hipError_t hx_launch_alk(const HxArgs *d_args, int nmem_launch, hipStream_t st) 
 #endif
 template <int B>
 static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st, int nb = B, bool two_wave = false) {
+                         int iy_from, int iy_to, hipStream_t st, int nb = B, bool two_wave = false,
+                         int cus = 256) {
   const int blocks = npad / 64;
   const size_t lds = (B == HX_DYN) ? hx_dyn_lds_bytes(nb) : 0;
   if constexpr (B == HX_DYN) {
@@ -1762,13 +1763,9 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 #ifndef HX_W2_ONLY   // (HX_W2_ONLY, with HX_MINIMAL_BUILD: nothing but the plain one-biome kernels)
 #ifndef HX_HOST_EMULATION   // (the host build runs a block's threads one after the other)
   if constexpr (B >= 1 && B <= HX_TRK_COMPANION_MAXB) {  // the maps live on companion wavefronts
-    static const bool inline_maps = getenv("HECTOR_AMD_TRACK_INLINE") != nullptr;
-    static const int cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-      return n;
-    }();
+    // (read at every launch, like hx_looped_from(): a test switches it between two cores; the
+    // CU count is the launching core's device's, handed down by EnsembleCore::run)
+    const bool inline_maps = getenv("HECTOR_AMD_TRACK_INLINE") != nullptr;
     if (con == 2 && !inline_maps && (B == 1 || blocks <= cus)) {
       constexpr int threads = 64 * (1 + trk_waves<B>());
       if (kpm) hipLaunchKernelGGL((hx_run_kernel<B, true, true, 3>), dim3(blocks), dim3(threads), lds, st, d_args, iy_from, iy_to);
@@ -1825,16 +1822,16 @@ hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, boo
 #endif
 }
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
-                         int iy_from, int iy_to, hipStream_t st, bool two_wave) {
+                         int iy_from, int iy_to, hipStream_t st, bool two_wave, int cus) {
 #ifdef HX_W2_ONLY
   if (B != 1) return hipErrorInvalidValue;
-  launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave);
+  launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave, cus);
   return hipGetLastError();
 #else
   switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
-    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave); break;
+    case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave, cus); break;
 #ifndef HX_MINIMAL_BUILD
-    case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+    case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 2, false, cus); break;
     case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
 #endif
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
