@@ -154,6 +154,7 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   check(hipStreamCreate(&stream_), "hipStreamCreate");
   if (const char *e2 = std::getenv("HECTOR_AMD_PAIR_MAX_MEMBERS")) pair_max_members_ = std::atoi(e2);
   if (const char *e3 = std::getenv("HECTOR_AMD_TWO_WAVE_FROM")) two_wave_from_ = std::atoi(e3);
+  if (const char *e4 = std::getenv("HECTOR_AMD_PAIR_ORDER")) pair_costly_with_cheap_ = std::atoi(e4) != 0;
 #ifndef HX_HOST_EMULATION
   {
     hipDeviceProp_t prop;
@@ -1452,6 +1453,18 @@ void EnsembleCore::assign_lanes() {
     // measured cost, costliest first (ties keep the parameter order): wavefronts of members that
     // really take the same number of steps and stashes, the expensive ones dispatched first
     radix_stable_sort(order, 0, (size_t)n_, lane_cost_, true);
+    // Two resident wavefronts per SIMD (the two-wavefront flavour): the first `simds_` wavefronts
+    // get a SIMD each, the next ones join them in dispatch order -- wavefront simds_ + k next to
+    // wavefront k.  In descending order the costliest would share its SIMD with a median one and
+    // a median one with the cheapest; with the second batch ASCENDING the costliest pairs with the
+    // cheapest and every SIMD carries about twice the mean.
+    const int W = n_ / HX_WAVE;   // full wavefronts
+    if (pair_costly_with_cheap_ && W > simds_) {
+      const int hi = std::min(W, 2 * simds_);
+      for (int a = simds_, b = hi - 1; a < b; ++a, --b)
+        std::swap_ranges(order.begin() + (size_t)a * HX_WAVE, order.begin() + (size_t)(a + 1) * HX_WAVE,
+                         order.begin() + (size_t)b * HX_WAVE);
+    }
   }
   for (int l = 0; l < npad_; ++l) member_of_lane_[(size_t)l] = order[(size_t)std::min(l, n_ - 1)];
   for (int l = 0; l < n_; ++l) lane_of_member_[(size_t)order[(size_t)l]] = l;

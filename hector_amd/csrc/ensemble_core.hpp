@@ -234,6 +234,7 @@ class EnsembleCore {
   int pair_max_members_ = 32768;  // ensembles up to this size use the two-wavefront kernel (0: never)
   bool last_run_pair_ = false;
   int two_wave_from_ = -1;        // see set_two_wave_from()
+  bool pair_costly_with_cheap_ = true;   // lane order by measured cost: see assign_lanes()
   bool last_run_w2_ = false;
   int simds_ = 1024;              // SIMDs of this core's device (4 per compute unit)
   mutable double run_ms_ = 0, spin_ms_ = 0;

@@ -563,9 +563,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
     ya[4] = shn[HXSH_CH4N]; ya[5] = shn[HXSH_O3_NOX]; ya[6] = shn[HXSH_O3_CO]; ya[7] = shn[HXSH_O3_NMVOC];
     ya[8] = shn[HXSH_FFI]; ya[9] = shn[HXSH_DACCS]; ya[10] = shn[HXSH_LUC_E]; ya[11] = shn[HXSH_LUC_U];
   };
-#ifndef HX_NO_SCALAR_PREFETCH
   if constexpr (!hx_w2<B>()) load_year_a(iy_from + 1);
-#endif
   if constexpr (CON >= 2) m.trk_iy = args->kc.trk_iy;
   if constexpr (CON == 3) { m.trk_rec = s_trk_rec; m.trk_cmd = s_trk_cmd; }
   int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
@@ -630,9 +628,6 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         load_year_a(iy);
         pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold >= 1 ? iold : 0) * buf.npad, m.moff);
       }
-#ifdef HX_NO_SCALAR_PREFETCH
-      else load_year_a(iy);
-#endif
       const double tl_old = pf_tl_old;
       constexpr int NB = hx_nbc<B>();
       constexpr int SB = (B == HX_DYN) ? 1 : NB;  // (the looped kernels read these where they use them)
@@ -892,12 +887,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         const bool newblk = blk0 < 0 || iy >= blk0 + HX_DBLK;  // (then the pass has not run yet)
         pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iy - blk0) * buf.npad + mem];
         hx_ccd shc = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
-#ifndef HX_NO_SCALAR_PREFETCH
         yc4[0] = shc[HXSH_SQRT_N2O]; yc4[1] = shc[HXSH_RF_OTHER]; yc4[2] = shc[HXSH_RF_AERO]; yc4[3] = shc[HXSH_RF_VOL];
         load_year_a(iy + 1);
-#else
-        (void)shc;
-#endif
       }
       const double year = (double)(args->kc.start_year + iy);
       YearCon yc{};
@@ -952,7 +943,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #else
       constexpr bool TALL = hx_w2<B>();
 #endif
-#ifndef HX_W2_TALL_LATE   // (-DHX_W2_TALL_LATE, experiment builds: requested where they are used)
+      // (ahead of the forcing arithmetic; rows from this year on -- stale values of an earlier
+      // run -- are replaced by row 0, the SST anomaly of startDate = 0 for every member, like in
+      // the history pass: a scalar row choice, the terms enter as 0 * Ker with no vector select)
       [[maybe_unused]] double Tall[HX_DBLK];
       if constexpr (TALL) {
 #pragma unroll
@@ -961,12 +954,6 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           Tall[r] = hx_ldm(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
         }
       }
-#endif
-#ifdef HX_NO_SCALAR_PREFETCH
-      if constexpr (!hx_w2<B>()) {
-        yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
-      }
-#endif
       if constexpr (hx_w2<B>()) {  // what the other kernels request ahead of the solver
         pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(iy - blk0) * buf.npad, m.moff);
         yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
@@ -1068,20 +1055,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // which leaves the sums bit for bit what the entry-by-entry loop gives
         const int nchunk = (jb + 7) >> 3;
         if constexpr (TALL) {
-          // Kernels without the LDS tile read the block's SSTs back from the output array: the
-          // two-wavefront flavour requests the whole block at once (chunk after chunk each would
-          // wait out its own trip to L2 / HBM).  Rows from this year on (stale values of an
-          // earlier run) are replaced by row 0, the SST anomaly of startDate = 0 for every member,
-          // like in the history pass: the row choice is scalar arithmetic, the terms enter as
-          // 0 * Ker with no select on the vector side.
-#ifdef HX_W2_TALL_LATE
-          double Tall[HX_DBLK];
-#pragma unroll
-          for (int r = 0; r < HX_DBLK; ++r) {
-            const int i = blk0 + r;
-            Tall[r] = hx_ldm(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
-          }
-#endif
+          // (the block's SSTs were requested at the head of this phase: Tall)
 #pragma unroll
           for (int c = 0; c < HX_DBLK / 8; ++c) {
             if (c < nchunk) {

@@ -188,7 +188,8 @@ int hx_set_member_sorting(hx_core *core, int on);
  * stashes, and the first hx_reset(startDate) after a run that covered startDate..endDate reorders
  * the lanes by it -- wavefronts of members that really walk the same schedule, the costliest
  * dispatched first, so that an ensemble of more wavefronts than SIMDs does not end on its most
- * expensive ones -- and spins up again (once; a parameter change falls back to the parameter
+ * expensive ones; where two wavefronts share a SIMD (hx_set_two_wave_from) the second batch in
+ * ascending cost, so that the costliest shares with the cheapest -- and spins up again (once; a parameter change falls back to the parameter
  * key until the next complete run).  Only ensembles of more wavefronts than the GPU has SIMDs
  * (65 536 members on an MI355X) are reordered: a smaller one lasts as long as its costliest
  * wavefront under any order.  Default on; results do not depend on it.

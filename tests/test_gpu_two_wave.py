@@ -217,3 +217,31 @@ def test_two_wave_kernel_with_rows_that_differ_between_members(hip_lib, oracle):
         assert (np.abs(a.fetchvars("CO2_concentration", (1745, 2300))[:, i] - ref) / ref).max() < REL_CO2
         assert np.abs(a.fetchvars("global_tas", (1745, 2300))[:, i] - r["global_tas"]).max() < ABS_T
     a.shutdown(); b.shutdown()
+
+
+def test_measured_cost_lane_order_pairs_costly_with_cheap_wavefronts(hip_lib):
+    """Beyond one wavefront per SIMD the measured-cost lane order puts the costliest wavefronts
+    first (one per SIMD) and the next batch in ASCENDING cost, so that the wavefront that joins the
+    costliest one on its SIMD is the cheapest: same results bit for bit under either order."""
+    n = 131072
+    S, q10 = ensemble.ecs_q10(n)
+    c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
+    c.set_outputs(["CO2_concentration", "global_tas", "solver_steps", "timesteps"])
+    c.run(2300)
+    assert c.last_run_kernel() == "run2" and not c.lanes_calibrated()
+    ref = {v: c.fetchvars(v, (2290, 2300)).copy() for v in ("CO2_concentration", "global_tas")}
+    cost = 4 * c.fetchvars("solver_steps", (1746, 2300)).sum(0) + 5 * c.fetchvars("timesteps", (1746, 2300)).sum(0)
+    ms0 = c.last_run_ms()
+    c.reset(1745)
+    assert c.lanes_calibrated()
+    by_wave = cost[np.argsort(c.lane_of_member())].reshape(-1, 64).mean(1)   # 2048 wavefronts
+    simds = 1024
+    assert (np.diff(by_wave[:simds]) <= 1e-9).all()       # the first batch: costliest first
+    assert (np.diff(by_wave[simds:]) >= -1e-9).all()      # the second: cheapest first
+    assert by_wave[simds - 1] >= by_wave[-1] - 1e-9
+    c.run(2300)
+    for v, x in ref.items():
+        assert np.array_equal(c.fetchvars(v, (2290, 2300)), x), v
+    print("kernel ms, parameter key / measured cost paired: %.3f / %.3f" % (ms0, c.last_run_ms()))
+    c.shutdown()
