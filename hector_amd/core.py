@@ -345,7 +345,7 @@ class Core:
         return self
 
     def set_two_wave_from(self, min_members):
-        """Ensembles of at least min_members members (one biome, shared diffusivity, no
+        """Ensembles of at least min_members members (one biome, no
         constraints) run on the flavour of the kernel built for two resident
         wavefronts per SIMD (include/hector_amd.h); < 0: the default (more wavefronts than the
         GPU has SIMDs), 0: never."""

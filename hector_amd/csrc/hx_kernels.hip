@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void hx_derive_kernel(const double *params, do
 // compiler a real call inside this kernel turned out fragile -- two of the 32 instantiations
 // faulted on the device after unrelated edits, see doeclim_pass_mfma -- so it is inlined.  It
 // now serves only ensembles whose members differ in diffusivity.)
-template <bool KERPM, bool HF>
+// NA: block years per sweep (16 accumulators in two sweeps; 8 in four for the two-wavefront
+// flavour, whose 256 registers do not hold 16 + a 31-entry kernel window + two chunks of history)
+template <bool KERPM, bool HF, int NA = 16>
 __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
                                                            const double *ker, double *part,
                                                            double *part2, int ns, int npad,
@@ -159,10 +161,10 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
     if constexpr (KERPM) return HX_GCD(ker)[(size_t)idx * np + mem];
     else return HX_CCD(ker)[idx];
   };
-  for (int j0 = 0; j0 < HX_DBLK; j0 += 16) {
-    double acc[16], acc2[16];
+  for (int j0 = 0; j0 < HX_DBLK; j0 += NA) {
+    double acc[NA], acc2[NA];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { acc[j] = 0; acc2[j] = 0; }
+    for (int j = 0; j < NA; ++j) { acc[j] = 0; acc2[j] = 0; }
     // window entry w of chunk i0 = Ker[(ns - (blk0 + j0) - 1) + i0 - 15 + w]
     const int k0 = ns - (blk0 + j0) - 1 - 15 + HX_KPAD;
     if (blk0 + j0 < ns) {
@@ -178,13 +180,14 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
         }
       };
       auto compute_chunk = [&](const double *T, int i0) {
+        // (entries 16 - NA ... 31 of the window are the ones NA accumulators touch)
         double kw[32];
 #pragma unroll
-        for (int w = 0; w < 32; ++w) kw[w] = ldk(k0 + i0 + w);
+        for (int w = 16 - NA; w < 32; ++w) kw[w] = ldk(k0 + i0 + w);
 #pragma unroll
         for (int ii = 0; ii < 16; ++ii) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
+          for (int j = 0; j < NA; ++j) {
             acc[j] += T[ii] * kw[15 + ii - j];
             if (HF) acc2[j] += T[ii] * kw[16 + ii - j];
           }
@@ -202,7 +205,7 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
       }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < NA; ++j) {
       HX_GD(part)[(size_t)(j0 + j) * np + mem] = acc[j];
       if (HF) HX_GD(part2)[(size_t)(j0 + j) * np + mem] = acc2[j];
     }
@@ -929,7 +932,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
                                 const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem, blk0);
         else
 #endif
-        doeclim_pass_dev<KERPM, HF>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
+        doeclim_pass_dev<KERPM, HF, (hx_w2<B>() ? 8 : 16)>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                     const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem, blk0);
         HX_FENCE();
         pf_dpart = HX_GCD(buf.dpart)[mem];
@@ -1716,10 +1719,10 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   }
   if constexpr (B == 1) {
     // the flavour built for two resident wavefronts per SIMD (EnsembleCore::run decides)
-    // (shared diffusivity only: the per-member history pass, two sweeps of 16 accumulators over a
-    //  32-entry kernel window, does not fit 256 registers -- 77 to 120 of them spill)
-    if (two_wave && !con && !kpm) {
-      if (hf) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    if (two_wave && !con) {
+      if (hf && kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else if (hf) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       return;
     }

@@ -245,3 +245,37 @@ def test_measured_cost_lane_order_pairs_costly_with_cheap_wavefronts(hip_lib):
         assert np.array_equal(c.fetchvars(v, (2290, 2300)), x), v
     print("kernel ms, parameter key / measured cost paired: %.3f / %.3f" % (ms0, c.last_run_ms()))
     c.shutdown()
+
+
+@pytest.mark.parametrize("heatflux", [False, True])
+def test_two_wave_kernel_with_per_member_diffusivity(hip_lib, oracle, heatflux):
+    """hx_run_kernel<HX_B1W2, HF, KERPM>: every member its own DOECLIM kernel table, the history
+    pass on the vector ALU in four sweeps of 8 block years -- against the plain kernel's
+    instantiation and the oracle."""
+    n = 1024
+    outs = ["CO2_concentration", "global_tas", "timesteps"] + (["heatflux"] if heatflux else [])
+    S, q10 = ensemble.ecs_q10(n)
+    diff = 1.2 + 2.2 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 5)
+    cores = []
+    for two_wave in (True, False):
+        c, _, _ = _core(hip_lib, n, two_wave, outs)
+        c.setvar("diff", diff, "cm2/s")
+        c.run(2300)
+        assert (c.status() == 0).all()
+        cores.append(c)
+    a, b = cores
+    assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run"
+    assert np.array_equal(a.fetchvars("timesteps", (1745, 2300)), b.fetchvars("timesteps", (1745, 2300)))
+    for v in outs[:2] + outs[3:]:
+        x, y = a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))
+        assert (np.abs(x - y) / np.maximum(np.abs(y), 1.0)).max() < REL_CO2, v
+    for i in (0, 500, 1023):
+        p = oracle.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]; p.diff = diff[i]
+        r, err, _ = oracle.run(p)
+        assert err == 0
+        ref = r["CO2_concentration"]
+        assert (np.abs(a.fetchvars("CO2_concentration", (1745, 2300))[:, i] - ref) / ref).max() < REL_CO2
+        assert np.abs(a.fetchvars("global_tas", (1745, 2300))[:, i] - r["global_tas"]).max() < ABS_T
+        if heatflux:
+            assert np.abs(a.fetchvars("heatflux", (1745, 2300))[:, i] - r["heatflux"]).max() < ABS_T
+    a.shutdown(); b.shutdown()

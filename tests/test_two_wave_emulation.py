@@ -88,6 +88,22 @@ def test_two_wave_flavour_in_pieces_through_history_and_across_kernels(emul_lib)
         assert np.array_equal(want[v], c.fetchvars(v, (1745, 2300))), v
 
 
+def test_two_wave_flavour_with_per_member_diffusivity(emul_lib):
+    """Members that differ in ocean heat diffusivity (each its own DOECLIM kernel table; the
+    flavour's history pass sweeps the block in four groups of 8 years instead of two of 16: the
+    same sums in the same order), with and without the heat-flux output."""
+    n = 12
+    S, q10 = ensemble.ecs_q10(n)
+    diff = np.linspace(1.2, 3.4, n)
+    for outs in (["CO2_concentration", "global_tas", "sst"], ["CO2_concentration", "global_tas", "heatflux"]):
+        a = mk(emul_lib, n, True, outs, S=S, q10_rh=q10, diff=diff)
+        b = mk(emul_lib, n, False, outs, S=S, q10_rh=q10, diff=diff)
+        a.run(2300); b.run(2300)
+        assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run"
+        for v in outs:
+            assert np.array_equal(a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))), v
+
+
 def test_two_wave_flavour_is_not_taken_where_it_does_not_apply(emul_lib):
     n = 4
     c = hector_amd.Core(SCENARIO, n, lib_path=emul_lib, allow_emulation=True)
@@ -95,7 +111,7 @@ def test_two_wave_flavour_is_not_taken_where_it_does_not_apply(emul_lib):
     c.run(1750)
     assert c.last_run_kernel() == "run"          # default: only beyond one wavefront per SIMD
     c.set_two_wave_from(1)
-    c.setvar("diff", np.linspace(1.5, 3.0, n))   # per-member diffusivity: the plain kernels
+    c.set_outputs(["CO2_concentration", "gmst"])  # a diagnostic of the extended kernel
     c.reset(1745); c.run(1750)
     assert c.last_run_kernel() == "run"
     c.shutdown()

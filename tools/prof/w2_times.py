@@ -16,9 +16,11 @@ import hector_amd  # noqa: E402
 
 
 def main():
-    sizes, lib = [], None
+    sizes, lib, per_member_diff = [], None, False
     for a in sys.argv[1:]:
-        if a.startswith("--lib="):
+        if a == "--diff":          # every member its own ocean heat diffusivity (KERPM kernels)
+            per_member_diff = True
+        elif a.startswith("--lib="):
             lib = os.path.abspath(a.split("=", 1)[1])
         else:
             sizes.append(int(a))
@@ -31,6 +33,9 @@ def main():
             c = bench.make_core(n, 1, 0, 0)
             c.set_pair_kernel_limit(0)
             c.set_two_wave_from(two_wave)
+            if per_member_diff:
+                from hector_amd import ensemble
+                c.setvar("diff", 1.2 + 2.2 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 5), "cm2/s")
             ms = []
             for _ in range(6):
                 c.reset(1745); c.run(2300); ms.append(c.last_run_ms())
