@@ -345,8 +345,8 @@ class Core:
         return self
 
     def set_two_wave_from(self, min_members):
-        """Ensembles of at least min_members members (one biome, no
-        constraints) run on the flavour of the kernel built for two resident
+        """Ensembles of at least min_members members (one biome, no carbon
+        tracking) run on the flavour of the kernel built for two resident
         wavefronts per SIMD (include/hector_amd.h); < 0: the default (more wavefronts than the
         GPU has SIMDs), 0: never."""
         self._ck(self._lib.hx_set_two_wave_from(self._h, int(min_members)))

@@ -1771,7 +1771,7 @@ void EnsembleCore::run(double runtodate) {
   last_run_pair_ = pair;
   // more wavefronts than SIMDs: the one-biome kernel built for two resident wavefronts per SIMD
   const int w2_from = two_wave_from_ < 0 ? simds_ * HX_WAVE + 1 : two_wave_from_;
-  const bool w2 = !pair && B_ == 1 && con == 0 && w2_from > 0 && n_ >= w2_from;
+  const bool w2 = !pair && B_ == 1 && con <= 1 && w2_from > 0 && n_ >= w2_from;
   last_run_w2_ = w2;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,

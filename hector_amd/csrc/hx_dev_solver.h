@@ -542,6 +542,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         y[0] = m.atmos; y[1] = m.veg[0]; y[2] = m.det[0]; y[3] = m.soil[0];
         y[4] = m.cDO + m.cIO + PKM(m, w2_slot(23)) + PKM(m, w2_slot(22));
         l4 = m.pf[0]; l5 = m.thawed[0]; l7 = m.earth;
+        if constexpr (CON) y[5] = m.thawed[0];
         return;
       }
     }

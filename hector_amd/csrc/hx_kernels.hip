@@ -494,7 +494,7 @@ template <int B, bool HF, bool KERPM, int CON>
 __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 : B)>()) : 64) HX_WAVES_PER_SIMD(B)
 void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   static_assert(CON != 3 || (B >= 1 && B <= 4), "tracking companions: the unrolled kernels");
-  static_assert(!hx_w2<B>() || CON == 0, "two-wavefront flavour: the plain kernel");
+  static_assert(!hx_w2<B>() || CON <= 1, "two-wavefront flavour: the plain and the extended kernel");
   // LDS: the SSTs produced inside this launch's block of years (<= HX_DBLK), per lane
   // (multi-biome kernels need that LDS for the per-biome arrays and re-read the block's SSTs
   // from the output array instead)
@@ -1152,6 +1152,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         const size_t orow = (size_t)iy * buf.npad;
         hx_stm(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
         hx_stm(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
+        if constexpr (CON) { if (buf.out[HXO_SST_LO]) hx_stm(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
         if (buf.out[HXO_CO2]) hx_stm(HX_GD(buf.out[HXO_CO2]) + orow, m.moff, co2c);
         if (buf.out[HXO_TGAV]) hx_stm(HX_GD(buf.out[HXO_TGAV]) + orow, m.moff, tgav);
       } else {
@@ -1719,6 +1720,11 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   }
   if constexpr (B == 1) {
     // the flavour built for two resident wavefronts per SIMD (EnsembleCore::run decides)
+    if (two_wave && con == 1) {
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
     if (two_wave && !con) {
       if (hf && kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       else if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, true, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);

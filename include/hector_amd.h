@@ -310,8 +310,8 @@ int hx_set_pair_kernel_limit(hx_core *core, int max_members);
  * one-biome kernel compiled for TWO resident wavefronts per SIMD (at most 256 registers and 20 KB
  * of LDS a wavefront; hx_dev_member.h, HX_B1W2): the second wavefront issues into the slots a
  * dependent fp64 chain of the first leaves empty.  Same model code, same decisions; it serves what
- * the plain kernel serves (one biome, shared or per-member diffusivity, heat flux; no constraints or
- * diagnostics of the extended kernel).
+ * the one-biome kernels serve -- shared or per-member diffusivity, heat flux, and the extended kernel's
+ * constraints, land-ocean warming ratio and diagnostics -- except carbon tracking.
  * hx_set_two_wave_from: ensembles of at least min_members members use it (< 0: the default, one
  * more wavefront than the device has SIMDs; 0: never; the environment variable
  * HECTOR_AMD_TWO_WAVE_FROM sets the default of new cores).  hx_last_run_kernel then says "run2". */

@@ -279,3 +279,44 @@ def test_two_wave_kernel_with_per_member_diffusivity(hip_lib, oracle, heatflux):
         if heatflux:
             assert np.abs(a.fetchvars("heatflux", (1745, 2300))[:, i] - r["heatflux"]).max() < ABS_T
     a.shutdown(); b.shutdown()
+
+
+def test_two_wave_flavour_of_the_extended_kernel_on_gpu(hip_lib, oracle, tmp_path):
+    """hx_run_kernel<HX_B1W2, HF, KERPM, 1>: a tas constraint, a land-ocean warming ratio for every
+    other member and diagnostics written from inside the stash -- against the plain extended
+    kernel (same decisions) and, for a few members, the oracle reading the same scenario."""
+    import oracle_binding
+    from conftest import edited_pack
+    n = 1024
+    S, q10 = ensemble.ecs_q10(n)
+    years = np.arange(1950, 2011)
+    path = edited_pack(tmp_path / "tas.hxs", "temperature", "tas_constrain", years, 0.3 + 0.01 * (years - 1950))
+    lo = np.where(np.arange(n) % 2, 1.6, 0.0)
+    outs = ["CO2_concentration", "global_tas", "sst", "land_tas", "gmst", "NPP", "RH", "timesteps"]
+    cores = []
+    for two_wave in (True, False):
+        c = hector_amd.Core(path, n, device=0, lib_path=hip_lib)
+        c.set_pair_kernel_limit(0)
+        c.set_two_wave_from(1 if two_wave else 0)
+        c.setvar("S", S, "degC").setvar("q10_rh", q10).setvar("lo_warming_ratio", lo)
+        c.set_outputs(outs)
+        c.run(2300)
+        assert (c.status() == 0).all()
+        cores.append(c)
+    a, b = cores
+    assert a.last_run_kernel() == "run2" and b.last_run_kernel() == "run"
+    assert np.array_equal(a.fetchvars("timesteps", (1745, 2300)), b.fetchvars("timesteps", (1745, 2300)))
+    for v in outs[:-1]:
+        x, y = a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))
+        scale = 1000.0 if v in ("NPP", "RH") else np.maximum(np.abs(y), 1.0)
+        assert (np.abs(x - y) / scale).max() < REL_CO2, v
+    o = oracle_binding.Oracle(path)
+    for i in (0, 1, 511, 1022):
+        p = o.default_params(); p.S = S[i]; p.q10_rh[0] = q10[i]; p.lo_warming_ratio = lo[i]
+        r, err, _ = o.run(p)
+        assert err == 0
+        ref = r["CO2_concentration"]
+        assert (np.abs(a.fetchvars("CO2_concentration", (1745, 2300))[:, i] - ref) / ref).max() < REL_CO2
+        for v in ("global_tas", "sst", "land_tas"):
+            assert np.abs(a.fetchvars(v, (1745, 2300))[:, i] - r[v]).max() < ABS_T, (v, i)
+    a.shutdown(); b.shutdown()

@@ -104,16 +104,36 @@ def test_two_wave_flavour_with_per_member_diffusivity(emul_lib):
             assert np.array_equal(a.fetchvars(v, (1745, 2300)), b.fetchvars(v, (1745, 2300))), v
 
 
-def test_two_wave_flavour_is_not_taken_where_it_does_not_apply(emul_lib):
+def test_two_wave_flavour_of_the_extended_kernel(emul_lib, tmp_path):
+    """Constraints, a land-ocean warming ratio and the diagnostics written from inside the stash:
+    the extended instantiation in the two-wavefront flavour against the plain one, bit for bit."""
+    from conftest import edited_pack
+    n = 8
+    S, q10 = ensemble.ecs_q10(n)
+    years = np.arange(1950, 2011)
+    path = edited_pack(tmp_path / "tas.hxs", "temperature", "tas_constrain", years, 0.3 + 0.01 * (years - 1950))
+    outs = ["CO2_concentration", "global_tas", "sst", "land_tas", "gmst", "NPP", "RH", "HL_ocean_uptake",
+            "f_frozen", "timesteps"]
+    res = []
+    for two_wave in (True, False):
+        c = hector_amd.Core(path, n, lib_path=emul_lib, allow_emulation=True)
+        c.set_two_wave_from(1 if two_wave else 0)
+        c.setvar("S", S).setvar("q10_rh", q10).setvar("lo_warming_ratio", np.where(np.arange(n) % 2, 1.6, 0.0))
+        c.set_outputs(outs)
+        c.run(2300)
+        assert c.last_run_kernel() == ("run2" if two_wave else "run") and (c.status() == 0).all()
+        res.append({v: c.fetchvars(v, (1745, 2300)) for v in outs})
+    for v in outs:
+        assert np.array_equal(res[0][v], res[1][v]), v
+
+
+def test_two_wave_flavour_is_not_taken_where_it_does_not_apply(emul_lib, monkeypatch):
+    monkeypatch.delenv("HECTOR_AMD_TWO_WAVE_FROM", raising=False)
     n = 4
     c = hector_amd.Core(SCENARIO, n, lib_path=emul_lib, allow_emulation=True)
     c.set_outputs(["CO2_concentration"])
     c.run(1750)
     assert c.last_run_kernel() == "run"          # default: only beyond one wavefront per SIMD
-    c.set_two_wave_from(1)
-    c.set_outputs(["CO2_concentration", "gmst"])  # a diagnostic of the extended kernel
-    c.reset(1745); c.run(1750)
-    assert c.last_run_kernel() == "run"
     c.shutdown()
     c = hector_amd.Core(SCENARIO, n, lib_path=emul_lib, allow_emulation=True)
     c.set_two_wave_from(1)

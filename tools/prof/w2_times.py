@@ -16,10 +16,12 @@ import hector_amd  # noqa: E402
 
 
 def main():
-    sizes, lib, per_member_diff = [], None, False
+    sizes, lib, per_member_diff, extended = [], None, False, False
     for a in sys.argv[1:]:
         if a == "--diff":          # every member its own ocean heat diffusivity (KERPM kernels)
             per_member_diff = True
+        elif a == "--ext":         # a diagnostic of the extended kernel (CON = 1)
+            extended = True
         elif a.startswith("--lib="):
             lib = os.path.abspath(a.split("=", 1)[1])
         else:
@@ -33,6 +35,8 @@ def main():
             c = bench.make_core(n, 1, 0, 0)
             c.set_pair_kernel_limit(0)
             c.set_two_wave_from(two_wave)
+            if extended:
+                c.set_outputs(["CO2_concentration", "global_tas", "NPP"])
             if per_member_diff:
                 from hector_amd import ensemble
                 c.setvar("diff", 1.2 + 2.2 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 5), "cm2/s")
