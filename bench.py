@@ -592,6 +592,13 @@ def main():
                 "collective_world_size": cworld,
                 "native_collective_fallback": r["native_fallback"],
                 "rehearsal_not_rccl": bool(use_dist and args.dist_backend != "nccl"),
+                # (say so until it has) the builder's boxes have ONE GPU -- a communicator
+                # of world size > 1, the grouped all-gather over several shards and per-shard host
+                # threads on distinct devices execute for the first time wherever this line is
+                # printed with n_gpus > 1; the assertions above (complete statistics, world size,
+                # RCCL) are what vouches for that run
+                "multi_gpu_path": ("executed here: world size %d" % n_gpus) if n_gpus > 1 else
+                                  "not exercised (one GPU)",
                 "spinup_ms_excluded": r["spin_ms"], "members_with_model_errors": r["bad"],
                 "lanes_ordered_by": "measured cost" if r["calibrated"] else "parameter key",
                 "members_in_statistics": in_stats,
