@@ -129,3 +129,30 @@ def test_c_host_example_builds_and_runs_over_a_device_list(emul_lib, tmp_path):
     got = [float(x) for x in line.split(":")[1].split()]
     np.testing.assert_allclose(got, [tas[0], tas[3], tas[5]], atol=5e-7)
     one.shutdown()
+
+
+def test_a_call_that_fails_on_a_later_shard_poisons_the_core(emul_lib):
+    """A routed call that went through on shard 0 and failed on shard 1 has left the shards
+    different: the core says which shard and why, and refuses every later call
+    instead of mixing them silently."""
+    _, many = _cores(emul_lib)
+    fv = np.full(N, 0.35)
+    fv[4] = 1.7                       # member 4 lives on shard 1: f_nppv > 1 fails its parameter check
+    many.setvar("f_nppv", fv)
+    with pytest.raises(hector_amd.HectorAmdError, match="f_nppv"):
+        many.run(1760)                # shard 0 ran, shard 1 refused
+    for call in (lambda: many.run(1770), lambda: many.setvar("beta", [0.4]), lambda: many.reset(1745),
+                 lambda: many.fetchvars("CO2_concentration", (1745, 1750))):
+        with pytest.raises(hector_amd.HectorAmdError, match="inconsistent and refuses further calls.*shard 1 of 3"):
+            call()
+    many.shutdown()
+    # a failure on the FIRST shard leaves nothing half-done: the core stays usable
+    _, many = _cores(emul_lib)
+    fv = np.full(N, 0.35); fv[0] = 1.7
+    many.setvar("f_nppv", fv)
+    with pytest.raises(hector_amd.HectorAmdError, match="f_nppv"):
+        many.run(1760)
+    many.setvar("f_nppv", np.full(N, 0.35))
+    many.run(1760)
+    assert (many.status() == 0).all()
+    many.shutdown()
