@@ -69,6 +69,17 @@ template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || hx_nbc<B>
 // used: three loads a year against a model year of ~100k cycles): 14 + 10 nb slots -- 33 KB for
 // five biomes, 49 KB for eight -- so that up to four wavefronts share a CU where the fixed
 // 97.5 KB allowed one.
+// Kernels that read a member's constants from the tables where they are used (the lean park):
+// every such access is a wave-uniform row address in scalar registers plus the lane's 32-bit byte
+// offset (hx_ldm / w2_ld below).  As `table[row * npad + mem]` with a 64-bit per-lane index the
+// optimiser computed each row's per-lane ADDRESS once, ahead of the year loop -- ~45 register
+// pairs in the eight-biome kernel, kept in AGPRs and scratch; every use then waited for its own
+// scratch reload before the load itself could be issued (13 of them in a row in phase C):
+// 65 536 members x 7 / 8 biomes 16.9 / 18.9 -> 15.1 / 16.5 ms, no scratch left.  (Five and six
+// biomes have the registers for the hoisted addresses and lose 2 % to the scalar form's spill
+// lanes: they keep the indexed form; the looped kernels are indifferent.)
+template <int B> constexpr bool hx_slim_park_() { return B == 7 || B == 8; }
+template <int B> constexpr bool hx_tbl() { return hx_w2<B>() || B == HX_DYN || hx_slim_park_<B>(); }
 template <int B> constexpr int pk_ff0() {
   return hx_w2<B>() ? (int)PK_AERO : hx_lean_park<B>() ? (int)PK_D0 : (int)PK_FFROZEN0;
 }
@@ -108,11 +119,22 @@ struct RegArr1 {
 template <int B> struct BiomeArr { using type = ParkArr; };
 template <> struct BiomeArr<1> { using type = RegArr1; };
 template <> struct BiomeArr<HX_B1W2> { using type = RegArr1; };
-// a per-biome array in HBM: element b of this lane at base[b * stride]
+// a per-biome array in HBM: element b of this lane in row row0 + b * rstride of a [rows][npad]
+// table (wave-uniform row address + the lane's byte offset, see hx_tbl)
+struct TblRef {
+  char HX_GLOBAL *row;
+  unsigned moff;
+  __device__ __forceinline__ operator double() const { return *(hx_gcd)(row + moff); }
+  __device__ __forceinline__ void operator=(double v) const { *(hx_gd)(row + moff) = v; }
+};
 struct GlobArr {
-  hx_gd base;
-  size_t stride;
-  __device__ __forceinline__ double HX_GLOBAL &operator[](int b) const { return base[(size_t)b * stride]; }
+  double *tbl;
+  int row0, rstride;
+  int npad;   // (a copy of the member's: hx_tbl_local refreshes it with the region's)
+  unsigned moff;
+  __device__ __forceinline__ TblRef operator[](int b) const {
+    return TblRef{(char HX_GLOBAL *)HX_GD(tbl) + (size_t)((unsigned)(row0 + b * rstride) * ((unsigned)npad * 8u)), moff};
+  }
 };
 template <int B> struct BiomeArrThaw { using type = typename BiomeArr<B>::type; };
 template <> struct BiomeArrThaw<7> { using type = GlobArr; };
@@ -149,7 +171,7 @@ struct Member {
   double (*pk)[64];  // LDS park
   int lane;
   hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
-  const HxBuffers *bufp;  // run kernel only: for the diagnostics written inside the stash
+  const HxBuffers *bufp;  // the core's tables (bind_member)
   int iy;                 // year index being integrated
   int trk_iy;             // first tracked year index (tracking kernels)
   int nb;                 // biome count (looped kernels)
@@ -203,9 +225,16 @@ __device__ __forceinline__ void w2_st(double *tbl, int npad, int row, unsigned m
   *(hx_gd)(r + moff) = v;
 }
 template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, int row) {
-  if constexpr (hx_w2<B>()) return w2_ld(m.bufp->derived, m.npad, row, m.moff);
+  if constexpr (hx_tbl<B>()) return w2_ld(m.bufp->derived, m.npad, row, m.moff);
   else if constexpr (hx_lean_park<B>()) return m.der[(size_t)row * m.npad];
   else return PKM(m, row >= HXD_KLH && row < HXD_KLH + 7 ? PK_K0 + (row - HXD_KLH) : PK_D0 + (row - HXD_A0));
+}
+
+// head of a region with uniform control flow in a lean-park kernel: the row products are this
+// region's own (HX_W2_LOCAL)
+template <int B> __device__ __forceinline__ void hx_tbl_local(Member<B> &m) {
+  HX_W2_LOCAL(m);
+  if constexpr (hx_slim_park<B>()) { m.ffz.npad = m.npad; m.f_new_thaw.npad = m.npad; }
 }
 
 // biome constants of the land model, fetched where they are used
@@ -218,11 +247,13 @@ struct LandK {
 // uniform table when every member shares the biome constants, else the member's row)
 struct ParamCol {
   hx_ccd upar;
-  hx_gcd par;
-  int npad, col;
+  const double *par;   // the parameter table
+  int npad;
+  unsigned moff;
+  int col;
   __device__ __forceinline__ double operator[](int b) const {
     const int row = HXP_NGLOBAL + b * HXPB_N + col;
-    return upar ? upar[row] : par[(size_t)row * npad];
+    return upar ? upar[row] : w2_ld(par, npad, row, moff);
   }
 };
 template <>
@@ -233,7 +264,7 @@ template <int B>
 __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
   HX_FENCE();
   if constexpr (B == HX_DYN) {
-    const ParamCol c{m.upar, m.par, m.npad, 0};
+    const ParamCol c{m.upar, m.bufp->params, m.npad, m.moff, 0};
     k.npp0 = c; k.npp0.col = HXPB_NPP0; k.f_nppv = c; k.f_nppv.col = HXPB_F_NPPV;
     k.f_nppd = c; k.f_nppd.col = HXPB_F_NPPD; k.f_litterd = c; k.f_litterd.col = HXPB_F_LITTERD;
     k.rh_ch4_frac = c; k.rh_ch4_frac.col = HXPB_RH_CH4_FRAC;
@@ -276,13 +307,24 @@ __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
     }
 #pragma unroll
     for (int b = 0; b < hx_nbc<B>(); ++b) {
-      hx_gcd r = m.par + (size_t)(HXP_NGLOBAL + b * HXPB_N) * m.npad;
+      const int r0 = HXP_NGLOBAL + b * HXPB_N;
+      if constexpr (hx_tbl<B>()) {
+        const double *p = m.bufp->params;
+        k.npp0[b] = w2_ld(p, m.npad, r0 + HXPB_NPP0, m.moff);
+        k.f_nppv[b] = w2_ld(p, m.npad, r0 + HXPB_F_NPPV, m.moff);
+        k.f_nppd[b] = w2_ld(p, m.npad, r0 + HXPB_F_NPPD, m.moff);
+        k.f_litterd[b] = w2_ld(p, m.npad, r0 + HXPB_F_LITTERD, m.moff);
+        k.rh_ch4_frac[b] = w2_ld(p, m.npad, r0 + HXPB_RH_CH4_FRAC, m.moff);
+        k.fpf_static[b] = w2_ld(p, m.npad, r0 + HXPB_FPF_STATIC, m.moff);
+      } else {
+      hx_gcd r = m.par + (size_t)r0 * m.npad;
       k.npp0[b] = r[(size_t)HXPB_NPP0 * m.npad];
       k.f_nppv[b] = r[(size_t)HXPB_F_NPPV * m.npad];
       k.f_nppd[b] = r[(size_t)HXPB_F_NPPD * m.npad];
       k.f_litterd[b] = r[(size_t)HXPB_F_LITTERD * m.npad];
       k.rh_ch4_frac[b] = r[(size_t)HXPB_RH_CH4_FRAC * m.npad];
       k.fpf_static[b] = r[(size_t)HXPB_FPF_STATIC * m.npad];
+      }
     }
   }
 }
@@ -307,6 +349,7 @@ __device__ __forceinline__ void sto_(const HxBuffers &b, int var, size_t off, do
 template <int B>
 __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Member<B> &m,
                                             double (*park)[64], int lane) {
+  m.bufp = &buf;
   m.par = HX_GCD(buf.params) + mem;
   m.der = HX_GCD(buf.derived) + mem;
   m.npad = buf.npad;
@@ -323,10 +366,8 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
                                          &m.co2fert, &m.tempfertd};
 #pragma unroll
       for (int k = 0; k < HX_NBIOME_ARR - 1; ++k) { arr[k]->base = park + o + k * bm; arr[k]->lane = lane; }
-      m.f_new_thaw.base = HX_GD(buf.bscratch) + mem;
-      m.f_new_thaw.stride = (size_t)buf.npad;
-      m.ffz.base = HX_GD(buf.state) + (size_t)(HXS_NGLOBAL + HXSB_F_FROZEN) * buf.npad + mem;
-      m.ffz.stride = (size_t)HXSB_N * buf.npad;
+      m.f_new_thaw = GlobArr{buf.bscratch, 0, 1, m.npad, m.moff};
+      m.ffz = GlobArr{buf.state, HXS_NGLOBAL + HXSB_F_FROZEN, HXSB_N, m.npad, m.moff};
     } else {
     ParkArr *arr[HX_NBIOME_ARR] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
                                    &m.co2fert, &m.tempfertd, &m.f_new_thaw};

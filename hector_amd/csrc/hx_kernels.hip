@@ -490,6 +490,13 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
 // instantiation, so that plain runs carry none of it.
 // CON = 2: ... with carbon tracking inside the stash (hx_dev_track.h); CON = 3 (one biome): ...
 // with carbon tracking on two companion wavefronts -- 192 threads a block, waves 1 and 2 only track.
+// the year loop's own rows (outputs, the values requested a phase ahead) as row address + lane
+// offset: the lean-park kernels (hx_tbl); -DHX_ROWIO_ALL: every kernel (experiment builds)
+#ifdef HX_ROWIO_ALL
+template <int B> constexpr bool hx_rowio() { return true; }
+#else
+template <int B> constexpr bool hx_rowio() { return hx_tbl<B>(); }
+#endif
 template <int B, bool HF, bool KERPM, int CON>
 __global__ __launch_bounds__(CON == 3 ? 64 * (1 + trk_waves<(B < 1 || B > 4 ? 1 : B)>()) : 64) HX_WAVES_PER_SIMD(B)
 void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
@@ -522,7 +529,6 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
   double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
-  if constexpr (CON || hx_w2<B>()) m.bufp = &args->buf;
   bind_member<B>(args->buf, mem, m, s_park, lane);
 #ifdef HX_PHASE_CLOCK
   for (int k = 0; k < HX_NCLK; ++k) hx_s_clk[k] = 0;
@@ -602,6 +608,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       const double prev_ch4 = PKM(m, PK_CH4);
       double sst = PKM(m, PK_SST);
       double eos;
+      if constexpr (hx_tbl<B>() && !hx_w2<B>()) hx_tbl_local<B>(m);
       if constexpr (hx_w2<B>()) {   // values that live in the tables (hx_dev_member.h)
         HX_W2_LOCAL(m);
         eos = w2_ld(buf.state, m.npad, HXS_EOS_VEGC, m.moff);
@@ -664,22 +671,28 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           lk.rh_ch4_frac[b] = PKM(m, o + PKB_RH_CH4_FRAC);
         } else {
           const int pr = HXP_NGLOBAL + b * HXPB_N;
-          p_wf[b] = ldp(buf, pr + HXPB_WF, mem);
+          // (lean park: row address + the lane's offset, hx_tbl)
+          auto ldpm = [&](int row) -> double {
+            if constexpr (hx_tbl<B>()) return w2_ld(buf.params, m.npad, row, m.moff);
+            else return ldp(buf, row, mem);
+          };
+          p_wf[b] = ldpm(pr + HXPB_WF);
           if (buf.uni_bio) {  // beta, permafrost mu/sigma uniform over members: scalar loads
             hx_ccd u = HX_CCD(buf.uparams) + pr;
             p_beta[b] = u[HXPB_BETA]; p_mu[b] = u[HXPB_PF_MU]; p_sigma[b] = u[HXPB_PF_SIGMA];
           } else {
-            p_beta[b] = ldp(buf, pr + HXPB_BETA, mem);
-            p_mu[b] = ldp(buf, pr + HXPB_PF_MU, mem);
-            p_sigma[b] = ldp(buf, pr + HXPB_PF_SIGMA, mem);
+            p_beta[b] = ldpm(pr + HXPB_BETA);
+            p_mu[b] = ldpm(pr + HXPB_PF_MU);
+            p_sigma[b] = ldpm(pr + HXPB_PF_SIGMA);
           }
-          p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
+          if constexpr (hx_tbl<B>()) p_lnq10[b] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
+          else p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
           if (m.upar) {
             lk.fpf_static[b] = m.upar[pr + HXPB_FPF_STATIC];
             lk.rh_ch4_frac[b] = m.upar[pr + HXPB_RH_CH4_FRAC];
           } else {
-            lk.fpf_static[b] = ldp(buf, pr + HXPB_FPF_STATIC, mem);
-            lk.rh_ch4_frac[b] = ldp(buf, pr + HXPB_RH_CH4_FRAC, mem);
+            lk.fpf_static[b] = ldpm(pr + HXPB_FPF_STATIC);
+            lk.rh_ch4_frac[b] = ldpm(pr + HXPB_RH_CH4_FRAC);
           }
         }
       }
@@ -839,16 +852,17 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // looped kernels: the same per biome, one at a time, parameters read where they are used
         for (int b = 0; b < m.nb; ++b) {
           const int pr = HXP_NGLOBAL + b * HXPB_N;
-          const double wf = ldp(buf, pr + HXPB_WF, mem), lnq10 = ldd(buf, HXD_NGLOBAL + b, mem);
-          m.co2fert[b] = 1 + ldp(buf, pr + HXPB_BETA, mem) * lnc;
+          const double wf = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
+          const double lnq10 = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
+          m.co2fert[b] = 1 + w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff) * lnc;
           const double Tbb = tland * wf;
           m.tempfertd[b] = hx_exp(lnq10 * (Tbb * 0.1));
           m.f_new_thaw[b] = 0.0;
           if (m.pf[b] != 0.0) {
             double ff = 1.0;
             if (Tbb > 0) {
-              const double d = hx_div(hx_log(Tbb) - ldp(buf, pr + HXPB_PF_MU, mem),
-                                      ldp(buf, pr + HXPB_PF_SIGMA, mem) * 1.4142135623730951);
+              const double d = hx_div(hx_log(Tbb) - w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff),
+                                      w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff) * 1.4142135623730951);
               ff = 1 - erfc(-d) / 2;
             }
             m.f_new_thaw[b] = ffrozen_of<B>(m, b) - ff;
@@ -886,9 +900,14 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       if constexpr (!hx_w2<B>()) {  // next year's window entry, this year's history partial sum (see pf_* above)
         const HxBuffers &buf = args->buf;
         const int iold1 = iy + 1 - 203;
-        pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
         const bool newblk = blk0 < 0 || iy >= blk0 + HX_DBLK;  // (then the pass has not run yet)
+        if constexpr (hx_rowio<B>()) {
+          pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad, m.moff);
+          pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(newblk ? 0 : iy - blk0) * buf.npad, m.moff);
+        } else {
+        pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
         pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iy - blk0) * buf.npad + mem];
+        }
         hx_ccd shc = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
         yc4[0] = shc[HXSH_SQRT_N2O]; yc4[1] = shc[HXSH_RF_OTHER]; yc4[2] = shc[HXSH_RF_AERO]; yc4[3] = shc[HXSH_RF_VOL];
         load_year_a(iy + 1);
@@ -935,7 +954,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         doeclim_pass_dev<KERPM, HF, (hx_w2<B>() ? 8 : 16)>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
                                     const_cast<double *>(buf.dpart2), ns, buf.npad, blk0, mem, blk0);
         HX_FENCE();
-        pf_dpart = HX_GCD(buf.dpart)[mem];
+        if constexpr (hx_rowio<B>()) pf_dpart = hx_ldm(HX_GCD(buf.dpart), m.moff);
+        else pf_dpart = HX_GCD(buf.dpart)[mem];
         HX_STAMP(m, 11);  // DOECLIM history pass (once per HX_DBLK years)
       }
       // (every kernel without the LDS tile of in-block SSTs -- the two-wavefront flavour and the
@@ -979,6 +999,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           m.C0 = w2_ld(buf.params, m.npad, HXP_C0, m.moff);
         }
       } else {
+        if constexpr (hx_tbl<B>()) hx_tbl_local<B>(m);
         p_aero = PKM(m, PK_AERO); p_vol = PKM(m, PK_VOL);
       }
 #define HXDK(row) dconst<B>(m, (row))
@@ -990,7 +1011,11 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #undef HXDK
       const int jb = iy - blk0;
       double dpast = pf_dpart;
-      double hint = want_hf ? HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem] : 0.0;
+      double hint = 0.0;
+      if (want_hf) {
+        if constexpr (hx_rowio<B>()) hint = hx_ldm(HX_GCD(buf.dpart2) + (size_t)jb * buf.npad, m.moff);
+        else hint = HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem];
+      }
       // ---- forcing ----
       const double co2c = m.atmos * PGC2PPM;
       const double ln_co2r = hx_log(hx_div(co2c, m.C0), kc.mtab);
@@ -1050,7 +1075,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // Ker is stored with HX_KPAD zeros in front: entry k lives at k + HX_KPAD
         const int kq = ns - iy - 1 + HX_KPAD;
         auto ldk = [&](int idx) -> double {
-          if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * buf.npad + mem];
+          if constexpr (KERPM && hx_rowio<B>()) return hx_ldm(HX_GCD(buf.ker) + (size_t)idx * buf.npad, m.moff);
+          else if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * buf.npad + mem];
           else return HX_CCD(buf.ker)[idx];
         };
         // in chunks of 8 so that the loads of a chunk are in flight together (one exposed
@@ -1148,7 +1174,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #endif
       // ---- outputs ----
       const size_t o = (size_t)iy * buf.npad + mem;
-      if constexpr (hx_w2<B>()) {  // (wave-uniform row address + the lane's 32-bit offset)
+      if constexpr (hx_rowio<B>()) {  // (wave-uniform row address + the lane's 32-bit offset)
         const size_t orow = (size_t)iy * buf.npad;
         hx_stm(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
         hx_stm(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
@@ -1644,6 +1670,13 @@ static void hx_allow_dynamic_lds(const void *kernel, size_t bytes) {
 #endif
 }
 
+// experiment builds (tools/prof/build_variant.sh <name> -DHX_ONLY_B=<biomes>, with HX_MINIMAL_BUILD):
+// nothing but that biome count's kernels (0: the looped ones) -- a compile of seconds
+#ifdef HX_ONLY_B
+#define HX_ONLY_B_IS(b) (HX_ONLY_B == (b))
+#else
+#define HX_ONLY_B_IS(b) 1
+#endif
 // biome counts from this one on take the looped kernels (default: 9; HECTOR_AMD_LOOPED_BIOMES_FROM=5
 // sends 5-8 there as well -- the tests hold the unrolled and the looped kernels against each other)
 static int hx_looped_from() {   // (read at every launch: a test switches it between two cores)
@@ -1661,16 +1694,29 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
   return hipGetLastError();
 #else
   switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
+#if HX_ONLY_B_IS(1)
     case 1: hipLaunchKernelGGL(hx_spinup_kernel<1>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
 #ifndef HX_MINIMAL_BUILD
     case 2: hipLaunchKernelGGL(hx_spinup_kernel<2>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
     case 3: hipLaunchKernelGGL(hx_spinup_kernel<3>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
 #endif
+#if HX_ONLY_B_IS(4)
     case 4: hipLaunchKernelGGL(hx_spinup_kernel<4>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
+#if HX_ONLY_B_IS(5)
     case 5: hipLaunchKernelGGL(hx_spinup_kernel<5>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
+#if HX_ONLY_B_IS(6)
     case 6: hipLaunchKernelGGL(hx_spinup_kernel<6>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
+#if HX_ONLY_B_IS(7)
     case 7: hipLaunchKernelGGL(hx_spinup_kernel<7>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
+#if HX_ONLY_B_IS(8)
     case 8: hipLaunchKernelGGL(hx_spinup_kernel<8>, dim3(blocks), dim3(64), 0, st, d_args, d_steps); break;
+#endif
+#if HX_ONLY_B_IS(0)
     default:
       if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
       {
@@ -1678,6 +1724,9 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
         hx_allow_dynamic_lds(reinterpret_cast<const void *>(&hx_spinup_kernel<HX_DYN>), lds);
         hipLaunchKernelGGL(hx_spinup_kernel<HX_DYN>, dim3(blocks), dim3(64), lds, st, d_args, d_steps);
       }
+#else
+    default: return hipErrorInvalidValue;
+#endif
   }
   return hipGetLastError();
 #endif
@@ -1788,7 +1837,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
 #endif
 }
-#if HX_HAS_MFMA && (!defined(HX_W2_ONLY) || defined(HX_WITH_PAIR))
+#if HX_HAS_MFMA && ((!defined(HX_W2_ONLY) && !defined(HX_ONLY_B)) || defined(HX_WITH_PAIR))
 #define HX_HAS_PAIR 1
 #include "hx_dev_pair.h"
 #else
@@ -1819,25 +1868,57 @@ hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, b
   return hipGetLastError();
 #else
   switch (B >= hx_looped_from() ? HX_BDYN + 1 : B) {
+#if HX_ONLY_B_IS(1)
     case 1: launch_run_b<1>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 1, two_wave, cus); break;
+#endif
 #ifndef HX_MINIMAL_BUILD
     case 2: launch_run_b<2>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, 2, false, cus); break;
     case 3: launch_run_b<3>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
 #endif
+#if HX_ONLY_B_IS(4)
     case 4: launch_run_b<4>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break;
+#endif
     // five to eight biomes: unrolled like 1-4 (lean park, hx_dev_member.h); carbon tracking on the
     // looped kernels' 8-column chunks
+#if HX_ONLY_B_IS(5)
     case 5: if (con != 2) { launch_run_b<5>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+#if HX_ONLY_B_IS(0)
             launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+#else
+            return hipErrorInvalidValue;
+#endif
+#endif
+#if HX_ONLY_B_IS(6)
     case 6: if (con != 2) { launch_run_b<6>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+#if HX_ONLY_B_IS(0)
             launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+#else
+            return hipErrorInvalidValue;
+#endif
+#endif
+#if HX_ONLY_B_IS(7)
     case 7: if (con != 2) { launch_run_b<7>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+#if HX_ONLY_B_IS(0)
             launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+#else
+            return hipErrorInvalidValue;
+#endif
+#endif
+#if HX_ONLY_B_IS(8)
     case 8: if (con != 2) { launch_run_b<8>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st); break; }
+#if HX_ONLY_B_IS(0)
             launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B); break;
+#else
+            return hipErrorInvalidValue;
+#endif
+#endif
     default:
+#if HX_ONLY_B_IS(0)
       if (B < 1 || B > HX_BDYN) return hipErrorInvalidValue;
       launch_run_b<HX_DYN>(d_args, npad, heatflux, kpm, con, iy_from, iy_to, st, B);
+#else
+      return hipErrorInvalidValue;
+#endif
   }
   return hipGetLastError();
 #endif
