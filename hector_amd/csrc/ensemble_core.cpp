@@ -570,8 +570,8 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
   check(hipMalloc(&d_cost_, sizeof(double) * np), "hipMalloc lane cost");
-  check(hipMalloc(&d_bscratch_, sizeof(double) * np * (size_t)B_), "hipMalloc biome scratch");
-  check(hipMemsetAsync(d_bscratch_, 0, sizeof(double) * np * (size_t)B_, stream_), "zero");
+  check(hipMalloc(&d_bscratch_, sizeof(double) * np * (size_t)(3 * B_)), "hipMalloc biome scratch");
+  check(hipMemsetAsync(d_bscratch_, 0, sizeof(double) * np * (size_t)(3 * B_), stream_), "zero");
   cost_from_iy_ = -1;
   for (int v = 0; v < HXO_NVAR; ++v)
     if (out_enabled_[v]) {

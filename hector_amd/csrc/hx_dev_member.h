@@ -56,6 +56,13 @@ template <int B> constexpr bool hx_w2() { return B == HX_B1W2; }
 // compile-time biome count of the unrolled kernels (0: the looped ones)
 template <int B> constexpr int hx_nbc() { return B == HX_B1W2 ? 1 : B; }
 template <int B> constexpr bool hx_one() { return hx_nbc<B>() == 1; }
+// unroll factor of the per-biome loops: the biome count, or (looped kernels, runtime count) four --
+// rolled, every iteration waits out its own LDS / table latencies; in fours the loads of a chunk
+// are in flight together
+#ifndef HX_DYN_UNROLL
+#define HX_DYN_UNROLL 4
+#endif
+template <int B> constexpr int hx_ur() { return B == HX_DYN ? HX_DYN_UNROLL : hx_nbc<B>(); }
 template <int B> constexpr int hx_bmax() { return B == HX_DYN ? HX_BDYN : hx_nbc<B>(); }
 // Five to eight biomes have unrolled kernels too (round 3: the looped kernel waits out a memory
 // latency per biome and loop -- 22.8 ms against 10.9 for four biomes at 8 192 members; unrolled,
@@ -87,7 +94,19 @@ template <int B> constexpr int pk_ff0() {
 // written once a year; it IS a row of the state table) and f_new_thaw (written once a year, read
 // by the three or so flow computations) -- stay in HBM: 14 + 8 B slots = 35 / 39 KB, four
 // wavefronts a CU where 42 / 47 KB allowed three (65 536 members then take one round, not two).
-template <int B> constexpr bool hx_slim_park() { return B == 7 || B == 8; }
+template <int B> constexpr bool hx_slim_park() { return B == 7 || B == 8 || B == HX_DYN; }
+// The looped kernels (9 to HX_BDYN biomes) go further: only four POOLS of a biome -- vegetation,
+// detritus, soil, permafrost: what a stash reads, mixes and writes back -- live in the park; the
+// thawed-permafrost pool and tempferts (rows of the state table anyway), co2fert, tempfertd and
+// f_new_thaw (written once a year, read by the stashes: three scratch rows per biome) stay in HBM.
+// 14 + 4 nb slots = 25 ... 39 KB: four wavefronts a CU up to 16 biomes, 65 536 members in ONE
+// round where 53 ... 89 KB took two to four: 9 / 13 / 16 biomes 59.9 / 84.3 / 181 -> 39.7 / 54.9 /
+// 64.8 ms.  (Measured alternatives, profiles/r04_variant_log.md: the thawed pool parked too --
+// 37.6 / 50.9 ms but two rounds from 14 biomes on, 16 biomes 102 ms; parked or not by a
+// wave-uniform branch per access -- 47 / 67 / 76 ms, the branches keep a chunk's loads from being
+// in flight together.  An ensemble of one wavefront per CU pays the HBM trips without needing the
+// occupancy: 8 192 members x 9 biomes 31.2 -> 34.3 ms.)
+template <int B> constexpr bool hx_pools_only_park() { return B == HX_DYN; }
 template <int B> constexpr int hx_npark_arr() { return hx_slim_park<B>() ? HX_NBIOME_ARR - 1 : HX_NBIOME_ARR; }
 template <int B> constexpr int hx_nff() { return hx_slim_park<B>() ? 0 : hx_bmax<B>(); }  // parked f_frozen slots
 // two-wavefront flavour: what the step loop does not touch waits in these slots (w2_park_out)
@@ -99,7 +118,9 @@ template <int B> constexpr int hx_npark() {
   if (hx_w2<B>()) return PK_W2_0 + PK_W2_N - 1;   // 40 slots = 20 KB: eight wavefronts a CU
   return pk_ff0<B>() + hx_nff<B>() + (B == 1 ? (int)PKB_N : hx_npark_arr<B>() * hx_bmax<B>());
 }
-__host__ __device__ inline int hx_npark_dyn(int nb) { return PK_D0 + nb + HX_NBIOME_ARR * nb; }
+__host__ __device__ inline int hx_npark_dyn(int nb) { return PK_D0 + 4 * nb; }
+// rows of HxBuffers::bscratch a core of nb biomes needs
+__host__ __device__ inline int hx_bscratch_rows(int nb) { return 3 * nb; }
 template <int B> constexpr int hx_pkb1() { return pk_ff0<B>() + hx_nff<B>(); }
 
 // Per-biome arrays of a member.  One biome: plain registers.  More: the LDS park -- kept in
@@ -139,6 +160,11 @@ struct GlobArr {
 template <int B> struct BiomeArrThaw { using type = typename BiomeArr<B>::type; };
 template <> struct BiomeArrThaw<7> { using type = GlobArr; };
 template <> struct BiomeArrThaw<8> { using type = GlobArr; };
+template <> struct BiomeArrThaw<HX_DYN> { using type = GlobArr; };
+// tempferts, co2fert, tempfertd: the park, or (looped kernels) HBM rows
+template <int B> struct BiomeArrYear { using type = typename BiomeArr<B>::type; };
+template <> struct BiomeArrYear<HX_DYN> { using type = GlobArr; };
+
 
 // What stays in registers through the carbon-cycle solver of one year.
 template <int B>
@@ -146,14 +172,15 @@ struct Member {
   double C0;
   // state
   double cHL, cLL, cIO, cDO, atmos, earth;
-  typename BiomeArr<B>::type veg, det, soil, pf, thawed, tempferts;
+  typename BiomeArr<B>::type veg, det, soil, pf;
+  typename BiomeArrYear<B>::type thawed, tempferts;
   double cum_luc_va, cum_pf_ch4, masstot;
   double max_ts, lastflux_ann, sdt;
   int ts_timeout;
   double alkH, alkL, hH, hL;
   unsigned status;
   // per-year
-  typename BiomeArr<B>::type co2fert, tempfertd;
+  typename BiomeArrYear<B>::type co2fert, tempfertd;
   typename BiomeArrThaw<B>::type f_new_thaw;
   GlobArr ffz;   // slim park: f_frozen of this lane in the state table
   double luc_e, luc_u, ffi, daccs, npp_luc_adjust;
@@ -235,6 +262,9 @@ template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, in
 template <int B> __device__ __forceinline__ void hx_tbl_local(Member<B> &m) {
   HX_W2_LOCAL(m);
   if constexpr (hx_slim_park<B>()) { m.ffz.npad = m.npad; m.f_new_thaw.npad = m.npad; }
+  if constexpr (hx_pools_only_park<B>()) {
+    m.thawed.npad = m.npad; m.tempferts.npad = m.npad; m.co2fert.npad = m.npad; m.tempfertd.npad = m.npad;
+  }
 }
 
 // biome constants of the land model, fetched where they are used
@@ -361,7 +391,17 @@ __device__ __forceinline__ void bind_member(const HxBuffers &buf, int mem, Membe
   if constexpr (!hx_one<B>()) {
     const int bm = (B == HX_DYN) ? buf.nbiome : hx_bmax<B>();   // slots per array
     const int o = pk_ff0<B>() + (hx_slim_park<B>() ? 0 : bm);
-    if constexpr (hx_slim_park<B>()) {
+    if constexpr (hx_pools_only_park<B>()) {
+      ParkArr *arr[4] = {&m.veg, &m.det, &m.soil, &m.pf};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { arr[k]->base = park + o + k * bm; arr[k]->lane = lane; }
+      m.thawed = GlobArr{buf.state, HXS_NGLOBAL + HXSB_THAWED, HXSB_N, m.npad, m.moff};
+      m.tempferts = GlobArr{buf.state, HXS_NGLOBAL + HXSB_TEMPFERTS, HXSB_N, m.npad, m.moff};
+      m.co2fert = GlobArr{buf.bscratch, 0, 1, m.npad, m.moff};
+      m.tempfertd = GlobArr{buf.bscratch, bm, 1, m.npad, m.moff};
+      m.f_new_thaw = GlobArr{buf.bscratch, 2 * bm, 1, m.npad, m.moff};
+      m.ffz = GlobArr{buf.state, HXS_NGLOBAL + HXSB_F_FROZEN, HXSB_N, m.npad, m.moff};
+    } else if constexpr (hx_slim_park<B>()) {
       ParkArr *arr[HX_NBIOME_ARR - 1] = {&m.veg, &m.det, &m.soil, &m.pf, &m.thawed, &m.tempferts,
                                          &m.co2fert, &m.tempfertd};
 #pragma unroll
@@ -457,7 +497,7 @@ __device__ __forceinline__ void load_state(const HxBuffers &buf, int mem, Member
   // needs them: read from their rows there instead of held in registers through the year)
   if constexpr (!hx_w2<B>()) { m.alkH = lds_(buf, HXS_ALK_HL, mem); m.alkL = lds_(buf, HXS_ALK_LL, mem); }
   m.hH = lds_(buf, HXS_H_HL, mem); m.hL = lds_(buf, HXS_H_LL, mem);
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b) {
     const int r = HXS_NGLOBAL + b * HXSB_N;
     m.veg[b] = lds_(buf, r + HXSB_VEG, mem); m.det[b] = lds_(buf, r + HXSB_DET, mem);
@@ -493,7 +533,7 @@ __device__ __forceinline__ void store_state(const HxBuffers &buf_, int mem,
   sts_(buf, HXS_ALK_HL, mem, m.alkH); sts_(buf, HXS_ALK_LL, mem, m.alkL);
   }
   sts_(buf, HXS_H_HL, mem, m.hH); sts_(buf, HXS_H_LL, mem, m.hL);
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b) {
     const int r = HXS_NGLOBAL + b * HXSB_N;
     sts_(buf, r + HXSB_VEG, mem, m.veg[b]); sts_(buf, r + HXSB_DET, mem, m.det[b]);
@@ -522,7 +562,7 @@ __device__ __forceinline__ void store_park_state(const HxBuffers &buf_, int mem,
   if (base) sts_(buf, HXS_EOS_VEGC, mem, PKM(m, PK_EOS));
   }
   if (hx_slim_park<B>() && !base) return;  // (the live table's rows are where f_frozen lives)
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b)
     sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, ffrozen_of<B>(m, b));
 }

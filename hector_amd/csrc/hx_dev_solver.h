@@ -101,7 +101,7 @@ __device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B>
                                               Flows &F) {
   double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
   double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b) {
     const double n = m_npp(m, lk, b);
     npp_c += n;
@@ -294,17 +294,17 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
   double npp_t = 0, rh_t = 0, pf_t = 0;
   const int NB = nbio<B>(m);
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b) npp_t += m_npp(m, lk, b);
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b)
     rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b) pf_t += m.pf[b];
   [[maybe_unused]] double sp_rd = 0, sp_rs = 0, sp_rc = 0;  // spinup record: final_rh_detritus / _soil, thawed part
   if constexpr (SPIN) {
     if (m.spin_row) {
-#pragma unroll
+#pragma unroll hx_ur<B>()
       for (int b = 0; b < NB; ++b) { sp_rd += m_rh_fda(m, b); sp_rs += m_rh_fsa(m, b); sp_rc += m_rh_tp_co2(m, lk, b); }
     }
   }
@@ -356,7 +356,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       else track_stash<B>(m, lk, tk);
     }
   }
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b) {
     const double wt = hx_one<B>() ? 1.0
         : hx_div_cr(m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b)),
@@ -547,7 +547,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       }
     }
     double v = 0, d = 0, s = 0, p = 0, th = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
     for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                             p += m.pf[b]; th += m.thawed[b]; }
     y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   // on S and diff, which the spinup never sees: they are OR'ed in per member after the spinup,
   // hx_or_flags_kernel, so that a shared spinup neither loses nor spreads them)
   m.status = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b) {
     const int r = HXP_NGLOBAL + b * HXPB_N;
     m.veg[b] = ldp(buf, r + HXPB_VEG0, mem); m.det[b] = ldp(buf, r + HXPB_DET0, mem);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
     if (!spun) {
       const double o0 = m.atmos, oO = m.cDO + m.cIO + m.cLL + m.cHL, oE = m.earth;
       double ov = 0, od = 0, os = 0, op = 0, ot = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
       for (int b = 0; b < nbio<B>(m); ++b) { ov += m.veg[b]; od += m.det[b]; os += m.soil[b];
                                      op += m.pf[b]; ot += m.thawed[b]; }
       m.nstash = 0; m.nsteps = 0;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
       }
       solve_year<B, true>(m, kc, (double)(step - 1), (double)step, YearCon{});
       double nv = 0, nd = 0, nso = 0, np = 0, nt = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
       for (int b = 0; b < nbio<B>(m); ++b) { nv += m.veg[b]; nd += m.det[b]; nso += m.soil[b];
                                      np += m.pf[b]; nt += m.thawed[b]; }
       double mx = fabs(m.atmos - o0);
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   store_state<B>(buf, mem, m);
   // SimpleNbox::run, first call: end_of_spinup_vegc  runtime.cpp:209-213
   double v1 = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b) {
     v1 += m.veg[b];
     sts_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem, 1.0);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   put(HXO_HL_PH, 0.0); put(HXO_LL_PH, 0.0); put(HXO_ATMOS_C, m.atmos);
   {
     double v = 0, d = 0, s = 0, p = 0, th = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
     for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                    p += m.pf[b]; th += m.thawed[b]; }
     put(HXO_PERMAFROST_C, p); put(HXO_VEG_C, v); put(HXO_DET_C, d);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   put(HXO_NSTASH, 0.0); put(HXO_NSTEPS, 0.0);
   put(HXO_C_HL, m.cHL); put(HXO_C_LL, m.cLL); put(HXO_C_IO, m.cIO); put(HXO_C_DO, m.cDO);
   put(HXO_F_FROZEN, 1.0); put(HXO_TAU_OH, kc.TOH0);
-#pragma unroll
+#pragma unroll hx_ur<B>()
   for (int b = 0; b < nbio<B>(m); ++b) {
     put(HXO_B(HXOB_VEG, b), m.veg[b]); put(HXO_B(HXOB_DET, b), m.det[b]);
     put(HXO_B(HXOB_SOIL, b), m.soil[b]); put(HXO_B(HXOB_PF, b), m.pf[b]);
@@ -547,7 +547,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
     PKM(m, PK_LN_CH4) = hx_log(lds_(buf, HXS_CH4, mem));
     PKM(m, PK_LN_CO2R) = hx_log(hx_div(m.atmos * PGC2PPM, m.C0));
     if constexpr (!hx_slim_park<B>()) {
-#pragma unroll
+#pragma unroll hx_ur<B>()
     for (int b = 0; b < nbio<B>(m); ++b)
       PKM(m, pk_ff0<B>() + b) = lds_(buf, HXS_NGLOBAL + b * HXSB_N + HXSB_F_FROZEN, mem);
     }
@@ -700,7 +700,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       // ---- OH, CH4, O3 ----
       double rh_ch4 = 0;  // D_RH_CH4 as recorded at the end of last year
       if (iy > 1) {
-#pragma unroll
+#pragma unroll hx_ur<B>()
         for (int b = 0; b < nbio<B>(m); ++b) rh_ch4 += m_rh_tp_ch4(m, lk, b);
       }
       // (a select, not a branch: four operations, and a divergent region here is one of the
@@ -850,6 +850,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       const double lnc = PKM(m, PK_LN_CO2R);  // = log((atmos C * PGC2PPM) / C0), from last year's phase C
       if constexpr (B == HX_DYN) {
         // looped kernels: the same per biome, one at a time, parameters read where they are used
+#pragma unroll hx_ur<B>()
         for (int b = 0; b < m.nb; ++b) {
           const int pr = HXP_NGLOBAL + b * HXPB_N;
           const double wf = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
@@ -1206,7 +1207,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       if (buf.out[HXO_PERMAFROST_C] || buf.out[HXO_VEG_C] || buf.out[HXO_DET_C] ||
           buf.out[HXO_SOIL_C] || buf.out[HXO_THAWED_C]) {
         double v = 0, d = 0, s = 0, p = 0, th = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
         for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                        p += m.pf[b]; th += m.thawed[b]; }
         if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, p);
@@ -1228,7 +1229,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       if (buf.biome_diag) {  // "<biome>.veg_c" ...: pools and factors of each biome
         LandK<B> lkb;
         load_landk<B>(m, lkb);
-#pragma unroll
+#pragma unroll hx_ur<B>()
         for (int b = 0; b < nbio<B>(m); ++b) {
           auto putb = [&](int k, double v) { if (buf.out[HXO_B(k, b)]) sto_(buf, HXO_B(k, b), o, v); };
           putb(HXOB_VEG, m.veg[b]); putb(HXOB_DET, m.det[b]); putb(HXOB_SOIL, m.soil[b]);
@@ -1244,10 +1245,10 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         LandK<B> lk;
         load_landk<B>(m, lk);
         double rch4 = 0, ptot = 0, ff = 0;
-#pragma unroll
+#pragma unroll hx_ur<B>()
         for (int b = 0; b < nbio<B>(m); ++b) { rch4 += m_rh_tp_ch4(m, lk, b); ptot += m.pf[b]; }
         if (ptot > 0.0) {
-#pragma unroll
+#pragma unroll hx_ur<B>()
           for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * ffrozen_of<B>(m, b);
         } else ff = 1.0;
         if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rch4);

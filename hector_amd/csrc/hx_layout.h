@@ -234,8 +234,9 @@ struct HxBuffers {
   // optional (hx_enable_spinup_record): what the reference's output stream sees after every spinup
   // step -- its "spinup = 1" rows (csv_outputstream_visitor.cpp:86-95) -- [max_spinup][HXSR_N][npad]
   double *spin_rec;
-  // seven- and eight-biome kernels: f_new_thaw of every biome, [nbiome][npad] (their park holds
-  // eight arrays per biome instead of ten, so that four wavefronts share a CU: hx_dev_member.h)
+  // per-biome values of the year that wait in HBM instead of the park (hx_dev_member.h): f_new_thaw
+  // of every biome for the seven- and eight-biome kernels; co2fert, tempfertd and f_new_thaw for the
+  // looped ones -- [3 nbiome][npad]
   double *bscratch;
 };
 // rows of HxBuffers::spin_rec: the carbon-cycle variables of the stream, which are the ones that
