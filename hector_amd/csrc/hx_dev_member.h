@@ -16,6 +16,26 @@ namespace {
 // limits this kernel (DESIGN.md "registers").
 #define HX_FENCE() asm volatile("" ::: "memory")
 
+// Table accesses of the form row address + lane offset (hx_ldm / hx_stm / w2_ld below):
+// (HX_SROW: the row address passes through an empty asm as a scalar pair -- left alone the
+// optimiser folds base + lane offset into one 64-bit VECTOR address per lane and adds each row's
+// scalar offset to it with a v_lshl_add_u64, 32 of them a year for the block's SSTs alone; as an
+// opaque scalar the row offset is added on the scalar unit and the access takes the
+// `global_load v, v_off, s[base:base+1]` form.  Only where control flow is wave-uniform.)
+#if !defined(HX_HOST_EMULATION) && !defined(HX_NO_SROW)
+#define HX_SROW(p) asm("" : "+s"(p))
+#else
+#define HX_SROW(p)
+#endif
+// (HX_VOFF: and the lane offset through one as a 32-bit vector register -- its zero extension to
+// 64 bits is then made next to the access, where instruction selection can see it and fold it
+// into the instruction; hoisted out of the block as a 64-bit pair, it cannot.)
+#if !defined(HX_HOST_EMULATION) && !defined(HX_NO_VOFF)
+#define HX_VOFF(o) asm("" : "+v"(o))
+#else
+#define HX_VOFF(o)
+#endif
+
 // Per-lane LDS scratchpad ("park"): year-level state and the constants that the
 // phases and the stash block need a few times per year.  One wavefront per SIMD
 // means every HBM/L2 access is an exposed ~1-2k-cycle stall; LDS answers in ~64.
@@ -237,22 +257,34 @@ template <int B> __device__ __forceinline__ void set_ffrozen(const Member<B> &m,
 // wave-uniform row address plus the lane's 32-bit byte offset -- the form global_load takes an
 // SGPR base and one VGPR for, no 64-bit vector address arithmetic.  Tables of up to 4 GB.
 // the same for a row whose (wave-uniform, 64-bit) address the caller has: any table size
+// S: the two-wavefront flavour, whose limit is the vector unit's issue slots -- there the scalar
+// form pays (131 072 members 10.29 -> 10.21 ms, 262 144 19.59 -> 19.24); one wavefront per SIMD
+// waits for the five dependent scalar instructions of a row address instead (9 / 16 biomes
+// 39.7 / 64.3 -> 45.9 / 85.2 ms, four biomes 10.06 -> 10.19): those keep the optimiser's choice.
+template <bool S = false>
 __device__ __forceinline__ double hx_ldm(hx_gcd row, unsigned moff) {
+  if constexpr (S) { HX_SROW(row); HX_VOFF(moff); }
   return *(hx_gcd)((const char HX_GLOBAL *)row + moff);
 }
+template <bool S = false>
 __device__ __forceinline__ void hx_stm(hx_gd row, unsigned moff, double v) {
+  if constexpr (S) { HX_SROW(row); HX_VOFF(moff); }
   *(hx_gd)((char HX_GLOBAL *)row + moff) = v;
 }
+template <bool S = false>
 __device__ __forceinline__ double w2_ld(const double *tbl, int npad, int row, unsigned moff) {
   const char HX_GLOBAL *r = (const char HX_GLOBAL *)HX_GCD(tbl) + (size_t)((unsigned)row * ((unsigned)npad * 8u));
+  if constexpr (S) HX_VOFF(moff);
   return *(hx_gcd)(r + moff);
 }
+template <bool S = false>
 __device__ __forceinline__ void w2_st(double *tbl, int npad, int row, unsigned moff, double v) {
   char HX_GLOBAL *r = (char HX_GLOBAL *)HX_GD(tbl) + (size_t)((unsigned)row * ((unsigned)npad * 8u));
+  if constexpr (S) HX_VOFF(moff);
   *(hx_gd)(r + moff) = v;
 }
 template <int B> __device__ __forceinline__ double dconst(const Member<B> &m, int row) {
-  if constexpr (hx_tbl<B>()) return w2_ld(m.bufp->derived, m.npad, row, m.moff);
+  if constexpr (hx_tbl<B>()) return w2_ld<hx_w2<B>()>(m.bufp->derived, m.npad, row, m.moff);
   else if constexpr (hx_lean_park<B>()) return m.der[(size_t)row * m.npad];
   else return PKM(m, row >= HXD_KLH && row < HXD_KLH + 7 ? PK_K0 + (row - HXD_KLH) : PK_D0 + (row - HXD_A0));
 }
@@ -310,12 +342,12 @@ __device__ __forceinline__ void load_landk(const Member<B> &m, LandK<B> &k) {
       k.fpf_static[0] = u[HXPB_FPF_STATIC];
     } else {
       const double *p = m.bufp->params;
-      k.npp0[0] = w2_ld(p, m.npad, r + HXPB_NPP0, m.moff);
-      k.f_nppv[0] = w2_ld(p, m.npad, r + HXPB_F_NPPV, m.moff);
-      k.f_nppd[0] = w2_ld(p, m.npad, r + HXPB_F_NPPD, m.moff);
-      k.f_litterd[0] = w2_ld(p, m.npad, r + HXPB_F_LITTERD, m.moff);
-      k.rh_ch4_frac[0] = w2_ld(p, m.npad, r + HXPB_RH_CH4_FRAC, m.moff);
-      k.fpf_static[0] = w2_ld(p, m.npad, r + HXPB_FPF_STATIC, m.moff);
+      k.npp0[0] = w2_ld<true>(p, m.npad, r + HXPB_NPP0, m.moff);
+      k.f_nppv[0] = w2_ld<true>(p, m.npad, r + HXPB_F_NPPV, m.moff);
+      k.f_nppd[0] = w2_ld<true>(p, m.npad, r + HXPB_F_NPPD, m.moff);
+      k.f_litterd[0] = w2_ld<true>(p, m.npad, r + HXPB_F_LITTERD, m.moff);
+      k.rh_ch4_frac[0] = w2_ld<true>(p, m.npad, r + HXPB_RH_CH4_FRAC, m.moff);
+      k.fpf_static[0] = w2_ld<true>(p, m.npad, r + HXPB_FPF_STATIC, m.moff);
     }
   } else if constexpr (B == 1) {
     constexpr int o = hx_pkb1<B>();

@@ -611,9 +611,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       if constexpr (hx_tbl<B>() && !hx_w2<B>()) hx_tbl_local<B>(m);
       if constexpr (hx_w2<B>()) {   // values that live in the tables (hx_dev_member.h)
         HX_W2_LOCAL(m);
-        eos = w2_ld(buf.state, m.npad, HXS_EOS_VEGC, m.moff);
-        m.alkH = w2_ld(buf.state, m.npad, HXS_ALK_HL, m.moff);
-        m.alkL = w2_ld(buf.state, m.npad, HXS_ALK_LL, m.moff);
+        eos = w2_ld<true>(buf.state, m.npad, HXS_EOS_VEGC, m.moff);
+        m.alkH = w2_ld<true>(buf.state, m.npad, HXS_ALK_HL, m.moff);
+        m.alkL = w2_ld<true>(buf.state, m.npad, HXS_ALK_LL, m.moff);
       } else {
         eos = PKM(m, PK_EOS);
       }
@@ -636,7 +636,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // (two resident wavefronts hide a load's latency: nothing is requested a phase ahead, so
         // nothing waits in registers through the solver)
         load_year_a(iy);
-        pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold >= 1 ? iold : 0) * buf.npad, m.moff);
+        pf_tl_old = hx_ldm<true>(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold >= 1 ? iold : 0) * buf.npad, m.moff);
       }
       const double tl_old = pf_tl_old;
       constexpr int NB = hx_nbc<B>();
@@ -651,16 +651,16 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         if constexpr (hx_w2<B>()) {
           const int pr = HXP_NGLOBAL;
           if (buf.uni_wf) p_wf[b] = HX_CCD(buf.uparams)[pr + HXPB_WF];
-          else p_wf[b] = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
+          else p_wf[b] = w2_ld<true>(buf.params, m.npad, pr + HXPB_WF, m.moff);
           if (buf.uni_bio) {
             hx_ccd u = HX_CCD(buf.uparams) + pr;
             p_beta[b] = u[HXPB_BETA]; p_mu[b] = u[HXPB_PF_MU]; p_sigma[b] = u[HXPB_PF_SIGMA];
           } else {
-            p_beta[b] = w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff);
-            p_mu[b] = w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
-            p_sigma[b] = w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
+            p_beta[b] = w2_ld<true>(buf.params, m.npad, pr + HXPB_BETA, m.moff);
+            p_mu[b] = w2_ld<true>(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
+            p_sigma[b] = w2_ld<true>(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
           }
-          p_lnq10[b] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL, m.moff);
+          p_lnq10[b] = w2_ld<true>(buf.derived, m.npad, HXD_NGLOBAL, m.moff);
           load_landk<B>(m, lk);
         } else if constexpr (B == 1) {
           constexpr int o = hx_pkb1<B>();
@@ -975,11 +975,11 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #pragma unroll
         for (int r = 0; r < HX_DBLK; ++r) {
           const int i = blk0 + r;
-          Tall[r] = hx_ldm(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
+          Tall[r] = hx_ldm<hx_w2<B>()>(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
         }
       }
       if constexpr (hx_w2<B>()) {  // what the other kernels request ahead of the solver
-        pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(iy - blk0) * buf.npad, m.moff);
+        pf_dpart = hx_ldm<true>(HX_GCD(buf.dpart) + (size_t)(iy - blk0) * buf.npad, m.moff);
         yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
         ch4 = PKM(m, PK_CH4);
         o3 = ((5 * PKM(m, PK_LN_CH4) + sh[HXSH_O3_NOX]) + sh[HXSH_O3_CO]) + sh[HXSH_O3_NMVOC];
@@ -996,8 +996,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           hx_ccd u = HX_CCD(buf.uparams);
           p_aero = u[HXP_AERO]; p_vol = u[HXP_VOL]; m.C0 = u[HXP_C0];
         } else {
-          p_aero = w2_ld(buf.params, m.npad, HXP_AERO, m.moff); p_vol = w2_ld(buf.params, m.npad, HXP_VOL, m.moff);
-          m.C0 = w2_ld(buf.params, m.npad, HXP_C0, m.moff);
+          p_aero = w2_ld<true>(buf.params, m.npad, HXP_AERO, m.moff); p_vol = w2_ld<true>(buf.params, m.npad, HXP_VOL, m.moff);
+          m.C0 = w2_ld<true>(buf.params, m.npad, HXP_C0, m.moff);
         }
       } else {
         if constexpr (hx_tbl<B>()) hx_tbl_local<B>(m);
@@ -1014,7 +1014,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       double dpast = pf_dpart;
       double hint = 0.0;
       if (want_hf) {
-        if constexpr (hx_rowio<B>()) hint = hx_ldm(HX_GCD(buf.dpart2) + (size_t)jb * buf.npad, m.moff);
+        if constexpr (hx_rowio<B>()) hint = hx_ldm<hx_w2<B>()>(HX_GCD(buf.dpart2) + (size_t)jb * buf.npad, m.moff);
         else hint = HX_GCD(buf.dpart2)[(size_t)jb * buf.npad + mem];
       }
       // ---- forcing ----
@@ -1076,7 +1076,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // Ker is stored with HX_KPAD zeros in front: entry k lives at k + HX_KPAD
         const int kq = ns - iy - 1 + HX_KPAD;
         auto ldk = [&](int idx) -> double {
-          if constexpr (KERPM && hx_rowio<B>()) return hx_ldm(HX_GCD(buf.ker) + (size_t)idx * buf.npad, m.moff);
+          if constexpr (KERPM && hx_rowio<B>()) return hx_ldm<hx_w2<B>()>(HX_GCD(buf.ker) + (size_t)idx * buf.npad, m.moff);
           else if constexpr (KERPM) return HX_GCD(buf.ker)[(size_t)idx * buf.npad + mem];
           else return HX_CCD(buf.ker)[idx];
         };
@@ -1177,11 +1177,11 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       const size_t o = (size_t)iy * buf.npad + mem;
       if constexpr (hx_rowio<B>()) {  // (wave-uniform row address + the lane's 32-bit offset)
         const size_t orow = (size_t)iy * buf.npad;
-        hx_stm(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
-        hx_stm(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
-        if constexpr (CON) { if (buf.out[HXO_SST_LO]) hx_stm(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
-        if (buf.out[HXO_CO2]) hx_stm(HX_GD(buf.out[HXO_CO2]) + orow, m.moff, co2c);
-        if (buf.out[HXO_TGAV]) hx_stm(HX_GD(buf.out[HXO_TGAV]) + orow, m.moff, tgav);
+        hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
+        hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
+        if constexpr (CON) { if (buf.out[HXO_SST_LO]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
+        if (buf.out[HXO_CO2]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_CO2]) + orow, m.moff, co2c);
+        if (buf.out[HXO_TGAV]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_TGAV]) + orow, m.moff, tgav);
       } else {
       sto_(buf, HXO_SST, o, sst_new);
       sto_(buf, HXO_TLAND, o, tl_rep);
