@@ -222,7 +222,12 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // HF: the ocean heat flux is recorded ("heatflux"; its two parts are extended diagnostics of the run
 // kernel): a second history sum with the kernel table shifted by a year.
 template <bool KERPM, bool HF>
-__global__ __launch_bounds__(128) void hx_pair_kernel(const HxArgs *__restrict__ args, int iy_from,
+#ifdef HX_PAIR_TWO_PER_SIMD   // experiment builds: the register / LDS budget of two blocks' wavefronts per SIMD
+#define HX_PAIR_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define HX_PAIR_OCC
+#endif
+__global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *__restrict__ args, int iy_from,
                                                       int iy_to) {
   __shared__ double s_tblk[HX_DBLK + 1][64];  // SSTs of years blk0-1 .. blk0+31 (the ocean side's)
   __shared__ double s_st[2][PS_N][64];        // step hand-offs, double-buffered
