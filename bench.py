@@ -66,7 +66,7 @@ FP64_VECTOR_PEAK = 78.6e12   # fp64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop 
 YEARS = 555
 KERNEL_SOURCES = ["hx_kernels.hip", "hx_dev_chem.h", "hx_dev_const.h", "hx_dev_member.h",
                   "hx_dev_solver.h", "hx_dev_track.h", "hx_dev_math.h", "hx_dev_clock.h", "hx_dev_pair.h",
-                  "hx_layout.h", "hx_addrspace.h", "hx_chem_fit.inc"]
+                  "hx_layout.h", "hx_addrspace.h", "hx_chem_fit.inc", "hx_erfc_fit.inc"]
 
 
 def kernel_source_hash():

@@ -146,6 +146,62 @@ __device__ __forceinline__ double hx_log(double x, const double *T = nullptr) {
   return a[0];
 }
 
+// The frozen-permafrost fraction of N biomes from their lognormal arguments
+// d = (ln Tb - mu) / (sigma sqrt 2):  1 - erfc(-d) / 2  (simpleNbox-runtime.cpp:1006-1034; boost's
+// lognormal cdf is erfc(-d) / 2).  One argument range for every d (tools/make_erfc_fit.py):
+//   erfc(z) = t exp(-z^2 + P(u)),  t = 2 / (2 + z),  u = 2 t - 1,  z = |d|;  erfc(-z) = 2 - erfc(z)
+// P of degree 27 with coefficients below 0.7, evaluated coefficient by coefficient over the N
+// biomes like hx_exp_batch: ~65 vector instructions per biome where the device library's erfc (both
+// of its ranges evaluated, then selected) takes ~160, 60 of them moves of coefficients into
+// vector registers.  Absolute error <= 4.4e-16 (profiles/erfc_fit_report.json).
+#include "hx_erfc_fit.inc"
+template <int N>
+__device__ __forceinline__ void hx_frozen_fraction_batch(const double (&d)[N], double (&ff)[N]) {
+#ifdef HX_OCML_ERFC   // experiment builds: the device library's erfc
+#pragma unroll
+  for (int i = 0; i < N; ++i) ff[i] = 1 - erfc(-d[i]) / 2;
+  return;
+#endif
+  constexpr double c[HX_ERFC_FIT_DEGREE + 1] = HX_ERFC_FIT_COEFFS;
+  double a[N], t[N], u[N], p[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    a[i] = fabs(d[i]);
+    const double den = 2.0 + a[i];
+    double rc = HX_RCP(den);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    t[i] = rc + rc;
+    u[i] = (t[i] + t[i]) - 1.0;
+    p[i] = c[0];
+  }
+  // (the coefficient as the SCALAR addend of a v_fma_f64, spelled out: left to the compiler a
+  // coefficient that is used once becomes two v_mov into the destination of a v_fmac_f64 -- three
+  // vector instructions per term instead of one)
+#pragma unroll
+  for (int j = 1; j <= HX_ERFC_FIT_DEGREE; ++j) {
+    [[maybe_unused]] const double cj = c[j];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#ifndef HX_HOST_EMULATION
+      double r;
+      asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p[i]), "v"(u[i]), "s"(cj));
+      p[i] = r;
+#else
+      p[i] = fma(p[i], u[i], c[j]);
+#endif
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) p[i] = fmax(fma(-a[i], a[i], p[i]), -746.0);   // (exp(-inf) = 0)
+  hx_exp_batch<N>(p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double half = 0.5 * (t[i] * p[i]);   // erfc(|d|) / 2
+    ff[i] = (d[i] > 0.0) ? half : 1.0 - half;
+  }
+}
+
 // sqrt(x), x >= 0 and normal (sqrt(0) = 0: rsq(0) = inf and 0 * inf would be NaN -- a zero
 // concentration in the forcing formulas, e.g. a constraint of 0, must stay finite like libm's)
 __device__ __forceinline__ double hx_sqrt(double x) {

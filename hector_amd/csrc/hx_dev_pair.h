@@ -690,8 +690,10 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       if (pf != 0.0) {
         double ff = 1.0;
         if (Tb > 0) {
-          const double d = hx_div(hx_log(Tb) - pmu, psigma * 1.4142135623730951);
-          ff = 1 - erfc(-d) / 2;
+          const double d[1] = {hx_div(hx_log(Tb) - pmu, psigma * 1.4142135623730951)};
+          double f1[1];
+          hx_frozen_fraction_batch<1>(d, f1);
+          ff = f1[0];
         }
         f_new_thaw = ffrozen - ff;
         ffrozen = ff;

@@ -554,6 +554,19 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   }
   constexpr bool want_hf = HF;  // heat-flux diagnostic needs a second history sum
   int blk0 = -1;  // first year index of the current DOECLIM block
+  // (-DHX_BLOCK_STAGGER, experiment builds: the launch's FIRST block cut short by a
+  // wavefront-dependent amount, so that the wavefronts do not all read their SST history in the
+  // same model years.  The sums do not depend on where the blocks start, bit for bit -- the pass
+  // and the in-block terms add the history years in ascending order either way -- and neither
+  // does the time: 65 536 / 131 072 / 262 144 members 6.77-6.82 / 10.11-10.17 / 19.2-19.6 ms with
+  // and without it.  The pass is bound by the matrix pipe, 64 cycles per v_mfma_f64_16x16x4_f64
+  // on this part, not by an HBM burst.)
+#ifdef HX_BLOCK_STAGGER
+  const int blk_len0 = 1 + (int)((blockIdx.x * 13u) & (HX_DBLK - 1));
+#else
+  const int blk_len0 = HX_DBLK;
+#endif
+  int blk_end = 0;  // first year index after the current block
   // Two values a year come straight from HBM -- land temperature of 203 years ago (Q10 window)
   // and the block's history partial sum -- and with one wavefront on the SIMD a load's latency is
   // waited out in full: they are requested a phase ahead, before the solver (pf_*).
@@ -862,9 +875,11 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           if (m.pf[b] != 0.0) {
             double ff = 1.0;
             if (Tbb > 0) {
-              const double d = hx_div(hx_log(Tbb) - w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff),
-                                      w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff) * 1.4142135623730951);
-              ff = 1 - erfc(-d) / 2;
+              const double d[1] = {hx_div(hx_log(Tbb) - w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff),
+                                          w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff) * 1.4142135623730951)};
+              double f1[1];
+              hx_frozen_fraction_batch<1>(d, f1);
+              ff = f1[0];
             }
             m.f_new_thaw[b] = ffrozen_of<B>(m, b) - ff;
             set_ffrozen<B>(m, b, ff);
@@ -875,19 +890,24 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           m.tempferts[b] = fmax(tfs, last);
         }
       }
+      // the frozen fractions of all biomes as one batch (hx_dev_math.h); a biome at or below
+      // 0 degC is frozen through (lg holds ln 1 there), one without permafrost keeps what it has
+      [[maybe_unused]] double ffb[NB > 0 ? NB : 1];
+      if constexpr (NB > 0) {
+        double dfr[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dfr[b] = hx_div(lg[2 + b] - p_mu[b], p_sigma[b] * 1.4142135623730951);
+        hx_frozen_fraction_batch<(NB > 0 ? NB : 1)>(dfr, ffb);
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         m.co2fert[b] = 1 + p_beta[b] * lnc;
         m.tempfertd[b] = ex[13 + 2 * b];  // exp(ln q10 * Tb / 10)
-        m.f_new_thaw[b] = 0.0;
-        if (m.pf[b] != 0.0) {
-          double ff = 1.0;
-          if (Tb[b] > 0) {
-            const double d = hx_div(lg[2 + b] - p_mu[b], p_sigma[b] * 1.4142135623730951);
-            ff = 1 - erfc(-d) / 2;
-          }
-          m.f_new_thaw[b] = s_ffrozen[b] - ff;
-          set_ffrozen<B>(m, b, ff);
+        {
+          const bool has_pf = m.pf[b] != 0.0;
+          const double ff = (Tb[b] > 0) ? ffb[b] : 1.0;
+          m.f_new_thaw[b] = has_pf ? s_ffrozen[b] - ff : 0.0;
+          set_ffrozen<B>(m, b, has_pf ? ff : s_ffrozen[b]);
         }
         const double tfs = ex[14 + 2 * b];  // exp(ln q10 * Trm / 10), Trm = 200-year mean
         const double last = (iy > 1) ? m.tempferts[b] : 0.0;
@@ -901,7 +921,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       if constexpr (!hx_w2<B>()) {  // next year's window entry, this year's history partial sum (see pf_* above)
         const HxBuffers &buf = args->buf;
         const int iold1 = iy + 1 - 203;
-        const bool newblk = blk0 < 0 || iy >= blk0 + HX_DBLK;  // (then the pass has not run yet)
+        const bool newblk = blk0 < 0 || iy >= blk_end;  // (then the pass has not run yet)
         if constexpr (hx_rowio<B>()) {
           pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad, m.moff);
           pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(newblk ? 0 : iy - blk0) * buf.npad, m.moff);
@@ -943,8 +963,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       const HxConst &kc = args->kc;
       const int ns = kc.ns;
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
-      if (blk0 < 0 || iy >= blk0 + HX_DBLK) {
+      if (blk0 < 0 || iy >= blk_end) {
         // new DOECLIM block: this lane's partial sums over its SST history
+        blk_end = iy + (blk0 < 0 ? blk_len0 : HX_DBLK);
         blk0 = iy;
 #if HX_HAS_MFMA
         if constexpr (!KERPM)
