@@ -188,12 +188,15 @@ def test_config5_every_member_vs_oracle(hip_lib, oracle):
                           "warmingfactor 1, 1.5, 2, 2.5 (hector_amd/ensemble.py biome4)"})
 
 
-@pytest.mark.parametrize("nb", [6, 8])
+@pytest.mark.parametrize("nb", [6, 8, 12])
 def test_unrolled_many_biome_kernels_every_member_vs_oracle(hip_lib, oracle, nb):
     """The unrolled kernels of five to eight biomes (round 3; six: the lean park, eight: the slim
-    one with f_frozen / f_new_thaw in HBM): 16 384 members, every one against the oracle -- S,
-    a Q10 per biome, warming factors 1 ... 2.5 -- with identical stash schedules."""
-    n = 16384
+    one with f_frozen / f_new_thaw in HBM, its tables read as row address + lane offset) and the
+    looped kernel (twelve: four pools in the park, the thawed pool, tempferts, f_frozen in their
+    state rows, the year's per-biome values in scratch rows): 16 384 members (twelve biomes: 8 192),
+    every one against the oracle -- S, a Q10 per biome, warming factors 1 ... 2.5 -- with identical
+    stash schedules."""
+    n = 16384 if nb <= 8 else 8192
     idx = np.arange(n, dtype=np.uint64)
     S = 1.5 + 4.5 * ensemble.uniform01(idx, 0)
     q10s = [1.0 + 2.0 * ensemble.uniform01(idx, 10 + b) for b in range(nb)]
@@ -215,7 +218,7 @@ def test_unrolled_many_biome_kernels_every_member_vs_oracle(hip_lib, oracle, nb)
         for b in range(nb):
             p.q10_rh[b] = q10s[b][i]; p.warmingfactor[b] = wfs[b]
         return p
-    _compare("unrolled_16384x%d" % nb, c, oracle, mp, np.arange(n), n,
+    _compare(("unrolled_%dx%d" if nb <= 8 else "looped_%dx%d") % (n, nb), c, oracle, mp, np.arange(n), n,
              {"ensemble": "%d equal biomes, S ~ U(1.5, 6), q10_rh ~ U(1, 3) per biome, warmingfactor "
                           "1, 1.5, 2, 2.5 repeating (tools/prof/biome_times.py)" % nb})
 
