@@ -136,12 +136,140 @@ __device__ __forceinline__ void compute_flows(const Member<B> &m, const LandK<B>
   F.thaw = thaw; F.refr = refr;
 }
 
+// ---- looped kernels (9 to HX_BDYN biomes): the per-biome loops in chunks ------------------------
+// Their per-biome values live in LDS (four pools), in HBM rows (the thawed pool, tempferts,
+// co2fert, tempfertd, f_new_thaw) and in the parameter table.  Written as one loop per sum, every
+// biome of every loop waited out its own scalar and HBM loads -- a stash's land half 1.6 k
+// cycles PER BIOME, the interval constants 1.1 k (section clock, profiles/r04_phase_clock_8192x9
+// .json): a store to one per-biome array may alias the next biome's loads as far as the compiler
+// can tell.  Here a chunk's values are all requested first (nothing is stored in between), then
+// the chunk is worked through in biome order -- the same operations and the same order of every
+// sum as the unrolled kernels' loops.
+#ifndef HX_DYN_CHUNK
+#define HX_DYN_CHUNK 4
+#endif
+struct BioIn {
+  double veg, det, soil, pf, thw, tfs, tfd, co2f, fnt, npp0, f_nppv, f_nppd, f_litterd, fpf, rch4;
+};
+// FLOWS: also what only the flows of an interval need (vegetation, f_new_thaw, the allocation
+// fractions); POOLS: the pools themselves (false: the caller has a chunk's NEW pools in hand)
+template <bool FLOWS, bool POOLS = true>
+__device__ __forceinline__ void load_bio(const Member<HX_DYN> &m, const LandK<HX_DYN> &lk, int b, BioIn &v) {
+  if constexpr (POOLS) {
+    v.det = m.det[b]; v.soil = m.soil[b]; v.pf = m.pf[b]; v.thw = m.thawed[b];
+    if constexpr (FLOWS) v.veg = m.veg[b];
+  }
+  v.tfs = m.tempferts[b]; v.tfd = m.tempfertd[b]; v.co2f = m.co2fert[b];
+  v.npp0 = lk.npp0[b]; v.fpf = lk.fpf_static[b]; v.rch4 = lk.rh_ch4_frac[b];
+  if constexpr (FLOWS) {
+    v.fnt = m.f_new_thaw[b];
+    v.f_nppv = lk.f_nppv[b]; v.f_nppd = lk.f_nppd[b]; v.f_litterd = lk.f_litterd[b];
+  }
+}
+// A per-biome loop in chunks: load(b0, v) requests chunk b0's values into v, work(b0, v) uses them
+// (and may store).  (One chunk's loads AHEAD of the chunk being worked on, two register sets in
+// turn, was measured and lost: 240 more live registers, 512 + scratch; 65 536 members x 9 / 12 /
+// 16 biomes 30.8 / 33.6 / 42.5 -> 34.2 / 36.6 / 45.3 ms.  Chunks of two that way: 29.2 / 35.3 /
+// 44.2.  Chunks of eight: 36.2 / 39.0 / 42.8.  profiles/r04_looped_kernel_variants.txt)
+template <class T, class L, class W>
+__device__ __forceinline__ void chunk_pipeline(int nb, L load, W work) {
+  for (int b0 = 0; b0 < nb; b0 += HX_DYN_CHUNK) {
+    T v[HX_DYN_CHUNK];
+    load(b0, v);
+    work(b0, v);
+  }
+}
+// the fluxes of one biome from its values (m_npp ... m_rh_tp_ch4 above, operation by operation)
+__device__ __forceinline__ double bio_npp(const BioIn &v, double adj) { return (v.npp0 * v.co2f) * adj; }
+__device__ __forceinline__ double bio_fda(const BioIn &v) { return (v.det * 0.25) * v.tfd; }
+__device__ __forceinline__ double bio_fsa(const BioIn &v) { return (v.soil * 0.02) * v.tfs; }
+__device__ __forceinline__ double bio_tpc(const BioIn &v) {
+  return ((v.thw * (1 - v.fpf)) * 0.02) * v.tfs * (1.0 - v.rch4);
+}
+__device__ __forceinline__ double bio_tpm(const BioIn &v) {
+  return ((v.thw * (1 - v.fpf)) * 0.02) * v.tfs * v.rch4;
+}
+// one biome's terms of the land flows (the body of compute_flows' loop)
+template <bool SPIN>
+__device__ __forceinline__ void flows_add(const BioIn &v, double adj, Flows &F) {
+  const double n = bio_npp(v, adj);
+  F.npp += n;
+  F.fav += n * v.f_nppv;
+  F.fad += n * v.f_nppd;
+  F.fas += n * (1 - v.f_nppv - v.f_nppd);
+  F.fda += bio_fda(v);
+  F.fsa += bio_fsa(v);
+  const double co2 = bio_tpc(v), ch4 = bio_tpm(v);
+  F.tpc += co2;
+  F.tpm += ch4;
+  const double vv = v.veg * 0.035;
+  F.litter += vv;
+  F.lfvd += vv * v.f_litterd;
+  F.lfvs += vv * (1 - v.f_litterd);
+  F.detsoil += v.det * 0.6;
+  if (!SPIN) {
+    double c_thaw = v.pf * v.fnt;
+    double r_tp = 0.0;
+    if (c_thaw < 0) {
+      const double want = -c_thaw;
+      c_thaw = 0.0;
+      r_tp = fmin(want, v.thw - co2 - ch4);
+    }
+    F.thaw += c_thaw;
+    F.refr += r_tp;
+  }
+}
+__device__ __forceinline__ void flows_zero(Flows &F) {
+  F.npp = F.rh = F.fav = F.fad = F.fas = F.fda = F.fsa = F.tpc = F.tpm = 0;
+  F.litter = F.lfvd = F.lfvs = F.detsoil = F.thaw = F.refr = 0;
+}
+template <bool SPIN>
+__device__ __forceinline__ void compute_flows_chunked(const Member<HX_DYN> &m, const LandK<HX_DYN> &lk,
+                                                      Flows &F) {
+  flows_zero(F);
+  const int nb = m.nb;
+  chunk_pipeline<BioIn>(
+      nb,
+      [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+        for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<true>(m, lk, min(b0 + j, nb - 1), v[j]);
+      },
+      [&](int b0, const BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+        for (int j = 0; j < HX_DYN_CHUNK; ++j)
+          if (b0 + j < nb) flows_add<SPIN>(v[j], m.npp_luc_adjust, F);
+      });
+  F.rh = F.fda + F.fsa + F.tpc;
+}
+
+// the interval's constants from its land flows
+template <int B, bool SPIN, int CON = 0>
+__device__ __forceinline__ void finish_interval(const Member<B> &m, const Flows &F, Interval &K,
+                                                Interval &K2, const YearCon &yc) {
+  if constexpr (CON && !SPIN) {
+    if (yc.mask & HXC_NBP) {
+      make_interval_nbp<B>(m, F, yc.nbp_lo, K);
+      make_interval_nbp<B>(m, F, yc.nbp_hi, K2);
+      return;
+    }
+    make_interval<B>(m, F, K);
+    K2 = K;
+    return;
+  }
+  make_interval<B>(m, F, K);
+}
+
 // K: the interval's constants; K2 (CON kernels): the same for the second half of the year,
 // where round(t) picks the next date's NBP constraint
 template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B> &lk,
                                               Interval &K, Interval &K2, const YearCon &yc) {
   Flows F;
+  if constexpr (B == HX_DYN) {
+    compute_flows_chunked<SPIN>(m, lk, F);
+    finish_interval<B, SPIN, CON>(m, F, K, K2, yc);
+    return;
+  } else
   compute_flows<B, SPIN>(m, lk, F);
   if constexpr (CON && !SPIN) {
     if (yc.mask & HXC_NBP) {
@@ -294,6 +422,26 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   // ---- land: simpleNbox-runtime.cpp:270-609 --------------------------------
   double npp_t = 0, rh_t = 0, pf_t = 0;
   const int NB = nbio<B>(m);
+  [[maybe_unused]] double sp_rd = 0, sp_rs = 0, sp_rc = 0;  // spinup record: final_rh_detritus / _soil, thawed part
+  if constexpr (B == HX_DYN) {   // (looped kernels: a chunk's values requested together, see load_bio)
+    chunk_pipeline<BioIn>(
+        NB,
+        [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+          for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<false>(m, lk, min(b0 + j, NB - 1), v[j]);
+        },
+        [&](int b0, const BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+          for (int j = 0; j < HX_DYN_CHUNK; ++j) {
+            if (b0 + j < NB) {
+              npp_t += bio_npp(v[j], m.npp_luc_adjust);
+              rh_t += (bio_fda(v[j]) + bio_fsa(v[j])) + bio_tpc(v[j]);
+              pf_t += v[j].pf;
+              if constexpr (SPIN) { sp_rd += bio_fda(v[j]); sp_rs += bio_fsa(v[j]); sp_rc += bio_tpc(v[j]); }
+            }
+          }
+        });
+  } else {
 #pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b) npp_t += m_npp(m, lk, b);
 #pragma unroll hx_ur<B>()
@@ -301,12 +449,12 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     rh_t += (m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b);
 #pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b) pf_t += m.pf[b];
-  [[maybe_unused]] double sp_rd = 0, sp_rs = 0, sp_rc = 0;  // spinup record: final_rh_detritus / _soil, thawed part
   if constexpr (SPIN) {
     if (m.spin_row) {
 #pragma unroll hx_ur<B>()
       for (int b = 0; b < NB; ++b) { sp_rd += m_rh_fda(m, b); sp_rs += m_rh_fsa(m, b); sp_rc += m_rh_tp_co2(m, lk, b); }
     }
+  }
   }
   double alf = ((npp_t - rh_t) - m.luc_e) + m.luc_u;
   const double npp_rh = npp_t + rh_t;
@@ -356,6 +504,44 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       else track_stash<B>(m, lk, tk);
     }
   }
+  [[maybe_unused]] Flows Fn;   // looped kernels: the next interval's land flows, from the new pools
+  if constexpr (B == HX_DYN) {
+    flows_zero(Fn);
+    chunk_pipeline<BioIn>(
+        NB,
+        [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+          for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<true>(m, lk, min(b0 + j, NB - 1), v[j]);
+        },
+        [&](int b0, const BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+      for (int j = 0; j < HX_DYN_CHUNK; ++j) {
+        if (b0 + j < NB) {
+          const int b = b0 + j;
+          const double fda = bio_fda(v[j]), fsa = bio_fsa(v[j]), tpc = bio_tpc(v[j]), tpm = bio_tpm(v[j]);
+          const double wt = hx_div_cr(bio_npp(v[j], m.npp_luc_adjust) + ((fda + fsa) + tpc), npp_rh, inv_nr);
+          const double wt_pf = hx_div_cr(v[j].pf, pf_t, inv_pf);
+          if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
+            const double a = fda * rh_adj, bb = fsa * rh_adj, cc = tpc * rh_adj, dd = tpm * rh_adj;
+            fin_npp += npp_fin_total * wt;
+            fin_rh += ((a + bb) + cc) + dd;
+            const HxBuffers &buf = *m.bufp;
+            if (buf.out[HXO_B(HXOB_NPP, b)]) HX_GD(buf.out[HXO_B(HXOB_NPP, b)])[dgo] = npp_fin_total * wt;
+            if (buf.out[HXO_B(HXOB_RH, b)]) HX_GD(buf.out[HXO_B(HXOB_RH, b)])[dgo] = ((a + bb) + cc) + dd;
+            fin_det += a;
+            fin_soil += bb;
+          }
+          if constexpr (CON) m.cum_pf_ch4 += (tpm * rh_adj) * yf;
+          else m.cum_pf_ch4 += tpm * yf;  // :481
+          BioIn w = v[j];   // the biome after the stash
+          w.veg = nveg * wt; w.det = ndet * wt; w.soil = nsoil * wt; w.pf = c4 * wt_pf; w.thw = tpf * wt_pf;
+          m.veg[b] = w.veg; m.det[b] = w.det; m.soil[b] = w.soil; m.pf[b] = w.pf; m.thawed[b] = w.thw;
+          if (more) flows_add<SPIN>(w, m.npp_luc_adjust, Fn);
+        }
+      }
+        });
+    Fn.rh = Fn.fda + Fn.fsa + Fn.tpc;
+  } else
 #pragma unroll hx_ur<B>()
   for (int b = 0; b < NB; ++b) {
     const double wt = hx_one<B>() ? 1.0
@@ -426,7 +612,10 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   }
   m.ode_start = t;
   HX_STAMP(m, 8);   // stash: ocean boxes + land pools
-  if (more) prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);  // constants of the next segment
+  if (more) {  // constants of the next segment
+    if constexpr (B == HX_DYN) finish_interval<B, SPIN, CON>(m, Fn, K, K2, yc);
+    else prep_interval<B, SPIN, CON>(m, lk, K, K2, yc);
+  }
   HX_STAMP(m, 9);   // stash: next segment's interval constants
 }
 

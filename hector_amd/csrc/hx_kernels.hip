@@ -862,32 +862,54 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
       const double lnc = PKM(m, PK_LN_CO2R);  // = log((atmos C * PGC2PPM) / C0), from last year's phase C
       if constexpr (B == HX_DYN) {
-        // looped kernels: the same per biome, one at a time, parameters read where they are used
-#pragma unroll hx_ur<B>()
-        for (int b = 0; b < m.nb; ++b) {
-          const int pr = HXP_NGLOBAL + b * HXPB_N;
-          const double wf = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
-          const double lnq10 = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
-          m.co2fert[b] = 1 + w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff) * lnc;
-          const double Tbb = tland * wf;
-          m.tempfertd[b] = hx_exp(lnq10 * (Tbb * 0.1));
-          m.f_new_thaw[b] = 0.0;
-          if (m.pf[b] != 0.0) {
-            double ff = 1.0;
-            if (Tbb > 0) {
-              const double d[1] = {hx_div(hx_log(Tbb) - w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff),
-                                          w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff) * 1.4142135623730951)};
-              double f1[1];
-              hx_frozen_fraction_batch<1>(d, f1);
-              ff = f1[0];
-            }
-            m.f_new_thaw[b] = ffrozen_of<B>(m, b) - ff;
-            set_ffrozen<B>(m, b, ff);
+        // looped kernels: the same in chunks of HX_DYN_CHUNK biomes -- a chunk's parameters, pools
+        // and last year's values requested together, its exponentials, logarithms and frozen
+        // fractions evaluated as batches (hx_dev_math.h), then stored (hx_dev_solver.h: load_bio)
+        constexpr int CH = HX_DYN_CHUNK;
+        const int nb = m.nb;
+        for (int b0 = 0; b0 < nb; b0 += CH) {
+          double wf[CH], lnq[CH], beta[CH], pmu[CH], psg[CH], pfv[CH], ffz[CH], tfl[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int b = min(b0 + j, nb - 1);
+            const int pr = HXP_NGLOBAL + b * HXPB_N;
+            wf[j] = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
+            lnq[j] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
+            beta[j] = w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff);
+            pmu[j] = w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
+            psg[j] = w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
+            pfv[j] = m.pf[b];
+            ffz[j] = ffrozen_of<B>(m, b);
+            tfl[j] = m.tempferts[b];
           }
-          const double Trm = (iy > 1) ? (twin * wf) * 0.005 : 0.0;
-          const double tfs = hx_exp(lnq10 * (Trm * 0.1));
-          const double last = (iy > 1) ? m.tempferts[b] : 0.0;
-          m.tempferts[b] = fmax(tfs, last);
+          double Tbc[CH], exc[2 * CH], lgc[CH], dfc[CH], ffc[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            Tbc[j] = tland * wf[j];
+            const double Trm = (iy > 1) ? (twin * wf[j]) * 0.005 : 0.0;
+            exc[2 * j] = fmax(lnq[j] * (Tbc[j] * 0.1), -746.0);
+            exc[2 * j + 1] = fmax(lnq[j] * (Trm * 0.1), -746.0);
+            lgc[j] = (Tbc[j] > 0) ? Tbc[j] : 1.0;
+          }
+          hx_log_batch<CH>(lgc);
+          hx_exp_chunks<2 * CH>(exc);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) dfc[j] = hx_div(lgc[j] - pmu[j], psg[j] * 1.4142135623730951);
+          hx_frozen_fraction_batch<CH>(dfc, ffc);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            if (b0 + j < nb) {
+              const int b = b0 + j;
+              m.co2fert[b] = 1 + beta[j] * lnc;
+              m.tempfertd[b] = exc[2 * j];
+              const bool has_pf = pfv[j] != 0.0;
+              const double ff = (Tbc[j] > 0) ? ffc[j] : 1.0;
+              m.f_new_thaw[b] = has_pf ? ffz[j] - ff : 0.0;
+              set_ffrozen<B>(m, b, has_pf ? ff : ffz[j]);
+              const double last = (iy > 1) ? tfl[j] : 0.0;
+              m.tempferts[b] = fmax(exc[2 * j + 1], last);
+            }
+          }
         }
       }
       // the frozen fractions of all biomes as one batch (hx_dev_math.h); a biome at or below
