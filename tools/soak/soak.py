@@ -53,13 +53,15 @@ def biomes(gpu, argv):
 
 
 def biomes_many(gpu, argv):
-    """5-9 biomes (the unrolled five- to eight-biome kernels, the looped kernel for nine),
-    per-member pool splits, every per-biome parameter."""
+    """5-9 biomes (the unrolled five- to eight-biome kernels, the looped kernel for nine), then
+    10-16 (the looped kernel's chunks of four with every tail length), per-member pool splits,
+    every per-biome parameter."""
     import test_random_sweep as T
-    for seed in range(2):
+    for seed in range(3):
         if gpu:
             w = T.sweep_biomes(HIP, 512, seed=100 + seed, scenarios=("ssp245", "ssp585", "ssp119"),
-                               check_every=8, counts=(5, 6, 7, 8, 9), device=0)
+                               check_every=8, counts=(5, 6, 7, 8, 9) if seed < 2 else (10, 11, 13, 14, 15, 16),
+                               device=0)
         else:
             w = T.sweep_biomes(EMUL, 4, seed=100 + seed, scenarios=("ssp245",), counts=(5, 6, 7, 8, 9),
                                allow_emulation=True)
