@@ -105,8 +105,8 @@ template <int B> constexpr bool hx_lean_park() { return B == HX_DYN || hx_nbc<B>
 // 65 536 members x 7 / 8 biomes 16.9 / 18.9 -> 15.1 / 16.5 ms, no scratch left.  (Five and six
 // biomes have the registers for the hoisted addresses and lose 2 % to the scalar form's spill
 // lanes: they keep the indexed form; the looped kernels are indifferent.)
-template <int B> constexpr bool hx_slim_park_() { return B == 7 || B == 8; }
-template <int B> constexpr bool hx_tbl() { return hx_w2<B>() || B == HX_DYN || hx_slim_park_<B>(); }
+template <int B> constexpr bool hx_b78() { return B == 7 || B == 8; }
+template <int B> constexpr bool hx_tbl() { return hx_w2<B>() || B == HX_DYN || hx_b78<B>(); }
 template <int B> constexpr int pk_ff0() {
   return hx_w2<B>() ? (int)PK_AERO : hx_lean_park<B>() ? (int)PK_D0 : (int)PK_FFROZEN0;
 }

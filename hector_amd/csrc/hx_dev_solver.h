@@ -172,7 +172,7 @@ __device__ __forceinline__ void load_bio(const Member<HX_DYN> &m, const LandK<HX
 // 16 biomes 30.8 / 33.6 / 42.5 -> 34.2 / 36.6 / 45.3 ms.  Chunks of two that way: 29.2 / 35.3 /
 // 44.2.  Chunks of eight: 36.2 / 39.0 / 42.8.  profiles/r04_looped_kernel_variants.txt)
 template <class T, class L, class W>
-__device__ __forceinline__ void chunk_pipeline(int nb, L load, W work) {
+__device__ __forceinline__ void chunk_loop(int nb, L load, W work) {
   for (int b0 = 0; b0 < nb; b0 += HX_DYN_CHUNK) {
     T v[HX_DYN_CHUNK];
     load(b0, v);
@@ -228,7 +228,7 @@ __device__ __forceinline__ void compute_flows_chunked(const Member<HX_DYN> &m, c
                                                       Flows &F) {
   flows_zero(F);
   const int nb = m.nb;
-  chunk_pipeline<BioIn>(
+  chunk_loop<BioIn>(
       nb,
       [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
 #pragma unroll
@@ -424,7 +424,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   const int NB = nbio<B>(m);
   [[maybe_unused]] double sp_rd = 0, sp_rs = 0, sp_rc = 0;  // spinup record: final_rh_detritus / _soil, thawed part
   if constexpr (B == HX_DYN) {   // (looped kernels: a chunk's values requested together, see load_bio)
-    chunk_pipeline<BioIn>(
+    chunk_loop<BioIn>(
         NB,
         [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
 #pragma unroll
@@ -507,7 +507,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   [[maybe_unused]] Flows Fn;   // looped kernels: the next interval's land flows, from the new pools
   if constexpr (B == HX_DYN) {
     flows_zero(Fn);
-    chunk_pipeline<BioIn>(
+    chunk_loop<BioIn>(
         NB,
         [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
 #pragma unroll

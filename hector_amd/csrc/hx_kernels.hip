@@ -30,8 +30,10 @@
 // (all <= a few ulp, see DESIGN.md "numerics"): FMA contraction on; exp / log /
 // sqrt of hx_dev_math.h; quintic root by warm-started Newton with a safeguarded
 // restart (same root, different path);
-// T-only equilibrium constants computed once per year per box; LUC ratio via
-// one division; 200-year Q10 window as a running sum; forcing summed in groups.
+// T-only equilibrium constants once per year per box, from fitted polynomials inside their
+// interval (hx_chem_fit.inc); the permafrost curve's erfc as one polynomial range
+// (hx_erfc_fit.inc); LUC ratio via one division; 200-year Q10 window as a running sum; forcing
+// summed in groups.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <math.h>
