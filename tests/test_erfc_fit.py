@@ -55,3 +55,14 @@ def test_frozen_fraction_of_the_default_biome():
     ff = _frozen_fraction(d, c)
     assert abs(ff[4] - 0.5) < 1e-15
     assert (np.diff(ff) < 0).all() and ff[0] > 0.9999 and ff[-1] < 0.2
+
+
+def test_committed_table_is_what_the_generator_produces(tmp_path):
+    import importlib.util
+    import pytest
+    pytest.importorskip("mpmath")
+    spec = importlib.util.spec_from_file_location("make_erfc_fit", os.path.join(ROOT, "tools", "make_erfc_fit.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.main(str(tmp_path / "fit.inc"), str(tmp_path / "report.json"))
+    assert open(tmp_path / "fit.inc").read() == open(os.path.join(ROOT, "hector_amd", "csrc", "hx_erfc_fit.inc")).read()
