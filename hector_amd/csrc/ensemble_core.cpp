@@ -1748,7 +1748,11 @@ void EnsembleCore::run(double runtodate) {
   bool ext = con_mask != 0;  // extended kernel: constraints or the extra diagnostics
   for (int v = HXO_NPP; v < HXO_NVAR; ++v) if (d_out_[v]) ext = true;
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) ext = true;
-  int con = ext ? 1 : 0;
+  // (the extended kernel without the NBP machinery -- five solver variables, one interval set --
+  // unless the scenario or a member holds an NBP constraint; HECTOR_AMD_EXTENDED_NBP=1: always
+  // the one with it, the tests hold the two against each other)
+  const bool force_nbp = getenv("HECTOR_AMD_EXTENDED_NBP") != nullptr;
+  int con = ext ? (((con_mask & HXC_NBP) || force_nbp) ? 1 : -1) : 0;
   if (d_track_out_f_) {
     if (con_mask & (HXC_CO2 | HXC_NBP))
       throw std::runtime_error("carbon tracking together with a CO2 or NBP constraint is not "

@@ -46,6 +46,12 @@ template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &
   return ((m.thawed[b] * (1 - k.fpf_static[b])) * 0.02) * m.tempferts[b] * k.rh_ch4_frac[b];
 }
 
+// CON = -1: the extended kernel for a scenario WITHOUT an NBP constraint (EnsembleCore::run picks
+// it from con_mask and the per-member series): diagnostics, the other constraints and the warming
+// ratio like CON = 1, but the solver as in the plain kernel -- five variables (the thawed pool's
+// derivative is constant within an interval), one set of interval constants, the land-use rates of
+// an attempt's stages side by side.  hx_nbp<CON>(): the instantiations that carry the NBP machinery.
+template <int CON> constexpr bool hx_nbp() { return CON >= 1; }
 // constraints of one model year, as the solver and the stash see them (CON kernels only)
 struct YearCon {
   int mask;          // HXC_* bits
@@ -246,7 +252,7 @@ __device__ __forceinline__ void compute_flows_chunked(const Member<HX_DYN> &m, c
 template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void finish_interval(const Member<B> &m, const Flows &F, Interval &K,
                                                 Interval &K2, const YearCon &yc) {
-  if constexpr (CON && !SPIN) {
+  if constexpr (hx_nbp<CON>() && !SPIN) {
     if (yc.mask & HXC_NBP) {
       make_interval_nbp<B>(m, F, yc.nbp_lo, K);
       make_interval_nbp<B>(m, F, yc.nbp_hi, K2);
@@ -271,7 +277,7 @@ __device__ __forceinline__ void prep_interval(const Member<B> &m, const LandK<B>
     return;
   } else
   compute_flows<B, SPIN>(m, lk, F);
-  if constexpr (CON && !SPIN) {
+  if constexpr (hx_nbp<CON>() && !SPIN) {
     if (yc.mask & HXC_NBP) {
       make_interval_nbp<B>(m, F, yc.nbp_lo, K);
       make_interval_nbp<B>(m, F, yc.nbp_hi, K2);
@@ -297,8 +303,8 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, cons
                                     double rate = 0.0) {
   // CON kernels carry the thawed-permafrost pool as a sixth solver variable: with an NBP
   // constraint its derivative changes where round(t) does, so it is no longer constant
-  const Interval &K = (CON && !SPIN && t >= yc.t_half) ? K2 : K1;
-  if constexpr (CON) d[5] = K.k5;
+  const Interval &K = (hx_nbp<CON>() && !SPIN && t >= yc.t_half) ? K2 : K1;
+  if constexpr (hx_nbp<CON>()) d[5] = K.k5;
   double r;
   if constexpr (RATE) {
     r = rate;
@@ -465,7 +471,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   double nveg = y[1], ndet = y[2], nsoil = y[3];
   double rh_adj = 1.0;
   double npp_fin_total = npp_t;  // npp_total after any NBP constraint (final_npp weights it)
-  if constexpr (CON && !SPIN) {
+  if constexpr (hx_nbp<CON>() && !SPIN) {
     // NBP constraint in stashCValues :343-383: fluxes moved by +-diff/2, the pools by
     // diff * yf shared by size, the same amount taken out of the deep ocean
     const double target = (t >= yc.t_half) ? yc.nbp_hi : yc.nbp_lo;
@@ -659,7 +665,7 @@ __device__ __forceinline__ double pow_m15(double x) {
 template <int B, bool SPIN, int CON = 0>
 __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                                            double t0, double tnew, const YearCon &yc) {
-  constexpr int NP = CON ? 6 : 5;  // solver variables (see rhs)
+  constexpr int NP = hx_nbp<CON>() ? 6 : 5;  // solver variables (see rhs)
   // dopri5 tableau (odeint runge_kutta_dopri5)
 #ifndef HX_TAB_LITERALS
   // The tableau as DATA (HxConst::tab, in the order a step uses it) behind wide scalar loads:
@@ -714,7 +720,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   constexpr double EPS = 2.220446049250313e-16;
 
   Interval K, K2s;
-  Interval &K2 = CON ? K2s : K;
+  Interval &K2 = hx_nbp<CON>() ? K2s : K;
   if constexpr (hx_w2<B>()) HX_W2_LOCAL(m);
   {
     LandK<B> lk;
@@ -731,7 +737,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         y[0] = m.atmos; y[1] = m.veg[0]; y[2] = m.det[0]; y[3] = m.soil[0];
         y[4] = m.cDO + m.cIO + PKM(m, w2_slot(23)) + PKM(m, w2_slot(22));
         l4 = m.pf[0]; l5 = m.thawed[0]; l7 = m.earth;
-        if constexpr (CON) y[5] = m.thawed[0];
+        if constexpr (hx_nbp<CON>()) y[5] = m.thawed[0];
         return;
       }
     }
@@ -741,7 +747,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                                             p += m.pf[b]; th += m.thawed[b]; }
     y[0] = m.atmos; y[1] = v; y[2] = d; y[3] = s; y[4] = m.cDO + m.cIO + m.cLL + m.cHL;
     l4 = p; l5 = th; l7 = m.earth;
-    if constexpr (CON) y[5] = th;
+    if constexpr (hx_nbp<CON>()) y[5] = th;
   };
   load_pools(false);
   m.ode_start = t0;
@@ -822,7 +828,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 #ifdef HX_NO_RATE   // (experiment builds: the division at the head of every stage)
       constexpr bool RT = false;
 #else
-      constexpr bool RT = (CON == 0);
+      constexpr bool RT = !hx_nbp<CON>();
 #endif
       double rr[5] = {0, 0, 0, 0, 0};
       if constexpr (RT) {
@@ -881,7 +887,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         } else {          // accept
           // pools with a constant derivative over the interval advance exactly
           l4 += dtl * K.k4; l7 += dtl * K.k7;
-          if constexpr (!CON) l5 += dtl * K.k5;
+          if constexpr (!hx_nbp<CON>()) l5 += dtl * K.k5;
           t += dtl;
           if (err < 0.5) dtl *= grow;
 #pragma unroll
@@ -905,7 +911,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       // the solver keeps integrating its own c[] afterwards (no getCValues,
       // carbon-cycle-solver.cpp:282-287); only the frozen-pool constants move
       retry = 0;
-      stash<B, SPIN, CON>(m, t, y, l4, CON ? y[NP - 1] : l5, l7, K, K2, yc, t < tnew);
+      stash<B, SPIN, CON>(m, t, y, l4, hx_nbp<CON>() ? y[NP - 1] : l5, l7, K, K2, yc, t < tnew);
       if (m.status != 0) alive = false;
     }
   }

@@ -1806,6 +1806,8 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 0>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 1>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, -1>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, -1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 2>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 2>),
 #endif
@@ -1818,6 +1820,11 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     if (two_wave && con == 1) {
       if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
+    if (two_wave && con == -1) {   // (extended, no NBP constraint: hx_dev_solver.h, hx_nbp)
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       return;
     }
     if (two_wave && !con) {
@@ -1869,7 +1876,11 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     return;
   }
   }
-  if (con && kpm)
+  if (con == -1 && kpm)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, true, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (con == -1)
+    hipLaunchKernelGGL((hx_run_kernel<B, true, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (con && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (con)
     hipLaunchKernelGGL((hx_run_kernel<B, true, false, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
