@@ -1807,6 +1807,7 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, -1>),
+                          reinterpret_cast<const void *>(&hx_run_kernel<B, false, false, -1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, -1>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, false, 2>),
                           reinterpret_cast<const void *>(&hx_run_kernel<B, true, true, 2>),
@@ -1824,7 +1825,8 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     }
     if (two_wave && con == -1) {   // (extended, no NBP constraint: hx_dev_solver.h, hx_nbp)
       if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
-      else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else if (hf) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       return;
     }
     if (two_wave && !con) {
@@ -1878,8 +1880,10 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
   }
   if (con == -1 && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
-  else if (con == -1)
+  else if (con == -1 && hf)
     hipLaunchKernelGGL((hx_run_kernel<B, true, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+  else if (con == -1)   // (shared diffusivity, no heat-flux output: without the second history sum)
+    hipLaunchKernelGGL((hx_run_kernel<B, false, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (con && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   else if (con)
