@@ -19,11 +19,15 @@ them over RCCL.  Inputs (parameters, scenario tables, spun-up state) are
 resident in HBM before the timed region; spinup and upload are excluded, as
 SURVEY.md 8(d) defines the metric.  Weak scaling: per-GPU members fixed.
 
-N = 1 workload: BASELINE.json configs[2] -- 65 536-member perturbed ECS/Q10
-ensemble on one MI355X.  N > 1 workload: BASELINE.json configs[3]'s shape -- 131 072 members
-on every GPU, the named 1 048 576 members at N = 8 -- as the line's `value`, and
-configs[2]-per-GPU (65 536 members on every GPU: the N = 1 workload, weak-scaled) timed after it
-in the same job as `other_configs[0]`.  (--members M: M per GPU at any N, nothing else.)
+The line's `value` is the SAME per-GPU workload at every N -- BASELINE.json configs[2], a
+65 536-member perturbed ECS/Q10 ensemble on every MI355X -- so that the values of a
+--gpus 1, 2, 4, 8 series form one weak-scaling curve.  BASELINE.json configs[3]'s shape --
+131 072 members on every GPU, the named 1 048 576 members at N = 8 -- is timed after it in the
+same job (`other_configs`), and both workloads are at the line's top level at every N:
+`value_per_gpu_workload` {"65536": ..., "131072": ...} (whole-job member-years/s),
+`kernel_ms` and `first_run_kernel_ms` -- the run kernel of a one-shot run (the first run of a
+fresh core) next to the steady state of the timed steps.  (--members M: M per GPU at any N,
+nothing else.)
 A multi-GPU line is only valid if every member of the ensemble is in the gathered statistics,
 the collective spans as many ranks as the job has GPUs and it travelled over RCCL: the line says
 so (`members_in_statistics`, `collective_world_size`, `collective_backend`) and the process
@@ -245,7 +249,9 @@ def time_config(n, biomes, steps, warmup, device):
         core.stats_device("global_tas", start, end, stats[1].data_ptr())
         return core.last_run_ms()
     core.status()
-    core.run(end); core.reset(start); core.status()   # lane calibration pass (see main)
+    core.run(end)                                     # lane calibration pass (see main) ...
+    first_ms = core.last_run_ms()                     # ... and what a one-shot run of this core costs
+    core.reset(start); core.status()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -259,7 +265,8 @@ def time_config(n, biomes, steps, warmup, device):
     kernel_ms = float(np.mean(kms))
     rf = roofline_object(n, biomes, kernel_ms, which)
     return {"members": n, "biomes": biomes, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-            "kernel": rf["kernel"], "kernel_ms": kernel_ms, "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
+            "kernel": rf["kernel"], "kernel_ms": kernel_ms, "first_run_kernel_ms": first_ms,
+            "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
             "members_with_model_errors": bad,
             "fp64_valu_frac": rf["frac"], "hbm_yardstick_frac": rf["hbm_yardstick"]["frac"],
             "pmc_profile_stale": rf.get("pmc_profile_stale")}
@@ -317,14 +324,26 @@ def setup_native_collective(core, dist, world, rank, timeout_s=COMM_INIT_TIMEOUT
     th = threading.Thread(target=work, daemon=True)
     th.start()
     th.join(timeout_s)
-    if th.is_alive():
+    hung = th.is_alive()
+    if hung:
         ok, msg = 0, "hx_comm_init_rank did not return within %.0f s" % timeout_s
     else:
         ok, msg = (1, "") if res.get("ok") else (0, res.get("msg", "unknown error"))
-    flag = torch.tensor([ok], dtype=torch.int32,
+    # (min over ranks of "ok", max over ranks of "a helper thread is still inside the call")
+    flag = torch.tensor([ok, -int(hung)], dtype=torch.int32,
                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(flag.item()), msg
+    if int(flag[1].item()) != 0:
+        # An abandoned helper thread is still inside hx_comm_init_rank on SOME rank: it goes on
+        # mutating that core (communicators, world size, the statistics buffers) while the main
+        # thread would run and fetch on it -- no fallback is safe.  Every rank ends the job here.
+        if rank == 0:
+            print(json.dumps({"invalid": ["hx_comm_init_rank hung on at least one rank (%.0f s): job "
+                                          "abandoned, no collective fallback on a core in that state" % timeout_s]}))
+        sys.stdout.flush(); sys.stderr.write("bench.py: rank %d: %s; exiting\n" % (rank, msg or "a peer's communicator setup hung"))
+        sys.stderr.flush()
+        os._exit(3)
+    return bool(flag[0].item()), msg
 
 
 def runtime_versions():
@@ -409,6 +428,7 @@ def run_workload(args, ctx, n, steps, warmup):
     # wavefronts of like members, the costliest dispatched first) and spins up again.  (Every
     # hx_run_kernel dispatch a profiler sees is a full 555-year one.)
     core.run(end)
+    first_ms = core.last_run_ms()   # the one-shot run: lanes in the order a fresh core gives them
     core.reset(start)
     core.status()
     spin_ms = core.last_spinup_ms()
@@ -427,13 +447,14 @@ def run_workload(args, ctx, n, steps, warmup):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    km = torch.tensor([float(np.mean(kern_ms)), first_ms], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
     r = {"n": n, "steps": steps, "warmup": warmup,
          "elapsed": float(t.item()),
-         "kernel_ms": float(km.item()),   # slowest rank's (and slowest shard's) mean kernel time
+         "kernel_ms": float(km[0].item()),   # slowest rank's (and slowest shard's) mean kernel time
+         "first_run_kernel_ms": float(km[1].item()),   # ... and its first (one-shot) run's
          "bad": int((core.status() != 0).sum()),
          "stats_host": stats.cpu().numpy(),
          "which_kernel": core.last_run_kernel(),
@@ -539,14 +560,16 @@ def main():
     n_gpus = world * shards
     ctx = {"dist": dist, "world": world, "rank": rank, "local_rank": local_rank, "dev": dev,
            "use_dist": use_dist, "shards": shards}
-    # The headline workload.  One GPU: BASELINE configs[2] (65 536 members).  Several GPUs: configs[3]'s
-    # shape -- 131 072 members on every GPU, 1 048 576 at N = 8 -- with configs[2]-per-GPU (the N = 1
-    # line's workload, weak-scaled) timed after it and reported in other_configs.
-    n = args.members if args.members else (65536 if n_gpus == 1 else 131072)
+    # The headline workload is the SAME per-GPU work at every N, so that the values of a --gpus
+    # 1, 2, 4, 8 series are one weak-scaling curve: BASELINE configs[2], 65 536 members on every
+    # GPU.  configs[3]'s shape -- 131 072 members on every GPU, the named 1 048 576 at N = 8 -- is
+    # timed after it in the same job (N > 1: other_configs[0]; N = 1: among other_configs), and
+    # both are at the top level of every line: value_per_gpu_workload, first_run_kernel_ms.
+    n = args.members if args.members else 65536
     r = run_workload(args, ctx, n, args.steps, args.warmup)
     second = None
     if n_gpus > 1 and not args.members and not args.no_other_configs:
-        second = run_workload(args, ctx, 65536, max(5, args.steps // 2), 1)
+        second = run_workload(args, ctx, 131072, max(5, args.steps // 2), 1)
 
     failures = []
     if rank == 0:
@@ -577,6 +600,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            "scaling_workload": "value: %d members on EVERY GPU at every N (one weak-scaling curve; "
+                                "N = 1 is BASELINE configs[2]); BASELINE configs[3]'s shape, 131 072 members "
+                                "per GPU = 1 048 576 at N = 8: value_per_gpu_workload['131072']" % n,
+            "value_per_gpu_workload": {str(n): value},
+            "first_run_kernel_ms": {str(n): r["first_run_kernel_ms"]},
+            "kernel_ms": {str(n): kernel_ms},
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -619,7 +648,13 @@ def main():
                 "scaling": "weak", "kernel": rf2["kernel"], "kernel_ms": second["kernel_ms"],
                 "collective_backend": backend2, "collective_world_size": cworld2,
                 "members_in_statistics": in2, "members_with_model_errors": second["bad"],
+                "first_run_kernel_ms": second["first_run_kernel_ms"],
+                "lanes_ordered_by": "measured cost" if second["calibrated"] else "parameter key",
                 "fp64_valu_frac": rf2["frac"], "pmc_profile_stale": rf2.get("pmc_profile_stale")}]
+            k2 = str(second["n"])
+            out["value_per_gpu_workload"][k2] = out["other_configs"][0]["value"]
+            out["first_run_kernel_ms"][k2] = second["first_run_kernel_ms"]
+            out["kernel_ms"][k2] = second["kernel_ms"]
         if n_gpus == 1 and not args.no_other_configs:
             others = []
             for (m2, b2) in ((1024, 1), (32768, 1), (131072, 1), (65536, 4)):
@@ -627,6 +662,11 @@ def main():
                     continue
                 others.append(time_config(m2, b2, 5, 1, local_rank))
             out["other_configs"] = others
+            for o in others:   # (one biome: the ensemble sizes of the --gpus N series and configs[1])
+                if o["biomes"] == args.biomes:
+                    out["value_per_gpu_workload"][str(o["members"])] = o["value"]
+                    out["first_run_kernel_ms"][str(o["members"])] = o["first_run_kernel_ms"]
+                    out["kernel_ms"][str(o["members"])] = o["kernel_ms"]
         if n_gpus == 1 and not args.no_cpu_baseline:
             v, dt, ns, cores = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = {

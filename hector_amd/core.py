@@ -344,6 +344,17 @@ class Core:
         self._ck(self._lib.hx_set_pair_kernel_limit(self._h, int(max_members)))
         return self
 
+    def wave_clock(self, shard=0):
+        """-> int64 array [wavefronts][2]: start and end of every wavefront of the last run's
+        year-loop launch, in ticks of the device's constant 100 MHz clock relative to the earliest
+        start (hx_wave_clock): the launch's tail, wavefront by wavefront."""
+        cap = 2 * ((self.n_members + 63) // 64)
+        buf = np.zeros((cap, 2), dtype=np.int64)
+        n = ctypes.c_int(0)
+        self._ck(self._lib.hx_wave_clock(self._h, int(shard), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                         cap, ctypes.byref(n)))
+        return buf[:n.value]
+
     def set_two_wave_from(self, min_members):
         """Ensembles of at least min_members members (one biome, no carbon
         tracking) run on the flavour of the kernel built for two resident

@@ -151,17 +151,18 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
         "hector_amd: no HIP device available -- the ensemble integrator has no CPU path");
   if (device < 0 || device >= ndev) throw std::runtime_error("invalid device index");
   check(hipSetDevice(device_), "hipSetDevice");
-  check(hipStreamCreate(&stream_), "hipStreamCreate");
-  if (const char *e2 = std::getenv("HECTOR_AMD_PAIR_MAX_MEMBERS")) pair_max_members_ = std::atoi(e2);
-  if (const char *e3 = std::getenv("HECTOR_AMD_TWO_WAVE_FROM")) two_wave_from_ = std::atoi(e3);
-  if (const char *e4 = std::getenv("HECTOR_AMD_PAIR_ORDER")) pair_costly_with_cheap_ = std::atoi(e4) != 0;
 #ifndef HX_HOST_EMULATION
-  {
+  {  // (ahead of the stream: nothing to release if the query fails)
     hipDeviceProp_t prop;
     check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
     simds_ = 4 * prop.multiProcessorCount;
   }
 #endif
+  check(hipStreamCreate(&stream_), "hipStreamCreate");
+  if (const char *e2 = std::getenv("HECTOR_AMD_PAIR_MAX_MEMBERS")) pair_max_members_ = std::atoi(e2);
+  if (const char *e3 = std::getenv("HECTOR_AMD_TWO_WAVE_FROM")) two_wave_from_ = std::atoi(e3);
+  if (const char *e4 = std::getenv("HECTOR_AMD_PAIR_ORDER")) pair_costly_with_cheap_ = std::atoi(e4) != 0;
+  if (const char *e5 = std::getenv("HECTOR_AMD_KEY_ORDER")) key_order_mode_ = std::atoi(e5);
   try {  // a constructor that throws gets no destructor: release the stream and events here
     check(hipEventCreate(&ev0_), "hipEventCreate");
     check(hipEventCreate(&ev1_), "hipEventCreate");
@@ -501,6 +502,7 @@ void EnsembleCore::free_device() {
   fr(d_hist_status_);
   fr(d_gas_par_); fr(d_gas_ser_); d_gas_par_ = d_gas_ser_ = nullptr;
   fr(d_cost_); d_cost_ = nullptr; cost_from_iy_ = -1;
+  fr(d_wave_clk_); d_wave_clk_ = nullptr;
   fr(d_bscratch_); d_bscratch_ = nullptr;
   fr(d_spin_rec_); d_spin_rec_ = nullptr;
   d_hist_ = nullptr; d_hist_status_ = nullptr;
@@ -517,6 +519,17 @@ void EnsembleCore::alloc_device() {
   check(hipSetDevice(device_), "hipSetDevice");
   free_device();
   const size_t np = (size_t)npad_, ns = (size_t)scen_.ns();
+  {  // The kernels that read their tables as row address + lane offset (hx_dev_member.h: w2_ld,
+    // GlobArr) form the row's byte offset row * npad * 8 in 32 bits: a table must stay below 4 GB
+    // (253 parameter rows of a 16-biome core reach that at 2.1 million members).
+    const size_t rows = std::max({(size_t)HX_NPARAM(B_), (size_t)HX_NSTATE(B_), (size_t)HX_NDERIVED(B_),
+                                  (size_t)(3 * B_)});
+    if (rows * np * sizeof(double) >= (size_t(1) << 32))
+      throw std::runtime_error("an ensemble of " + std::to_string(n_) + " members with " + std::to_string(B_) +
+                               " biome(s) needs a per-member table of " + std::to_string(rows) +
+                               " rows >= 4 GB, beyond the kernels' 32-bit row offsets: split it over "
+                               "several cores (hx_newcore_devices)");
+  }
   check(hipMalloc(&d_params_, sizeof(double) * np * HX_NPARAM(B_)), "hipMalloc params");
   check(hipMalloc(&d_uparams_, sizeof(double) * (HX_NPARAM(B_) + HX_NDERIVED(B_))), "hipMalloc uniform params");
   if (trk_iy() >= 0) {  // carbon tracking: the yearly record of the origin matrices from the tracking
@@ -570,6 +583,8 @@ void EnsembleCore::alloc_device() {
   check(hipMalloc(&d_dpart_, sizeof(double) * np * 2 * (size_t)hx_doeclim_block_years()),
         "hipMalloc doeclim partial sums");
   check(hipMalloc(&d_cost_, sizeof(double) * np), "hipMalloc lane cost");
+  check(hipMalloc(&d_wave_clk_, sizeof(long long) * 4 * (np / HX_WAVE)), "hipMalloc wave clock");
+  check(hipMemsetAsync(d_wave_clk_, 0, sizeof(long long) * 4 * (np / HX_WAVE), stream_), "zero");
   check(hipMalloc(&d_bscratch_, sizeof(double) * np * (size_t)(3 * B_)), "hipMalloc biome scratch");
   check(hipMemsetAsync(d_bscratch_, 0, sizeof(double) * np * (size_t)(3 * B_), stream_), "zero");
   cost_from_iy_ = -1;
@@ -623,6 +638,7 @@ HxBuffers EnsembleCore::buffers() const {
   b.cost = d_cost_;
   b.spin_rec = d_spin_rec_;
   b.bscratch = d_bscratch_;
+  b.wave_clk = d_wave_clk_;
   return b;
 }
 
@@ -1419,6 +1435,13 @@ void radix_stable_sort(std::vector<int> &order, size_t from, size_t to, const st
 }
 }  // namespace
 
+// Will run() take the two-wavefront flavour (hx_run_kernel<HX_B1W2>)?  One biome, no carbon
+// tracking, at least hx_set_two_wave_from() members (default: more wavefronts than SIMDs).
+bool EnsembleCore::two_wave_expected() const {
+  const int w2_from = two_wave_from_ < 0 ? simds_ * HX_WAVE + 1 : two_wave_from_;
+  return B_ == 1 && trk_iy() < 0 && !d_track_out_f_ && w2_from > 0 && n_ >= w2_from;
+}
+
 void EnsembleCore::assign_lanes() {
   member_of_lane_.resize((size_t)npad_);
   lane_of_member_.resize((size_t)n_);
@@ -1458,13 +1481,28 @@ void EnsembleCore::assign_lanes() {
     // wavefront k.  In descending order the costliest would share its SIMD with a median one and
     // a median one with the cheapest; with the second batch ASCENDING the costliest pairs with the
     // cheapest and every SIMD carries about twice the mean.
+    // (Only then: the kernels that keep one wavefront per SIMD -- several biomes, carbon tracking,
+    // hx_set_two_wave_from(0) -- run their second batch after the first, and costliest-first is
+    // the order that ends the launch soonest there.)
     const int W = n_ / HX_WAVE;   // full wavefronts
-    if (pair_costly_with_cheap_ && W > simds_) {
+    if (pair_costly_with_cheap_ && W > simds_ && two_wave_expected()) {
       const int hi = std::min(W, 2 * simds_);
       for (int a = simds_, b = hi - 1; a < b; ++a, --b)
         std::swap_ranges(order.begin() + (size_t)a * HX_WAVE, order.begin() + (size_t)(a + 1) * HX_WAVE,
                          order.begin() + (size_t)b * HX_WAVE);
     }
+  }
+  else if (sort_members_ && key_order_mode_ > 0 && n_ / HX_WAVE > simds_ && two_wave_expected()) {
+    // (experiment switch HECTOR_AMD_KEY_ORDER, no measured cost yet: 1 = the second batch of
+    // wavefronts reversed, so that the ends of the parameter order share SIMDs; 2 = the whole
+    // order reversed as well -- the last parameter bins dispatched first)
+    const int W = n_ / HX_WAVE, hi = std::min(W, 2 * simds_);
+    auto swap_waves = [&](int a, int b) {
+      std::swap_ranges(order.begin() + (size_t)a * HX_WAVE, order.begin() + (size_t)(a + 1) * HX_WAVE,
+                       order.begin() + (size_t)b * HX_WAVE);
+    };
+    if (key_order_mode_ == 2) for (int a = 0, b = W - 1; a < b; ++a, --b) swap_waves(a, b);
+    for (int a = simds_, b = hi - 1; a < b; ++a, --b) swap_waves(a, b);
   }
   for (int l = 0; l < npad_; ++l) member_of_lane_[(size_t)l] = order[(size_t)std::min(l, n_ - 1)];
   for (int l = 0; l < n_; ++l) lane_of_member_[(size_t)order[(size_t)l]] = l;
@@ -1774,8 +1812,7 @@ void EnsembleCore::run(double runtodate) {
     }
   last_run_pair_ = pair;
   // more wavefronts than SIMDs: the one-biome kernel built for two resident wavefronts per SIMD
-  const int w2_from = two_wave_from_ < 0 ? simds_ * HX_WAVE + 1 : two_wave_from_;
-  const bool w2 = !pair && B_ == 1 && con <= 1 && w2_from > 0 && n_ >= w2_from;
+  const bool w2 = !pair && con <= 1 && two_wave_expected();
   last_run_w2_ = w2;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,
@@ -1799,6 +1836,22 @@ void EnsembleCore::sync() {
     run_ms_ = ms;
     run_timed_ = false;
   }
+}
+
+// Start and end of every wavefront of the last year-loop launch (HxBuffers::wave_clk), relative to
+// the earliest start, in ticks of the constant 100 MHz clock.  -> wavefronts written (0 before the
+// first run); the small-ensemble kernel has two per 64 members.
+int EnsembleCore::wave_clock(long long *ticks, int cap) {
+  if (!d_wave_clk_ || last_iy_ == 0) return 0;
+  sync();
+  const int nw = (npad_ / HX_WAVE) * (last_run_pair_ ? 2 : 1);
+  std::vector<long long> t((size_t)nw * 2);
+  check(hipMemcpy(t.data(), d_wave_clk_, sizeof(long long) * t.size(), hipMemcpyDeviceToHost), "wave clock");
+  long long t0 = t[0];
+  for (int w = 0; w < nw; ++w) t0 = std::min(t0, t[(size_t)2 * w]);
+  const int n = std::min(nw, cap);
+  for (int w = 0; w < n; ++w) { ticks[2 * w] = t[(size_t)2 * w] - t0; ticks[2 * w + 1] = t[(size_t)2 * w + 1] - t0; }
+  return n;
 }
 
 // Variables answered on the host: scenario INPUT series, the member-independent gas cycles
@@ -2158,7 +2211,7 @@ void EnsembleCore::check_component_enabled(const std::string &capability_in) con
   else if ((cap == "O3_concentration" || cap == "RF_O3_trop") && component_disabled("ozone")) sec = "ozone";
   else if ((cap == "CH4_concentration" || cap == "RF_CH4" || cap == "RF_H2O_strat") && component_disabled("CH4")) sec = "CH4";
   else if ((cap == "N2O_concentration" || cap == "RF_N2O") && component_disabled("N2O")) sec = "N2O";
-  else if ((cap == "RF_CH4" || cap == "RF_H2O_strat" || cap == "RF_N2O") &&
+  else if ((cap == "RF_CO2" || cap == "RF_CH4" || cap == "RF_H2O_strat" || cap == "RF_N2O") &&
            (component_disabled("N2O") || component_disabled("CH4")))
     sec = component_disabled("N2O") ? "N2O" : "CH4";   // (not computed: forcing_component.cpp:315-317)
   else if (cap == "TAU_OH" && component_disabled("OH")) sec = "OH";

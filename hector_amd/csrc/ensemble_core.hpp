@@ -136,6 +136,7 @@ class EnsembleCore {
   // wavefronts per SIMD (hx_run_kernel<HX_B1W2>): < 0 the default -- more wavefronts than the
   // device has SIMDs --, 0 never
   void set_two_wave_from(int min_members) { two_wave_from_ = min_members; }
+  int wave_clock(long long *ticks, int cap);   // [wavefront][start, end] of the last launch, 100 MHz ticks
   const char *last_run_kernel() const { return last_run_pair_ ? "pair" : last_run_w2_ ? "run2" : "run"; }
   double last_spinup_ms() const { return spin_ms_; }
   hipStream_t stream() const { return stream_; }
@@ -161,6 +162,7 @@ class EnsembleCore {
   bool sort_members_ = true, calibrate_lanes_ = true;
   std::vector<double> lane_cost_;  // [n_] measured cost per member (empty: parameter key)
   double *d_cost_ = nullptr;
+  long long *d_wave_clk_ = nullptr;   // HxBuffers::wave_clk
   double *d_bscratch_ = nullptr;  // [nbiome][npad] f_new_thaw of the seven- and eight-biome kernels
   int cost_from_iy_ = -1;         // d_cost_ covers the years cost_from_iy_+1..last_iy_ (-1: nothing)
   void maybe_calibrate_lanes();
@@ -235,7 +237,9 @@ class EnsembleCore {
   bool last_run_pair_ = false;
   int two_wave_from_ = -1;        // see set_two_wave_from()
   bool pair_costly_with_cheap_ = true;   // lane order by measured cost: see assign_lanes()
+  int key_order_mode_ = 0;               // HECTOR_AMD_KEY_ORDER (experiments, see assign_lanes)
   bool last_run_w2_ = false;
+  bool two_wave_expected() const;   // run() will take hx_run_kernel<HX_B1W2> (see assign_lanes)
   int simds_ = 1024;              // SIMDs of this core's device (4 per compute unit)
   mutable double run_ms_ = 0, spin_ms_ = 0;
 };

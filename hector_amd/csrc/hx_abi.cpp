@@ -368,6 +368,11 @@ int hx_set_pair_kernel_limit(hx_core *core, int max_members) {
 int hx_set_two_wave_from(hx_core *core, int min_members) {
   HX_TRY(core->core->set_two_wave_from(min_members))
 }
+int hx_wave_clock(hx_core *core, int shard, long long *ticks, int cap, int *n_waves) {
+  if (!ticks || !n_waves || cap < 0) return fail("hx_wave_clock: bad argument");
+  HX_TRY(if (shard < 0 || shard >= core->core->n_shards()) throw std::runtime_error("bad shard index");
+         *n_waves = core->core->wave_clock(shard, ticks, cap))
+}
 int hx_last_run_kernel(hx_core *core, const char **name) { HX_TRY(*name = core->core->last_run_kernel()) }
 
 }  // extern "C"

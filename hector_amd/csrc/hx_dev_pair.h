@@ -237,6 +237,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
   const HxBuffers &buf = args->buf;
   const HxConst &kc = args->kc;
   const size_t np = (size_t)buf.npad;
+  hx_wave_stamp(buf, 2 * blockIdx.x + role, 0, lane);
   unsigned status = HX_GU(buf.status)[mem];
   PairCtl c;
   c.sdt = lds_(buf, HXS_SOLVER_DT, mem);
@@ -902,6 +903,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
   __syncthreads();
   if (role == 0)
     HX_GU(buf.status)[mem] = status | (unsigned)s_yr[PY_STATUS1][lane];
+  hx_wave_stamp(buf, 2 * blockIdx.x + role, 1, lane);
 #ifdef HX_PHASE_CLOCK
   __syncthreads();
   if (role == 0 && buf.out[HXO_TGAV])

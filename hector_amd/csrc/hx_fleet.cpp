@@ -348,6 +348,11 @@ void Fleet::tracking_data(int member, int year0, int year1, double *values, doub
   use(s);
   s.core->tracking_data(member - s.offset, year0, year1, values, fractions, source_masks);
 }
+int Fleet::wave_clock(int shard_index, long long *ticks, int cap) {
+  Shard &s = shards_[(size_t)shard_index];
+  use(s);
+  return s.core->wave_clock(ticks, cap);
+}
 double Fleet::last_run_kernel_ms() {
   double ms = 0;
   for (Shard &s : shards_) { use(s); s.core->sync(); ms = std::max(ms, s.core->last_run_kernel_ms()); }

@@ -88,6 +88,7 @@ class Fleet {
   void tracking_data(int member, int year0, int year1, double *values, double *fractions,
                      unsigned long long *source_masks);
   double last_run_kernel_ms();  // slowest shard
+  int wave_clock(int shard_index, long long *ticks, int cap);
   double last_spinup_ms();
   hipStream_t stream(int shard_index = 0) const { return shards_[(size_t)shard_index].core->stream(); }
   void set_pair_kernel_limit(int max_members);

@@ -531,6 +531,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
   double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
+  hx_wave_stamp(args->buf, blockIdx.x, 0, lane);
   bind_member<B>(args->buf, mem, m, s_park, lane);
 #ifdef HX_PHASE_CLOCK
   for (int k = 0; k < HX_NCLK; ++k) hx_s_clk[k] = 0;
@@ -1335,6 +1336,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   store_park_state<B>(args->buf, mem, m);
   // (a dopri5 pass of the wavefront costs ~2.7k cycles, a stash ~3.4k: tools/prof/phase_clock.py)
   if (args->buf.cost) HX_GD(args->buf.cost)[mem] += (double)(4 * cost_steps + 5 * cost_stash);
+  hx_wave_stamp(args->buf, blockIdx.x, 1, lane);
 #ifdef HX_PHASE_CLOCK
   if (args->buf.out[HXO_TGAV])
     for (int k = 0; k < HX_NCLK; ++k)

@@ -238,6 +238,10 @@ struct HxBuffers {
   // of every biome for the seven- and eight-biome kernels; co2fert, tempfertd and f_new_thaw for the
   // looped ones -- [3 nbiome][npad]
   double *bscratch;
+  // [2 * npad / 64][2] start and end of every wavefront of the last year-loop launch, in ticks of
+  // the constant 100 MHz clock (s_memrealtime): what the launch's tail looks like -- the launch
+  // lasts as long as its last wavefront (hx_wave_clock)
+  long long *wave_clk;
 };
 // rows of HxBuffers::spin_rec: the carbon-cycle variables of the stream, which are the ones that
 // move during the spinup

@@ -322,6 +322,15 @@ int hx_set_two_wave_from(hx_core *core, int min_members);
  * (src/csv_outputstream_visitor.cpp, every visit()); hector-amd's stream does the same. */
 int hx_component_output(hx_core *core, const char *component, int *enabled);
 int hx_last_run_kernel(hx_core *core, const char **name);
+/* When every wavefront of the last hx_run's year-loop launch started and ended: ticks[2 w] and
+ * ticks[2 w + 1] for wavefront w of shard `shard` (64 members in lane order; the small-ensemble
+ * kernel has two wavefronts per 64 members), in ticks of the device's constant 100 MHz clock
+ * relative to the earliest start; *n_waves = wavefronts written (at most cap; 0 before a run).
+ * The launch lasts as long as its last wavefront: this is the launch's tail, wavefront by
+ * wavefront -- what bench.py reports as roofline.wave_time and what decides whether another lane
+ * order or more resident wavefronts can shorten a launch.  No counterpart in the reference
+ * (src/core.cpp:483-504 runs one member). */
+int hx_wave_clock(hx_core *core, int shard, long long *ticks, int cap, int *n_waves);
 
 #define HX_ERR_MASS 1u     /* mass not conserved        simpleNbox-runtime.cpp:553-563 */
 #define HX_ERR_RETRIES 2u  /* solver retries exhausted  carbon-cycle-solver.cpp:242-294 */

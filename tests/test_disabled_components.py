@@ -58,11 +58,11 @@ def disabled_component_checks(lib, tmp_path, **kw):
                 c.fetchvars("slr", (2000, 2010))
             assert np.isfinite(c.fetchvars("RF_CFC11", (1800, 1810))).all()
         if name in ("n2o", "ch4_oh_ozone"):
-            for v in ("RF_CH4", "RF_N2O", "RF_H2O_strat"):
+            # (RF_CO2 too: the reference computes the four together or not at all, so its forcings
+            #  map never gets the entry -- forcing_component.cpp:315-317, 584-590)
+            for v in ("RF_CO2", "RF_CH4", "RF_N2O", "RF_H2O_strat"):
                 with pytest.raises(hector_amd.HectorAmdError, match="disabled"):
                     c.fetchvars(v, (1800, 1810))
-            c.set_outputs(["RF_CO2"]); c.reset(Y0); c.run(1800)
-            assert (c.fetchvars("RF_CO2", (Y0, 1800)) == 0.0).all()
     for sec in ("temperature", "forcing", "simpleNbox"):
         path = edited_pack(tmp_path / ("no_%s.hxs" % sec), None, None, [], [], scalars={(sec, "enabled"): 0.0})
         with pytest.raises(hector_amd.HectorAmdError, match="not supported"):

@@ -111,6 +111,28 @@ def test_sharded_core_on_a_duplicate_device_list_equals_one_core(hip_lib, monkey
     one.shutdown(); many.shutdown()
 
 
+def test_eight_shards_on_one_device_equal_one_core(hip_lib, monkeypatch):
+    """hx_newcore_devices([0] * 8) under the rehearsal switch: BASELINE configs[3]'s control flow
+    behind the C ABI -- eight shards, eight member blocks, eight host threads, the statistics of
+    every shard gathered and folded in shard order -- against ONE core over the same members."""
+    monkeypatch.setenv("HECTOR_AMD_FLEET_REHEARSAL", "1")
+    n = 8 * 2048
+    S, q10 = ensemble.ecs_q10(n)
+    one = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    many = hector_amd.Core(SCENARIO, n, devices=[0] * 8, lib_path=hip_lib)
+    assert many.shards() == ([0] * 8, [2048 * k for k in range(9)])
+    for c in (one, many):
+        c.set_pair_kernel_limit(0)   # the same kernel on both sides: bitwise comparison
+        c.setvar("S", S, "degC").setvar("q10_rh", q10)
+        c.run(2300, wait=False)
+    for v in VARS:
+        np.testing.assert_array_equal(one.fetchvars(v, (1745, 2300)), many.fetchvars(v, (1745, 2300)))
+    assert (many.status() == 0).all()
+    _check_stats(many.ensemble_stats(VARS, (1745, 2300)), one, 1745, 2300)
+    assert many.comm_info()[0] == 8 and "rehearsal" in many.comm_info()[2]
+    one.shutdown(); many.shutdown()
+
+
 def test_duplicate_devices_are_refused_without_the_switch(hip_lib, monkeypatch):
     monkeypatch.delenv("HECTOR_AMD_FLEET_REHEARSAL", raising=False)
     with pytest.raises(hector_amd.HectorAmdError, match="appears twice"):
@@ -253,10 +275,11 @@ def test_bench_two_ranks_over_rccl_on_two_gpus():
 
 
 def test_bench_multi_gpu_default_times_the_named_configurations():
-    """`bench.py --gpus N` without --members: the line's value is BASELINE configs[3]'s shape
-    (131 072 members per GPU, 1 048 576 at N = 8) and other_configs[0] the N = 1 workload
-    weak-scaled (65 536 per GPU), both checked for complete statistics.  Two gloo ranks on this
-    box's one GPU (rehearsal: the line says so)."""
+    """`bench.py --gpus N` without --members: the line's value is the N = 1 workload weak-scaled
+    (BASELINE configs[2], 65 536 members per GPU: one curve over N) and other_configs[0] is
+    BASELINE configs[3]'s shape (131 072 members per GPU, 1 048 576 at N = 8); both are at the
+    line's top level (value_per_gpu_workload, first_run_kernel_ms), both checked for complete
+    statistics.  Two gloo ranks on this box's one GPU (rehearsal: the line says so)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MASTER_PORT"] = str(29800 + os.getpid() % 90)
@@ -269,11 +292,18 @@ def test_bench_multi_gpu_default_times_the_named_configurations():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and "invalid" not in out
     cfg = out["config"]
-    assert cfg["members_per_gpu"] == 131072 and cfg["global_members"] == 262144
-    assert cfg["members_in_statistics"] == 262144 and cfg["collective_world_size"] == 2
-    assert "configs[3]" in cfg["workload"] and cfg["rehearsal_not_rccl"] is True
-    assert out["roofline"]["kernel"].startswith("hx_run_kernel<HX_B1W2")
+    assert cfg["members_per_gpu"] == 65536 and cfg["global_members"] == 131072
+    assert cfg["members_in_statistics"] == 131072 and cfg["collective_world_size"] == 2
+    assert "configs[2]" in cfg["workload"] and cfg["rehearsal_not_rccl"] is True
+    assert out["roofline"]["kernel"].startswith("hx_run_kernel<1")
     o = out["other_configs"][0]
-    assert o["members_per_gpu"] == 65536 and o["global_members"] == 131072
-    assert o["members_in_statistics"] == 131072 and "configs[2]" in o["workload"]
+    assert o["members_per_gpu"] == 131072 and o["global_members"] == 262144
+    assert o["members_in_statistics"] == 262144 and "configs[3]" in o["workload"]
+    assert o["kernel"].startswith("hx_run_kernel<HX_B1W2")
     assert "hip_runtime" in cfg["versions"] and "compiler" in cfg["versions"]
+    # both workloads at the top level of the line, each with its one-shot (first run) kernel time
+    assert out["value_per_gpu_workload"]["65536"] == out["value"]
+    assert out["value_per_gpu_workload"]["131072"] == o["value"]
+    for k in ("65536", "131072"):
+        assert out["first_run_kernel_ms"][k] > 0 and out["kernel_ms"][k] > 0
+    assert "65536 members on EVERY GPU" in out["scaling_workload"]

@@ -1,9 +1,11 @@
-"""The whole bench.py multi-process flow on ONE GPU box: two ranks launched with
+"""The whole bench.py multi-process flow on ONE GPU box: two -- and eight -- ranks launched with
 torch.distributed.run share device 0 (--dist-backend gloo: RCCL needs one GPU per rank),
 each integrates its own contiguous member block with the HIP kernels, the packed statistics
 all-reduce merges them.  Checked against a single-process run over the union of the members:
 count / mean of CO2 and Tgav in 2300 (on an 8-GPU node the driver runs the
-same script with backend nccl = RCCL)."""
+same script with backend nccl = RCCL).  Eight ranks x 2 048 members is BASELINE configs[3]'s
+control flow -- eight processes, eight contiguous member blocks, one statistics exchange per
+step -- minus RCCL and the seven other devices."""
 import json
 import os
 import subprocess
@@ -19,29 +21,32 @@ from conftest import ROOT, SCENARIO
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_sharing_one_gpu_through_bench(hip_lib):
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_sharing_one_gpu_through_bench(hip_lib, world):
     n = 2048   # members per rank
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    port = 29700 + os.getpid() % 200
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    port = 29700 + (os.getpid() + world) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--members", str(n), "--dist-backend", "gloo"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["config"]["global_members"] == 2 * n
-    assert out["config"]["members_in_statistics"] == 2 * n
+    assert out["n_gpus"] == world and out["config"]["global_members"] == world * n
+    assert out["config"]["members_in_statistics"] == world * n
     assert out["config"]["members_with_model_errors"] == 0
-    assert out["config"]["collective_world_size"] == 2
+    assert out["config"]["collective_world_size"] == world
     assert out["roofline"]["kernel_ms"] > 0 and out["value"] > 0
-    # single process over the union of both blocks
-    S, q10 = ensemble.ecs_q10(2 * n)
-    c = hector_amd.Core(SCENARIO, 2 * n, device=0, lib_path=hip_lib)
+    assert out["first_run_kernel_ms"][str(n)] > 0 and out["value_per_gpu_workload"][str(n)] == out["value"]
+    # single process over the union of the blocks
+    S, q10 = ensemble.ecs_q10(world * n)
+    c = hector_amd.Core(SCENARIO, world * n, device=0, lib_path=hip_lib)
     c.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)").run(2300)
     co2 = c.fetchvars("CO2_concentration", (2300, 2300))[0]
     tg = c.fetchvars("global_tas", (2300, 2300))[0]
     assert abs(out["config"]["co2_2300_mean_ppm"] - co2.mean()) < 1e-9 * co2.mean()
     assert abs(out["config"]["tgav_2300_mean_K"] - tg.mean()) < 1e-9
+    c.shutdown()
