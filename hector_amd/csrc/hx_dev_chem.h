@@ -462,6 +462,35 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
   // step is scaled by act = 1.0 while the box iterates, 0.0 afterwards (h - 0 * delta = h
   // exactly), so both boxes' chains stay interleaved and an iteration is ~40 instructions.
   double act[2] = {1.0, 1.0};
+#ifndef HX_NO_CHEM_BLIND
+  // Two plain Newton steps first, without the stop test, the freeze and the wavefront's vote: from
+  // a warm start a fraction of a percent away the errors go 1e-3 -> 1e-6 -> 1e-12, so no step
+  // before the third can meet the stop rule (|step| <= |h| 2^-30) -- unless the start already
+  // was the root, and then the steps are zero.  Every lane takes exactly these two steps whatever
+  // its neighbours hold, so results stay independent of the lane assignment.  The steps divide by
+  // the raw v_rcp_f64 (4.6e-8): a Newton correction's relative error is multiplied by the
+  // correction's size, which the next iteration squares away -- here and in the tested iterations
+  // below, whose last step is ~1e-11 of [H+].  24 instructions a step instead of 49.
+  // (-DHX_NO_CHEM_BLIND: every iteration tested, divisions to 2e-15: the round-4 form.)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    HX_COUNT(0, 18);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const double x = h[b];
+      double f = -1.0;
+      f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
+      f = f * x + p0[b];
+      double fp = -5.0;
+      fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
+      fp = fp * x + p1[b];
+      h[b] = x - f * HX_RCP(fp);
+    }
+  }
+#define HX_CHEM_NEWTON_DIV(f, fp) ((f) * HX_RCP(fp))
+#else
+#define HX_CHEM_NEWTON_DIV(f, fp) hx_div1((f), (fp))
+#endif
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     HX_COUNT(0, 18);  // (profiling build) Newton iterations
@@ -474,7 +503,7 @@ __device__ __forceinline__ void chem_solve2(const ChemK &kH, const ChemK &kL, do
       double fp = -5.0;
       fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
       fp = fp * x + p1[b];
-      const double delta = hx_div1(f, fp) * act[b];
+      const double delta = HX_CHEM_NEWTON_DIV(f, fp) * act[b];
       const double hn = x - delta;
       h[b] = hn;
       // (a frozen box: delta = 0, the test holds again)

@@ -325,6 +325,34 @@ __device__ __forceinline__ void rhs(const Member<B> &m, const Interval &K1, cons
   d[4] = ao;
 }
 
+// The land half of rhs() alone: vegetation, detritus, soil (the same operations in the same order).
+template <int B>
+__device__ __forceinline__ void rhs_land(const Member<B> &m, const Interval &K, const double *y, double *d,
+                                         double r) {
+  d[1] = (K.v1 - r * y[1]) + m.luc_u;
+  d[2] = K.d2 - r * y[2];
+  d[3] = K.s3 - r * y[3];
+}
+
+// ---- the atmosphere-ocean pair of a dopri5 attempt as ONE chain -----------------------------------
+// Within a stash interval (constants K) the two pools enter the right-hand side only through the
+// air-sea flux  z = ao(c0, c4) = c0 aoA - ((c4 - totC) aoB + pG),  d c0/dt = Pn - z,  d c4/dt = z,
+// and z obeys its own scalar linear equation  dz/dt = aoA (Pn - z) - aoB z = alp - lam z.  A
+// Runge-Kutta stage is an affine combination, and affine maps commute with it: the stage values of
+// z computed by the dopri5 recursion on z alone ARE ao(stage c0, stage c4) of the recursion on the
+// pair (to rounding).  So the attempt carries z through its stages (one variable instead of two),
+// and the pair follows from the stage fluxes at the end:
+//   c4' = c4 + Z,  c0' = (c0 + h Pn) - Z,   Z = h sum_l c_l z_l      (sum_l c_l = 1)
+//   error estimates  xe_0 = -E, xe_4 = +E,  E = h sum_l dc_l z_l      (sum_l dc_l = 0),
+// whose two quotients share the numerator: max(|E| / d_0, |E| / d_4) = |E| / min(d_0, d_4).
+// 39 operations and one division where the pair took 80 and two; same scheme, same decisions,
+// results within rounding of the pairwise form (-DHX_NO_ZCHAIN: the pairwise form, experiments).
+#ifndef HX_NO_ZCHAIN
+template <int CON, bool SPIN> constexpr bool hx_zchain() { return !hx_nbp<CON>() && !SPIN; }
+#else
+template <int CON, bool SPIN> constexpr bool hx_zchain() { return false; }
+#endif
+
 }  // namespace
 #include "hx_dev_track.h"
 namespace {
@@ -830,6 +858,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 #else
       constexpr bool RT = !hx_nbp<CON>();
 #endif
+      constexpr bool ZCH = hx_zchain<CON, SPIN>() && RT;
       double rr[5] = {0, 0, 0, 0, 0};
       if constexpr (RT) {
         const double tot0 = (y[1] + y[2]) + y[3];
@@ -840,6 +869,67 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         rr[3] = hx_div1(m.luc_e, fma(hC, f5, tot0));
         rr[4] = hx_div1(m.luc_e, tot0 + hC);
       }
+      double err = 0.0;
+      if constexpr (ZCH) {
+        // atmosphere + ocean as the flux chain z (see hx_zchain above); vegetation, detritus and
+        // soil through the stages as before.  dxdt[4] carries z at (t, y) from pass to pass.
+        const double lam = K.aoA + K.aoB, alp = K.aoA * K.Pn;
+        const double z1 = dxdt[4];
+        const double kz1 = fma(-lam, z1, alp);
+        const double z2 = z1 + dtl * b21 * kz1;
+#pragma unroll
+        for (int i = 1; i <= 3; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
+        rhs_land<B>(m, K, xt, k2, rr[0]);
+        const double kz2 = fma(-lam, z2, alp);
+        const double z3 = z1 + dtl * b31 * kz1 + dtl * b32 * kz2;
+#pragma unroll
+        for (int i = 1; i <= 3; ++i) xt[i] = y[i] + dtl * b31 * dxdt[i] + dtl * b32 * k2[i];
+        rhs_land<B>(m, K, xt, k3, rr[1]);
+        const double kz3 = fma(-lam, z3, alp);
+        const double z4 = z1 + dtl * b41 * kz1 + dtl * b42 * kz2 + dtl * b43 * kz3;
+#pragma unroll
+        for (int i = 1; i <= 3; ++i)
+          xt[i] = y[i] + dtl * b41 * dxdt[i] + dtl * b42 * k2[i] + dtl * b43 * k3[i];
+        rhs_land<B>(m, K, xt, k4, rr[2]);
+        const double kz4 = fma(-lam, z4, alp);
+        const double z5 = z1 + dtl * b51 * kz1 + dtl * b52 * kz2 + dtl * b53 * kz3 + dtl * b54 * kz4;
+#pragma unroll
+        for (int i = 1; i <= 3; ++i)
+          xt[i] = y[i] + dtl * b51 * dxdt[i] + dtl * b52 * k2[i] + dtl * b53 * k3[i] + dtl * b54 * k4[i];
+        rhs_land<B>(m, K, xt, k5, rr[3]);
+        const double kz5 = fma(-lam, z5, alp);
+        const double z6 = z1 + dtl * b61 * kz1 + dtl * b62 * kz2 + dtl * b63 * kz3 + dtl * b64 * kz4 +
+                          dtl * b65 * kz5;
+#pragma unroll
+        for (int i = 1; i <= 3; ++i)
+          xt[i] = y[i] + dtl * b61 * dxdt[i] + dtl * b62 * k2[i] + dtl * b63 * k3[i] + dtl * b64 * k4[i] +
+                  dtl * b65 * k5[i];
+        rhs_land<B>(m, K, xt, k6, rr[4]);
+#pragma unroll
+        for (int i = 1; i <= 3; ++i)
+          xn[i] = y[i] + dtl * c1 * dxdt[i] + dtl * c3 * k3[i] + dtl * c4 * k4[i] + dtl * c5 * k5[i] +
+                  dtl * c6 * k6[i];
+        rhs_land<B>(m, K, xn, dn, rr[4]);
+        // the pair from the stage fluxes
+        const double Z = dtl * c1 * z1 + dtl * c3 * z3 + dtl * c4 * z4 + dtl * c5 * z5 + dtl * c6 * z6;
+        xn[0] = fma(dtl, K.Pn, y[0]) - Z;
+        xn[4] = y[4] + Z;
+        const double z7 = fma(xn[0], K.aoA, -fma(xn[4] - K.totC, K.aoB, K.pG));   // = rhs()'s ao at the candidate
+        dn[0] = K.Pn - z7;
+        dn[4] = z7;
+        const double E = dtl * dc1 * z1 + dtl * dc3 * z3 + dtl * dc4 * z4 + dtl * dc5 * z5 + dtl * dc6 * z6 +
+                         dtl * dc7 * z7;
+        const double d0 = kc.eps_abs + kc.eps_rel * (fabs(y[0]) + dtl * fabs(K.Pn - z1));
+        const double d4 = kc.eps_abs + kc.eps_rel * (fabs(y[4]) + dtl * fabs(z1));
+        err = hx_div(fabs(E), fmin(d0, d4));
+#pragma unroll
+        for (int i = 1; i <= 3; ++i) {
+          const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] + dtl * dc4 * k4[i] + dtl * dc5 * k5[i] +
+                            dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
+          const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
+          err = fmax(err, hx_div(fabs(xe), d));
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NP; ++i) xt[i] = y[i] + dtl * b21 * dxdt[i];
       rhs<B, SPIN, CON, RT>(m, K, K2, yc, t + dtl * (1.0 / 5), xt, k2, rr[0]);
@@ -869,7 +959,6 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
       // default_error_checker: err = max_i |xe_i| / (eps_abs + eps_rel (|y_i| + dt |dy_i|)):
       // the quotients side by side (five independent reciprocals), then their maximum -- odeint's
       // own order of operations, and no chain of compare-and-select from one variable to the next.
-      double err = 0.0;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         const double xe = dtl * dc1 * dxdt[i] + dtl * dc3 * k3[i] +
@@ -877,6 +966,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
                           dtl * dc6 * k6[i] + dtl * dc7 * dn[i];
         const double d = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i]));
         err = fmax(err, hx_div(fabs(xe), d));
+      }
       }
       // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
       const double grow = 0.9 * pow_m15(fmax(0.00032, err));
