@@ -209,6 +209,17 @@ class Core:
         self._ck(self._lib.hx_set_lane_calibration(self._h, 1 if on else 0))
         return self
 
+    def lane_order_source(self):
+        """What the lanes are ordered by: "parameter key", "measured cost" (a complete run of this
+        core) or "cost model" (fitted to an earlier core's measurements: hx_lane_order_source)."""
+        v = ctypes.c_int(0)
+        self._ck(self._lib.hx_lane_order_source(self._h, ctypes.byref(v)))
+        return ("parameter key", "measured cost", "cost model")[v.value]
+
+    def set_cost_model(self, on=True):
+        self._ck(self._lib.hx_set_cost_model(self._h, 1 if on else 0))
+        return self
+
     def lanes_calibrated(self):
         v = ctypes.c_int()
         self._ck(self._lib.hx_lanes_calibrated(self._h, ctypes.byref(v)))

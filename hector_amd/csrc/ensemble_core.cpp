@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <map>
+#include <mutex>
 
 // launchers defined in hx_kernels.hip
 hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d_steps,
@@ -163,6 +165,9 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   if (const char *e3 = std::getenv("HECTOR_AMD_TWO_WAVE_FROM")) two_wave_from_ = std::atoi(e3);
   if (const char *e4 = std::getenv("HECTOR_AMD_PAIR_ORDER")) pair_costly_with_cheap_ = std::atoi(e4) != 0;
   if (const char *e5 = std::getenv("HECTOR_AMD_KEY_ORDER")) key_order_mode_ = std::atoi(e5);
+  if (const char *e6 = std::getenv("HECTOR_AMD_COST_MODEL")) cost_model_ = std::atoi(e6) != 0;
+  // (tests: the lane-order logic of a GPU with fewer SIMDs, so that small ensembles exercise it)
+  if (const char *e7 = std::getenv("HECTOR_AMD_SIMDS")) simds_ = std::max(1, std::atoi(e7));
   try {  // a constructor that throws gets no destructor: release the stream and events here
     check(hipEventCreate(&ev0_), "hipEventCreate");
     check(hipEventCreate(&ev1_), "hipEventCreate");
@@ -1435,6 +1440,137 @@ void radix_stable_sort(std::vector<int> &order, size_t from, size_t to, const st
 }
 }  // namespace
 
+// ---- a fitted cost model on the parameter key ------------------------------------------------
+// What a member's solver costs (dopri5 steps, stashes) is a smooth function of its perturbed
+// parameters.  After a complete run the core fits  cost ~ quadratic in the standardised varying
+// parameter rows  to the measured per-member costs (least squares on a sample of members) and
+// files it in a process-wide registry under the scenario's per-year table, the biome count and
+// the list of varying rows.  A core with the same key -- the next, larger ensemble of a study, the
+// next iteration of a calibration loop after a setvar -- orders its lanes by the PREDICTED cost
+// from its first run on, costliest wavefronts first like the measured order, instead of waiting
+// for a complete run of its own.  (A pilot in time cannot do this: the members' costs of the
+// first 160 years of SSP2-4.5 have a rank correlation of 0.2 with those of the rest; a quadratic
+// in S and Q10 has 0.89 with the total, and orders 131 072 members as well as their measured
+// costs do -- scratch analysis on the oracle's schedules)
+namespace {
+struct CostModel {
+  std::vector<int> rows;            // varying parameter rows the model knows
+  std::vector<double> mean, sd;     // their standardisation at fit time
+  bool cross = true;                // with the products x_k x_l (k < l)
+  std::vector<double> beta;         // 1, x_k, x_k^2, [x_k x_l]
+};
+std::mutex g_cost_mu;
+std::map<uint64_t, CostModel> g_cost_models;
+
+size_t cost_terms(size_t k, bool cross) { return 1 + 2 * k + (cross ? k * (k - 1) / 2 : 0); }
+void cost_features(const CostModel &m, const double *x, double *f) {
+  const size_t k = m.rows.size();
+  size_t o = 0;
+  f[o++] = 1.0;
+  for (size_t a = 0; a < k; ++a) f[o++] = x[a];
+  for (size_t a = 0; a < k; ++a) f[o++] = x[a] * x[a];
+  if (m.cross)
+    for (size_t a = 0; a < k; ++a)
+      for (size_t b = a + 1; b < k; ++b) f[o++] = x[a] * x[b];
+}
+}  // namespace
+
+uint64_t EnsembleCore::cost_model_key(const std::vector<int> &varying) const {
+  uint64_t h = 1469598103934665603ull;   // FNV-1a
+  auto mix = [&](const void *p, size_t n) {
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+  };
+  mix(shared_.data(), shared_.size() * sizeof(double));
+  mix(&B_, sizeof B_);
+  for (int r : varying) mix(&r, sizeof r);
+  return h;
+}
+
+// member_cost: [n_] measured cost per member (member order)
+void EnsembleCore::fit_cost_model(const std::vector<double> &member_cost) {
+  std::vector<int> varying;
+  for (int r = 0; r < HX_NPARAM(B_); ++r) if (!row_uniform_[r]) varying.push_back(r);
+  if (varying.empty() || varying.size() > 24 || n_ < 256) return;
+  CostModel m;
+  m.rows = varying;
+  const size_t k = varying.size();
+  m.cross = k <= 8;
+  const size_t nt = cost_terms(k, m.cross);
+  const size_t stride = std::max<size_t>(1, (size_t)n_ / 16384);
+  std::vector<size_t> sample;
+  for (size_t i = 0; i < (size_t)n_; i += stride) sample.push_back(i);
+  if (sample.size() < 4 * nt) return;
+  m.mean.assign(k, 0.0); m.sd.assign(k, 1.0);
+  for (size_t a = 0; a < k; ++a) {
+    const std::vector<double> &r = params_[(size_t)varying[a]];
+    double mu = 0, var = 0;
+    for (size_t i : sample) mu += r[i];
+    mu /= (double)sample.size();
+    for (size_t i : sample) var += (r[i] - mu) * (r[i] - mu);
+    m.mean[a] = mu;
+    m.sd[a] = var > 0 ? std::sqrt(var / (double)sample.size()) : 1.0;
+  }
+  // normal equations, Cholesky with a small ridge
+  std::vector<double> A(nt * nt, 0.0), b(nt, 0.0), f(nt), x(k);
+  for (size_t i : sample) {
+    for (size_t a = 0; a < k; ++a) x[a] = (params_[(size_t)varying[a]][i] - m.mean[a]) / m.sd[a];
+    cost_features(m, x.data(), f.data());
+    for (size_t p = 0; p < nt; ++p) {
+      b[p] += f[p] * member_cost[i];
+      for (size_t q = 0; q <= p; ++q) A[p * nt + q] += f[p] * f[q];
+    }
+  }
+  for (size_t p = 0; p < nt; ++p) A[p * nt + p] += 1e-9 * (double)sample.size();
+  for (size_t p = 0; p < nt; ++p) {     // A = L L^T in the lower triangle
+    for (size_t q = 0; q <= p; ++q) {
+      double v = A[p * nt + q];
+      for (size_t t = 0; t < q; ++t) v -= A[p * nt + t] * A[q * nt + t];
+      if (p == q) { if (!(v > 0)) return; A[p * nt + p] = std::sqrt(v); }
+      else A[p * nt + q] = v / A[q * nt + q];
+    }
+  }
+  for (size_t p = 0; p < nt; ++p) {     // L y = b
+    double v = b[p];
+    for (size_t t = 0; t < p; ++t) v -= A[p * nt + t] * b[t];
+    b[p] = v / A[p * nt + p];
+  }
+  for (size_t p = nt; p-- > 0;) {       // L^T beta = y
+    double v = b[p];
+    for (size_t t = p + 1; t < nt; ++t) v -= A[t * nt + p] * b[t];
+    b[p] = v / A[p * nt + p];
+  }
+  m.beta = b;
+  for (double v : m.beta) if (!std::isfinite(v)) return;
+  std::lock_guard<std::mutex> lk(g_cost_mu);
+  g_cost_models[cost_model_key(varying)] = std::move(m);
+}
+
+// -> predicted cost per member (member order), or false if the registry holds no model for this
+// core's scenario / biome count / varying rows
+bool EnsembleCore::predict_cost(const std::vector<int> &varying, std::vector<double> &out) const {
+  if (!cost_model_ || varying.empty()) return false;
+  CostModel m;
+  {
+    std::lock_guard<std::mutex> lk(g_cost_mu);
+    auto it = g_cost_models.find(cost_model_key(varying));
+    if (it == g_cost_models.end()) return false;
+    m = it->second;
+  }
+  const size_t k = m.rows.size(), nt = cost_terms(k, m.cross);
+  if (m.beta.size() != nt) return false;
+  out.resize((size_t)n_);
+  std::vector<double> f(nt), x(k);
+  for (int i = 0; i < n_; ++i) {
+    for (size_t a = 0; a < k; ++a) x[a] = (params_[(size_t)m.rows[a]][(size_t)i] - m.mean[a]) / m.sd[a];
+    cost_features(m, x.data(), f.data());
+    double v = 0;
+    for (size_t p = 0; p < nt; ++p) v += m.beta[p] * f[p];
+    out[(size_t)i] = v;
+  }
+  return true;
+}
+
 // Will run() take the two-wavefront flavour (hx_run_kernel<HX_B1W2>)?  One biome, no carbon
 // tracking, at least hx_set_two_wave_from() members (default: more wavefronts than SIMDs).
 bool EnsembleCore::two_wave_expected() const {
@@ -1472,10 +1608,20 @@ void EnsembleCore::assign_lanes() {
         radix_stable_sort(order, (size_t)b0, (size_t)std::min(n_, b0 + per), q, false);
     }
   }
-  if (sort_members_ && n_ > HX_WAVE && (int)lane_cost_.size() == n_) {
-    // measured cost, costliest first (ties keep the parameter order): wavefronts of members that
+  // the cost the lanes are ordered by: measured (a complete run of this core), or predicted by a
+  // model fitted to an earlier core's measurements (see fit_cost_model), where the order matters:
+  // more wavefronts than SIMDs
+  const std::vector<double> *cost = nullptr;
+  std::vector<double> predicted;
+  lane_order_source_ = 0;
+  if (sort_members_ && n_ > HX_WAVE && (int)lane_cost_.size() == n_) { cost = &lane_cost_; lane_order_source_ = 1; }
+  else if (sort_members_ && calibrate_lanes_ && n_ / HX_WAVE > simds_ && predict_cost(varying, predicted)) {
+    cost = &predicted; lane_order_source_ = 2;
+  }
+  if (cost) {
+    // costliest first (ties keep the parameter order): wavefronts of members that
     // really take the same number of steps and stashes, the expensive ones dispatched first
-    radix_stable_sort(order, 0, (size_t)n_, lane_cost_, true);
+    radix_stable_sort(order, 0, (size_t)n_, *cost, true);
     // Two resident wavefronts per SIMD (the two-wavefront flavour): the first `simds_` wavefronts
     // get a SIMD each, the next ones join them in dispatch order -- wavefront simds_ + k next to
     // wavefront k.  In descending order the costliest would share its SIMD with a median one and
@@ -1512,17 +1658,24 @@ void EnsembleCore::assign_lanes() {
 void EnsembleCore::maybe_calibrate_lanes() {
   if (!calibrate_lanes_ || !sort_members_ || n_ <= HX_WAVE || !lane_cost_.empty() || !d_cost_) return;
   if (cost_from_iy_ != 0 || last_iy_ != scen_.ns() - 1 || last_run_pair_) return;
+  bool adopt = true;
 #ifndef HX_HOST_EMULATION
   {  // With no more wavefronts than SIMDs every wavefront has a SIMD to itself from start to end
-    // and the launch lasts as long as its costliest one under any order: nothing to gain.
-    if (npad_ / HX_WAVE <= simds_ && !std::getenv("HECTOR_AMD_CALIBRATE_ALWAYS")) return;
+    // and the launch lasts as long as its costliest one under any order: nothing to gain for THIS
+    // core -- but its measurements still make the cost model that a larger core of the same study
+    // orders its first run by (once per core: cost_fitted_).
+    if (npad_ / HX_WAVE <= simds_ && !std::getenv("HECTOR_AMD_CALIBRATE_ALWAYS")) adopt = false;
   }
 #endif
+  if (!adopt && (cost_fitted_ || !cost_model_ || n_ < 4096)) return;
   sync();
   std::vector<double> tmp((size_t)npad_);
   check(hipMemcpy(tmp.data(), d_cost_, sizeof(double) * (size_t)npad_, hipMemcpyDeviceToHost), "lane cost");
-  lane_cost_.resize((size_t)n_);
-  for (int i = 0; i < n_; ++i) lane_cost_[(size_t)i] = tmp[(size_t)lane_of_member_[(size_t)i]];
+  std::vector<double> member_cost((size_t)n_);
+  for (int i = 0; i < n_; ++i) member_cost[(size_t)i] = tmp[(size_t)lane_of_member_[(size_t)i]];
+  if (cost_model_) { fit_cost_model(member_cost); cost_fitted_ = true; }
+  if (!adopt) return;
+  lane_cost_ = std::move(member_cost);
   // nothing to gain if the order stays (e.g. every member alike)
   const std::vector<int> before = lane_of_member_;
   assign_lanes();

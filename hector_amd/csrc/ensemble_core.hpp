@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <map>
 #include <string>
 #include <vector>
@@ -74,6 +75,11 @@ class EnsembleCore {
   // until the next complete run.
   void set_lane_calibration(bool on) { calibrate_lanes_ = on; }
   bool lanes_calibrated() const { return !lane_cost_.empty(); }
+  // what the lanes of the last upload are ordered by: 0 the parameter key, 1 this core's measured
+  // cost, 2 the cost a model predicts that was fitted to an earlier core's measurements (same
+  // scenario table, biome count and varying rows, this process; ensemble_core.cpp: fit_cost_model)
+  int lane_order_source() const { return lane_order_source_; }
+  void set_cost_model(bool on) { cost_model_ = on; }
   // keep every year's component state in HBM (272 B per member-year for one biome) so that
   // reset(date) can go back to any computed year, like the reference's tseries records
   void enable_history(bool on);
@@ -166,6 +172,11 @@ class EnsembleCore {
   double *d_bscratch_ = nullptr;  // [nbiome][npad] f_new_thaw of the seven- and eight-biome kernels
   int cost_from_iy_ = -1;         // d_cost_ covers the years cost_from_iy_+1..last_iy_ (-1: nothing)
   void maybe_calibrate_lanes();
+  uint64_t cost_model_key(const std::vector<int> &varying) const;
+  void fit_cost_model(const std::vector<double> &member_cost);
+  bool predict_cost(const std::vector<int> &varying, std::vector<double> &out) const;
+  int lane_order_source_ = 0;
+  bool cost_model_ = true, cost_fitted_ = false;
   void assign_lanes();
   bool params_dirty_ = true, need_spinup_ = true, layout_dirty_ = true, ker_per_member_ = false;
   // What the device holds of the parameter table: the rows set since the last upload and the lane

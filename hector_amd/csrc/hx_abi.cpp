@@ -198,6 +198,11 @@ int hx_output_capabilities(const char *const **names, int *count) {
 }
 int hx_set_member_sorting(hx_core *core, int on) { HX_TRY(core->core->set_member_sorting(on != 0)) }
 int hx_set_lane_calibration(hx_core *core, int on) { HX_TRY(core->core->set_lane_calibration(on != 0)) }
+int hx_lane_order_source(hx_core *core, int *source) {
+  if (!source) return fail("null argument");
+  HX_TRY(*source = core->core->lane_order_source())
+}
+int hx_set_cost_model(hx_core *core, int on) { HX_TRY(core->core->set_cost_model(on != 0)) }
 int hx_lanes_calibrated(hx_core *core, int *yes) {
   if (!yes) return fail("null argument");
   HX_TRY(*yes = core->core->lanes_calibrated() ? 1 : 0)

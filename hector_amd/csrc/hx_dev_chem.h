@@ -598,6 +598,24 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
   double act[N];
 #pragma unroll
   for (int b = 0; b < N; ++b) act[b] = 1.0;
+#ifndef HX_NO_CHEM_BLIND
+  // (two untested steps on the raw reciprocal first: see chem_solve2)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    HX_COUNT(0, 18);
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+      const double x = h[b];
+      double f = -1.0;
+      f = f * x + p4[b]; f = f * x + p3[b]; f = f * x + p2[b]; f = f * x + p1[b];
+      f = f * x + p0[b];
+      double fp = -5.0;
+      fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
+      fp = fp * x + p1[b];
+      h[b] = x - f * HX_RCP(fp);
+    }
+  }
+#endif
 #pragma unroll 1
   for (int it = 0; it < 8; ++it) {
     HX_COUNT(0, 18);  // (profiling build) Newton iterations
@@ -611,7 +629,7 @@ __device__ __forceinline__ void chem_solve_boxes(const ChemK *const (&k)[N], con
       double fp = -5.0;
       fp = fp * x + q4[b]; fp = fp * x + q3[b]; fp = fp * x + q2[b];
       fp = fp * x + p1[b];
-      const double delta = hx_div1(f, fp) * act[b];
+      const double delta = HX_CHEM_NEWTON_DIV(f, fp) * act[b];
       const double hn = x - delta;
       h[b] = hn;
       act[b] = (fabs(hn * factor) < fabs(delta)) ? act[b] : 0.0;

@@ -273,6 +273,7 @@ void Fleet::rename_biome(const std::string &a, const std::string &b) { HX_EACH(r
 void Fleet::set_outputs(const std::vector<std::string> &caps) { HX_EACH(set_outputs(caps)) }
 void Fleet::set_member_sorting(bool on) { HX_EACH(set_member_sorting(on)) }
 void Fleet::set_lane_calibration(bool on) { HX_EACH(set_lane_calibration(on)) }
+void Fleet::set_cost_model(bool on) { HX_EACH(set_cost_model(on)) }
 bool Fleet::lanes_calibrated() const {
   for (const Shard &s : shards_) if (!s.core->lanes_calibrated()) return false;
   return true;

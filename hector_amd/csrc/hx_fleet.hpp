@@ -68,6 +68,8 @@ class Fleet {
   void set_member_sorting(bool on);
   void set_lane_calibration(bool on);
   bool lanes_calibrated() const;
+  int lane_order_source() const { return shards_[0].core->lane_order_source(); }
+  void set_cost_model(bool on);
   void enable_history(bool on);
   void enable_spinup_record(bool on);
   int spinup_record(int member, double *values, int max_steps);

@@ -202,6 +202,17 @@ int hx_set_member_sorting(hx_core *core, int on);
  * hx_lanes_calibrated: 1 once the measured order is in use. */
 int hx_set_lane_calibration(hx_core *core, int on);
 int hx_lanes_calibrated(hx_core *core, int *yes);
+/* A one-shot run has no measured costs of its own.  After a complete run every core fits
+ * cost ~ quadratic in its varying parameter rows (standardised) to what it measured and files the
+ * model under its scenario table, biome count and varying rows, process-wide; a LATER core with
+ * the same key (the larger ensemble of the same study, the next iteration of a calibration loop
+ * after hx_setvar) orders its lanes by the predicted cost from its first run on -- where the
+ * order matters, more wavefronts than SIMDs.  hx_lane_order_source: what the lanes of the last
+ * upload are ordered by -- 0 the parameter key, 1 this core's measured cost, 2 the model's
+ * prediction.  hx_set_cost_model(core, 0) / HECTOR_AMD_COST_MODEL=0: neither fit nor use one.
+ * Results do not depend on the order.  No counterpart in the reference. */
+int hx_lane_order_source(hx_core *core, int *source);
+int hx_set_cost_model(hx_core *core, int on);
 int hx_lane_of_member(hx_core *core, int *out /* n_members */);
 
 /* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.

@@ -195,6 +195,60 @@ def test_lane_calibration_reorders_lanes_and_keeps_results(emul_lib):
     c.shutdown(); off.shutdown()
 
 
+def test_cost_model_orders_the_first_run_of_a_later_core(emul_lib, monkeypatch):
+    """A core's measured costs make a model (cost ~ quadratic in the varying parameter rows, filed
+    under scenario table / biomes / varying rows); a LATER core of the same study orders its lanes
+    by the predicted cost from its first run on -- where the order matters, more wavefronts than
+    SIMDs (HECTOR_AMD_SIMDS: the logic of a small GPU).  Results do not depend on it, bit for bit."""
+    import hector_amd
+    from hector_amd import ensemble
+    monkeypatch.setenv("HECTOR_AMD_SIMDS", "2")
+    kw = dict(lib_path=emul_lib, allow_emulation=True)
+    n = 512
+    S, q = ensemble.ecs_q10(n)
+    a = hector_amd.Core(n_members=n, **kw)
+    a.setvar("S", S).setvar("q10_rh", q)
+    a.status()
+    assert a.lane_order_source() == "parameter key"        # nothing measured anywhere yet
+    a.run(2300); a.reset(1745)
+    assert a.lane_order_source() == "measured cost" and a.lanes_calibrated()
+    # another ensemble of the same study: other members, another size
+    m = 768
+    S2, q2 = ensemble.ecs_q10(m, offset=5000)
+    b = hector_amd.Core(n_members=m, **kw)
+    b.setvar("S", S2).setvar("q10_rh", q2)
+    b.set_outputs(["global_tas", "CO2_concentration", "solver_steps", "timesteps"])
+    b.status()
+    assert b.lane_order_source() == "cost model" and not b.lanes_calibrated()
+    b.run(2300)
+    cost = 4 * b.fetchvars("solver_steps", (1746, 2300)).sum(0) + 5 * b.fetchvars("timesteps", (1746, 2300)).sum(0)
+    by_lane = cost[np.argsort(b.lane_of_member())]
+    q4 = m // 4
+    assert by_lane[:q4].mean() > by_lane[q4:2 * q4].mean() > by_lane[-q4:].mean()    # costliest lanes first
+    rank = np.argsort(np.argsort(-by_lane))
+    assert np.corrcoef(rank, np.arange(m))[0, 1] > 0.8
+    # the same members without the model: other lanes, the same results
+    off = hector_amd.Core(n_members=m, **kw)
+    off.set_cost_model(False).setvar("S", S2).setvar("q10_rh", q2)
+    off.run(2300)
+    assert off.lane_order_source() == "parameter key"
+    assert not np.array_equal(off.lane_of_member(), b.lane_of_member())
+    for v in ("global_tas", "CO2_concentration"):
+        assert np.array_equal(off.fetchvars(v), b.fetchvars(v)), v
+    # a parameter change keeps the model's order (the measured one is void until the next complete run)
+    b.reset(1745)
+    assert b.lane_order_source() == "measured cost"
+    b.setvar("S", S2[::-1].copy()); b.status()
+    assert b.lane_order_source() == "cost model"
+    # other varying rows: another key, no model
+    d = hector_amd.Core(n_members=m, **kw)
+    d.setvar("S", S2).setvar("beta", 0.3 + 0.2 * ensemble.uniform01(np.arange(m, dtype=np.uint64), 7))
+    d.status()
+    assert d.lane_order_source() == "parameter key"
+    for c in (a, b, off, d):
+        c.shutdown()
+
+
 def test_hip_runtime_preload_checks_the_soname(hip_lib, monkeypatch, capsys):
     """PyTorch's bundled HIP runtime is preloaded only if it is the runtime the library
     was linked against (its SONAME among the library's DT_NEEDED), and not at all with
