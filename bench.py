@@ -45,7 +45,10 @@ Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
                    and hbm_yardstick -- the north star's "algorithmic bytes" figure (2 680 B
                    per member-year, SURVEY.md 8d, x members x 555): a yardstick the kernel
                    beats by design (block-causal DOECLIM pass, LDS-resident state), not a
-                   ceiling.
+                   ceiling.  wave_time: how long the wavefronts of the last timed launch ran
+                   (the kernels' own s_memrealtime stamps, hx_wave_clock) -- mean, max and
+                   max / mean: with one wavefront per SIMD the launch lasts as long as its
+                   costliest wavefront.
   other_configs -- the other single-GPU BASELINE configurations (1 024 members and 32 768, the
                    two-wavefront kernel's range; 131 072
                    members = configs[3]'s per-GPU share; 65 536 members x 4 biomes), 5 steps
@@ -234,6 +237,20 @@ def roofline_object(members, biomes, kernel_ms, kernel="run"):
     return r
 
 
+def wave_time(core):
+    """The tail of the last year-loop launch from the kernels' own stamps (hx_wave_clock, 100 MHz
+    s_memrealtime): how long the wavefronts ran, and the longest over the mean -- the launch lasts
+    as long as its last wavefront."""
+    import numpy as np
+    w = core.wave_clock().astype(np.float64) * 1e-5   # ms
+    if len(w) == 0:
+        return None
+    dur = w[:, 1] - w[:, 0]
+    return {"waves": int(len(w)), "mean_ms": float(dur.mean()), "max_ms": float(dur.max()), "min_ms": float(dur.min()),
+            "max_over_mean": float(dur.max() / dur.mean()), "last_start_ms": float(w[:, 0].max()),
+            "span_ms": float(w[:, 1].max() - w[:, 0].min())}
+
+
 def time_config(n, biomes, steps, warmup, device):
     """One extra configuration, timed like the headline: -> dict for other_configs."""
     import numpy as np
@@ -249,6 +266,7 @@ def time_config(n, biomes, steps, warmup, device):
         core.stats_device("global_tas", start, end, stats[1].data_ptr())
         return core.last_run_ms()
     core.status()
+    first_by = core.lane_order_source()               # (the cost model of an earlier core of this process, if any)
     core.run(end)                                     # lane calibration pass (see main) ...
     first_ms = core.last_run_ms()                     # ... and what a one-shot run of this core costs
     core.reset(start); core.status()
@@ -261,11 +279,15 @@ def time_config(n, biomes, steps, warmup, device):
     elapsed = time.perf_counter() - t0
     bad = int((core.status() != 0).sum())
     which = core.last_run_kernel()
+    lanes_by = core.lane_order_source()
+    wt = wave_time(core)
     core.shutdown()
     kernel_ms = float(np.mean(kms))
     rf = roofline_object(n, biomes, kernel_ms, which)
     return {"members": n, "biomes": biomes, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
             "kernel": rf["kernel"], "kernel_ms": kernel_ms, "first_run_kernel_ms": first_ms,
+            "lanes_ordered_by": lanes_by, "first_run_lanes_ordered_by": first_by,
+            "wave_max_over_mean": wt and wt["max_over_mean"], "wave_mean_ms": wt and wt["mean_ms"],
             "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
             "members_with_model_errors": bad,
             "fp64_valu_frac": rf["frac"], "hbm_yardstick_frac": rf["hbm_yardstick"]["frac"],
@@ -427,6 +449,7 @@ def run_workload(args, ctx, n, steps, warmup):
     # solver costs; the reset adopts the lane order by measured cost (hx_set_lane_calibration:
     # wavefronts of like members, the costliest dispatched first) and spins up again.  (Every
     # hx_run_kernel dispatch a profiler sees is a full 555-year one.)
+    first_by = core.lane_order_source()
     core.run(end)
     first_ms = core.last_run_ms()   # the one-shot run: lanes in the order a fresh core gives them
     core.reset(start)
@@ -458,7 +481,8 @@ def run_workload(args, ctx, n, steps, warmup):
          "bad": int((core.status() != 0).sum()),
          "stats_host": stats.cpu().numpy(),
          "which_kernel": core.last_run_kernel(),
-         "calibrated": core.lanes_calibrated(),
+         "calibrated": core.lanes_calibrated(), "lanes_by": core.lane_order_source(), "first_run_lanes_by": first_by,
+         "wave_time": wave_time(core),   # (this rank's first shard, the last timed launch)
          "spin_ms": spin_ms, "collective": collective, "native_fallback": fallback}
     r["comm_world"], _, r["comm_backend"] = core.comm_info()
     core.shutdown()
@@ -629,7 +653,7 @@ def main():
                 "multi_gpu_path": ("executed here: world size %d" % n_gpus) if n_gpus > 1 else
                                   "not exercised (one GPU)",
                 "spinup_ms_excluded": r["spin_ms"], "members_with_model_errors": r["bad"],
-                "lanes_ordered_by": "measured cost" if r["calibrated"] else "parameter key",
+                "lanes_ordered_by": r["lanes_by"], "first_run_lanes_ordered_by": r["first_run_lanes_by"],
                 "members_in_statistics": in_stats,
                 "co2_2300_mean_ppm": float(mean[0, -1]), "tgav_2300_mean_K": float(mean[1, -1]),
                 "versions": runtime_versions(),
@@ -637,6 +661,7 @@ def main():
             # per-rank maximum of the mean kernel time when N > 1
             "roofline": roofline_object(n, args.biomes, kernel_ms, r["which_kernel"]),
         }
+        out["roofline"]["wave_time"] = r["wave_time"]
         if second is not None:
             tm2, mean2, backend2, cworld2, in2 = summary(second)
             rf2 = roofline_object(second["n"], args.biomes, second["kernel_ms"], second["which_kernel"])
@@ -649,7 +674,7 @@ def main():
                 "collective_backend": backend2, "collective_world_size": cworld2,
                 "members_in_statistics": in2, "members_with_model_errors": second["bad"],
                 "first_run_kernel_ms": second["first_run_kernel_ms"],
-                "lanes_ordered_by": "measured cost" if second["calibrated"] else "parameter key",
+                "lanes_ordered_by": second["lanes_by"], "first_run_lanes_ordered_by": second["first_run_lanes_by"],
                 "fp64_valu_frac": rf2["frac"], "pmc_profile_stale": rf2.get("pmc_profile_stale")}]
             k2 = str(second["n"])
             out["value_per_gpu_workload"][k2] = out["other_configs"][0]["value"]

@@ -42,13 +42,18 @@ int fail(const char *msg) { g_err = msg; return 1; }
 // every loader makes first -- and in hx_build_info()'s string.
 namespace {
 std::string build_info_string() {
-  char b[256];
+  char b[384];
 #ifndef HX_HOST_EMULATION
   int rt = 0, drv = 0;
   (void)hipRuntimeGetVersion(&rt);
   (void)hipDriverGetVersion(&drv);
-  std::snprintf(b, sizeof b, "built with HIP %d.%d.%d (%s), gfx950; runtime %d, driver %d",
-                HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, __VERSION__, rt, drv);
+  // (HX_BUILD_TAG: which of the Makefile's builds this is -- the product's code generation flags,
+  //  or `make safe`'s defaults)
+#ifndef HX_BUILD_TAG
+#define HX_BUILD_TAG "flags unknown"
+#endif
+  std::snprintf(b, sizeof b, "built with HIP %d.%d.%d (%s), gfx950, %s; runtime %d, driver %d",
+                HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, __VERSION__, HX_BUILD_TAG, rt, drv);
 #else
   std::snprintf(b, sizeof b, "host emulation (%s)", __VERSION__);
 #endif

@@ -36,15 +36,20 @@
 namespace {
 
 enum PairStep {  // per step attempt, double-buffered
-  PS_N0 = 0, PS_D0, PS_N4, PS_D4, PS_X0, PS_X4,  // ocean -> land: error quotients of y0, y4; candidates
-  PS_NL, PS_DL,                                  // land -> ocean: largest quotient of y1..y3
+  PS_N0 = 0, PS_X3, PS_N4, PS_D4, PS_X0, PS_X4,  // ocean -> land: largest error quotient of its variables; candidates
+                                                 // (atmosphere, ocean total, and the soil pool, which this side integrates)
+  PS_NL, PS_DL,                                  // land -> ocean: largest quotient of vegetation and detritus
   PS_N
 };
 enum PairYear {  // per year / per stash, each slot written and read on opposite sides of a barrier
   PY_PN = 0, PY_CH4, PY_O3, PY_STATUS1, PY_PCO2L,               // land -> ocean
+  PY_S3C, PY_DTOT, PY_SOIL, PY_TOT0,                             // land -> ocean, per interval: the soil pool's constant
+                                                                 // inflow, d(veg + det + soil)/dt, the pool, the three pools' sum
   PY_MAXTS, PY_STATUS0, PY_TLAND, PY_LNC, PY_CLL,                // ocean -> land
   PY_KL_K1, PY_KL_K2, PY_KL_KB, PY_KL_KW, PY_KL_KH,              // ocean -> land, once a year
   PY_HSTAT,                                                      // ocean -> land at year end (state history)
+  PY_HL, PY_HLO,                                                 // [H+] of the LL box: land -> ocean at year end (the
+                                                                 // year-start solve of BOTH boxes is the ocean side's), and back
   PY_N
 };
 
@@ -126,6 +131,59 @@ __device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double 
     en[i] = hx_div(fabs(xe), eps_abs + eps_rel * (fabs(y[i]) + dtl * fabs(dxdt[i])));
   }
   (void)ed;
+}
+
+// The ocean side's attempt (round 5): the atmosphere-ocean pair as ONE flux chain z (hx_dev_solver.h,
+// hx_zchain: dz/dt = alp - lam z within an interval, the pair follows from the stage fluxes) AND
+// the soil pool, whose equation d soil/dt = s3c - r(t) soil needs nothing of the land side within
+// an interval but the loss rates r -- and those follow from the three pools' sum, which moves at
+// the constant rate dtot (both sides carry the sum by the same recurrence).  Two dependency chains
+// here, two (vegetation, detritus) on the land side, where it used to be two and three: the
+// attempt is as long as its longer side.  -> candidates x0n / x4n / x3n, z at the candidate, the
+// soil pool's derivative there, and the largest error quotient of the three variables.
+struct PairZs { double Pn, aoA, aoB, pG, totC, s3c; };
+__device__ __forceinline__ void pair_attempt_zs(const PairZs &k, double dtl, double eps_abs, double eps_rel,
+                                                double y0, double y4, double z1, double y3, double dx3,
+                                                const double *rr,   // loss rates of stages 2..6 (rr[1..5])
+                                                double &x0n, double &x4n, double &z7, double &x3n,
+                                                double &dn3, double &q, const double *T) {
+  const double b21 = T[0], b31 = T[2], b32 = T[3], b41 = T[5], b42 = T[6], b43 = T[7], b51 = T[9],
+               b52 = T[10], b53 = T[11], b54 = T[12], b61 = T[14], b62 = T[15], b63 = T[16], b64 = T[17],
+               b65 = T[18], c1 = T[19], c3 = T[20], c4 = T[21], c5 = T[22], c6 = T[23], dc1 = T[24],
+               dc3 = T[25], dc4 = T[26], dc5 = T[27], dc6 = T[28], dc7 = T[29];
+  const double lam = k.aoA + k.aoB, alp = k.aoA * k.Pn;
+  const double kz1 = fma(-lam, z1, alp);
+  const double z2 = z1 + dtl * b21 * kz1;
+  double xt = y3 + dtl * b21 * dx3;
+  const double k2 = k.s3c - rr[1] * xt;
+  const double kz2 = fma(-lam, z2, alp);
+  const double z3 = z1 + dtl * b31 * kz1 + dtl * b32 * kz2;
+  xt = y3 + dtl * b31 * dx3 + dtl * b32 * k2;
+  const double k3 = k.s3c - rr[2] * xt;
+  const double kz3 = fma(-lam, z3, alp);
+  const double z4 = z1 + dtl * b41 * kz1 + dtl * b42 * kz2 + dtl * b43 * kz3;
+  xt = y3 + dtl * b41 * dx3 + dtl * b42 * k2 + dtl * b43 * k3;
+  const double k4 = k.s3c - rr[3] * xt;
+  const double kz4 = fma(-lam, z4, alp);
+  const double z5 = z1 + dtl * b51 * kz1 + dtl * b52 * kz2 + dtl * b53 * kz3 + dtl * b54 * kz4;
+  xt = y3 + dtl * b51 * dx3 + dtl * b52 * k2 + dtl * b53 * k3 + dtl * b54 * k4;
+  const double k5 = k.s3c - rr[4] * xt;
+  const double kz5 = fma(-lam, z5, alp);
+  const double z6 = z1 + dtl * b61 * kz1 + dtl * b62 * kz2 + dtl * b63 * kz3 + dtl * b64 * kz4 + dtl * b65 * kz5;
+  xt = y3 + dtl * b61 * dx3 + dtl * b62 * k2 + dtl * b63 * k3 + dtl * b64 * k4 + dtl * b65 * k5;
+  const double k6 = k.s3c - rr[5] * xt;
+  x3n = y3 + dtl * c1 * dx3 + dtl * c3 * k3 + dtl * c4 * k4 + dtl * c5 * k5 + dtl * c6 * k6;
+  dn3 = k.s3c - rr[5] * x3n;
+  const double Z = dtl * c1 * z1 + dtl * c3 * z3 + dtl * c4 * z4 + dtl * c5 * z5 + dtl * c6 * z6;
+  x0n = fma(dtl, k.Pn, y0) - Z;
+  x4n = y4 + Z;
+  z7 = fma(x0n, k.aoA, -fma(x4n - k.totC, k.aoB, k.pG));
+  const double E = dtl * dc1 * z1 + dtl * dc3 * z3 + dtl * dc4 * z4 + dtl * dc5 * z5 + dtl * dc6 * z6 + dtl * dc7 * z7;
+  const double d0 = eps_abs + eps_rel * (fabs(y0) + dtl * fabs(k.Pn - z1));
+  const double d4 = eps_abs + eps_rel * (fabs(y4) + dtl * fabs(z1));
+  const double xe3 = dtl * dc1 * dx3 + dtl * dc3 * k3 + dtl * dc4 * k4 + dtl * dc5 * k5 + dtl * dc6 * k6 + dtl * dc7 * dn3;
+  const double d3 = eps_abs + eps_rel * (fabs(y3) + dtl * fabs(dx3));
+  q = fmax(hx_div(fabs(E), fmin(d0, d4)), hx_div(fabs(xe3), d3));
 }
 
 // default_error_checker over all five variables: the maximum of the quotients (the land side
@@ -211,9 +269,8 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // hx_pair_kernel: years (iy_from, iy_to], 128-thread workgroups = 2 wavefronts per 64 members
 //
 // One model year, left to right (| = workgroup barrier):
-//   ocean:  constants of both boxes | solve HL | interval | steps ... stash | (solve HL) | ... forcing, DOECLIM |
-//   land:   Tland-dependent factors | solve LL | flows    | steps ... stash | (solve LL) | ... next year's CH4/OH/O3,
-//                                                                                            Q10 window, history sums |
+//   ocean:  solve HL               | interval | steps ... stash | (solve HL) | ... forcing, DOECLIM, next year's constants of both boxes |
+//   land:   Tland factors, solve LL | flows    | steps ... stash | (solve LL) | ... next year's CH4/OH/O3, Q10 window, history sums   |
 // The carbonate solve a stash needs (pre-update carbon = the carbon left by the stash before) is
 // done right after that earlier stash, one box per wavefront, so no stash waits for it.
 // ===========================================================================
@@ -257,7 +314,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
     double cHL = lds_(buf, HXS_C_HL, mem), cLL = lds_(buf, HXS_C_LL, mem),
            cIO = lds_(buf, HXS_C_IO, mem), cDO = lds_(buf, HXS_C_DO, mem);
     double atmos = lds_(buf, HXS_ATMOS, mem);
-    const double alkH = lds_(buf, HXS_ALK_HL, mem);
+    const double alkH = lds_(buf, HXS_ALK_HL, mem), alkL = lds_(buf, HXS_ALK_LL, mem);
     double hH = lds_(buf, HXS_H_HL, mem);
     int ts_timeout = (int)lds_(buf, HXS_TS_TIMEOUT, mem);
     double lastflux_ann = lds_(buf, HXS_LASTFLUX_ANN, mem);
@@ -331,10 +388,13 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       sums_done = true;
     };
 
-    for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
-      hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
-      // ---- year start (ocean): equilibrium constants of both boxes; LL's go to the land side ----
-      const double TcH = sst + 18 + (-16.4), TcL = sst + 18 + 2.9;
+    // The equilibrium constants of both boxes for a year whose starting SST is sst_v; LL's go to the
+    // land side through LDS.  Evaluated at the END of the year before (the SST is known there, and
+    // this side would otherwise wait for the land side's year end), ahead of the loop for a launch's
+    // first year: nothing of it is left on the year start's critical path, and the barrier that
+    // used to publish LL's constants there is gone (they are read after barrier C / the entry barrier).
+    auto year_consts = [&](double sst_v) {
+      const double TcH = sst_v + 18 + (-16.4), TcL = sst_v + 18 + 2.9;
       double ex[12];
 #ifndef HX_NO_CHEM_FIT
       // (see hx_run_kernel, phase A: the fitted polynomials; the formulas themselves for the lanes
@@ -361,12 +421,28 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       chem_from_exponentials(TcH, &ex[0], O_AsHL, kH);
       chem_from_exponentials(TcL, &ex[6], O_AsLL, kL);
       chem_poly_constants(alkH, kH);
+      chem_poly_constants(alkL, kL);
       s_yr[PY_KL_K1][lane] = kL.K1; s_yr[PY_KL_K2][lane] = kL.K2; s_yr[PY_KL_KB][lane] = kL.Kb;
       s_yr[PY_KL_KW][lane] = kL.Kw; s_yr[PY_KL_KH][lane] = kL.rKh;
+    };
+    year_consts(sst);
+    __syncthreads();  // ---- entry barrier: LL constants of the launch's first year published
+
+    for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
+      hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
+      // ---- year start (ocean): the constants are in hand (year_consts) ----
       PSTAMP(0);
-      __syncthreads();  // ---- barrier A0: LL constants published
       PSTAMP(1);
-      chem_solve1(kH, cHL, alkH, 1.0 / O_vHL, hH, pco2H, status);
+      // The year-start solve of BOTH boxes, interleaved (1.4x the time of one), while the land side
+      // evaluates its Tland-dependent factors and flows: it used to do those AND the LL solve ahead
+      // of barrier A, with this side waiting.  [H+] of LL comes from the land side (its solves after
+      // the stashes keep it) and goes back with the result.
+      {
+        double hL = s_yr[PY_HL][lane];
+        chem_solve2_select(kH, kL, cHL, cLL, alkH, alkL, hH, hL, pco2H, pco2L, status);
+        s_yr[PY_HLO][lane] = hL;
+        s_yr[PY_PCO2L][lane] = pco2L;   // (what the year's first stash reads)
+      }
       s_yr[PY_MAXTS][lane] = c.max_ts;
       s_yr[PY_STATUS0][lane] = (double)status;
       PSTAMP(2);
@@ -379,23 +455,27 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       dpart_pf = HX_GCD(buf.dpart)[(size_t)(iy - blk0) * np + mem];  // (the land side ran the pass last year end)
       if constexpr (HF) dpart2_pf = HX_GCD(buf.dpart2)[(size_t)(iy - blk0) * np + mem];
       sums_done = false;
-      pco2L = s_yr[PY_PCO2L][lane];
       status |= (unsigned)s_yr[PY_STATUS1][lane];
+      // the soil pool of the interval (this side integrates it: pair_attempt_zs), the three land
+      // pools' sum and its rate
+      double s3c = s_yr[PY_S3C][lane], dtot = s_yr[PY_DTOT][lane], soil_seg = s_yr[PY_SOIL][lane],
+             tot_seg = s_yr[PY_TOT0][lane];
+      const double luc_e = sh[HXSH_LUC_E];
       // flux constants of the interval (make_interval)
       double totC = cDO + cIO + cLL + cHL;
       double pG = pco2H * kH.g + pco2L * kL.g;
       double aoA = PGC2PPM * (kH.g + kL.g);
       double aoB = pG * hx_recip(cLL + cHL);
-      auto rhs = [&](const double *y, double *d, int) {
-        const double ao = fma(y[0], aoA, -fma(y[1] - totC, aoB, pG));
-        d[0] = Pn - ao;
-        d[1] = ao;
-      };
-      // ---- solver (ocean): y[0] = atmosphere, y[1] = ocean total ----
+      // ---- solver (ocean): y[0] = atmosphere, y[1] = ocean total (as the flux chain z), y3 = soil ----
       const double year = (double)(kc.start_year + iy);
       const double t0 = year - 1.0, tnew = year;
-      double y[2], dxdt[2];
-      auto load_pools = [&]() { y[0] = atmos; y[1] = cDO + cIO + cLL + cHL; };
+      double y[2], z1, y3, dx3, tot0;
+      // (the fresh stepper's first right-hand side: z at (t, y), the soil pool's derivative)
+      auto first_rhs = [&]() {
+        z1 = fma(y[0], aoA, -fma(y[1] - totC, aoB, pG));
+        dx3 = s3c - hx_div1(luc_e, tot0) * y3;
+      };
+      auto load_pools = [&]() { y[0] = atmos; y[1] = cDO + cIO + cLL + cHL; y3 = soil_seg; tot0 = tot_seg; };
       load_pools();
       c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
       c.alive = status == 0;
@@ -407,30 +487,43 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         c.stepping = seg;
         // (as in solve_year: the fresh stepper's first RHS ahead of the loop, the attempt as
         // straight-line code for every lane, retries behind a uniform rare branch)
-        rhs(y, dxdt, 0);
+        first_rhs();
         for (bool go_ = __any(c.stepping); go_; go_ = __any(c.stepping)) {
-          double xn[2], dn[2], en[2], ed[2];
           if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
-            if (c.stepping && pair_retry(c, status)) { load_pools(); rhs(y, dxdt, 0); }
+            if (c.stepping && pair_retry(c, status)) { load_pools(); first_rhs(); }
           }
           const bool tried = c.stepping;
-#ifndef HX_PAIR_TAB_LITERALS
+          double rrs[6];   // loss rates luc_e / (veg + det + soil) at the stage times (see the land side)
+          {
+            const double hC = c.dtl * dtot;
+            rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
+            rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
+            rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
+            rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
+            rrs[5] = hx_div1(luc_e, tot0 + hC);
+          }
           const double *Tp;
+#ifndef HX_PAIR_TAB_LITERALS
           { int toff = 0; asm volatile("" : "+s"(toff)); Tp = kc.tab + toff; }   // (read in this pass: see solve_year)
-          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed, Tp);
 #else
-          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+          Tp = kc.tab;
 #endif
+          double x0n, x4n, z7, x3n, dn3, qo;
+          const PairZs zk{Pn, aoA, aoB, pG, totC, s3c};
+          pair_attempt_zs(zk, c.dtl, eps_abs, eps_rel, y[0], y[1], z1, y3, dx3, rrs, x0n, x4n, z7, x3n, dn3, qo, Tp);
           if (!sums_done) history_sums(iy);
-          s_st[par][PS_N0][lane] = en[0];
-          s_st[par][PS_N4][lane] = en[1];
-          s_st[par][PS_X0][lane] = xn[0]; s_st[par][PS_X4][lane] = xn[1];
+          s_st[par][PS_N0][lane] = qo;
+          s_st[par][PS_X0][lane] = x0n; s_st[par][PS_X4][lane] = x4n; s_st[par][PS_X3][lane] = x3n;
           PSTAMPF(12);
           __syncthreads();
           PSTAMPF(13);
           if (tried) {
-            const double err = pair_err(en[0], s_st[par][PS_NL][lane], en[1]);
-            if (pair_control(c, err, status)) { y[0] = xn[0]; y[1] = xn[1]; dxdt[0] = dn[0]; dxdt[1] = dn[1]; }
+            const double err = pair_err(qo, s_st[par][PS_NL][lane], 0.0);
+            const double used = c.dtl;
+            if (pair_control(c, err, status)) {
+              y[0] = x0n; y[1] = x4n; z1 = z7; y3 = x3n; dx3 = dn3;
+              tot0 = fma(used, dtot, tot0);   // (the land side's copy moves by the same operation)
+            }
           }
           par ^= 1;
           PSTAMPF(14);
@@ -489,6 +582,9 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         status |= (unsigned)s_yr[PY_STATUS1][lane];
         if (seg && c.alive) {
           Pn = s_yr[PY_PN][lane];  // the next interval's land flows
+          s3c = s_yr[PY_S3C][lane]; dtot = s_yr[PY_DTOT][lane];
+          soil_seg = s_yr[PY_SOIL][lane]; tot_seg = s_yr[PY_TOT0][lane];
+          y3 = soil_seg; tot0 = tot_seg;
           totC = cDO + cIO + cLL + cHL;
           pG = pco2H * kH.g + pco2L * kL.g;
           aoA = PGC2PPM * (kH.g + kL.g);
@@ -581,6 +677,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         store_ocean(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
         s_yr[PY_HSTAT][lane] = (double)status;
       }
+      if (iy < iy_to) year_consts(sst);   // next year's equilibrium constants (sst is this year's result now)
       PSTAMP(10);
       __syncthreads();  // ---- barrier C: year end (SST and land temperature published)
       PSTAMP(11);
@@ -678,6 +775,8 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
     };
     prefetch(iy_from + 1);
     prepare(iy_from + 1);
+    s_yr[PY_HL][lane] = hL;
+    __syncthreads();  // ---- entry barrier (the ocean side's year_consts of the first year; this side's [H+] of LL)
 
     for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
       hx_ccd sh = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
@@ -723,20 +822,23 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       };
       prep();
       PSTAMP(0);
-      __syncthreads();  // ---- barrier A0
       PSTAMP(1);
+      // (LL's constants of this year: published before barrier C of the year before / the entry barrier)
       kL.K1 = s_yr[PY_KL_K1][lane]; kL.K2 = s_yr[PY_KL_K2][lane]; kL.Kb = s_yr[PY_KL_KB][lane];
       kL.Kw = s_yr[PY_KL_KW][lane]; kL.rKh = s_yr[PY_KL_KH][lane];
-      chem_poly_constants(alkL, kL);
-      chem_solve1(kL, cLL, alkL, 1.0 / O_vLL, hL, pco2L, status);
+      chem_poly_constants(alkL, kL);   // (for this side's solves after the stashes; the year-start solve is the ocean side's)
       s_yr[PY_PN][lane] = Pn; s_yr[PY_CH4][lane] = ch4; s_yr[PY_O3][lane] = o3;
       s_yr[PY_STATUS1][lane] = (double)status;
-      s_yr[PY_PCO2L][lane] = pco2L;
+      // the soil pool is integrated by the ocean side (pair_attempt_zs): its constants, the pool, and
+      // the three pools' sum with its rate -- both sides carry the sum by the same recurrence
+      double dtot = (((v1 + luc_u) + d2c) + s3c) - luc_e, tot_seg = (veg + det) + soil;
+      s_yr[PY_S3C][lane] = s3c; s_yr[PY_DTOT][lane] = dtot; s_yr[PY_SOIL][lane] = soil; s_yr[PY_TOT0][lane] = tot_seg;
       PSTAMP(2);
       __syncthreads();  // ---- barrier A
       PSTAMP(3);
       c.max_ts = s_yr[PY_MAXTS][lane];
       status |= (unsigned)s_yr[PY_STATUS0][lane];
+      hL = s_yr[PY_HLO][lane];   // the year-start solve's [H+] of LL
       // the pools' sum moves at a constant rate within an interval (every LUC loss rr * y_i adds up to
       // luc_e), and a Runge-Kutta stage preserves that: the loss rates of all stages of an attempt are
       // known before it starts -- six independent divisions instead of one at the head of each stage
@@ -745,13 +847,12 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         const double rr = rrs[s];
         d[0] = (v1 - rr * y[0]) + luc_u;
         d[1] = d2c - rr * y[1];
-        d[2] = s3c - rr * y[2];
       };
-      // ---- solver (land): y = veg, detritus, soil; permafrost, thawed, earth advance exactly ----
+      // ---- solver (land): y = veg, detritus (soil: the ocean side); permafrost, thawed, earth advance exactly ----
       const double year = (double)(kc.start_year + iy);
       const double t0 = year - 1.0, tnew = year;
-      double y[3], dxdt[3], l4, l5, l7;
-      auto load_pools = [&]() { y[0] = veg; y[1] = det; y[2] = soil; l4 = pf; l5 = thawed; l7 = earth; };
+      double y[2], dxdt[2], l4, l5, l7, tot0;
+      auto load_pools = [&]() { y[0] = veg; y[1] = det; l4 = pf; l5 = thawed; l7 = earth; tot0 = tot_seg; };
       load_pools();
       c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
       c.alive = status == 0;
@@ -768,18 +869,17 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         const bool seg = c.alive && c.t < tnew;
         c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = false; c.fails = 0;
         c.stepping = seg;
-        double y0c = 0, y4c = 0;  // the ocean side's atmosphere / ocean totals after the last accepted step
-        auto first_rhs = [&]() { rrs[0] = hx_div1(luc_e, y[0] + y[1] + y[2]); rhs(y, dxdt, 0); };
+        double y0c = 0, y4c = 0, y3c = soil;  // the ocean side's atmosphere / ocean totals / soil pool after the last accepted step
+        auto first_rhs = [&]() { rrs[0] = hx_div1(luc_e, tot0); rhs(y, dxdt, 0); };
         first_rhs();  // (the fresh stepper's first RHS, ahead of the loop: see the ocean side)
         for (bool go_ = __any(c.stepping); go_; go_ = __any(c.stepping)) {
-          double xn[3], dn[3], en[3], ed[3];
+          double xn[2], dn[2], en[2], ed[2];
           if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
             if (c.stepping && pair_retry(c, status)) { load_pools(); first_rhs(); }
           }
           const bool tried = c.stepping;
           {
-            const double tot0 = y[0] + y[1] + y[2];
-            const double hC = c.dtl * ((((v1 + luc_u) + d2c) + s3c) - luc_e);
+            const double hC = c.dtl * dtot;
             rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
             rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
             rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
@@ -789,23 +889,24 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
 #ifndef HX_PAIR_TAB_LITERALS
           const double *Tp;
           { int toff = 0; asm volatile("" : "+s"(toff)); Tp = kc.tab + toff; }   // (read in this pass: see solve_year)
-          pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed, Tp);
+          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed, Tp);
 #else
-          pair_attempt<3>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
 #endif
-          const double bn = fmax(fmax(en[0], en[1]), en[2]);  // largest quotient of the three
+          const double bn = fmax(en[0], en[1]);  // the larger quotient of this side's two
           s_st[par][PS_NL][lane] = bn;
           PSTAMPF(12);
           __syncthreads();
           PSTAMPF(13);
           if (tried) {
-            const double err = pair_err(s_st[par][PS_N0][lane], bn, s_st[par][PS_N4][lane]);
+            const double err = pair_err(s_st[par][PS_N0][lane], bn, 0.0);
             const double used = c.dtl;
             if (pair_control(c, err, status)) {
               l4 += used * k4; l7 += used * k7; l5 += used * k5;
 #pragma unroll
-              for (int i = 0; i < 3; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
-              y0c = s_st[par][PS_X0][lane]; y4c = s_st[par][PS_X4][lane];
+              for (int i = 0; i < 2; ++i) { y[i] = xn[i]; dxdt[i] = dn[i]; }
+              y0c = s_st[par][PS_X0][lane]; y4c = s_st[par][PS_X4][lane]; y3c = s_st[par][PS_X3][lane];
+              tot0 = fma(used, dtot, tot0);
             }
           }
           par ^= 1;
@@ -833,21 +934,26 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
           }
           double tpf = l5;
           if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
-          if (y[0] < 0 || y[1] < 0 || y[2] < 0 || l4 < 0 || tpf < 0) status |= HX_ERR_NEGPOOL;
-          const double total = y[0] + y[1] + y[2];
+          if (y[0] < 0 || y[1] < 0 || y3c < 0 || l4 < 0 || tpf < 0) status |= HX_ERR_NEGPOOL;
+          const double total = y[0] + y[1] + y3c;
           cum_luc_va += hx_div((luc_e - luc_u) * y[0], total);  // no yf: :388-393
           cum_pf_ch4 += rh_tp_ch4() * yf;  // :481
           const double wt_pf = (pf > 0) ? 1.0 : 0.0;
-          veg = y[0]; det = y[1]; soil = y[2];
+          veg = y[0]; det = y[1]; soil = y3c;
           pf = l4 * wt_pf; thawed = tpf * wt_pf;
           earth = l7;
-          const double sum = ((((((y0c + y[0]) + y[1]) + y[2]) + l4) + l5) + y4c) + l7 + cum_pf_ch4;
+          const double sum = ((((((y0c + y[0]) + y[1]) + y3c) + l4) + l5) + y4c) + l7 + cum_pf_ch4;
           if (masstot > 0.0 && !(fabs(sum - masstot) <= 0.001)) status |= HX_ERR_MASS;
           masstot = sum;
           c.ode_start = t;
-          if (t < tnew) prep();  // constants of the next segment
+          if (t < tnew) {  // constants of the next segment
+            prep();
+            dtot = (((v1 + luc_u) + d2c) + s3c) - luc_e; tot_seg = (veg + det) + soil;
+            tot0 = tot_seg;
+          }
         }
         s_yr[PY_PN][lane] = Pn;
+        s_yr[PY_S3C][lane] = s3c; s_yr[PY_DTOT][lane] = dtot; s_yr[PY_SOIL][lane] = soil; s_yr[PY_TOT0][lane] = tot_seg;
         s_yr[PY_STATUS1][lane] = (double)status;
         PSTAMP(6);
         __syncthreads();  // ---- stash hand-off
@@ -887,6 +993,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       }
       if (__builtin_expect(!!(buf.hist), 0)) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
       if (iy < iy_to) prepare(iy + 1);
+      s_yr[PY_HL][lane] = hL;
       PSTAMP(10);
       __syncthreads();  // ---- barrier C
       PSTAMP(11);

@@ -668,12 +668,22 @@ __device__ __forceinline__ double pow_m13(double x) {
   return y;
 }
 
-// x^(-1/5) for the step-growth rule: single-precision seed, two Newton steps on
-// y^-5 = x in fp64 (relative error e -> 3e^2: 1e-6 -> 3e-12 -> ~1e-16).  The
-// fp64 log/exp pair it replaces is a ~75-instruction dependent chain, the longest
-// in the step block, and a single resident wavefront cannot hide it.
+// x^(-1/5) for the step-growth rule.  The fp64 log/exp pair it replaces is a ~75-instruction
+// dependent chain; the result sits on the step loop's critical path (error -> growth -> dt ->
+// the next attempt's first stage) and a single resident wavefront cannot hide it.
+// Single-precision seed y (v_log_f32 / v_exp_f32: ~2e-7), then ONE step of third order: with
+// d = 1 - x y^5 the root is y (1 - d)^(-1/5) = y (1 + d/5 + 3 d^2 / 25 + O(d^3)) exactly, d ~ 1e-6,
+// so the two terms leave 0.09 d^3 ~ 1e-19; d itself is one fused operation on x y and y^4 (its
+// rounding, 3e-16, enters the result by a fifth).  Seven dependent operations behind the seed
+// where two Newton steps (round 1-4) were twelve.  (-DHX_POW_NEWTON: those, experiments.)
 __device__ __forceinline__ double pow_m15(double x) {
   double y = (double)HX_EXP2F(-0.2f * HX_LOG2F((float)x));  // (x in [3.2e-4, 1]: normal range)
+#ifndef HX_POW_NEWTON
+  const double y2 = y * y, xy = x * y;
+  const double y4 = y2 * y2;
+  const double d = fma(-xy, y4, 1.0);
+  return fma(y * d, fma(0.12, d, 0.2), y);
+#else
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const double y2 = y * y;
@@ -681,6 +691,7 @@ __device__ __forceinline__ double pow_m15(double x) {
     y = y + y * ((1.0 - x * y5) * 0.2);
   }
   return y;
+#endif
 }
 
 // CarbonCycleSolver::run for one model year t0 -> tnew (carbon-cycle-solver.cpp:

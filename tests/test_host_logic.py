@@ -24,7 +24,7 @@ def test_abi_library_loads_and_exports_every_declared_symbol(hip_lib):
     # the toolchain pairing behind a run's figures (no device needed to ask)
     lib.hx_build_info.restype = ctypes.c_char_p
     info = lib.hx_build_info().decode()
-    assert re.match(r"built with HIP \d+\.\d+\.\d+ \(.*\), gfx950; runtime -?\d+, driver -?\d+$", info), info
+    assert re.match(r"built with HIP \d+\.\d+\.\d+ \(.*\), gfx950, product build: .*; runtime -?\d+, driver -?\d+$", info), info
 
 
 def test_product_fails_loudly_without_gpu(hip_lib):

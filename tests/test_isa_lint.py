@@ -42,6 +42,29 @@ _Z6kernelv:
 """
 
 
+# if / else whose join label (the execz target) opens the else part: between s_or_saveexec (EXEC =
+# then | else lanes) and the s_xor that narrows it, a save of an outside value is stored for every
+# lane of the region -- fine; AHEAD of the s_or_saveexec it runs for the then-lanes only -- lost
+FINE_ELSE_HEAD = """
+_Z6kernelv:
+\ts_and_saveexec_b64 s[20:21], s[0:1]
+\ts_xor_b64 s[0:1], exec, s[20:21]
+\ts_cbranch_execz .LBB0_2
+; %bb.1:
+\tv_add_f64 v[8:9], v[8:9], v[10:11]
+.LBB0_2:
+\ts_or_saveexec_b64 s[0:1], s[0:1]
+\tv_accvgpr_write_b32 a2, v162
+\ts_xor_b64 exec, exec, s[0:1]
+\tv_mov_b32_e32 v8, 0
+\ts_or_b64 exec, exec, s[0:1]
+\ts_endpgm
+"""
+BUG_AHEAD_OF_ELSE_HEAD = FINE_ELSE_HEAD.replace(
+    ".LBB0_2:\n\ts_or_saveexec_b64 s[0:1], s[0:1]\n\tv_accvgpr_write_b32 a2, v162",
+    ".LBB0_2:\n\tv_accvgpr_write_b32 a2, v162\n\ts_or_saveexec_b64 s[0:1], s[0:1]")
+
+
 def _scan(text, tmp_path, name):
     p = tmp_path / name
     p.write_text(text)
@@ -53,6 +76,9 @@ def test_lint_tells_a_lost_save_from_a_merge(tmp_path):
     assert len(hits) == 1 and "a18, v80" in hits[0][3]
     assert _scan(FINE_COMPUTED, tmp_path, "fine1.s") == []
     assert _scan(FINE_MERGE, tmp_path, "fine2.s") == []
+    assert _scan(FINE_ELSE_HEAD, tmp_path, "fine3.s") == []
+    hits = _scan(BUG_AHEAD_OF_ELSE_HEAD, tmp_path, "bug2.s")
+    assert len(hits) == 1 and "a2, v162" in hits[0][3]
 
 
 MFMA_EARLY = """

@@ -59,6 +59,7 @@ def scan(path):
     kernel, block = None, None
     stack = [set()]        # VGPRs written since each enclosing saveexec
     pend = []              # saves seen since the label of the current block
+    widened = False        # inside the full-mask window of an if / else join (see below)
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+|hx_\w+):", l)
         if m:
@@ -66,15 +67,32 @@ def scan(path):
             continue
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
-            block, pend = m.group(1), []
+            block, pend, widened = m.group(1), [], False
             continue
         s = l.strip()
         if not s or s[0] in ";.":
             continue
         op = s.split()[0]
         if "saveexec" in op:
+            if op.startswith("s_or_saveexec") and block in execz_targets:
+                # an else part's head at a join label: a save AHEAD of it ran under the then-lanes'
+                # mask only (none, if the label was reached by the execz skip)
+                for (ln, src, text, dst) in pend:
+                    if src not in stack[-1]:
+                        found.append((kernel, block, ln, text))
             stack.append(set())
             pend = []      # what follows belongs to the region opened here
+            # (s_or_saveexec at the head of an else part: EXEC = then-lanes | else-lanes, the whole
+            #  region's mask, until the s_xor that narrows it to the else lanes)
+            widened = op.startswith("s_or_saveexec")
+            continue
+        if widened and s.replace(" ", "").startswith("s_xor_b64exec,exec,"):
+            # if / else: between `s_or_saveexec_b64 sX, sX` at the join label and this `s_xor_b64 exec,
+            # exec, sX` every lane of the region is active -- a save there stores the value for all
+            # of them, whichever way the block was reached (round 5: hx_run_kernel<looped, HF, KERPM,
+            # NBP>, two spills of values from outside the NBP-constraint block, correct code)
+            pend = []
+            widened = False
             continue
         if s.replace(" ", "").startswith("s_or_b64exec,exec,"):
             inner = stack.pop() if len(stack) > 1 else set()
