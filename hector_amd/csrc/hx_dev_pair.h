@@ -142,48 +142,113 @@ __device__ __forceinline__ void pair_attempt(const Rhs &rhs, double dtl, double 
 // attempt is as long as its longer side.  -> candidates x0n / x4n / x3n, z at the candidate, the
 // soil pool's derivative there, and the largest error quotient of the three variables.
 struct PairZs { double Pn, aoA, aoB, pG, totC, s3c; };
-__device__ __forceinline__ void pair_attempt_zs(const PairZs &k, double dtl, double eps_abs, double eps_rel,
+// (Both attempts below work on SCALED stage derivatives H = h k like solve_year's: the affine
+//  right-hand sides take h into their constants once per attempt, the stage combinations read the
+//  tableau straight from scalar registers.  The loss rates of the stage times are part of the
+//  attempt: luc_e / (tot0 + h dtot f_j), scaled by h, and unscaled at the candidate for the
+//  derivative that the next attempt starts from.)
+struct PairRates { double hr[5], r5; };
+__device__ __forceinline__ void pair_rates(double h, double luc_e, double tot0, double dtot, PairRates &R) {
+  const double hC = h * dtot, hle = h * luc_e;
+  R.hr[0] = hx_div1(hle, fma(hC, 0.2, tot0));
+  R.hr[1] = hx_div1(hle, fma(hC, 0.3, tot0));
+  R.hr[2] = hx_div1(hle, fma(hC, 0.8, tot0));
+  R.hr[3] = hx_div1(hle, fma(hC, 8.0 / 9.0, tot0));
+  double inv = HX_RCP(tot0 + hC);
+  inv = fma(fma(-(tot0 + hC), inv, 1.0), inv, inv);
+  R.hr[4] = hle * inv;
+  R.r5 = luc_e * inv;
+}
+__device__ __forceinline__ void pair_attempt_zs(const PairZs &k, double h, double eps_abs, double eps_rel,
+                                                double luc_e, double tot0, double dtot,
                                                 double y0, double y4, double z1, double y3, double dx3,
-                                                const double *rr,   // loss rates of stages 2..6 (rr[1..5])
                                                 double &x0n, double &x4n, double &z7, double &x3n,
                                                 double &dn3, double &q, const double *T) {
   const double b21 = T[0], b31 = T[2], b32 = T[3], b41 = T[5], b42 = T[6], b43 = T[7], b51 = T[9],
                b52 = T[10], b53 = T[11], b54 = T[12], b61 = T[14], b62 = T[15], b63 = T[16], b64 = T[17],
                b65 = T[18], c1 = T[19], c3 = T[20], c4 = T[21], c5 = T[22], c6 = T[23], dc1 = T[24],
                dc3 = T[25], dc4 = T[26], dc5 = T[27], dc6 = T[28], dc7 = T[29];
-  const double lam = k.aoA + k.aoB, alp = k.aoA * k.Pn;
-  const double kz1 = fma(-lam, z1, alp);
-  const double z2 = z1 + dtl * b21 * kz1;
-  double xt = y3 + dtl * b21 * dx3;
-  const double k2 = k.s3c - rr[1] * xt;
-  const double kz2 = fma(-lam, z2, alp);
-  const double z3 = z1 + dtl * b31 * kz1 + dtl * b32 * kz2;
-  xt = y3 + dtl * b31 * dx3 + dtl * b32 * k2;
-  const double k3 = k.s3c - rr[2] * xt;
-  const double kz3 = fma(-lam, z3, alp);
-  const double z4 = z1 + dtl * b41 * kz1 + dtl * b42 * kz2 + dtl * b43 * kz3;
-  xt = y3 + dtl * b41 * dx3 + dtl * b42 * k2 + dtl * b43 * k3;
-  const double k4 = k.s3c - rr[3] * xt;
-  const double kz4 = fma(-lam, z4, alp);
-  const double z5 = z1 + dtl * b51 * kz1 + dtl * b52 * kz2 + dtl * b53 * kz3 + dtl * b54 * kz4;
-  xt = y3 + dtl * b51 * dx3 + dtl * b52 * k2 + dtl * b53 * k3 + dtl * b54 * k4;
-  const double k5 = k.s3c - rr[4] * xt;
-  const double kz5 = fma(-lam, z5, alp);
-  const double z6 = z1 + dtl * b61 * kz1 + dtl * b62 * kz2 + dtl * b63 * kz3 + dtl * b64 * kz4 + dtl * b65 * kz5;
-  xt = y3 + dtl * b61 * dx3 + dtl * b62 * k2 + dtl * b63 * k3 + dtl * b64 * k4 + dtl * b65 * k5;
-  const double k6 = k.s3c - rr[5] * xt;
-  x3n = y3 + dtl * c1 * dx3 + dtl * c3 * k3 + dtl * c4 * k4 + dtl * c5 * k5 + dtl * c6 * k6;
-  dn3 = k.s3c - rr[5] * x3n;
-  const double Z = dtl * c1 * z1 + dtl * c3 * z3 + dtl * c4 * z4 + dtl * c5 * z5 + dtl * c6 * z6;
-  x0n = fma(dtl, k.Pn, y0) - Z;
+  PairRates R;
+  pair_rates(h, luc_e, tot0, dtot, R);
+  const double hl = h * (k.aoA + k.aoB), ha = h * (k.aoA * k.Pn), hs = h * k.s3c;
+  const double H1 = h * dx3;
+  const double Hz1 = fma(-hl, z1, ha);
+  const double z2 = z1 + b21 * Hz1;
+  double xt = y3 + b21 * H1;
+  const double H2 = fma(-R.hr[0], xt, hs);
+  const double Hz2 = fma(-hl, z2, ha);
+  const double z3 = z1 + b31 * Hz1 + b32 * Hz2;
+  xt = y3 + b31 * H1 + b32 * H2;
+  const double H3 = fma(-R.hr[1], xt, hs);
+  const double Hz3 = fma(-hl, z3, ha);
+  const double z4 = z1 + b41 * Hz1 + b42 * Hz2 + b43 * Hz3;
+  xt = y3 + b41 * H1 + b42 * H2 + b43 * H3;
+  const double H4 = fma(-R.hr[2], xt, hs);
+  const double Hz4 = fma(-hl, z4, ha);
+  const double z5 = z1 + b51 * Hz1 + b52 * Hz2 + b53 * Hz3 + b54 * Hz4;
+  xt = y3 + b51 * H1 + b52 * H2 + b53 * H3 + b54 * H4;
+  const double H5 = fma(-R.hr[3], xt, hs);
+  const double Hz5 = fma(-hl, z5, ha);
+  const double z6 = z1 + b61 * Hz1 + b62 * Hz2 + b63 * Hz3 + b64 * Hz4 + b65 * Hz5;
+  xt = y3 + b61 * H1 + b62 * H2 + b63 * H3 + b64 * H4 + b65 * H5;
+  const double H6 = fma(-R.hr[4], xt, hs);
+  x3n = y3 + c1 * H1 + c3 * H3 + c4 * H4 + c5 * H5 + c6 * H6;
+  dn3 = k.s3c - R.r5 * x3n;
+  const double H7 = fma(-R.hr[4], x3n, hs);
+  const double Z = h * (c1 * z1 + c3 * z3 + c4 * z4 + c5 * z5 + c6 * z6);
+  x0n = fma(h, k.Pn, y0) - Z;
   x4n = y4 + Z;
   z7 = fma(x0n, k.aoA, -fma(x4n - k.totC, k.aoB, k.pG));
-  const double E = dtl * dc1 * z1 + dtl * dc3 * z3 + dtl * dc4 * z4 + dtl * dc5 * z5 + dtl * dc6 * z6 + dtl * dc7 * z7;
-  const double d0 = eps_abs + eps_rel * (fabs(y0) + dtl * fabs(k.Pn - z1));
-  const double d4 = eps_abs + eps_rel * (fabs(y4) + dtl * fabs(z1));
-  const double xe3 = dtl * dc1 * dx3 + dtl * dc3 * k3 + dtl * dc4 * k4 + dtl * dc5 * k5 + dtl * dc6 * k6 + dtl * dc7 * dn3;
-  const double d3 = eps_abs + eps_rel * (fabs(y3) + dtl * fabs(dx3));
+  const double E = h * (dc1 * z1 + dc3 * z3 + dc4 * z4 + dc5 * z5 + dc6 * z6 + dc7 * z7);
+  const double d0 = eps_abs + eps_rel * (fabs(y0) + h * fabs(k.Pn - z1));
+  const double d4 = eps_abs + eps_rel * (fabs(y4) + h * fabs(z1));
+  const double xe3 = dc1 * H1 + dc3 * H3 + dc4 * H4 + dc5 * H5 + dc6 * H6 + dc7 * H7;
+  const double d3 = eps_abs + eps_rel * (fabs(y3) + fabs(H1));
   q = fmax(hx_div(fabs(E), fmin(d0, d4)), hx_div(fabs(xe3), d3));
+}
+// The land side's attempt: vegetation (c[0] = v1, + luc_u) and detritus (c[1] = d2c), scaled stages.
+__device__ __forceinline__ void pair_attempt_ld(double v1, double luc_u, double d2c, double h, double eps_abs,
+                                                double eps_rel, double luc_e, double tot0, double dtot,
+                                                const double *y, const double *dxdt, double *xn, double *dn,
+                                                double &q, const double *T) {
+  const double b21 = T[0], b31 = T[2], b32 = T[3], b41 = T[5], b42 = T[6], b43 = T[7], b51 = T[9],
+               b52 = T[10], b53 = T[11], b54 = T[12], b61 = T[14], b62 = T[15], b63 = T[16], b64 = T[17],
+               b65 = T[18], c1 = T[19], c3 = T[20], c4 = T[21], c5 = T[22], c6 = T[23], dc1 = T[24],
+               dc3 = T[25], dc4 = T[26], dc5 = T[27], dc6 = T[28], dc7 = T[29];
+  PairRates R;
+  pair_rates(h, luc_e, tot0, dtot, R);
+  const double cs[2] = {h * (v1 + luc_u), h * d2c};
+  double H1[2], H2[2], H3[2], H4[2], H5[2], H6[2], H7[2], xt[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { H1[i] = h * dxdt[i]; xt[i] = y[i] + b21 * H1[i]; H2[i] = fma(-R.hr[0], xt[i], cs[i]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { xt[i] = y[i] + b31 * H1[i] + b32 * H2[i]; H3[i] = fma(-R.hr[1], xt[i], cs[i]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { xt[i] = y[i] + b41 * H1[i] + b42 * H2[i] + b43 * H3[i]; H4[i] = fma(-R.hr[2], xt[i], cs[i]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    xt[i] = y[i] + b51 * H1[i] + b52 * H2[i] + b53 * H3[i] + b54 * H4[i];
+    H5[i] = fma(-R.hr[3], xt[i], cs[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    xt[i] = y[i] + b61 * H1[i] + b62 * H2[i] + b63 * H3[i] + b64 * H4[i] + b65 * H5[i];
+    H6[i] = fma(-R.hr[4], xt[i], cs[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    xn[i] = y[i] + c1 * H1[i] + c3 * H3[i] + c4 * H4[i] + c5 * H5[i] + c6 * H6[i];
+    H7[i] = fma(-R.hr[4], xn[i], cs[i]);
+  }
+  dn[0] = (v1 - R.r5 * xn[0]) + luc_u;   // (unscaled, the form of the step loop's first right-hand side)
+  dn[1] = d2c - R.r5 * xn[1];
+  double e[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double xe = dc1 * H1[i] + dc3 * H3[i] + dc4 * H4[i] + dc5 * H5[i] + dc6 * H6[i] + dc7 * H7[i];
+    e[i] = hx_div(fabs(xe), eps_abs + eps_rel * (fabs(y[i]) + fabs(H1[i])));
+  }
+  q = fmax(e[0], e[1]);
 }
 
 // default_error_checker over all five variables: the maximum of the quotients (the land side
@@ -493,15 +558,6 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
             if (c.stepping && pair_retry(c, status)) { load_pools(); first_rhs(); }
           }
           const bool tried = c.stepping;
-          double rrs[6];   // loss rates luc_e / (veg + det + soil) at the stage times (see the land side)
-          {
-            const double hC = c.dtl * dtot;
-            rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
-            rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
-            rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
-            rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
-            rrs[5] = hx_div1(luc_e, tot0 + hC);
-          }
           const double *Tp;
 #ifndef HX_PAIR_TAB_LITERALS
           { int toff = 0; asm volatile("" : "+s"(toff)); Tp = kc.tab + toff; }   // (read in this pass: see solve_year)
@@ -510,7 +566,8 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
 #endif
           double x0n, x4n, z7, x3n, dn3, qo;
           const PairZs zk{Pn, aoA, aoB, pG, totC, s3c};
-          pair_attempt_zs(zk, c.dtl, eps_abs, eps_rel, y[0], y[1], z1, y3, dx3, rrs, x0n, x4n, z7, x3n, dn3, qo, Tp);
+          pair_attempt_zs(zk, c.dtl, eps_abs, eps_rel, luc_e, tot0, dtot, y[0], y[1], z1, y3, dx3, x0n, x4n, z7,
+                          x3n, dn3, qo, Tp);
           if (!sums_done) history_sums(iy);
           s_st[par][PS_N0][lane] = qo;
           s_st[par][PS_X0][lane] = x0n; s_st[par][PS_X4][lane] = x4n; s_st[par][PS_X3][lane] = x3n;
@@ -873,27 +930,19 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         auto first_rhs = [&]() { rrs[0] = hx_div1(luc_e, tot0); rhs(y, dxdt, 0); };
         first_rhs();  // (the fresh stepper's first RHS, ahead of the loop: see the ocean side)
         for (bool go_ = __any(c.stepping); go_; go_ = __any(c.stepping)) {
-          double xn[2], dn[2], en[2], ed[2];
+          double xn[2], dn[2];
           if (__builtin_expect(__any(pair_clip_need(c)), 0)) {
             if (c.stepping && pair_retry(c, status)) { load_pools(); first_rhs(); }
           }
           const bool tried = c.stepping;
-          {
-            const double hC = c.dtl * dtot;
-            rrs[1] = hx_div1(luc_e, fma(hC, 0.2, tot0));
-            rrs[2] = hx_div1(luc_e, fma(hC, 0.3, tot0));
-            rrs[3] = hx_div1(luc_e, fma(hC, 0.8, tot0));
-            rrs[4] = hx_div1(luc_e, fma(hC, 8.0 / 9.0, tot0));
-            rrs[5] = hx_div1(luc_e, tot0 + hC);
-          }
-#ifndef HX_PAIR_TAB_LITERALS
           const double *Tp;
+#ifndef HX_PAIR_TAB_LITERALS
           { int toff = 0; asm volatile("" : "+s"(toff)); Tp = kc.tab + toff; }   // (read in this pass: see solve_year)
-          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed, Tp);
 #else
-          pair_attempt<2>(rhs, c.dtl, eps_abs, eps_rel, y, dxdt, xn, dn, en, ed);
+          Tp = kc.tab;
 #endif
-          const double bn = fmax(en[0], en[1]);  // the larger quotient of this side's two
+          double bn;   // the larger error quotient of this side's two
+          pair_attempt_ld(v1, luc_u, d2c, c.dtl, eps_abs, eps_rel, luc_e, tot0, dtot, y, dxdt, xn, dn, bn, Tp);
           s_st[par][PS_NL][lane] = bn;
           PSTAMPF(12);
           __syncthreads();
