@@ -19,7 +19,7 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
 int hx_track_value_rows(int B);
 int hx_pair_available();
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
-                              int iy_to, hipStream_t st);
+                              int iy_to, hipStream_t st, bool cons);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st, bool two_wave, int cus);
 int hx_doeclim_block_years();
@@ -1951,8 +1951,14 @@ void EnsembleCore::run(double runtodate) {
     con = 2;
   }
   // small ensembles (too few wavefronts to fill the SIMDs): two wavefronts per 64 members
-  bool plain = con_mask == 0 && !d_track_out_f_;  // (the extended run kernel is also taken for diagnostics
-  for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) plain = false;  //  this one records itself)
+  // (it serves scenario-wide CO2 / tas / RF_tot / CH4 constraints -- concentration-driven runs -- with
+  // shared diffusivity; an NBP constraint, constraint or emission series per member and a
+  // land-ocean warming ratio take the extended run kernel, which is also taken for diagnostics
+  // this one does not record itself)
+  const int pair_cons = con_mask & (HXC_CO2 | HXC_TAS | HXC_FTOT | HXC_CH4);
+  bool plain = (con_mask & ~(HXC_CO2 | HXC_TAS | HXC_FTOT | HXC_CH4)) == 0 && !d_track_out_f_ &&
+               !(pair_cons && ker_per_member_);
+  for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) plain = false;
   bool pair = hx_pair_available() && B_ == 1 && plain && n_ <= pair_max_members_;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
     if (d_out_[v]) {  // what hx_pair_kernel records
@@ -1969,7 +1975,7 @@ void EnsembleCore::run(double runtodate) {
   last_run_w2_ = w2;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,
-                             stream_), "run kernel (pair)");
+                             stream_, pair_cons != 0), "run kernel (pair)");
   else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
                       stream_, w2, simds_ / 4),

@@ -343,7 +343,12 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // ([ns + pad][npad] in HBM instead of one shared table) and the history pass runs on the vector ALU.
 // HF: the ocean heat flux is recorded ("heatflux"; its two parts are extended diagnostics of the run
 // kernel): a second history sum with the kernel table shifted by a year.
-template <bool KERPM, bool HF>
+// CONS: the scenario holds a CO2, tas, RF_tot or CH4 constraint (the reference's concentration-driven
+// runs: simpleNbox-runtime.cpp:567-603, temperature_component.cpp:510-525, forcing_component.cpp:498-505,
+// ch4_component.cpp:156-157) -- each is a test of the year's shared-table entry on the side that owns the
+// variable; an NBP constraint (inside the solver), per-member constraint series and a land-ocean
+// warming ratio take the extended run kernel.
+template <bool KERPM, bool HF, bool CONS = false>
 #ifdef HX_PAIR_TWO_PER_SIMD   // experiment builds: the register / LDS budget of two blocks' wavefronts per SIMD
 #define HX_PAIR_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
@@ -628,6 +633,16 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
           cDO = (cDO + (lHD + lID)) - lDI;
           if (y[0] < 0) status |= HX_ERR_NEGPOOL;
           atmos = y[0];
+          if constexpr (CONS) {
+            // user-supplied [CO2] at this date: the atmosphere is set to it, the residual goes to the
+            // deep ocean (simpleNbox-runtime.cpp:567-603); only whole dates exist
+            const double cc = sh[HXSH_CO2_CON];
+            if ((kc.con_mask & HXC_CO2) && !in_partial_year && !isnan(cc)) {
+              const double residual = atmos - cc / PGC2PPM;
+              cDO = residual + cDO;
+              atmos = atmos - residual;
+            }
+          }
           c.ode_start = t;
         }
         s_yr[PY_MAXTS][lane] = c.max_ts;
@@ -685,8 +700,12 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         const double fch4 = (kc.delta_ch4 * sarf_ch4) + sarf_ch4;
         const double fh2o = 0.0485 * ((ch4 - kc.M0f) * kc.inv_h2o_span);
         const double fo3 = kc.o3_rf * o3;
-        const double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
-                             p_aero * sh[HXSH_RF_AERO]) + p_vol * sh[HXSH_RF_VOL];
+        double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
+                       p_aero * sh[HXSH_RF_AERO]) + p_vol * sh[HXSH_RF_VOL];
+        if constexpr (CONS) {  // forcing_component.cpp:498-505
+          const double cf = sh[HXSH_FTOT_CON];
+          if ((kc.con_mask & HXC_FTOT) && !isnan(cf)) ftot = cf;
+        }
         if (iy == kc.baseyear_idx) { base_tot = ftot; base_co2 = fco2; }
         else { rf_tot = ftot - base_tot; rf_co2 = fco2 - base_co2; }
       }
@@ -697,9 +716,17 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       const double DQ2 = dDQ2 * (rf_tot + f_prev) + DelQ * dQC2;
       const double X1 = DQ1 + (dA0 * tland + dA1 * sst);
       const double X2 = (DQ2 + dpast) + (dA2 * tland + dA3 * sst);
-      const double tl_new = dIB0 * X1 + dIB1 * X2;
-      const double sst_new = dIB2 * X1 + dIB3 * X2;
-      const double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+      double tl_new = dIB0 * X1 + dIB1 * X2;
+      double sst_new = dIB2 * X1 + dIB3 * X2;
+      double tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
+      if constexpr (CONS) {  // user-supplied temperature: temperature_component.cpp:510-525
+        const double ct = sh[HXSH_TAS_CON];
+        if ((kc.con_mask & HXC_TAS) && !isnan(ct)) {
+          tgav = ct;
+          tl_new = (tgav - (1.0 - D_flnd) * D_bsi * sst_new) / D_flnd;
+          sst_new = (tgav - D_flnd * tl_new) / ((1.0 - D_flnd) * D_bsi);
+        }
+      }
       s_tblk[slot][lane] = sst_new;
       if (slot == HX_DBLK) s_tblk[0][lane] = sst_new;  // the year before the next block
       s_yr[PY_TLAND][lane] = tl_new;
@@ -817,6 +844,10 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
                           hx_div(prev_ch4, tau_oh);
       ch4 = prev_ch4 + dCH4;
+      if constexpr (CONS) {  // ch4_component.cpp:156-157
+        const double cm = shn[HXSH_CH4_CON];
+        if ((kc.con_mask & HXC_CH4) && !isnan(cm)) ch4 = cm;
+      }
       ln_ch4 = hx_log(ch4);
       o3 = ((5 * ln_ch4 + shn[HXSH_O3_NOX]) + shn[HXSH_O3_CO]) + shn[HXSH_O3_NMVOC];
       if (blk0 < 0 || iyn >= blk0 + HX_DBLK) {

@@ -1910,16 +1910,21 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 // constraints, the outputs listed in EnsembleCore::run; kpm: per-member DOECLIM kernel tables
 int hx_pair_available() { return HX_HAS_PAIR; }
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
-                              int iy_to, hipStream_t st) {
+                              int iy_to, hipStream_t st, bool cons) {
 #if HX_HAS_PAIR
   const dim3 g(npad / 64), b(128);
-  if (kpm && heatflux) hipLaunchKernelGGL((hx_pair_kernel<true, true>), g, b, 0, st, d_args, iy_from, iy_to);
+  // (with a CO2 / tas / RF_tot / CH4 constraint: the shared-diffusivity instantiations; the host
+  // sends per-member diffusivity with constraints to the run kernel)
+  if (cons && kpm) return hipErrorInvalidValue;
+  if (cons && heatflux) hipLaunchKernelGGL((hx_pair_kernel<false, true, true>), g, b, 0, st, d_args, iy_from, iy_to);
+  else if (cons) hipLaunchKernelGGL((hx_pair_kernel<false, false, true>), g, b, 0, st, d_args, iy_from, iy_to);
+  else if (kpm && heatflux) hipLaunchKernelGGL((hx_pair_kernel<true, true>), g, b, 0, st, d_args, iy_from, iy_to);
   else if (kpm) hipLaunchKernelGGL((hx_pair_kernel<true, false>), g, b, 0, st, d_args, iy_from, iy_to);
   else if (heatflux) hipLaunchKernelGGL((hx_pair_kernel<false, true>), g, b, 0, st, d_args, iy_from, iy_to);
   else hipLaunchKernelGGL((hx_pair_kernel<false, false>), g, b, 0, st, d_args, iy_from, iy_to);
   return hipGetLastError();
 #else
-  (void)d_args; (void)npad; (void)heatflux; (void)kpm; (void)iy_from; (void)iy_to; (void)st;
+  (void)d_args; (void)npad; (void)heatflux; (void)kpm; (void)iy_from; (void)iy_to; (void)st; (void)cons;
   return hipErrorInvalidValue;
 #endif
 }

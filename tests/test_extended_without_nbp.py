@@ -19,6 +19,7 @@ def _run(lib, scen, n, outs, monkeypatch, force_nbp, lo=False, **kw):
     else:
         monkeypatch.delenv("HECTOR_AMD_EXTENDED_NBP", raising=False)
     c = hector_amd.Core(scen, n, lib_path=lib, **kw)
+    c.set_pair_kernel_limit(0)   # (the run kernels: small CO2- / tas-constrained ensembles would take the pair kernel)
     S, q10 = ensemble.ecs_q10(n)
     c.setvar("S", S, "degC").setvar("q10_rh", q10)
     if lo:

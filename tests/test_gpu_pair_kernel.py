@@ -1,7 +1,8 @@
 """The small-ensemble kernel (two wavefronts per 64 members, hector_amd/csrc/hx_dev_pair.h) against
 the oracle and against the one-wavefront run kernel.
 
-Ensembles of up to 32 768 members (one biome, no constraints, the usual outputs) take it by
+Ensembles of up to 32 768 members (one biome, no constraints but scenario-wide CO2 / tas / RF_tot / CH4
+ones, the usual outputs) take it by
 default; `set_pair_kernel_limit(0)` forces the run kernel.  Same criterion as the other parity
 tests (test_gpu_parity.py); the per-year stash schedule ("timesteps": every retry and
 reduced-timestep decision of the reference) has to agree with the oracle member by
@@ -351,8 +352,8 @@ def test_pair_kernel_shipped_scenarios_vs_oracle(hip_lib, name):
     c.setvar("S", S, "degC").setvar("q10_rh", q10)
     c.set_outputs(["CO2_concentration", "global_tas", "timesteps", "RF_tot", "RF_CO2"])
     c.run(o.end)
-    # (picontrol prescribes its CO2 -- a constraint: that one stays on the run kernel)
-    assert c.last_run_kernel() == ("run" if name == "picontrol" else "pair")
+    # (picontrol prescribes its CO2 -- a scenario-wide constraint: the CONS instantiation, round 5)
+    assert c.last_run_kernel() == "pair"
     assert (c.status() == 0).all()
     co2 = c.fetchvars("CO2_concentration", (o.start, o.end))
     tg = c.fetchvars("global_tas", (o.start, o.end))

@@ -410,20 +410,25 @@ def test_constraints_on_gpu(hip_lib, oracle, tmp_path):
     tc.test_land_ocean_warming_ratio_per_member(hip_lib, oracle)
 
 
-def test_constrained_ensemble_vs_oracle_on_gpu(hip_lib, tmp_path):
+@pytest.mark.parametrize("pair_limit,kernel", [(32768, "pair"), (0, "run")])
+def test_constrained_ensemble_vs_oracle_on_gpu(hip_lib, tmp_path, pair_limit, kernel):
     """A 192-member ECS x Q10 ensemble under a CO2 + tas constraint (concentration-driven runs
-    are how the reference is used for emulation): every 7th member against the oracle."""
+    are how the reference is used for emulation): every 7th member against the oracle -- on the
+    small-ensemble kernel (round 5: it serves scenario-wide CO2 / tas / RF_tot / CH4 constraints)
+    and on the extended run kernel."""
     import oracle_binding
     from conftest import edited_pack
     n = 192
     S, q10 = ensemble.ecs_q10(n, offset=5000)
     yc = np.arange(1850, 2015)
     c = mk(hip_lib, n).setvar("S", S, "degC").setvar("q10_rh", q10)
+    c.set_pair_kernel_limit(pair_limit)
     c.set_outputs(["CO2_concentration", "global_tas", "RF_tot"])
     c.run(2300)
     co2 = c.fetchvars("CO2_concentration", (1850, 2014))[:, 0] * 1.1
     c.setvar_dated("CO2_constrain", yc, co2).setvar_dated("tas_constrain", [1900, 1950], [0.1, 0.4])
     c.run(2300)
+    assert c.last_run_kernel() == kernel
     assert (c.status() == 0).all()
     p1 = edited_pack(tmp_path / "a.hxs", "simpleNbox", "CO2_constrain", yc, co2)
     p2 = edited_pack(tmp_path / "b.hxs", "temperature", "tas_constrain", np.arange(1900, 1951),
