@@ -19,7 +19,7 @@ hipError_t hx_launch_spinup(int B, const HxArgs *d_args, int nmem_launch, int *d
 int hx_track_value_rows(int B);
 int hx_pair_available();
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
-                              int iy_to, hipStream_t st, bool cons);
+                              int iy_to, hipStream_t st, bool cons, int nbiome);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st, bool two_wave, int cus);
 int hx_doeclim_block_years();
@@ -1959,7 +1959,9 @@ void EnsembleCore::run(double runtodate) {
   bool plain = (con_mask & ~(HXC_CO2 | HXC_TAS | HXC_FTOT | HXC_CH4)) == 0 && !d_track_out_f_ &&
                !(pair_cons && ker_per_member_);
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) plain = false;
-  bool pair = hx_pair_available() && B_ == 1 && plain && n_ <= pair_max_members_;
+  bool pair = hx_pair_available() && B_ <= 4 && plain && n_ <= pair_max_members_;
+  // (two to four biomes: its plain instantiation only -- the land side owns the biome loops)
+  if (B_ > 1 && (pair_cons || ker_per_member_ || d_out_[HXO_HEATFLUX])) pair = false;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
     if (d_out_[v]) {  // what hx_pair_kernel records
       static const int ok[] = {HXO_SST, HXO_TLAND, HXO_CO2, HXO_TGAV, HXO_NSTASH, HXO_RF_TOT, HXO_RF_CO2,
@@ -1968,6 +1970,8 @@ void EnsembleCore::run(double runtodate) {
                                HXO_THAWED_C, HXO_EARTH_C, HXO_HEATFLUX, HXO_NPP, HXO_RH, HXO_RH_DET,
                                HXO_RH_SOIL, HXO_RH_CH4, HXO_F_FROZEN, HXO_GMST};
       if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) pair = false;
+      // (the NPP / RH diagnostics of a split core are sums of weighted per-biome parts: run kernels)
+      if (B_ > 1 && (v == HXO_NPP || v == HXO_RH || v == HXO_RH_DET || v == HXO_RH_SOIL)) pair = false;
     }
   last_run_pair_ = pair;
   // more wavefronts than SIMDs: the one-biome kernel built for two resident wavefronts per SIMD
@@ -1975,7 +1979,7 @@ void EnsembleCore::run(double runtodate) {
   last_run_w2_ = w2;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,
-                             stream_, pair_cons != 0), "run kernel (pair)");
+                             stream_, pair_cons != 0, B_), "run kernel (pair)");
   else
   check(hx_launch_run(B_, d_args_, npad_, hf || con == 2, ker_per_member_, con, last_iy_, target,
                       stream_, w2, simds_ / 4),

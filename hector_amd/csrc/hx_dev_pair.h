@@ -348,7 +348,10 @@ __device__ __forceinline__ void hx_pstamp(long long *clkp, int k) {
 // ch4_component.cpp:156-157) -- each is a test of the year's shared-table entry on the side that owns the
 // variable; an NBP constraint (inside the solver), per-member constraint series and a land-ocean
 // warming ratio take the extended run kernel.
-template <bool KERPM, bool HF, bool CONS = false>
+// NB: the biome count (1-4, unrolled): the land side owns the per-biome pools, factors and the
+// biome loops of the flows and of the stash (simpleNbox-runtime.cpp:270-609); the solver and the ocean
+// side see totals and are the same for every NB.
+template <bool KERPM, bool HF, bool CONS = false, int NB = 1>
 #ifdef HX_PAIR_TWO_PER_SIMD   // experiment builds: the register / LDS budget of two blocks' wavefronts per SIMD
 #define HX_PAIR_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         if (buf.out[HXO_GMST]) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
       }
       if (__builtin_expect(!!(buf.hist), 0)) {  // Core::reset(date) needs every component's state of every year
-        store_ocean(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
+        store_ocean(buf.hist + (size_t)iy * (size_t)HX_NSTATE(NB) * np);
         s_yr[PY_HSTAT][lane] = (double)status;
       }
       if (iy < iy_to) year_consts(sst);   // next year's equilibrium constants (sst is this year's result now)
@@ -769,11 +772,15 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
     store_ocean(nullptr);  // state back to the table
   } else {
     // ======================= wavefront 1: land, gases, history sums =======================
-    double veg = lds_(buf, HXS_NGLOBAL + HXSB_VEG, mem), det = lds_(buf, HXS_NGLOBAL + HXSB_DET, mem),
-           soil = lds_(buf, HXS_NGLOBAL + HXSB_SOIL, mem), pf = lds_(buf, HXS_NGLOBAL + HXSB_PF, mem),
-           thawed = lds_(buf, HXS_NGLOBAL + HXSB_THAWED, mem),
-           tempferts = lds_(buf, HXS_NGLOBAL + HXSB_TEMPFERTS, mem),
-           ffrozen = lds_(buf, HXS_NGLOBAL + HXSB_F_FROZEN, mem);
+    double veg[NB], det[NB], soil[NB], pf[NB], thawed[NB], tempferts[NB], ffrozen[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int rs = HXS_NGLOBAL + b * HXSB_N;
+      veg[b] = lds_(buf, rs + HXSB_VEG, mem); det[b] = lds_(buf, rs + HXSB_DET, mem);
+      soil[b] = lds_(buf, rs + HXSB_SOIL, mem); pf[b] = lds_(buf, rs + HXSB_PF, mem);
+      thawed[b] = lds_(buf, rs + HXSB_THAWED, mem); tempferts[b] = lds_(buf, rs + HXSB_TEMPFERTS, mem);
+      ffrozen[b] = lds_(buf, rs + HXSB_F_FROZEN, mem);
+    }
     double earth = lds_(buf, HXS_EARTH, mem), cum_luc_va = lds_(buf, HXS_CUM_LUC_VA, mem),
            cum_pf_ch4 = lds_(buf, HXS_CUM_PF_CH4, mem), masstot = lds_(buf, HXS_MASSTOT, mem);
     const double eos = lds_(buf, HXS_EOS_VEGC, mem);
@@ -784,15 +791,24 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
     double lnc = hx_log(hx_div(lds_(buf, HXS_ATMOS, mem) * PGC2PPM, ldp(buf, HXP_C0, mem)));
     double cLL = lds_(buf, HXS_C_LL, mem), hL = lds_(buf, HXS_H_LL, mem);
     const double alkL = lds_(buf, HXS_ALK_LL, mem);
-    const int r = HXP_NGLOBAL;
-    const double npp0 = ldp(buf, r + HXPB_NPP0, mem), f_nppv = ldp(buf, r + HXPB_F_NPPV, mem),
-                 f_nppd = ldp(buf, r + HXPB_F_NPPD, mem), f_litterd = ldp(buf, r + HXPB_F_LITTERD, mem),
-                 rh_ch4_frac = ldp(buf, r + HXPB_RH_CH4_FRAC, mem),
-                 fpf_static = ldp(buf, r + HXPB_FPF_STATIC, mem), beta = ldp(buf, r + HXPB_BETA, mem),
-                 wf = ldp(buf, r + HXPB_WF, mem), lnq10 = ldd(buf, HXD_NGLOBAL, mem),
-                 pmu = ldp(buf, r + HXPB_PF_MU, mem), psigma = ldp(buf, r + HXPB_PF_SIGMA, mem);
-    auto rh_tp_co2 = [&]() { return ((thawed * (1 - fpf_static)) * 0.02) * tempferts * (1.0 - rh_ch4_frac); };
-    auto rh_tp_ch4 = [&]() { return ((thawed * (1 - fpf_static)) * 0.02) * tempferts * rh_ch4_frac; };  // (see m_rh_tp_ch4)
+    double npp0[NB], f_nppv[NB], f_nppd[NB], f_litterd[NB], rh_ch4_frac[NB], fpf_static[NB], beta[NB], wf[NB],
+        lnq10[NB], pmu[NB], psigma[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int r = HXP_NGLOBAL + b * HXPB_N;
+      npp0[b] = ldp(buf, r + HXPB_NPP0, mem); f_nppv[b] = ldp(buf, r + HXPB_F_NPPV, mem);
+      f_nppd[b] = ldp(buf, r + HXPB_F_NPPD, mem); f_litterd[b] = ldp(buf, r + HXPB_F_LITTERD, mem);
+      rh_ch4_frac[b] = ldp(buf, r + HXPB_RH_CH4_FRAC, mem); fpf_static[b] = ldp(buf, r + HXPB_FPF_STATIC, mem);
+      beta[b] = ldp(buf, r + HXPB_BETA, mem); wf[b] = ldp(buf, r + HXPB_WF, mem);
+      lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
+      pmu[b] = ldp(buf, r + HXPB_PF_MU, mem); psigma[b] = ldp(buf, r + HXPB_PF_SIGMA, mem);
+    }
+    auto rh_tp_co2 = [&](int b) { return ((thawed[b] * (1 - fpf_static[b])) * 0.02) * tempferts[b] * (1.0 - rh_ch4_frac[b]); };
+    auto rh_tp_ch4 = [&](int b) { return ((thawed[b] * (1 - fpf_static[b])) * 0.02) * tempferts[b] * rh_ch4_frac[b]; };  // (see m_rh_tp_ch4)
+    auto rh_ch4_total = [&]() { double x = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) x += rh_tp_ch4(b);
+      return x; };
     ChemK kL;
     kL.Tr = 0; kL.g = 0;
     double pco2L = 0;
@@ -802,16 +818,21 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
     // summed by the ocean side from LDS) -- done while the ocean side finishes that year.  The
     // window's load from memory is issued a phase earlier (prefetch()): with one wavefront on the
     // SIMD a load's latency is otherwise waited out in full.
-    double tfs_cand = 0, tl_old_pf = 0;
+    double tfs_cand[NB], tl_old_pf = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) tfs_cand[b] = 0;
     // this side's rows of the state table (base == nullptr) or of a year's history slab
     auto store_land = [&](double *base) {
       HxBuffers b2 = buf;
       if (base) b2.state = base;
-      const int rr = HXS_NGLOBAL;
-      sts_(b2, rr + HXSB_VEG, mem, veg); sts_(b2, rr + HXSB_DET, mem, det);
-      sts_(b2, rr + HXSB_SOIL, mem, soil); sts_(b2, rr + HXSB_PF, mem, pf);
-      sts_(b2, rr + HXSB_THAWED, mem, thawed); sts_(b2, rr + HXSB_TEMPFERTS, mem, tempferts);
-      sts_(b2, rr + HXSB_F_FROZEN, mem, ffrozen);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int rr = HXS_NGLOBAL + b * HXSB_N;
+        sts_(b2, rr + HXSB_VEG, mem, veg[b]); sts_(b2, rr + HXSB_DET, mem, det[b]);
+        sts_(b2, rr + HXSB_SOIL, mem, soil[b]); sts_(b2, rr + HXSB_PF, mem, pf[b]);
+        sts_(b2, rr + HXSB_THAWED, mem, thawed[b]); sts_(b2, rr + HXSB_TEMPFERTS, mem, tempferts[b]);
+        sts_(b2, rr + HXSB_F_FROZEN, mem, ffrozen[b]);
+      }
       sts_(b2, HXS_EARTH, mem, earth); sts_(b2, HXS_CUM_LUC_VA, mem, cum_luc_va);
       sts_(b2, HXS_CUM_PF_CH4, mem, cum_pf_ch4); sts_(b2, HXS_MASSTOT, mem, masstot);
       sts_(b2, HXS_CH4, mem, ch4); sts_(b2, HXS_TWIN, mem, twin);
@@ -827,7 +848,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       hx_ccd shn = HX_CCD(buf.shared) + (size_t)iyn * HXSH_STRIDE;
       const int iold = iyn - 203;
       const double prev_ch4 = ch4;
-      const double rh_ch4 = (iyn > 1) ? rh_tp_ch4() : 0.0;
+      const double rh_ch4 = (iyn > 1) ? rh_ch4_total() : 0.0;
       double toh = 0.0;
       if (prev_ch4 != kc.M0)
         toh = ((kc.CCH4 * (ln_ch4 - kc.lnM0) + shn[HXSH_OH_B]) + shn[HXSH_OH_C]) + shn[HXSH_OH_D];
@@ -835,10 +856,16 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         twin += tl_m2;
         if (iold >= 1) twin -= tl_old_pf;
       }
-      const double Trm = (iyn > 1) ? (twin * wf) * 0.005 : 0.0;
-      double ex[2] = {-toh, lnq10 * (Trm * 0.1)};
-      hx_exp_batch<2>(ex);
-      tfs_cand = ex[1];
+      double ex[1 + NB];
+      ex[0] = -toh;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const double Trm = (iyn > 1) ? (twin * wf[b]) * 0.005 : 0.0;
+        ex[1 + b] = lnq10[b] * (Trm * 0.1);
+      }
+      hx_exp_batch<1 + NB>(ex);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) tfs_cand[b] = ex[1 + b];
       const double tau_oh = kc.TOH0 * ex[0];
       const double emisTocon = ((shn[HXSH_CH4_EM] + rh_ch4 * PG_C_TO_TG_CH4) + shn[HXSH_CH4N]) * kc.inv_UC_CH4;
       const double dCH4 = ((emisTocon - prev_ch4 * kc.inv_Tsoil) - prev_ch4 * kc.inv_Tstrat) -
@@ -871,43 +898,87 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       // ---- year start (land): what depends on last year's land temperature and CO2 ----
       const double ffi = sh[HXSH_FFI], daccs = sh[HXSH_DACCS], luc_e = sh[HXSH_LUC_E], luc_u = sh[HXSH_LUC_U];
       const double npp_luc_adjust = hx_div(eos - cum_luc_va, eos);
-      const double co2fert = 1 + beta * lnc;
-      const double Tb = tland * wf;
-      const double tempfertd = hx_exp(lnq10 * (Tb * 0.1));
-      double f_new_thaw = 0.0;
-      if (pf != 0.0) {
-        double ff = 1.0;
-        if (Tb > 0) {
-          const double d[1] = {hx_div(hx_log(Tb) - pmu, psigma * 1.4142135623730951)};
-          double f1[1];
-          hx_frozen_fraction_batch<1>(d, f1);
-          ff = f1[0];
+      double co2fert[NB], tempfertd[NB], f_new_thaw[NB];
+      if constexpr (NB == 1) {
+        co2fert[0] = 1 + beta[0] * lnc;
+        const double Tb = tland * wf[0];
+        tempfertd[0] = hx_exp(lnq10[0] * (Tb * 0.1));
+        f_new_thaw[0] = 0.0;
+        if (pf[0] != 0.0) {
+          double ff = 1.0;
+          if (Tb > 0) {
+            const double d[1] = {hx_div(hx_log(Tb) - pmu[0], psigma[0] * 1.4142135623730951)};
+            double f1[1];
+            hx_frozen_fraction_batch<1>(d, f1);
+            ff = f1[0];
+          }
+          f_new_thaw[0] = ffrozen[0] - ff;
+          ffrozen[0] = ff;
         }
-        f_new_thaw = ffrozen - ff;
-        ffrozen = ff;
+      } else {
+        // (several biomes: the logarithms, exponentials and frozen fractions as batches, like
+        // hx_run_kernel's phase A; a biome at or below 0 degC is frozen through, one without
+        // permafrost keeps what it has)
+        double Tb[NB], lg[NB], ex[NB], dfr[NB], ffb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          co2fert[b] = 1 + beta[b] * lnc;
+          Tb[b] = tland * wf[b];
+          lg[b] = (Tb[b] > 0) ? Tb[b] : 1.0;
+          ex[b] = lnq10[b] * (Tb[b] * 0.1);
+        }
+        hx_log_batch<NB>(lg);
+        hx_exp_batch<NB>(ex);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) dfr[b] = hx_div(lg[b] - pmu[b], psigma[b] * 1.4142135623730951);
+        hx_frozen_fraction_batch<NB>(dfr, ffb);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          tempfertd[b] = ex[b];
+          const bool has_pf = pf[b] != 0.0;
+          const double ff = (Tb[b] > 0) ? ffb[b] : 1.0;
+          f_new_thaw[b] = has_pf ? ffrozen[b] - ff : 0.0;
+          ffrozen[b] = has_pf ? ff : ffrozen[b];
+        }
       }
-      tempferts = fmax(tfs_cand, (iy > 1) ? tempferts : 0.0);  // sticky :1054-1059
+#pragma unroll
+      for (int b = 0; b < NB; ++b) tempferts[b] = fmax(tfs_cand[b], (iy > 1) ? tempferts[b] : 0.0);  // sticky :1054-1059
       tl_m2 = tl_m1; tl_m1 = tland;  // Tland of years iy-2, iy-1 for the next year
-      // ---- interval constants of the land side (compute_flows + make_interval, one biome) ----
+      // ---- interval constants of the land side (compute_flows + make_interval: sums over the biomes
+      // in biome order, operation by operation hx_dev_solver.h's) ----
       double v1, d2c, s3c, k4, k5, k7, Pn;
       auto prep = [&]() {
-        const double n = (npp0 * co2fert) * npp_luc_adjust;
-        const double fav = n * f_nppv, fad = n * f_nppd, fas = n * (1 - f_nppv - f_nppd);
-        const double fda = (det * 0.25) * tempfertd, fsa = (soil * 0.02) * tempferts;
-        const double tpc = rh_tp_co2(), tpm = rh_tp_ch4();
-        const double litter = veg * 0.035, lfvd = litter * f_litterd, lfvs = litter * (1 - f_litterd);
-        const double detsoil = det * 0.6;
-        double c_thaw = pf * f_new_thaw, r_tp = 0.0;
-        if (c_thaw < 0) { const double want = -c_thaw; c_thaw = 0.0; r_tp = fmin(want, thawed - tpc - tpm); }
+        double npp_c = 0, fav = 0, fad = 0, fas = 0, fda = 0, fsa = 0, tpc = 0, tpm = 0;
+        double litter = 0, lfvd = 0, lfvs = 0, detsoil = 0, thaw = 0, refr = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const double n = (npp0[b] * co2fert[b]) * npp_luc_adjust;
+          npp_c += n;
+          fav += n * f_nppv[b]; fad += n * f_nppd[b]; fas += n * (1 - f_nppv[b] - f_nppd[b]);
+          fda += (det[b] * 0.25) * tempfertd[b]; fsa += (soil[b] * 0.02) * tempferts[b];
+          const double co2 = rh_tp_co2(b), ch4b = rh_tp_ch4(b);
+          tpc += co2; tpm += ch4b;
+          const double v = veg[b] * 0.035;
+          litter += v; lfvd += v * f_litterd[b]; lfvs += v * (1 - f_litterd[b]);
+          detsoil += det[b] * 0.6;
+          double c_thaw = pf[b] * f_new_thaw[b], r_tp = 0.0;
+          if (c_thaw < 0) { const double want = -c_thaw; c_thaw = 0.0; r_tp = fmin(want, thawed[b] - co2 - ch4b); }
+          thaw += c_thaw; refr += r_tp;
+        }
         const double rh = fda + fsa + tpc;
-        Pn = ((((ffi - daccs) + luc_e) - luc_u) - n) + rh;
+        Pn = ((((ffi - daccs) + luc_e) - luc_u) - npp_c) + rh;
         v1 = fav - litter;
         d2c = ((fad + lfvd) - detsoil) - fda;
         s3c = ((fas + lfvs) + detsoil) - fsa;
-        k4 = -c_thaw + r_tp;
-        k5 = ((c_thaw - r_tp) - tpm) - tpc;
+        k4 = -thaw + refr;
+        k5 = ((thaw - refr) - tpm) - tpc;
         k7 = -ffi + daccs;
       };
+      // pool totals (what the solver starts a year from: getCValues sums the biomes)
+      auto total = [&](const double (&x)[NB]) { double t = 0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) t += x[b];
+        return t; };
       prep();
       PSTAMP(0);
       PSTAMP(1);
@@ -919,8 +990,9 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       s_yr[PY_STATUS1][lane] = (double)status;
       // the soil pool is integrated by the ocean side (pair_attempt_zs): its constants, the pool, and
       // the three pools' sum with its rate -- both sides carry the sum by the same recurrence
-      double dtot = (((v1 + luc_u) + d2c) + s3c) - luc_e, tot_seg = (veg + det) + soil;
-      s_yr[PY_S3C][lane] = s3c; s_yr[PY_DTOT][lane] = dtot; s_yr[PY_SOIL][lane] = soil; s_yr[PY_TOT0][lane] = tot_seg;
+      const double veg_t = total(veg), det_t = total(det), soil_t = total(soil);
+      double dtot = (((v1 + luc_u) + d2c) + s3c) - luc_e, tot_seg = (veg_t + det_t) + soil_t;
+      s_yr[PY_S3C][lane] = s3c; s_yr[PY_DTOT][lane] = dtot; s_yr[PY_SOIL][lane] = soil_t; s_yr[PY_TOT0][lane] = tot_seg;
       PSTAMP(2);
       __syncthreads();  // ---- barrier A
       PSTAMP(3);
@@ -940,7 +1012,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       const double year = (double)(kc.start_year + iy);
       const double t0 = year - 1.0, tnew = year;
       double y[2], dxdt[2], l4, l5, l7, tot0;
-      auto load_pools = [&]() { y[0] = veg; y[1] = det; l4 = pf; l5 = thawed; l7 = earth; tot0 = tot_seg; };
+      auto load_pools = [&]() { y[0] = total(veg); y[1] = total(det); l4 = total(pf); l5 = total(thawed); l7 = earth; tot0 = tot_seg; };
       load_pools();
       c.ode_start = t0; c.t = t0; c.retry = 0; c.nsteps = 0;
       c.alive = status == 0;
@@ -957,7 +1029,7 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
         const bool seg = c.alive && c.t < tnew;
         c.t_start = c.t; c.t_target = tnew; c.dtl = c.sdt; c.first_call = false; c.fails = 0;
         c.stepping = seg;
-        double y0c = 0, y4c = 0, y3c = soil;  // the ocean side's atmosphere / ocean totals / soil pool after the last accepted step
+        double y0c = 0, y4c = 0, y3c = total(soil);  // the ocean side's atmosphere / ocean totals / soil pool after the last accepted step
         auto first_rhs = [&]() { rrs[0] = hx_div1(luc_e, tot0); rhs(y, dxdt, 0); };
         first_rhs();  // (the fresh stepper's first RHS, ahead of the loop: see the ocean side)
         for (bool go_ = __any(c.stepping); go_; go_ = __any(c.stepping)) {
@@ -999,28 +1071,54 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
           c.retry = 0;
           ++nstash;
           const double t = c.t, yf = t - c.ode_start;
-          if (__builtin_expect(!!(want_nbp), 0)) {  // NBP of the interval that ends here, from the pools it started with
-            const double npp_t = (npp0 * co2fert) * npp_luc_adjust;
-            const double rh_t = ((det * 0.25) * tempfertd + (soil * 0.02) * tempferts) + rh_tp_co2();
-            nbp = ((npp_t - rh_t) - luc_e) + luc_u;
+          // the interval's NPP and RH from the pools it started with (their sum weighs the biomes)
+          double npp_b[NB], rhb[NB], npp_t = 0, rh_t = 0, pf_t = 0;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            npp_b[b] = (npp0[b] * co2fert[b]) * npp_luc_adjust;
+            rhb[b] = ((det[b] * 0.25) * tempfertd[b] + (soil[b] * 0.02) * tempferts[b]) + rh_tp_co2(b);
           }
-          if (__builtin_expect(!!(want_flux), 0)) {
-            const size_t o = (size_t)iy * np + mem;
-            const double rhd = (det * 0.25) * tempfertd, rhs = (soil * 0.02) * tempferts;
-            if (buf.out[HXO_NPP]) sto_(buf, HXO_NPP, o, (npp0 * co2fert) * npp_luc_adjust);
-            if (buf.out[HXO_RH]) sto_(buf, HXO_RH, o, ((rhd + rhs) + rh_tp_co2()) + rh_tp_ch4());
-            if (buf.out[HXO_RH_DET]) sto_(buf, HXO_RH_DET, o, rhd);
-            if (buf.out[HXO_RH_SOIL]) sto_(buf, HXO_RH_SOIL, o, rhs);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) npp_t += npp_b[b];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) rh_t += rhb[b];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) pf_t += pf[b];
+          if (__builtin_expect(!!(want_nbp), 0)) nbp = ((npp_t - rh_t) - luc_e) + luc_u;  // NBP of the interval that ends here
+          if constexpr (NB == 1) {
+            if (__builtin_expect(!!(want_flux), 0)) {
+              const size_t o = (size_t)iy * np + mem;
+              const double rhd = (det[0] * 0.25) * tempfertd[0], rhs = (soil[0] * 0.02) * tempferts[0];
+              if (buf.out[HXO_NPP]) sto_(buf, HXO_NPP, o, npp_b[0]);
+              if (buf.out[HXO_RH]) sto_(buf, HXO_RH, o, ((rhd + rhs) + rh_tp_co2(0)) + rh_tp_ch4(0));
+              if (buf.out[HXO_RH_DET]) sto_(buf, HXO_RH_DET, o, rhd);
+              if (buf.out[HXO_RH_SOIL]) sto_(buf, HXO_RH_SOIL, o, rhs);
+            }
           }
           double tpf = l5;
           if (fabs(tpf) < 1e-10) tpf = 0.0;  // :337-341
           if (y[0] < 0 || y[1] < 0 || y3c < 0 || l4 < 0 || tpf < 0) status |= HX_ERR_NEGPOOL;
-          const double total = y[0] + y[1] + y3c;
-          cum_luc_va += hx_div((luc_e - luc_u) * y[0], total);  // no yf: :388-393
-          cum_pf_ch4 += rh_tp_ch4() * yf;  // :481
-          const double wt_pf = (pf > 0) ? 1.0 : 0.0;
-          veg = y[0]; det = y[1]; soil = y3c;
-          pf = l4 * wt_pf; thawed = tpf * wt_pf;
+          const double total3 = y[0] + y[1] + y3c;
+          cum_luc_va += hx_div((luc_e - luc_u) * y[0], total3);  // no yf: :388-393
+          if constexpr (NB == 1) {
+            cum_pf_ch4 += rh_tp_ch4(0) * yf;  // :481
+            const double wt_pf = (pf[0] > 0) ? 1.0 : 0.0;
+            veg[0] = y[0]; det[0] = y[1]; soil[0] = y3c;
+            pf[0] = l4 * wt_pf; thawed[0] = tpf * wt_pf;
+          } else {
+            // the new totals go to the biomes by their share of NPP + RH (permafrost: by their share
+            // of it), correctly rounded quotients like hx_dev_solver.h's stash (hx_div_cr)
+            const double npp_rh = npp_t + rh_t;
+            const double inv_nr = hx_recip(npp_rh), inv_pf = (pf_t > 0) ? hx_recip(pf_t) : 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const double wt = hx_div_cr(npp_b[b] + rhb[b], npp_rh, inv_nr);
+              const double wt_pf = hx_div_cr(pf[b], pf_t, inv_pf);
+              cum_pf_ch4 += rh_tp_ch4(b) * yf;  // :481
+              veg[b] = y[0] * wt; det[b] = y[1] * wt; soil[b] = y3c * wt;
+              pf[b] = l4 * wt_pf; thawed[b] = tpf * wt_pf;
+            }
+          }
           earth = l7;
           const double sum = ((((((y0c + y[0]) + y[1]) + y3c) + l4) + l5) + y4c) + l7 + cum_pf_ch4;
           if (masstot > 0.0 && !(fabs(sum - masstot) <= 0.001)) status |= HX_ERR_MASS;
@@ -1028,12 +1126,14 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
           c.ode_start = t;
           if (t < tnew) {  // constants of the next segment
             prep();
-            dtot = (((v1 + luc_u) + d2c) + s3c) - luc_e; tot_seg = (veg + det) + soil;
+            // (the solver goes on from its own values, carbon-cycle-solver.cpp:282-287: their sum,
+            // not the sum of the biomes' new pools)
+            dtot = (((v1 + luc_u) + d2c) + s3c) - luc_e; tot_seg = (y[0] + y[1]) + y3c;
             tot0 = tot_seg;
           }
         }
         s_yr[PY_PN][lane] = Pn;
-        s_yr[PY_S3C][lane] = s3c; s_yr[PY_DTOT][lane] = dtot; s_yr[PY_SOIL][lane] = soil; s_yr[PY_TOT0][lane] = tot_seg;
+        s_yr[PY_S3C][lane] = s3c; s_yr[PY_DTOT][lane] = dtot; s_yr[PY_SOIL][lane] = y3c; s_yr[PY_TOT0][lane] = tot_seg;
         s_yr[PY_STATUS1][lane] = (double)status;
         PSTAMP(6);
         __syncthreads();  // ---- stash hand-off
@@ -1059,19 +1159,28 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       if (__builtin_expect(!!(buf.out_rare), 0)) {  // (one test for the rest of what this side can record)
         const size_t o = (size_t)iy * np + mem;
         if (buf.out[HXO_NBP]) sto_(buf, HXO_NBP, o, nbp);
-        if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, veg);
-        if (buf.out[HXO_DET_C]) sto_(buf, HXO_DET_C, o, det);
-        if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, soil);
-        if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, pf);
-        if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, thawed);
+        if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, total(veg));
+        if (buf.out[HXO_DET_C]) sto_(buf, HXO_DET_C, o, total(det));
+        if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, total(soil));
+        if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, total(pf));
+        if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, total(thawed));
         if (buf.out[HXO_EARTH_C]) sto_(buf, HXO_EARTH_C, o, earth);
         if (buf.out[HXO_LL_PH]) sto_(buf, HXO_LL_PH, o, -log10(hL));
         // record_state: RH_ch4 of the year-end pools (simpleNbox.cpp:800-812); f_frozen is 1 without
         // permafrost (:492-514)
-        if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rh_tp_ch4());
-        if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, pf > 0.0 ? ffrozen : 1.0);
+        if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rh_ch4_total());
+        if (buf.out[HXO_F_FROZEN]) {   // permafrost-weighted mean over the biomes
+          const double ptot = total(pf);
+          double ff = 1.0;
+          if (ptot > 0.0) {
+            ff = 0.0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) ff += (pf[b] / ptot) * ffrozen[b];
+          }
+          sto_(buf, HXO_F_FROZEN, o, ff);
+        }
       }
-      if (__builtin_expect(!!(buf.hist), 0)) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(1) * np);
+      if (__builtin_expect(!!(buf.hist), 0)) store_land(buf.hist + (size_t)iy * (size_t)HX_NSTATE(NB) * np);
       if (iy < iy_to) prepare(iy + 1);
       s_yr[PY_HL][lane] = hL;
       PSTAMP(10);

@@ -1910,9 +1910,18 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
 // constraints, the outputs listed in EnsembleCore::run; kpm: per-member DOECLIM kernel tables
 int hx_pair_available() { return HX_HAS_PAIR; }
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
-                              int iy_to, hipStream_t st, bool cons) {
+                              int iy_to, hipStream_t st, bool cons, int nbiome) {
 #if HX_HAS_PAIR
   const dim3 g(npad / 64), b(128);
+  // (two to four biomes: the plain instantiation -- shared diffusivity, no heat-flux sum, no constraint;
+  // the host sends every other split ensemble to the run kernels)
+  if (nbiome > 1) {
+    if (heatflux || kpm || cons || nbiome > 4) return hipErrorInvalidValue;
+    if (nbiome == 2) hipLaunchKernelGGL((hx_pair_kernel<false, false, false, 2>), g, b, 0, st, d_args, iy_from, iy_to);
+    else if (nbiome == 3) hipLaunchKernelGGL((hx_pair_kernel<false, false, false, 3>), g, b, 0, st, d_args, iy_from, iy_to);
+    else hipLaunchKernelGGL((hx_pair_kernel<false, false, false, 4>), g, b, 0, st, d_args, iy_from, iy_to);
+    return hipGetLastError();
+  }
   // (with a CO2 / tas / RF_tot / CH4 constraint: the shared-diffusivity instantiations; the host
   // sends per-member diffusivity with constraints to the run kernel)
   if (cons && kpm) return hipErrorInvalidValue;
@@ -1924,7 +1933,7 @@ hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, boo
   else hipLaunchKernelGGL((hx_pair_kernel<false, false>), g, b, 0, st, d_args, iy_from, iy_to);
   return hipGetLastError();
 #else
-  (void)d_args; (void)npad; (void)heatflux; (void)kpm; (void)iy_from; (void)iy_to; (void)st; (void)cons;
+  (void)d_args; (void)npad; (void)heatflux; (void)kpm; (void)iy_from; (void)iy_to; (void)st; (void)cons; (void)nbiome;
   return hipErrorInvalidValue;
 #endif
 }

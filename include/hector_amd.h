@@ -306,7 +306,7 @@ int hx_stream_shard(hx_core *core, int shard, void **stream);
 /* Small ensembles -- too few 64-member wavefronts to occupy the GPU's 1 024 SIMDs, BASELINE
  * configs[1] -- are run by a kernel that gives every 64 members TWO wavefronts (ocean / climate and
  * land, hx_dev_pair.h): same model, same decisions, ~20 % shorter launch.  It serves
- * one-biome ensembles without an NBP constraint, a land-ocean warming ratio, per-member series
+ * ensembles of one to four biomes without an NBP constraint, a land-ocean warming ratio, per-member series
  * (scenario-wide CO2 / tas / RF_tot / CH4 constraints -- concentration-driven runs -- are served,
  * with shared diffusivity) or diagnostics beyond CO2,
  * tas, RF_tot, RF_CO2, SST, land tas, timesteps, the carbon pools (atmos_co2, ocean_c, veg_c,

@@ -309,7 +309,13 @@ def test_pair_kernel_is_only_taken_where_it_applies(hip_lib, tmp_path):
     c.set_outputs(["CO2_concentration", "HL_PCO2"])          # an ocean-chemistry diagnostic: run kernel
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
-    c.split_biome(["a", "b"])                                 # more than one biome
+    c.split_biome(["a", "b"])                                 # two to four biomes: served (round 5)
+    assert c.run(1800).last_run_kernel() == "pair"
+    c = mk(hip_lib, n, S, q10)
+    c.split_biome(["a", "b", "c", "d", "e"])                  # five: the run kernels
+    assert c.run(1800).last_run_kernel() == "run"
+    c = mk(hip_lib, n, S, q10)
+    c.split_biome(["a", "b"]); c.set_outputs(["CO2_concentration", "NPP"])   # a split core's NPP: run kernel
     assert c.run(1800).last_run_kernel() == "run"
     c = mk(hip_lib, n, S, q10)
     c.setvar_dated_members("ffi_emissions", [1800], np.linspace(0.0, 1.0, n)[None, :])  # per-member series
@@ -397,3 +403,48 @@ def test_pair_kernel_runaway_member_is_flagged_and_does_not_hang(hip_lib):
     ok = [0, 2] if st[1] else [0, 1, 2]
     assert (np.abs(co2[:, ok] - out["run"][1][:, ok]) / out["run"][1][:, ok]).max() < 1e-8
     assert np.array_equal(ts[:, ok], out["run"][2][:, ok])
+
+
+@pytest.mark.parametrize("nb", [2, 3, 4])
+def test_pair_kernel_with_biomes_vs_oracle(hip_lib, nb):
+    """Two to four heterogeneous biomes on the small-ensemble kernel (the land wavefront owns the
+    biome loops; hx_pair_kernel<false, false, false, NB>): every 9th of 128 members against the
+    oracle, stash schedules identical, and the pools' totals against the run kernel's."""
+    import oracle_binding
+    n = 128
+    idx = np.arange(n, dtype=np.uint64)
+    S = 1.5 + 4.5 * ensemble.uniform01(idx, 0)
+    q10 = [1.0 + 2.0 * ensemble.uniform01(idx, 10 + b) for b in range(nb)]
+    wf = [np.full(n, 1.0 + 0.5 * b) for b in range(nb)]
+    names = ["b%d" % b for b in range(nb)]
+    outs = ["CO2_concentration", "global_tas", "timesteps", "veg_c", "soil_c", "permafrost_c", "thawedp_c", "f_frozen"]
+    res = {}
+    for limit, which in ((32768, "pair"), (0, "run")):
+        c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+        c.set_pair_kernel_limit(limit)
+        c.split_biome(names)
+        c.setvar("S", S, "degC")
+        for b, nm in enumerate(names):
+            c.setvar(nm + ".q10_rh", q10[b]).setvar(nm + ".warmingfactor", wf[b])
+        c.set_outputs(outs)
+        c.run(2300)
+        assert c.last_run_kernel() == which and (c.status() == 0).all()
+        res[which] = {v: c.fetchvars(v, (1745, 2300)) for v in outs}
+        c.shutdown()
+    o = oracle_binding.Oracle(SCENARIO)
+    for i in range(0, n, 9):
+        p = o.split_equal(o.default_params(), nb)
+        p.S = S[i]
+        for b in range(nb):
+            p.q10_rh[b] = q10[b][i]; p.warmingfactor[b] = wf[b][i]
+        r, err, _ = o.run(p)
+        assert err == 0
+        g = res["pair"]
+        assert (np.abs(g["CO2_concentration"][:, i] - r["CO2_concentration"]) / r["CO2_concentration"]).max() < REL_CO2
+        assert np.abs(g["global_tas"][:, i] - r["global_tas"]).max() < ABS_T
+        assert np.array_equal(g["timesteps"][1:, i], r["timesteps"][1:])
+        for v in ("veg_c", "soil_c", "permafrost_c", "thawedp_c"):
+            assert np.abs(g[v][1:, i] - r[v][1:]).max() <= 2e-8 * max(1.0, np.abs(r[v]).max()), v
+    for v in outs:   # and the two kernels agree with each other
+        a, b = res["pair"][v], res["run"][v]
+        assert np.abs(a - b).max() <= 5e-9 * max(1.0, np.abs(b).max()), v

@@ -96,12 +96,14 @@ def test_other_parameters_vs_oracle(hip_lib, oracle):
             assert np.abs(c.fetchvars(v, (1745, 2300))[:, i] - o[v]).max() < ABS_T, v
 
 
-def test_four_biome_ensemble_vs_oracle(hip_lib, oracle):
-    """BASELINE config 5 shape: 4-biome split, heterogeneous warming factor / Q10."""
+def test_four_biome_ensemble_vs_oracle(hip_lib, oracle, pair_limit=0):
+    """BASELINE config 5 shape: 4-biome split, heterogeneous warming factor / Q10 (on the run
+    kernel; test_gpu_pair_kernel.py holds the small-ensemble kernel's two to four biomes)."""
     n = 64
     S, q10s, wfs = ensemble.biome4(n)
     names = ["b1", "b2", "b3", "b4"]
     c = mk(hip_lib, n)
+    c.set_pair_kernel_limit(pair_limit)
     c.split_biome(names)
     c.setvar("S", S, "degC")
     for b, nm in enumerate(names):

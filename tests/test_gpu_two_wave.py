@@ -320,3 +320,52 @@ def test_two_wave_flavour_of_the_extended_kernel_on_gpu(hip_lib, oracle, tmp_pat
         for v in ("global_tas", "sst", "land_tas"):
             assert np.abs(a.fetchvars(v, (1745, 2300))[:, i] - r[v]).max() < ABS_T, (v, i)
     a.shutdown(); b.shutdown()
+
+
+def test_wave_clock_and_cost_model_on_gpu(hip_lib, monkeypatch):
+    """hx_wave_clock: every wavefront of the last launch with its start and end (100 MHz ticks);
+    the launch lasts as long as its last wavefront.  And the fitted cost model on the GPU: a core's
+    measured costs order the FIRST run of a later core of the same study (HECTOR_AMD_SIMDS: the
+    lane-order logic of a GPU with 8 SIMDs, so that 4 096 members are 'more wavefronts than
+    SIMDs'), results bit for bit those of the parameter-key order."""
+    monkeypatch.setenv("HECTOR_AMD_SIMDS", "8")
+    n = 4096
+    S, q = ensemble.ecs_q10(n)
+    a = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    a.set_pair_kernel_limit(0)
+    a.set_cost_model(False)    # (an earlier test of this process may have left a model for this key)
+    a.setvar("S", S, "degC").setvar("q10_rh", q)
+    assert len(a.wave_clock()) == 0                       # nothing has run yet
+    a.run(2300)
+    assert a.last_run_kernel() == "run2" and a.lane_order_source() == "parameter key"
+    a.set_cost_model(True)     # its measured costs make (or replace) the model at the reset below
+    w = a.wave_clock()
+    assert w.shape == (n // 64, 2) and (w[:, 1] > w[:, 0]).all() and w[:, 0].min() == 0
+    span_ms = (w[:, 1].max() - w[:, 0].min()) * 1e-5
+    assert 0.5 * a.last_run_ms() < span_ms <= 1.05 * a.last_run_ms() + 0.05
+    ref = a.fetchvars("CO2_concentration", (1745, 2300)).copy()
+    a.reset(1745)
+    assert a.lane_order_source() == "measured cost"
+    S2, q2 = ensemble.ecs_q10(n, offset=20000)
+    b = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    b.set_pair_kernel_limit(0)
+    b.setvar("S", S2, "degC").setvar("q10_rh", q2)
+    b.status()
+    assert b.lane_order_source() == "cost model"
+    b.run(2300)
+    off = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    off.set_pair_kernel_limit(0).set_cost_model(False)
+    off.setvar("S", S2, "degC").setvar("q10_rh", q2)
+    off.run(2300)
+    assert off.lane_order_source() == "parameter key"
+    assert not np.array_equal(off.lane_of_member(), b.lane_of_member())
+    for v in ("CO2_concentration", "global_tas"):
+        assert np.array_equal(off.fetchvars(v), b.fetchvars(v)), v
+    # the pair kernel stamps two wavefronts per 64 members
+    c = hector_amd.Core(SCENARIO, 256, device=0, lib_path=hip_lib)
+    c.setvar("S", S[:256], "degC").run(1800)
+    assert c.last_run_kernel() == "pair" and c.wave_clock().shape == (8, 2)
+    a.run(2300)
+    assert np.array_equal(a.fetchvars("CO2_concentration", (1745, 2300)), ref)
+    for x in (a, b, off, c):
+        x.shutdown()
