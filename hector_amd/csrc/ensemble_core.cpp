@@ -1960,8 +1960,9 @@ void EnsembleCore::run(double runtodate) {
                !(pair_cons && ker_per_member_);
   for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) plain = false;
   bool pair = hx_pair_available() && B_ <= 4 && plain && n_ <= pair_max_members_;
-  // (two to four biomes: its plain instantiation only -- the land side owns the biome loops)
-  if (B_ > 1 && (pair_cons || ker_per_member_ || d_out_[HXO_HEATFLUX])) pair = false;
+  // (two to four biomes -- the land side owns the biome loops --: with shared diffusivity and without
+  // the heat-flux sum)
+  if (B_ > 1 && (ker_per_member_ || d_out_[HXO_HEATFLUX])) pair = false;
   for (int v = 0; v < HXO_NVAR && pair; ++v)
     if (d_out_[v]) {  // what hx_pair_kernel records
       static const int ok[] = {HXO_SST, HXO_TLAND, HXO_CO2, HXO_TGAV, HXO_NSTASH, HXO_RF_TOT, HXO_RF_CO2,

@@ -992,6 +992,12 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // new DOECLIM block: this lane's partial sums over its SST history
         blk_end = iy + (blk0 < 0 ? blk_len0 : HX_DBLK);
         blk0 = iy;
+        if constexpr (B == 1) {
+          // (the block's SST tile starts out as zeros: an in-block term of a year that has not been
+          // computed yet then enters the sums as 0 * Ker by itself, without a select per entry)
+#pragma unroll
+          for (int r = 0; r < HX_DBLK; ++r) s_tblk[r][lane] = 0.0;
+        }
 #if HX_HAS_MFMA
         if constexpr (!KERPM)
           doeclim_pass_mfma<HF, hx_w2<B>()>(buf.out[HXO_SST], buf.ker, const_cast<double *>(buf.dpart),
@@ -1163,7 +1169,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           }
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            const double t = (i0 + r < iy) ? T[r] : 0.0;
+            // (B == 1: the tile holds zeros from this year on, see the block start)
+            const double t = (B == 1 || i0 + r < iy) ? T[r] : 0.0;
             dpast += t * K[r];
             if (want_hf) hint += t * K2[r];
           }
@@ -1913,10 +1920,16 @@ hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, boo
                               int iy_to, hipStream_t st, bool cons, int nbiome) {
 #if HX_HAS_PAIR
   const dim3 g(npad / 64), b(128);
-  // (two to four biomes: the plain instantiation -- shared diffusivity, no heat-flux sum, no constraint;
+  // (two to four biomes: shared diffusivity, no heat-flux sum -- plain or with scenario-wide constraints;
   // the host sends every other split ensemble to the run kernels)
   if (nbiome > 1) {
-    if (heatflux || kpm || cons || nbiome > 4) return hipErrorInvalidValue;
+    if (heatflux || kpm || nbiome > 4) return hipErrorInvalidValue;
+    if (cons) {
+      if (nbiome == 2) hipLaunchKernelGGL((hx_pair_kernel<false, false, true, 2>), g, b, 0, st, d_args, iy_from, iy_to);
+      else if (nbiome == 3) hipLaunchKernelGGL((hx_pair_kernel<false, false, true, 3>), g, b, 0, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_pair_kernel<false, false, true, 4>), g, b, 0, st, d_args, iy_from, iy_to);
+      return hipGetLastError();
+    }
     if (nbiome == 2) hipLaunchKernelGGL((hx_pair_kernel<false, false, false, 2>), g, b, 0, st, d_args, iy_from, iy_to);
     else if (nbiome == 3) hipLaunchKernelGGL((hx_pair_kernel<false, false, false, 3>), g, b, 0, st, d_args, iy_from, iy_to);
     else hipLaunchKernelGGL((hx_pair_kernel<false, false, false, 4>), g, b, 0, st, d_args, iy_from, iy_to);

@@ -448,3 +448,33 @@ def test_pair_kernel_with_biomes_vs_oracle(hip_lib, nb):
     for v in outs:   # and the two kernels agree with each other
         a, b = res["pair"][v], res["run"][v]
         assert np.abs(a - b).max() <= 5e-9 * max(1.0, np.abs(b).max()), v
+
+
+def test_pair_kernel_constrained_split_ensemble_vs_run_kernel(hip_lib):
+    """A CO2-constrained (concentration-driven) 4-biome ensemble of 256 members: the pair kernel's
+    <CONS, NB = 4> instantiation against the extended run kernel."""
+    n, nb = 256, 4
+    idx = np.arange(n, dtype=np.uint64)
+    S = 1.5 + 4.5 * ensemble.uniform01(idx, 0)
+    names = ["b%d" % b for b in range(nb)]
+    yrs = np.arange(1850, 2101)
+    res = {}
+    for limit, which in ((32768, "pair"), (0, "run")):
+        c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+        c.set_pair_kernel_limit(limit)
+        c.split_biome(names)
+        c.setvar("S", S, "degC")
+        for b, nm in enumerate(names):
+            c.setvar(nm + ".q10_rh", 1.0 + 2.0 * ensemble.uniform01(idx, 10 + b)).setvar(nm + ".warmingfactor", np.full(n, 1.0 + 0.5 * b))
+        c.set_outputs(["CO2_concentration", "global_tas", "timesteps", "soil_c", "ocean_c"])
+        c.setvar_dated("CO2_constrain", yrs, 285.0 + 0.004 * (yrs - 1850.0) ** 2)
+        c.run(2300)
+        assert c.last_run_kernel() == which and (c.status() == 0).all()
+        res[which] = {v: c.fetchvars(v, (1745, 2300)) for v in ("CO2_concentration", "global_tas", "timesteps", "soil_c", "ocean_c")}
+        c.shutdown()
+    assert np.array_equal(res["pair"]["timesteps"], res["run"]["timesteps"])
+    co2 = res["pair"]["CO2_concentration"]
+    assert np.abs(co2[1850 - 1745:2100 - 1745 + 1, :] - (285.0 + 0.004 * (yrs - 1850.0) ** 2)[:, None]).max() < 1e-9   # pinned
+    for v in ("CO2_concentration", "global_tas", "soil_c", "ocean_c"):
+        a, b = res["pair"][v], res["run"][v]
+        assert np.abs(a - b).max() <= 5e-9 * max(1.0, np.abs(b).max()), v
