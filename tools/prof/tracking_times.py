@@ -20,6 +20,7 @@ CASES = ((8192, 1), (65536, 1), (8192, 2), (8192, 4), (1024, 8), (256, 16))
 def run(n, nb, date):
     S, q = ensemble.ecs_q10(n)
     c = hector_amd.Core(n_members=n, device=0)
+    c.set_pair_kernel_limit(0)   # (like with like: the tracking kernels are flavours of the run kernel)
     if nb > 1:
         c.split_biome(["b%d" % i for i in range(nb)])
     else:
