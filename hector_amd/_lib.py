@@ -179,6 +179,7 @@ def _declare(lib):
         "hx_wave_clock": [P, c.c_int, c.POINTER(c.c_longlong), c.c_int, c.POINTER(c.c_int)],
         "hx_component_output": [P, c.c_char_p, c.POINTER(c.c_int)],
         "hx_last_run_kernel": [P, c.POINTER(c.c_char_p)],
+        "hx_last_run_variant": [P, c.POINTER(c.c_int)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -191,6 +192,6 @@ ABI_SYMBOLS = ["hx_backend", "hx_build_info", "hx_last_error", "hx_newcore", "hx
                "hx_set_member_sorting", "hx_lane_of_member", "hx_enable_history", "hx_enable_spinup_record", "hx_spinup_record", "hx_setvar_dated", "hx_halocarbons", "hx_run_name", "hx_tracking_pools", "hx_tracking_data", "hx_var_info", "hx_biomes", "hx_setvar_dated_members", "hx_unit_csys", "hx_unit_doeclim_kernel", "hx_reset", "hx_run", "hx_sync", "hx_fetchvars", "hx_device_var",
                "hx_stats_device", "hx_status", "hx_spinup_steps", "hx_state_row", "hx_dates", "hx_sizes",
                "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream", "hx_set_pair_kernel_limit", "hx_set_two_wave_from", "hx_wave_clock",
-               "hx_last_run_kernel", "hx_component_output", "hx_newcore_devices", "hx_shards",
+               "hx_last_run_kernel", "hx_last_run_variant", "hx_component_output", "hx_newcore_devices", "hx_shards",
                "hx_device_var_shard", "hx_stream_shard", "hx_comm_unique_id", "hx_comm_init_rank",
                "hx_comm_info", "hx_ensemble_stats", "hx_set_lane_calibration", "hx_lanes_calibrated", "hx_lane_order_source", "hx_set_cost_model"]

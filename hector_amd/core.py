@@ -380,6 +380,13 @@ class Core:
         self._ck(self._lib.hx_last_run_kernel(self._h, ctypes.byref(s)))
         return s.value.decode()
 
+    def last_run_variant(self):
+        """The run-kernel family of the last run(): 0 plain, -2 plain + diagnostics, -1 extended,
+        1 extended with the NBP machinery, 2 carbon tracking (hx_last_run_variant)."""
+        v = ctypes.c_int()
+        self._ck(self._lib.hx_last_run_variant(self._h, ctypes.byref(v)))
+        return v.value
+
     def last_spinup_ms(self):
         v = ctypes.c_double()
         self._ck(self._lib.hx_last_spinup_ms(self._h, ctypes.byref(v)))

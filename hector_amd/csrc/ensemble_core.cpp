@@ -638,6 +638,12 @@ HxBuffers EnsembleCore::buffers() const {
   for (int v = HXO_BIOME0; v < HXO_NVAR; ++v) if (d_out_[v]) b.biome_diag = 1;
   for (int bb = 0; bb < HX_BDYN; ++bb)
     if (d_out_[HXO_B(HXOB_NPP, bb)] || d_out_[HXO_B(HXOB_RH, bb)]) b.stash_diag = 1;
+  b.out_mask0 = 0; b.ms_mask = 0;
+  for (int v = 0; v < HXO_BIOME0; ++v) if (d_out_[v]) b.out_mask0 |= 1ull << v;
+  for (int bb = 0; bb < HX_BDYN; ++bb)
+    if (d_out_[HXO_B(HXOB_NPP, bb)] || d_out_[HXO_B(HXOB_RH, bb)]) b.out_mask0 |= 1ull << HX_OM_BIOME_FLUX;
+  if (b.biome_diag) b.out_mask0 |= 1ull << HX_OM_BIOME_ANY;
+  for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) b.ms_mask |= 1u << k;
   b.n = n_; b.npad = npad_; b.ker_per_member = ker_per_member_ ? 1 : 0;
   b.nbiome = B_;
   b.cost = d_cost_;
@@ -1944,6 +1950,15 @@ void EnsembleCore::run(double runtodate) {
   // the one with it, the tests hold the two against each other)
   const bool force_nbp = getenv("HECTOR_AMD_EXTENDED_NBP") != nullptr;
   int con = ext ? (((con_mask & HXC_NBP) || force_nbp) ? 1 : -1) : 0;
+  // (and without the constraint / warming-ratio / per-member-series code altogether when only a
+  // diagnostic output made the run "extended": the plain kernel + diagnostics, CON = -2 --
+  // 65 536 members with NPP recorded 6.75 -> 6.3 ms; HECTOR_AMD_EXTENDED_CONS=1: never, the tests
+  // hold the two against each other)
+  if (con == -1 && con_mask == 0 && !getenv("HECTOR_AMD_EXTENDED_CONS")) {
+    bool any_ms = false;
+    for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) any_ms = true;
+    if (!any_ms) con = -2;
+  }
   if (d_track_out_f_) {
     if (con_mask & (HXC_CO2 | HXC_NBP))
       throw std::runtime_error("carbon tracking together with a CO2 or NBP constraint is not "
@@ -1978,6 +1993,7 @@ void EnsembleCore::run(double runtodate) {
   // more wavefronts than SIMDs: the one-biome kernel built for two resident wavefronts per SIMD
   const bool w2 = !pair && con <= 1 && two_wave_expected();
   last_run_w2_ = w2;
+  last_run_con_ = con;
   if (pair)
     check(hx_launch_run_pair(d_args_, npad_, d_out_[HXO_HEATFLUX] != nullptr, ker_per_member_, last_iy_, target,
                              stream_, pair_cons != 0, B_), "run kernel (pair)");

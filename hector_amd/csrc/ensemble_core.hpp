@@ -144,6 +144,10 @@ class EnsembleCore {
   void set_two_wave_from(int min_members) { two_wave_from_ = min_members; }
   int wave_clock(long long *ticks, int cap);   // [wavefront][start, end] of the last launch, 100 MHz ticks
   const char *last_run_kernel() const { return last_run_pair_ ? "pair" : last_run_w2_ ? "run2" : "run"; }
+  // which instantiation family the last run() asked for (the CON template argument of
+  // hx_run_kernel): 0 plain, -2 plain + diagnostics, -1 extended, 1 extended with the NBP
+  // machinery, 2 carbon tracking
+  int last_run_variant() const { return last_run_con_; }
   double last_spinup_ms() const { return spin_ms_; }
   hipStream_t stream() const { return stream_; }
 
@@ -250,6 +254,7 @@ class EnsembleCore {
   bool pair_costly_with_cheap_ = true;   // lane order by measured cost: see assign_lanes()
   int key_order_mode_ = 0;               // HECTOR_AMD_KEY_ORDER (experiments, see assign_lanes)
   bool last_run_w2_ = false;
+  int last_run_con_ = 0;
   bool two_wave_expected() const;   // run() will take hx_run_kernel<HX_B1W2> (see assign_lanes)
   int simds_ = 1024;              // SIMDs of this core's device (4 per compute unit)
   mutable double run_ms_ = 0, spin_ms_ = 0;

@@ -384,5 +384,6 @@ int hx_wave_clock(hx_core *core, int shard, long long *ticks, int cap, int *n_wa
          *n_waves = core->core->wave_clock(shard, ticks, cap))
 }
 int hx_last_run_kernel(hx_core *core, const char **name) { HX_TRY(*name = core->core->last_run_kernel()) }
+int hx_last_run_variant(hx_core *core, int *variant) { HX_TRY(*variant = core->core->last_run_variant()) }
 
 }  // extern "C"

@@ -219,6 +219,7 @@ struct Member {
   int lane;
   hx_ccd upar;            // multi-biome kernels: the uniform-row table, or null if LandK rows vary
   const HxBuffers *bufp;  // the core's tables (bind_member)
+  unsigned long long omk; // extended kernels: HxBuffers::out_mask0 (wave-uniform, read once a launch)
   int iy;                 // year index being integrated
   int trk_iy;             // first tracked year index (tracking kernels)
   int nb;                 // biome count (looped kernels)

@@ -52,6 +52,16 @@ template <int B> __device__ __forceinline__ double m_rh_tp_ch4(const Member<B> &
 // derivative is constant within an interval), one set of interval constants, the land-use rates of
 // an attempt's stages side by side.  hx_nbp<CON>(): the instantiations that carry the NBP machinery.
 template <int CON> constexpr bool hx_nbp() { return CON >= 1; }
+// CON = -2: the plain kernel plus the DIAGNOSTICS of the extended one (NPP / RH / ocean-uptake /
+// box outputs ...) and nothing else: no constraint, no land-ocean warming ratio, no per-member
+// series -- what a run that merely records such an output needs.  EnsembleCore::run picks it when
+// the scenario and the members hold none of those.  hx_cons<CON>(): the instantiations that carry
+// constraints, the warming ratio and per-member series.
+#ifdef HX_EXT_NOCONS   // (experiment builds: CON = -1 without them, to time what their code costs)
+template <int CON> constexpr bool hx_cons() { return CON != 0 && CON != -2 && CON != -1; }
+#else
+template <int CON> constexpr bool hx_cons() { return CON != 0 && CON != -2; }
+#endif
 // constraints of one model year, as the solver and the stash see them (CON kernels only)
 struct YearCon {
   int mask;          // HXC_* bits
@@ -423,14 +433,26 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   }
   bool diag = false;
   size_t dgo = 0;
+  // which of the stash's diagnostics are recorded: bits of HxBuffers::out_mask0 (one scalar load
+  // a stash instead of a pointer load + branch per diagnostic)
+  [[maybe_unused]] unsigned long long omk = 0;
+  constexpr unsigned long long OM_STASH =
+      (1ull << HXO_NPP) | (1ull << HXO_RH) | (1ull << HXO_RH_DET) | (1ull << HXO_RH_SOIL) |
+      (1ull << HXO_HL_UPTAKE) | (1ull << HXO_LL_UPTAKE) | (1ull << HXO_HL_DO) |
+      (1ull << HXO_CA_RESIDUAL) | (1ull << HX_OM_BIOME_FLUX);
   if constexpr (CON && !SPIN) {
-    diag = m.bufp->stash_diag != 0;
+    omk = m.omk;
+#ifndef HX_HOST_EMULATION
+    asm volatile("" : "+s"(omk));   // (the tests below stay here: see HX_MASKS_LOCAL in hx_run_kernel)
+#endif
+    omk &= OM_STASH;
+    diag = omk != 0;
     if (diag) {  // annualflux_sumHL/LL, annual_box_fluxes[HL->DO]: sums over the year's stashes
       const HxBuffers &buf = *m.bufp;
       dgo = (size_t)m.iy * buf.npad + (blockIdx.x * 64 + m.lane);
-      if (buf.out[HXO_HL_UPTAKE]) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
-      if (buf.out[HXO_LL_UPTAKE]) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
-      if (buf.out[HXO_HL_DO]) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
+      if (omk & (1ull << HXO_HL_UPTAKE)) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
+      if (omk & (1ull << HXO_LL_UPTAKE)) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
+      if (omk & (1ull << HXO_HL_DO)) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
     }
   }
   [[maybe_unused]] TrkStashIn tk;
@@ -559,9 +581,11 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
             const double a = fda * rh_adj, bb = fsa * rh_adj, cc = tpc * rh_adj, dd = tpm * rh_adj;
             fin_npp += npp_fin_total * wt;
             fin_rh += ((a + bb) + cc) + dd;
+            if (omk & (1ull << HX_OM_BIOME_FLUX)) {
             const HxBuffers &buf = *m.bufp;
             if (buf.out[HXO_B(HXOB_NPP, b)]) HX_GD(buf.out[HXO_B(HXOB_NPP, b)])[dgo] = npp_fin_total * wt;
             if (buf.out[HXO_B(HXOB_RH, b)]) HX_GD(buf.out[HXO_B(HXOB_RH, b)])[dgo] = ((a + bb) + cc) + dd;
+            }
             fin_det += a;
             fin_soil += bb;
           }
@@ -587,9 +611,11 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
       fin_npp += npp_fin_total * wt;
       fin_rh += ((a + bb) + cc) + dd;
+      if (omk & (1ull << HX_OM_BIOME_FLUX)) {
       const HxBuffers &buf = *m.bufp;  // "<biome>.NPP", "<biome>.RH"
       if (buf.out[HXO_B(HXOB_NPP, b)]) HX_GD(buf.out[HXO_B(HXOB_NPP, b)])[dgo] = npp_fin_total * wt;
       if (buf.out[HXO_B(HXOB_RH, b)]) HX_GD(buf.out[HXO_B(HXOB_RH, b)])[dgo] = ((a + bb) + cc) + dd;
+      }
       fin_det += a;
       fin_soil += bb;
     }
@@ -624,7 +650,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
       r[HXSR_CA_RESIDUAL * np] = residual;
       r[HXSR_HL_UPTAKE * np] += aH; r[HXSR_LL_UPTAKE * np] += aL; r[HXSR_HL_DO * np] += lHD;
     }
-  } else if constexpr (CON) {
+  } else if constexpr (hx_cons<CON>()) {
     // user-supplied [CO2] at this date: same transfer (:567-603); only whole dates exist
     if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {
       const double match = yc.co2 / PGC2PPM;
@@ -637,11 +663,11 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   if constexpr (CON && !SPIN) {
     if (diag) {  // the last stash of the year is the one that stays
       const HxBuffers &buf = *m.bufp;
-      if (buf.out[HXO_NPP]) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
-      if (buf.out[HXO_RH]) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
-      if (buf.out[HXO_RH_DET]) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
-      if (buf.out[HXO_RH_SOIL]) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
-      if (buf.out[HXO_CA_RESIDUAL]) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
+      if (omk & (1ull << HXO_NPP)) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
+      if (omk & (1ull << HXO_RH)) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
+      if (omk & (1ull << HXO_RH_DET)) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
+      if (omk & (1ull << HXO_RH_SOIL)) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
+      if (omk & (1ull << HXO_CA_RESIDUAL)) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
     }
   }
   m.ode_start = t;

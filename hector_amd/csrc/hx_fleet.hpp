@@ -52,6 +52,7 @@ class Fleet {
   }
   bool component_output_enabled(const std::string &s) const { return shards_[0].core->component_output_enabled(s); }
   const char *last_run_kernel() const { return shards_[0].core->last_run_kernel(); }
+  int last_run_variant() const { return shards_[0].core->last_run_variant(); }
   std::vector<std::string> tracking_pools() const { return shards_[0].core->tracking_pools(); }
 
   void setvar(const std::string &capability, const double *values, int nvalues, const char *units);

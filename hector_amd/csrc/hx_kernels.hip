@@ -599,16 +599,42 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   // ~60 long-lived scalars into spill lanes (164 v_readlane / v_writelane a year against 63).
   // (Plain kernels; with constraints or a land-ocean warming ratio the year start may see another
   // SST than DOECLIM's, and the extended kernels evaluate the fit there.)
+  // (Extended kernels, one wavefront per SIMD: carried too, and used unless some member has a
+  // land-ocean warming ratio -- HXC_LO, a scenario-wide bit -- which is the one thing that lets the
+  // year start see another SST than the one phase C left: a temperature constraint replaces
+  // sst_new before it is parked.  The two-wavefront flavour's extended instantiations sit at
+  // their 256-register budget and keep the evaluation in phase A.)
+  constexpr bool FITC = !hx_cons<CON>() || (!hx_w2<B>() && (CON == 1 || CON == -1));
   [[maybe_unused]] double fitc[12];
-  if constexpr (CON == 0) {
+  if constexpr (FITC) {
     const double s0 = PKM(m, PK_SST);
     chem_constants_fit(s0 + 18 + (-16.4), s0 + 18 + 2.9, args->kc.kfit, fitc);
   }
 #endif
 
+  // Extended kernels: which constraints / per-member series / outputs exist -- HxConst::con_mask,
+  // HxBuffers::ms_mask, ::out_mask0 -- read ONCE and kept in scalar registers (laundered through an
+  // empty asm so that they stay values, not loads): a scalar load + test inside the year loop waits
+  // for every scalar load and LDS read in flight (one counter), e.g. for next year's table entries
+  // requested ahead of the solver.
+  [[maybe_unused]] unsigned cmk = 0, msk = 0;
+  [[maybe_unused]] unsigned long long omk = 0;
+  if constexpr (CON) {
+    cmk = (unsigned)args->kc.con_mask; msk = args->buf.ms_mask; omk = args->buf.out_mask0;
+    m.omk = omk;
+  }
+  // (... and laundered again at the head of every region that tests them: a test of an opaque
+  // but loop-invariant value is itself loop-invariant, and the optimiser would compute all ~50 of
+  // them ahead of the year loop and keep them in -- spilled -- scalar registers)
+#ifndef HX_HOST_EMULATION
+#define HX_MASKS_LOCAL() do { if constexpr (CON) asm volatile("" : "+s"(cmk), "+s"(msk), "+s"(omk)); } while (0)
+#else
+#define HX_MASKS_LOCAL() do { } while (0)
+#endif
   for (int iy = iy_from + 1; iy <= iy_to; ++iy) {
     HX_FENCE();
     HX_STAMP(m, 0);   // (kernel entry / loop overhead)
+    HX_MASKS_LOCAL();
     if constexpr (CON) m.iy = iy;
     double ch4, o3;
     // ======================= phase A ========================================
@@ -634,10 +660,12 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         eos = PKM(m, PK_EOS);
       }
       double tland = PKM(m, PK_TLAND);
-      if constexpr (CON) {
+      if constexpr (hx_cons<CON>()) {
         // land-ocean warming ratio: the carbon cycle and the ocean see temperatures derived
         // from global tas, DOECLIM keeps its own (temperature_component.cpp:586-625,722-739)
-        const double lo = ldp(buf, HXP_LO_RATIO, mem);
+        // (HXC_LO: some member has one -- no load of the parameter row otherwise)
+        double lo = 0.0;
+        if (cmk & HXC_LO) lo = ldp(buf, HXP_LO_RATIO, mem);
         if (lo != 0 && iy > 1) {
           const double tg = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
           const double toa = tg / ((lo * D_flnd) + (1 - D_flnd));
@@ -776,9 +804,15 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #ifndef HX_NO_CHEM_FIT
       const bool fit_in = chem_fit_applies(TcH, TcL);
 #ifdef HX_FIT_CARRIED
-      if constexpr (CON == 0) {
+      if constexpr (!hx_cons<CON>()) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) ex[i] = fitc[i];
+      } else if constexpr (FITC) {
+        if (cmk & HXC_LO) chem_constants_fit(TcH, TcL, kc.kfit, ex);
+        else {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) ex[i] = fitc[i];
+        }
       } else
 #endif
       chem_constants_fit(TcH, TcL, kc.kfit, ex);
@@ -808,18 +842,19 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       }
       const double tau_oh = kc.TOH0 * ex[12];
       if constexpr (CON) {
-      if (buf.out[HXO_TAU_OH]) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
-      if (buf.stash_diag) {  // sums over the year's stashes start at zero (oceanbox::new_year)
+      if (omk & (1ull << HXO_TAU_OH)) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
+      if (omk & ((1ull << HXO_HL_UPTAKE) | (1ull << HXO_LL_UPTAKE) | (1ull << HXO_HL_DO))) {
+        // sums over the year's stashes start at zero (oceanbox::new_year)
         const size_t o = (size_t)iy * buf.npad + mem;
-        if (buf.out[HXO_HL_UPTAKE]) sto_(buf, HXO_HL_UPTAKE, o, 0.0);
-        if (buf.out[HXO_LL_UPTAKE]) sto_(buf, HXO_LL_UPTAKE, o, 0.0);
-        if (buf.out[HXO_HL_DO]) sto_(buf, HXO_HL_DO, o, 0.0);
+        if (omk & (1ull << HXO_HL_UPTAKE)) sto_(buf, HXO_HL_UPTAKE, o, 0.0);
+        if (omk & (1ull << HXO_LL_UPTAKE)) sto_(buf, HXO_LL_UPTAKE, o, 0.0);
+        if (omk & (1ull << HXO_HL_DO)) sto_(buf, HXO_HL_DO, o, 0.0);
       }
       }
       {
         double ch4_em = ya[3];
-        if constexpr (CON) {
-          if (buf.mseries[HXM_CH4_EM])
+        if constexpr (hx_cons<CON>()) {
+          if (msk & (1u << HXM_CH4_EM))
             ch4_em = HX_GCD(buf.mseries[HXM_CH4_EM])[(size_t)iy * buf.npad + mem];
         }
         const double emisTocon =
@@ -828,10 +863,10 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
                             hx_div(prev_ch4, tau_oh);
         ch4 = prev_ch4 + dCH4;
       }
-      if constexpr (CON) {  // ch4_component.cpp:156-157
-        if (kc.con_mask & HXC_CH4) {
+      if constexpr (hx_cons<CON>()) {  // ch4_component.cpp:156-157
+        if (cmk & HXC_CH4) {
           double c = sh[HXSH_CH4_CON];
-          if (buf.mseries[HXM_CH4_CON]) c = HX_GCD(buf.mseries[HXM_CH4_CON])[(size_t)iy * buf.npad + mem];
+          if (msk & (1u << HXM_CH4_CON)) c = HX_GCD(buf.mseries[HXM_CH4_CON])[(size_t)iy * buf.npad + mem];
           if (!isnan(c)) ch4 = c;
         }
       }
@@ -855,12 +890,14 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       // ---- slowparameval (t = year-1) ----
       m.ffi = ya[8]; m.daccs = ya[9];
       m.luc_e = ya[10]; m.luc_u = ya[11];
-      if constexpr (CON) {  // emissions that differ between members
+      if constexpr (hx_cons<CON>()) {  // emissions that differ between members
+        if (msk & ((1u << HXM_FFI) | (1u << HXM_DACCS) | (1u << HXM_LUC_E) | (1u << HXM_LUC_U))) {
         const size_t o = (size_t)iy * buf.npad + mem;
-        if (buf.mseries[HXM_FFI]) m.ffi = HX_GCD(buf.mseries[HXM_FFI])[o];
-        if (buf.mseries[HXM_DACCS]) m.daccs = HX_GCD(buf.mseries[HXM_DACCS])[o];
-        if (buf.mseries[HXM_LUC_E]) m.luc_e = HX_GCD(buf.mseries[HXM_LUC_E])[o];
-        if (buf.mseries[HXM_LUC_U]) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
+        if (msk & (1u << HXM_FFI)) m.ffi = HX_GCD(buf.mseries[HXM_FFI])[o];
+        if (msk & (1u << HXM_DACCS)) m.daccs = HX_GCD(buf.mseries[HXM_DACCS])[o];
+        if (msk & (1u << HXM_LUC_E)) m.luc_e = HX_GCD(buf.mseries[HXM_LUC_E])[o];
+        if (msk & (1u << HXM_LUC_U)) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
+        }
       }
       m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
       const double lnc = PKM(m, PK_LN_CO2R);  // = log((atmos C * PGC2PPM) / C0), from last year's phase C
@@ -959,20 +996,27 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         load_year_a(iy + 1);
       }
       const double year = (double)(args->kc.start_year + iy);
+      HX_MASKS_LOCAL();
       YearCon yc{};
-      if constexpr (CON) {
+      if constexpr (hx_cons<CON>()) {
         hx_ccd sh = HX_CCD(args->buf.shared) + (size_t)iy * HXSH_STRIDE;
-        yc.mask = args->kc.con_mask;
-        yc.co2 = sh[HXSH_CO2_CON];
-        yc.nbp_hi = sh[HXSH_NBP_CON];
-        yc.nbp_lo = (sh - HXSH_STRIDE)[HXSH_NBP_CON];
-        {  // constraints that differ between members
+        yc.mask = (int)cmk;
+        // (the columns are read only under their mask bit -- the stash looks at the values only
+        // then; per-member series by their bit of HxBuffers::ms_mask)
+        if (yc.mask & HXC_CO2) yc.co2 = sh[HXSH_CO2_CON];
+        if constexpr (hx_nbp<CON>()) {
+          yc.nbp_hi = sh[HXSH_NBP_CON];
+          yc.nbp_lo = (sh - HXSH_STRIDE)[HXSH_NBP_CON];
+        }
+        if (msk & ((1u << HXM_CO2_CON) | (1u << HXM_NBP_CON))) {  // constraints that differ between members
           const HxBuffers &buf = args->buf;
           const size_t o = (size_t)iy * buf.npad + mem;
-          if (buf.mseries[HXM_CO2_CON]) yc.co2 = HX_GCD(buf.mseries[HXM_CO2_CON])[o];
-          if (buf.mseries[HXM_NBP_CON]) {
+          if (msk & (1u << HXM_CO2_CON)) yc.co2 = HX_GCD(buf.mseries[HXM_CO2_CON])[o];
+          if constexpr (hx_nbp<CON>()) {
+          if (msk & (1u << HXM_NBP_CON)) {
             yc.nbp_hi = HX_GCD(buf.mseries[HXM_NBP_CON])[o];
             yc.nbp_lo = HX_GCD(buf.mseries[HXM_NBP_CON])[o - buf.npad];
+          }
           }
         }
         yc.t_half = year - 0.5;
@@ -983,6 +1027,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
     HX_FENCE();
     HX_STAMP(m, 10);    // rest of the solver (loop control, lanes idling through others' segments)
     // ======================= phase C ========================================
+    HX_MASKS_LOCAL();
     {
       const HxBuffers &buf = args->buf;
       const HxConst &kc = args->kc;
@@ -1079,8 +1124,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         const double a2 = -3.4197e-4, b2 = 2.5455e-4, c2 = -2.4357e-4, d2 = 0.12173;
         const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
         double sqN = yc4[0], sqN0 = kc.sqrtN0, rf_other = yc4[1];
-        if constexpr (CON) {  // N2O / halocarbon parameters that differ between members
-          if (buf.mseries[HXM_N2O]) {
+        if constexpr (hx_cons<CON>()) {  // N2O / halocarbon parameters that differ between members
+          if (msk & (1u << HXM_N2O)) {
             sqN = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[(size_t)iy * buf.npad + mem]);
             sqN0 = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[mem]);
             rf_other = HX_GCD(buf.mseries[HXM_RF_OTHER])[(size_t)iy * buf.npad + mem];
@@ -1104,10 +1149,10 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         double ftot = ((((((fco2 + fn2o) + fch4) + fh2o) + fo3) + rf_other) +
                        p_aero * yc4[2]) +
                       p_vol * yc4[3];
-        if constexpr (CON) {  // forcing_component.cpp:498-505
-          if (kc.con_mask & HXC_FTOT) {
+        if constexpr (hx_cons<CON>()) {  // forcing_component.cpp:498-505
+          if (cmk & HXC_FTOT) {
             double c = sh[HXSH_FTOT_CON];
-            if (buf.mseries[HXM_FTOT_CON]) c = HX_GCD(buf.mseries[HXM_FTOT_CON])[(size_t)iy * buf.npad + mem];
+            if (msk & (1u << HXM_FTOT_CON)) c = HX_GCD(buf.mseries[HXM_FTOT_CON])[(size_t)iy * buf.npad + mem];
             if (!isnan(c)) ftot = c;
           }
         }
@@ -1184,10 +1229,10 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         tl_new = dIB0 * X1 + dIB1 * X2;
         sst_new = dIB2 * X1 + dIB3 * X2;
         tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
-        if constexpr (CON) {  // user-supplied temperature :510-525
-          if (kc.con_mask & HXC_TAS) {
+        if constexpr (hx_cons<CON>()) {  // user-supplied temperature :510-525
+          if (cmk & HXC_TAS) {
             double c = sh[HXSH_TAS_CON];
-            if (buf.mseries[HXM_TAS_CON]) c = HX_GCD(buf.mseries[HXM_TAS_CON])[(size_t)iy * buf.npad + mem];
+            if (msk & (1u << HXM_TAS_CON)) c = HX_GCD(buf.mseries[HXM_TAS_CON])[(size_t)iy * buf.npad + mem];
             if (!isnan(c)) {
               tgav = c;
               tl_new = (tgav - (1.0 - D_flnd) * D_bsi * sst_new) / D_flnd;
@@ -1205,8 +1250,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         if constexpr (B == 1) s_tblk[j][lane] = sst_new;
       }
       double tl_seen = tland, tl_rep = tl_new, sst_rep = sst_new;  // what D_LAND_TAS / D_SST return
-      if constexpr (CON) {
-        const double lo = ldp(buf, HXP_LO_RATIO, mem);
+      if constexpr (hx_cons<CON>()) {
+        double lo = 0.0;
+        if (cmk & HXC_LO) lo = ldp(buf, HXP_LO_RATIO, mem);
         if (lo != 0) {
           if (iy > 1) {
             const double tg0 = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
@@ -1224,62 +1270,80 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       PKM(m, PK_TLAND) = tl_new;
       PKM(m, PK_SST) = sst_new;
 #ifdef HX_FIT_CARRIED
-      if constexpr (CON == 0) chem_constants_fit(sst_new + 18 + (-16.4), sst_new + 18 + 2.9, kc.kfit, fitc);
+      if constexpr (FITC) chem_constants_fit(sst_new + 18 + (-16.4), sst_new + 18 + 2.9, kc.kfit, fitc);
 #endif
       // ---- outputs ----
+      HX_MASKS_LOCAL();
       const size_t o = (size_t)iy * buf.npad + mem;
       if constexpr (hx_rowio<B>()) {  // (wave-uniform row address + the lane's 32-bit offset)
         const size_t orow = (size_t)iy * buf.npad;
         hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
         hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
-        if constexpr (CON) { if (buf.out[HXO_SST_LO]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
+        if constexpr (hx_cons<CON>()) { if (omk & (1ull << HXO_SST_LO)) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
         if (buf.out[HXO_CO2]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_CO2]) + orow, m.moff, co2c);
         if (buf.out[HXO_TGAV]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_TGAV]) + orow, m.moff, tgav);
       } else {
       sto_(buf, HXO_SST, o, sst_new);
       sto_(buf, HXO_TLAND, o, tl_rep);
-      if constexpr (CON) { if (buf.out[HXO_SST_LO]) sto_(buf, HXO_SST_LO, o, sst_rep); }
+      if constexpr (hx_cons<CON>()) { if (omk & (1ull << HXO_SST_LO)) sto_(buf, HXO_SST_LO, o, sst_rep); }
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
       }
       if (buf.out_rare) {  // (one test instead of ~25 pointer loads and branches a year)
-      if (buf.out[HXO_RF_TOT]) sto_(buf, HXO_RF_TOT, o, rf_tot);
-      if (buf.out[HXO_RF_CO2]) sto_(buf, HXO_RF_CO2, o, rf_co2);
-      if (buf.out[HXO_OCEAN_C]) sto_(buf, HXO_OCEAN_C, o, m.cDO + m.cIO + m.cLL + m.cHL);
-      if (buf.out[HXO_HL_PH]) sto_(buf, HXO_HL_PH, o, -log10(m.hH));
-      if (buf.out[HXO_LL_PH]) sto_(buf, HXO_LL_PH, o, -log10(m.hL));
-      if (buf.out[HXO_ATMOS_C]) sto_(buf, HXO_ATMOS_C, o, m.atmos);
-      if (buf.out[HXO_HEATFLUX]) sto_(buf, HXO_HEATFLUX, o, heatflux);
-      if (buf.out[HXO_CH4]) sto_(buf, HXO_CH4, o, ch4);
-      if (buf.out[HXO_O3]) sto_(buf, HXO_O3, o, o3);
-      if (buf.out[HXO_EARTH_C]) sto_(buf, HXO_EARTH_C, o, m.earth);
-      if (buf.out[HXO_NBP]) sto_(buf, HXO_NBP, o, m.nbp);
-      if (buf.out[HXO_OCEAN_UPTAKE]) sto_(buf, HXO_OCEAN_UPTAKE, o, m.annualflux_sum);
-      if (buf.out[HXO_NSTASH]) sto_(buf, HXO_NSTASH, o, (double)m.nstash);
-      if (buf.out[HXO_NSTEPS]) sto_(buf, HXO_NSTEPS, o, (double)m.nsteps);
-      if (buf.out[HXO_PERMAFROST_C] || buf.out[HXO_VEG_C] || buf.out[HXO_DET_C] ||
-          buf.out[HXO_SOIL_C] || buf.out[HXO_THAWED_C]) {
+      // (and inside: a bit of HxBuffers::out_mask0 per output instead of its pointer)
+      // (in groups: a run that records one diagnostic skips the others a group at a time)
+      unsigned long long om = buf.out_mask0;
+      if constexpr (CON) om = omk;
+      constexpr unsigned long long OM_G1 =
+          (1ull << HXO_RF_TOT) | (1ull << HXO_RF_CO2) | (1ull << HXO_OCEAN_C) | (1ull << HXO_HL_PH) |
+          (1ull << HXO_LL_PH) | (1ull << HXO_ATMOS_C) | (1ull << HXO_HEATFLUX) | (1ull << HXO_CH4) |
+          (1ull << HXO_O3) | (1ull << HXO_EARTH_C) | (1ull << HXO_NBP) | (1ull << HXO_OCEAN_UPTAKE) |
+          (1ull << HXO_NSTASH) | (1ull << HXO_NSTEPS);
+      constexpr unsigned long long OM_G3 =
+          (1ull << HXO_GMST) | (1ull << HXO_FLUX_MIXED) | (1ull << HXO_FLUX_INTERIOR) | (1ull << HXO_C_HL) |
+          (1ull << HXO_C_LL) | (1ull << HXO_C_IO) | (1ull << HXO_C_DO) | (1ull << HXO_PCO2_HL) |
+          (1ull << HXO_PCO2_LL);
+      if (om & OM_G1) {
+      if ((om & (1ull << HXO_RF_TOT))) sto_(buf, HXO_RF_TOT, o, rf_tot);
+      if ((om & (1ull << HXO_RF_CO2))) sto_(buf, HXO_RF_CO2, o, rf_co2);
+      if ((om & (1ull << HXO_OCEAN_C))) sto_(buf, HXO_OCEAN_C, o, m.cDO + m.cIO + m.cLL + m.cHL);
+      if ((om & (1ull << HXO_HL_PH))) sto_(buf, HXO_HL_PH, o, -log10(m.hH));
+      if ((om & (1ull << HXO_LL_PH))) sto_(buf, HXO_LL_PH, o, -log10(m.hL));
+      if ((om & (1ull << HXO_ATMOS_C))) sto_(buf, HXO_ATMOS_C, o, m.atmos);
+      if ((om & (1ull << HXO_HEATFLUX))) sto_(buf, HXO_HEATFLUX, o, heatflux);
+      if ((om & (1ull << HXO_CH4))) sto_(buf, HXO_CH4, o, ch4);
+      if ((om & (1ull << HXO_O3))) sto_(buf, HXO_O3, o, o3);
+      if ((om & (1ull << HXO_EARTH_C))) sto_(buf, HXO_EARTH_C, o, m.earth);
+      if ((om & (1ull << HXO_NBP))) sto_(buf, HXO_NBP, o, m.nbp);
+      if ((om & (1ull << HXO_OCEAN_UPTAKE))) sto_(buf, HXO_OCEAN_UPTAKE, o, m.annualflux_sum);
+      if ((om & (1ull << HXO_NSTASH))) sto_(buf, HXO_NSTASH, o, (double)m.nstash);
+      if ((om & (1ull << HXO_NSTEPS))) sto_(buf, HXO_NSTEPS, o, (double)m.nsteps);
+      }
+      if ((om & (1ull << HXO_PERMAFROST_C)) || (om & (1ull << HXO_VEG_C)) || (om & (1ull << HXO_DET_C)) ||
+          (om & (1ull << HXO_SOIL_C)) || (om & (1ull << HXO_THAWED_C))) {
         double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll hx_ur<B>()
         for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                        p += m.pf[b]; th += m.thawed[b]; }
-        if (buf.out[HXO_PERMAFROST_C]) sto_(buf, HXO_PERMAFROST_C, o, p);
-        if (buf.out[HXO_VEG_C]) sto_(buf, HXO_VEG_C, o, v);
-        if (buf.out[HXO_DET_C]) sto_(buf, HXO_DET_C, o, d);
-        if (buf.out[HXO_SOIL_C]) sto_(buf, HXO_SOIL_C, o, s);
-        if (buf.out[HXO_THAWED_C]) sto_(buf, HXO_THAWED_C, o, th);
+        if ((om & (1ull << HXO_PERMAFROST_C))) sto_(buf, HXO_PERMAFROST_C, o, p);
+        if ((om & (1ull << HXO_VEG_C))) sto_(buf, HXO_VEG_C, o, v);
+        if ((om & (1ull << HXO_DET_C))) sto_(buf, HXO_DET_C, o, d);
+        if ((om & (1ull << HXO_SOIL_C))) sto_(buf, HXO_SOIL_C, o, s);
+        if ((om & (1ull << HXO_THAWED_C))) sto_(buf, HXO_THAWED_C, o, th);
       }
       if constexpr (CON) {  // diagnostics of the extended kernel
-      if (buf.out[HXO_GMST]) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
-      if (buf.out[HXO_FLUX_MIXED]) sto_(buf, HXO_FLUX_MIXED, o, flux_mixed);
-      if (buf.out[HXO_FLUX_INTERIOR]) sto_(buf, HXO_FLUX_INTERIOR, o, flux_interior);
-      if (buf.out[HXO_C_HL]) sto_(buf, HXO_C_HL, o, m.cHL);
-      if (buf.out[HXO_C_LL]) sto_(buf, HXO_C_LL, o, m.cLL);
-      if (buf.out[HXO_C_IO]) sto_(buf, HXO_C_IO, o, m.cIO);
-      if (buf.out[HXO_C_DO]) sto_(buf, HXO_C_DO, o, m.cDO);
-      if (buf.out[HXO_PCO2_HL]) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
-      if (buf.out[HXO_PCO2_LL]) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
-      if (buf.biome_diag) {  // "<biome>.veg_c" ...: pools and factors of each biome
+      if (om & OM_G3) {
+      if ((om & (1ull << HXO_GMST))) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
+      if ((om & (1ull << HXO_FLUX_MIXED))) sto_(buf, HXO_FLUX_MIXED, o, flux_mixed);
+      if ((om & (1ull << HXO_FLUX_INTERIOR))) sto_(buf, HXO_FLUX_INTERIOR, o, flux_interior);
+      if ((om & (1ull << HXO_C_HL))) sto_(buf, HXO_C_HL, o, m.cHL);
+      if ((om & (1ull << HXO_C_LL))) sto_(buf, HXO_C_LL, o, m.cLL);
+      if ((om & (1ull << HXO_C_IO))) sto_(buf, HXO_C_IO, o, m.cIO);
+      if ((om & (1ull << HXO_C_DO))) sto_(buf, HXO_C_DO, o, m.cDO);
+      if ((om & (1ull << HXO_PCO2_HL))) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
+      if ((om & (1ull << HXO_PCO2_LL))) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
+      }
+      if (om & (1ull << HX_OM_BIOME_ANY)) {  // "<biome>.veg_c" ...: pools and factors of each biome
         LandK<B> lkb;
         load_landk<B>(m, lkb);
 #pragma unroll hx_ur<B>()
@@ -1292,7 +1356,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           putb(HXOB_TEMPFERTD, m.tempfertd[b]); putb(HXOB_TEMPFERTS, m.tempferts[b]);
         }
       }
-      if (buf.out[HXO_RH_CH4] || buf.out[HXO_F_FROZEN]) {
+      if ((om & (1ull << HXO_RH_CH4)) || (om & (1ull << HXO_F_FROZEN))) {
         // record_state: RH_ch4 = rh_ftpa_ch4 of the year-end pools (simpleNbox.cpp:800-812);
         // f_frozen: permafrost-weighted mean over biomes, 1 without permafrost (:492-514)
         LandK<B> lk;
@@ -1304,8 +1368,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #pragma unroll hx_ur<B>()
           for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * ffrozen_of<B>(m, b);
         } else ff = 1.0;
-        if (buf.out[HXO_RH_CH4]) sto_(buf, HXO_RH_CH4, o, rch4);
-        if (buf.out[HXO_F_FROZEN]) sto_(buf, HXO_F_FROZEN, o, ff);
+        if ((om & (1ull << HXO_RH_CH4))) sto_(buf, HXO_RH_CH4, o, rch4);
+        if ((om & (1ull << HXO_F_FROZEN))) sto_(buf, HXO_F_FROZEN, o, ff);
       }
       }
       }  // out_rare
@@ -1825,8 +1889,17 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
       if (k)
       hx_allow_dynamic_lds(k, lds);
   }
+  // CON = -2 (the plain kernel + the extended one's diagnostics, hx_dev_solver.h) is built for one
+  // to four biomes and for the two-wavefront flavour; other biome counts take CON = -1 for it
+  if (con == -2 && !(B >= 1 && B <= 4)) con = -1;
   if constexpr (B == 1) {
     // the flavour built for two resident wavefronts per SIMD (EnsembleCore::run decides)
+    if (two_wave && con == -2) {
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else if (hf) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, false, false, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
     if (two_wave && con == 1) {
       if (kpm) hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, true, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
       else hipLaunchKernelGGL((hx_run_kernel<HX_B1W2, true, false, 1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
@@ -1860,6 +1933,18 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     return;
   }
 #endif
+#ifdef HX_MINIMAL_EXT    // ... and the extended ones without the NBP machinery / second history sum
+  if constexpr (B >= 1 && B <= 4) {
+    if (con == -2) {
+      hipLaunchKernelGGL((hx_run_kernel<B, false, false, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
+  }
+  if (con == -1) {
+    hipLaunchKernelGGL((hx_run_kernel<B, false, false, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+    return;
+  }
+#endif
   hipLaunchKernelGGL((hx_run_kernel<B, false, false, 0>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
   return;
 #endif
@@ -1886,6 +1971,14 @@ static void launch_run_b(const HxArgs *d_args, int npad, bool hf, bool kpm, int 
     hipLaunchKernelGGL((hx_run_kernel<B, true, false, 2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
     return;
   }
+  }
+  if constexpr (B >= 1 && B <= 4) {
+    if (con == -2) {   // diagnostics only: no constraint, warming ratio or per-member series anywhere
+      if (kpm) hipLaunchKernelGGL((hx_run_kernel<B, true, true, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else if (hf) hipLaunchKernelGGL((hx_run_kernel<B, true, false, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      else hipLaunchKernelGGL((hx_run_kernel<B, false, false, -2>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);
+      return;
+    }
   }
   if (con == -1 && kpm)
     hipLaunchKernelGGL((hx_run_kernel<B, true, true, -1>), dim3(blocks), dim3(64), lds, st, d_args, iy_from, iy_to);

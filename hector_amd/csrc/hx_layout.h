@@ -89,6 +89,9 @@ enum HxOutVar {
 enum HxBiomeOut { HXOB_VEG = 0, HXOB_DET, HXOB_SOIL, HXOB_PF, HXOB_THAWED, HXOB_NPP, HXOB_RH,
                    HXOB_RH_CH4, HXOB_F_FROZEN, HXOB_TEMPFERTD, HXOB_TEMPFERTS, HXOB_N };
 #define HXO_B(k, b) (HXO_BIOME0 + (k) * HX_BDYN + (b))
+#define HX_OM_BIOME_FLUX 62   // HxBuffers::out_mask0: some "<biome>.NPP" or "<biome>.RH" is recorded
+#define HX_OM_BIOME_ANY 61    // ... some "<biome>.<variable>" output at all (= HxBuffers::biome_diag)
+static_assert(HXO_BIOME0 <= HX_OM_BIOME_ANY, "HxBuffers::out_mask0 holds one bit per global output");
 
 // ---- shared per-year scenario table: row iy = year - startDate ------------
 enum HxSharedCol {
@@ -118,6 +121,7 @@ enum HxMemberSeries {
   HXM_N2O, HXM_RF_OTHER,
   HXM_N
 };
+static_assert(HXM_N <= 32, "HxBuffers::ms_mask holds one bit per member series");
 
 // ---- status bits (per member) ---------------------------------------------
 #define HX_ERR_MASS 1u       // mass balance > 1e-3 PgC   simpleNbox-runtime.cpp:553-563
@@ -229,6 +233,12 @@ struct HxBuffers {
                            // recorded: the year's output block tests the others only then
   int biome_diag;          // some "<biome>.<variable>" output is recorded
   int stash_diag;        // some of HXO_NPP..HXO_CA_RESIDUAL are recorded (written inside the stash)
+  // The same information bit by bit: bit v of out_mask0 = out[v] is recorded (v < HXO_BIOME0; bit
+  // HX_OM_BIOME_FLUX = some "<biome>.NPP" / "<biome>.RH"), bit k of ms_mask = mseries[k] is set.
+  // The extended kernels test a bit of one scalar register where they would load and test a
+  // pointer -- ~10 dependent scalar loads + branches per stash, ~45 a year otherwise.
+  unsigned long long out_mask0;
+  unsigned ms_mask;
   double *cost;          // [npad] what the launches since the last reset cost each lane (4 per dopri5
                          // step + 5 per stash): the host orders the lanes by it (EnsembleCore::assign_lanes)
   // optional (hx_enable_spinup_record): what the reference's output stream sees after every spinup

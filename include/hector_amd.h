@@ -335,6 +335,14 @@ int hx_set_two_wave_from(hx_core *core, int min_members);
  * (src/csv_outputstream_visitor.cpp, every visit()); hector-amd's stream does the same. */
 int hx_component_output(hx_core *core, const char *component, int *enabled);
 int hx_last_run_kernel(hx_core *core, const char **name);
+/* Which family of run-kernel instantiations the last hx_run asked for: 0 the plain kernel;
+ * -2 the plain kernel plus the diagnostics the reference's output stream writes (NPP, RH and its
+ * parts, the ocean boxes' carbon / pCO2 / uptake, gmst ...: csv_outputstream_visitor.cpp:126-365)
+ * when no constraint, land-ocean warming ratio or per-member series exists anywhere; -1 the
+ * extended kernel (those too: temperature_component.cpp:510-525,586-625, forcing_component.cpp:
+ * 498-505, ch4_component.cpp:156-157, simpleNbox-runtime.cpp:567-603); 1 the extended kernel with
+ * the NBP constraint's machinery (simpleNbox-runtime.cpp:343-383); 2 carbon tracking. */
+int hx_last_run_variant(hx_core *core, int *variant);
 /* When every wavefront of the last hx_run's year-loop launch started and ended: ticks[2 w] and
  * ticks[2 w + 1] for wavefront w of shard `shard` (64 members in lane order; the small-ensemble
  * kernel has two wavefronts per 64 members), in ticks of the device's constant 100 MHz clock

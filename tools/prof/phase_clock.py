@@ -26,6 +26,9 @@ SECTIONS = {0: "A: loop top", 1: "A: park reads + OH/CH4/O3", 2: "A: chem consta
 
 
 def main():
+    ext = "--ext" in sys.argv     # record NPP: the extended kernel (build with -DHX_MINIMAL_EXT)
+    if ext:
+        sys.argv.remove("--ext")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     biomes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpuwork", "libclk.so")
@@ -47,6 +50,9 @@ def main():
         for b, nm in enumerate(names):
             c.setvar(nm + ".q10_rh", 1.0 + 2.0 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 10 + b))
             c.setvar(nm + ".warmingfactor", np.full(n, 1.0 + 0.5 * (b % 4)))
+    if ext:
+        c.set_pair_kernel_limit(0)
+        c.set_outputs(["CO2_concentration", "global_tas", "NPP"])
     c.run(2300)
     ms = c.last_run_ms()
     t = c.fetchvars("global_tas", (1745, 1745 + 23))      # [24][members]: per-wave values
