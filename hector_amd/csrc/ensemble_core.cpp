@@ -540,6 +540,9 @@ void EnsembleCore::alloc_device() {
   if (trk_iy() >= 0) {  // carbon tracking: the yearly record of the origin matrices from the tracking
     // date on (the kernels update the current year's matrix in place, hx_dev_track.h)
     const size_t TP = (size_t)(2 + 5 * B_ + 4), nyt = ns - (size_t)trk_iy();
+    if (TP > 128)   // (the origin masks are two 64-bit words a pool: hx_trk_mask_words)
+      throw std::runtime_error("carbon tracking: at most 24 biomes (" + std::to_string(TP) +
+                               " pools; the kernels keep a pool's origin mask in two 64-bit words)");
     const size_t vr = (size_t)hx_track_value_rows(B_);
     // (slot 0: the identity of the tracking date; 4 rows of padding: the last chunk of source
     //  columns is read whole)

@@ -3,6 +3,11 @@
 // reference file:line map).
 #pragma once
 
+// a branch the common run does not take: its block is laid out behind the function's hot path, so
+// that the hot path falls through (a taken branch costs a lone wavefront an instruction-fetch
+// bubble of ~20 clocks; ~70 branches a model year, SQ_WAIT_INST_ANY = 6.6 % of the wavefront's time)
+#define HX_RARE(x) __builtin_expect(!!(x), 0)
+
 namespace {
 
 constexpr double PGC2PPM = 1.0 / 2.13;  // carbon-cycle-model.hpp:29

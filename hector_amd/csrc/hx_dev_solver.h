@@ -447,12 +447,12 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
 #endif
     omk &= OM_STASH;
     diag = omk != 0;
-    if (diag) {  // annualflux_sumHL/LL, annual_box_fluxes[HL->DO]: sums over the year's stashes
+    if (HX_RARE(diag)) {  // annualflux_sumHL/LL, annual_box_fluxes[HL->DO]: sums over the year's stashes
       const HxBuffers &buf = *m.bufp;
       dgo = (size_t)m.iy * buf.npad + (blockIdx.x * 64 + m.lane);
-      if (omk & (1ull << HXO_HL_UPTAKE)) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
-      if (omk & (1ull << HXO_LL_UPTAKE)) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
-      if (omk & (1ull << HXO_HL_DO)) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
+      if (HX_RARE(omk & (1ull << HXO_HL_UPTAKE))) HX_GD(buf.out[HXO_HL_UPTAKE])[dgo] += aH;
+      if (HX_RARE(omk & (1ull << HXO_LL_UPTAKE))) HX_GD(buf.out[HXO_LL_UPTAKE])[dgo] += aL;
+      if (HX_RARE(omk & (1ull << HXO_HL_DO))) HX_GD(buf.out[HXO_HL_DO])[dgo] += lHD;
     }
   }
   [[maybe_unused]] TrkStashIn tk;
@@ -577,11 +577,11 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
           const double fda = bio_fda(v[j]), fsa = bio_fsa(v[j]), tpc = bio_tpc(v[j]), tpm = bio_tpm(v[j]);
           const double wt = hx_div_cr(bio_npp(v[j], m.npp_luc_adjust) + ((fda + fsa) + tpc), npp_rh, inv_nr);
           const double wt_pf = hx_div_cr(v[j].pf, pf_t, inv_pf);
-          if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
+          if (HX_RARE(diag)) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
             const double a = fda * rh_adj, bb = fsa * rh_adj, cc = tpc * rh_adj, dd = tpm * rh_adj;
             fin_npp += npp_fin_total * wt;
             fin_rh += ((a + bb) + cc) + dd;
-            if (omk & (1ull << HX_OM_BIOME_FLUX)) {
+            if (HX_RARE(omk & (1ull << HX_OM_BIOME_FLUX))) {
             const HxBuffers &buf = *m.bufp;
             if (buf.out[HXO_B(HXOB_NPP, b)]) HX_GD(buf.out[HXO_B(HXOB_NPP, b)])[dgo] = npp_fin_total * wt;
             if (buf.out[HXO_B(HXOB_RH, b)]) HX_GD(buf.out[HXO_B(HXOB_RH, b)])[dgo] = ((a + bb) + cc) + dd;
@@ -606,12 +606,12 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
         : hx_div_cr(m_npp(m, lk, b) + ((m_rh_fda(m, b) + m_rh_fsa(m, b)) + m_rh_tp_co2(m, lk, b)),
                     npp_rh, inv_nr);
     const double wt_pf = hx_one<B>() ? ((pf_t > 0) ? 1.0 : 0.0) : hx_div_cr(m.pf[b], pf_t, inv_pf);
-    if (diag) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
+    if (HX_RARE(diag)) {  // final_npp / final_rh / final_rh_detritus / final_rh_soil :420-440
       const double a = m_rh_fda(m, b) * rh_adj, bb = m_rh_fsa(m, b) * rh_adj;
       const double cc = m_rh_tp_co2(m, lk, b) * rh_adj, dd = m_rh_tp_ch4(m, lk, b) * rh_adj;
       fin_npp += npp_fin_total * wt;
       fin_rh += ((a + bb) + cc) + dd;
-      if (omk & (1ull << HX_OM_BIOME_FLUX)) {
+      if (HX_RARE(omk & (1ull << HX_OM_BIOME_FLUX))) {
       const HxBuffers &buf = *m.bufp;  // "<biome>.NPP", "<biome>.RH"
       if (buf.out[HXO_B(HXOB_NPP, b)]) HX_GD(buf.out[HXO_B(HXOB_NPP, b)])[dgo] = npp_fin_total * wt;
       if (buf.out[HXO_B(HXOB_RH, b)]) HX_GD(buf.out[HXO_B(HXOB_RH, b)])[dgo] = ((a + bb) + cc) + dd;
@@ -652,7 +652,7 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     }
   } else if constexpr (hx_cons<CON>()) {
     // user-supplied [CO2] at this date: same transfer (:567-603); only whole dates exist
-    if ((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2)) {
+    if (HX_RARE((yc.mask & HXC_CO2) && !in_partial_year && !isnan(yc.co2))) {
       const double match = yc.co2 / PGC2PPM;
       const double residual = m.atmos - match;
       ca_residual = residual;
@@ -661,13 +661,13 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
     }
   }
   if constexpr (CON && !SPIN) {
-    if (diag) {  // the last stash of the year is the one that stays
+    if (HX_RARE(diag)) {  // the last stash of the year is the one that stays
       const HxBuffers &buf = *m.bufp;
-      if (omk & (1ull << HXO_NPP)) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
-      if (omk & (1ull << HXO_RH)) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
-      if (omk & (1ull << HXO_RH_DET)) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
-      if (omk & (1ull << HXO_RH_SOIL)) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
-      if (omk & (1ull << HXO_CA_RESIDUAL)) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
+      if (HX_RARE(omk & (1ull << HXO_NPP))) HX_GD(buf.out[HXO_NPP])[dgo] = fin_npp;
+      if (HX_RARE(omk & (1ull << HXO_RH))) HX_GD(buf.out[HXO_RH])[dgo] = fin_rh;
+      if (HX_RARE(omk & (1ull << HXO_RH_DET))) HX_GD(buf.out[HXO_RH_DET])[dgo] = fin_det;
+      if (HX_RARE(omk & (1ull << HXO_RH_SOIL))) HX_GD(buf.out[HXO_RH_SOIL])[dgo] = fin_soil;
+      if (HX_RARE(omk & (1ull << HXO_CA_RESIDUAL))) HX_GD(buf.out[HXO_CA_RESIDUAL])[dgo] = ca_residual;
     }
   }
   m.ode_start = t;

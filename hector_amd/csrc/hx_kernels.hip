@@ -664,13 +664,15 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // land-ocean warming ratio: the carbon cycle and the ocean see temperatures derived
         // from global tas, DOECLIM keeps its own (temperature_component.cpp:586-625,722-739)
         // (HXC_LO: some member has one -- no load of the parameter row otherwise)
-        double lo = 0.0;
-        if (cmk & HXC_LO) lo = ldp(buf, HXP_LO_RATIO, mem);
-        if (lo != 0 && iy > 1) {
+        // (every lane of the wavefront evaluates it and a lane without a ratio keeps its values:
+        // selects, no divergent region -- lo = 0 divides by 1 - flnd)
+        if (HX_RARE(cmk & HXC_LO)) {
+          const double lo = ldp(buf, HXP_LO_RATIO, mem);
+          const bool on = lo != 0 && iy > 1;
           const double tg = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
           const double toa = tg / ((lo * D_flnd) + (1 - D_flnd));
-          tland = toa * lo;
-          sst = toa / D_bsi;
+          tland = on ? toa * lo : tland;
+          sst = on ? toa / D_bsi : sst;
         }
       }
       double twin = PKM(m, PK_TWIN);
@@ -808,7 +810,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) ex[i] = fitc[i];
       } else if constexpr (FITC) {
-        if (cmk & HXC_LO) chem_constants_fit(TcH, TcL, kc.kfit, ex);
+        if (HX_RARE(cmk & HXC_LO)) chem_constants_fit(TcH, TcL, kc.kfit, ex);
         else {
 #pragma unroll
           for (int i = 0; i < 12; ++i) ex[i] = fitc[i];
@@ -842,19 +844,19 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       }
       const double tau_oh = kc.TOH0 * ex[12];
       if constexpr (CON) {
-      if (omk & (1ull << HXO_TAU_OH)) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
-      if (omk & ((1ull << HXO_HL_UPTAKE) | (1ull << HXO_LL_UPTAKE) | (1ull << HXO_HL_DO))) {
+      if (HX_RARE(omk & (1ull << HXO_TAU_OH))) sto_(buf, HXO_TAU_OH, (size_t)iy * buf.npad + mem, tau_oh);
+      if (HX_RARE(omk & ((1ull << HXO_HL_UPTAKE) | (1ull << HXO_LL_UPTAKE) | (1ull << HXO_HL_DO)))) {
         // sums over the year's stashes start at zero (oceanbox::new_year)
         const size_t o = (size_t)iy * buf.npad + mem;
-        if (omk & (1ull << HXO_HL_UPTAKE)) sto_(buf, HXO_HL_UPTAKE, o, 0.0);
-        if (omk & (1ull << HXO_LL_UPTAKE)) sto_(buf, HXO_LL_UPTAKE, o, 0.0);
-        if (omk & (1ull << HXO_HL_DO)) sto_(buf, HXO_HL_DO, o, 0.0);
+        if (HX_RARE(omk & (1ull << HXO_HL_UPTAKE))) sto_(buf, HXO_HL_UPTAKE, o, 0.0);
+        if (HX_RARE(omk & (1ull << HXO_LL_UPTAKE))) sto_(buf, HXO_LL_UPTAKE, o, 0.0);
+        if (HX_RARE(omk & (1ull << HXO_HL_DO))) sto_(buf, HXO_HL_DO, o, 0.0);
       }
       }
       {
         double ch4_em = ya[3];
         if constexpr (hx_cons<CON>()) {
-          if (msk & (1u << HXM_CH4_EM))
+          if (HX_RARE(msk & (1u << HXM_CH4_EM)))
             ch4_em = HX_GCD(buf.mseries[HXM_CH4_EM])[(size_t)iy * buf.npad + mem];
         }
         const double emisTocon =
@@ -864,9 +866,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         ch4 = prev_ch4 + dCH4;
       }
       if constexpr (hx_cons<CON>()) {  // ch4_component.cpp:156-157
-        if (cmk & HXC_CH4) {
+        if (HX_RARE(cmk & HXC_CH4)) {
           double c = sh[HXSH_CH4_CON];
-          if (msk & (1u << HXM_CH4_CON)) c = HX_GCD(buf.mseries[HXM_CH4_CON])[(size_t)iy * buf.npad + mem];
+          if (HX_RARE(msk & (1u << HXM_CH4_CON))) c = HX_GCD(buf.mseries[HXM_CH4_CON])[(size_t)iy * buf.npad + mem];
           if (!isnan(c)) ch4 = c;
         }
       }
@@ -891,12 +893,12 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       m.ffi = ya[8]; m.daccs = ya[9];
       m.luc_e = ya[10]; m.luc_u = ya[11];
       if constexpr (hx_cons<CON>()) {  // emissions that differ between members
-        if (msk & ((1u << HXM_FFI) | (1u << HXM_DACCS) | (1u << HXM_LUC_E) | (1u << HXM_LUC_U))) {
+        if (HX_RARE(msk & ((1u << HXM_FFI) | (1u << HXM_DACCS) | (1u << HXM_LUC_E) | (1u << HXM_LUC_U)))) {
         const size_t o = (size_t)iy * buf.npad + mem;
-        if (msk & (1u << HXM_FFI)) m.ffi = HX_GCD(buf.mseries[HXM_FFI])[o];
-        if (msk & (1u << HXM_DACCS)) m.daccs = HX_GCD(buf.mseries[HXM_DACCS])[o];
-        if (msk & (1u << HXM_LUC_E)) m.luc_e = HX_GCD(buf.mseries[HXM_LUC_E])[o];
-        if (msk & (1u << HXM_LUC_U)) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
+        if (HX_RARE(msk & (1u << HXM_FFI))) m.ffi = HX_GCD(buf.mseries[HXM_FFI])[o];
+        if (HX_RARE(msk & (1u << HXM_DACCS))) m.daccs = HX_GCD(buf.mseries[HXM_DACCS])[o];
+        if (HX_RARE(msk & (1u << HXM_LUC_E))) m.luc_e = HX_GCD(buf.mseries[HXM_LUC_E])[o];
+        if (HX_RARE(msk & (1u << HXM_LUC_U))) m.luc_u = HX_GCD(buf.mseries[HXM_LUC_U])[o];
         }
       }
       m.npp_luc_adjust = hx_div(eos - m.cum_luc_va, eos);
@@ -1008,12 +1010,12 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           yc.nbp_hi = sh[HXSH_NBP_CON];
           yc.nbp_lo = (sh - HXSH_STRIDE)[HXSH_NBP_CON];
         }
-        if (msk & ((1u << HXM_CO2_CON) | (1u << HXM_NBP_CON))) {  // constraints that differ between members
+        if (HX_RARE(msk & ((1u << HXM_CO2_CON) | (1u << HXM_NBP_CON)))) {  // constraints that differ between members
           const HxBuffers &buf = args->buf;
           const size_t o = (size_t)iy * buf.npad + mem;
-          if (msk & (1u << HXM_CO2_CON)) yc.co2 = HX_GCD(buf.mseries[HXM_CO2_CON])[o];
+          if (HX_RARE(msk & (1u << HXM_CO2_CON))) yc.co2 = HX_GCD(buf.mseries[HXM_CO2_CON])[o];
           if constexpr (hx_nbp<CON>()) {
-          if (msk & (1u << HXM_NBP_CON)) {
+          if (HX_RARE(msk & (1u << HXM_NBP_CON))) {
             yc.nbp_hi = HX_GCD(buf.mseries[HXM_NBP_CON])[o];
             yc.nbp_lo = HX_GCD(buf.mseries[HXM_NBP_CON])[o - buf.npad];
           }
@@ -1125,7 +1127,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         const double a3 = -8.9603e-5, b3 = -1.2462e-4, d3 = 0.045194;
         double sqN = yc4[0], sqN0 = kc.sqrtN0, rf_other = yc4[1];
         if constexpr (hx_cons<CON>()) {  // N2O / halocarbon parameters that differ between members
-          if (msk & (1u << HXM_N2O)) {
+          if (HX_RARE(msk & (1u << HXM_N2O))) {
             sqN = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[(size_t)iy * buf.npad + mem]);
             sqN0 = hx_sqrt(HX_GCD(buf.mseries[HXM_N2O])[mem]);
             rf_other = HX_GCD(buf.mseries[HXM_RF_OTHER])[(size_t)iy * buf.npad + mem];
@@ -1150,9 +1152,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
                        p_aero * yc4[2]) +
                       p_vol * yc4[3];
         if constexpr (hx_cons<CON>()) {  // forcing_component.cpp:498-505
-          if (cmk & HXC_FTOT) {
+          if (HX_RARE(cmk & HXC_FTOT)) {
             double c = sh[HXSH_FTOT_CON];
-            if (msk & (1u << HXM_FTOT_CON)) c = HX_GCD(buf.mseries[HXM_FTOT_CON])[(size_t)iy * buf.npad + mem];
+            if (HX_RARE(msk & (1u << HXM_FTOT_CON))) c = HX_GCD(buf.mseries[HXM_FTOT_CON])[(size_t)iy * buf.npad + mem];
             if (!isnan(c)) ftot = c;
           }
         }
@@ -1230,9 +1232,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         sst_new = dIB2 * X1 + dIB3 * X2;
         tgav = D_flnd * tl_new + (1.0 - D_flnd) * D_bsi * sst_new;
         if constexpr (hx_cons<CON>()) {  // user-supplied temperature :510-525
-          if (cmk & HXC_TAS) {
+          if (HX_RARE(cmk & HXC_TAS)) {
             double c = sh[HXSH_TAS_CON];
-            if (msk & (1u << HXM_TAS_CON)) c = HX_GCD(buf.mseries[HXM_TAS_CON])[(size_t)iy * buf.npad + mem];
+            if (HX_RARE(msk & (1u << HXM_TAS_CON))) c = HX_GCD(buf.mseries[HXM_TAS_CON])[(size_t)iy * buf.npad + mem];
             if (!isnan(c)) {
               tgav = c;
               tl_new = (tgav - (1.0 - D_flnd) * D_bsi * sst_new) / D_flnd;
@@ -1251,16 +1253,14 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       }
       double tl_seen = tland, tl_rep = tl_new, sst_rep = sst_new;  // what D_LAND_TAS / D_SST return
       if constexpr (hx_cons<CON>()) {
-        double lo = 0.0;
-        if (cmk & HXC_LO) lo = ldp(buf, HXP_LO_RATIO, mem);
-        if (lo != 0) {
-          if (iy > 1) {
-            const double tg0 = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
-            tl_seen = (tg0 / ((lo * D_flnd) + (1 - D_flnd))) * lo;
-          }
+        if (HX_RARE(cmk & HXC_LO)) {   // (selects, like at the year start)
+          const double lo = ldp(buf, HXP_LO_RATIO, mem);
+          const bool on = lo != 0;
+          const double tg0 = D_flnd * tland + (1.0 - D_flnd) * D_bsi * sst;
+          tl_seen = (on && iy > 1) ? (tg0 / ((lo * D_flnd) + (1 - D_flnd))) * lo : tl_seen;
           const double toa = tgav / ((lo * D_flnd) + (1 - D_flnd));
-          tl_rep = toa * lo;
-          sst_rep = toa / D_bsi;
+          tl_rep = on ? toa * lo : tl_rep;
+          sst_rep = on ? toa / D_bsi : sst_rep;
         }
       }
       HX_STAMP(m, 13);    // DOECLIM in-block sum + year step
@@ -1279,17 +1279,17 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         const size_t orow = (size_t)iy * buf.npad;
         hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST]) + orow, m.moff, sst_new);
         hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_TLAND]) + orow, m.moff, tl_rep);
-        if constexpr (hx_cons<CON>()) { if (omk & (1ull << HXO_SST_LO)) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
+        if constexpr (hx_cons<CON>()) { if (HX_RARE(omk & (1ull << HXO_SST_LO))) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_SST_LO]) + orow, m.moff, sst_rep); }
         if (buf.out[HXO_CO2]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_CO2]) + orow, m.moff, co2c);
         if (buf.out[HXO_TGAV]) hx_stm<hx_w2<B>()>(HX_GD(buf.out[HXO_TGAV]) + orow, m.moff, tgav);
       } else {
       sto_(buf, HXO_SST, o, sst_new);
       sto_(buf, HXO_TLAND, o, tl_rep);
-      if constexpr (hx_cons<CON>()) { if (omk & (1ull << HXO_SST_LO)) sto_(buf, HXO_SST_LO, o, sst_rep); }
+      if constexpr (hx_cons<CON>()) { if (HX_RARE(omk & (1ull << HXO_SST_LO))) sto_(buf, HXO_SST_LO, o, sst_rep); }
       if (buf.out[HXO_CO2]) sto_(buf, HXO_CO2, o, co2c);
       if (buf.out[HXO_TGAV]) sto_(buf, HXO_TGAV, o, tgav);
       }
-      if (buf.out_rare) {  // (one test instead of ~25 pointer loads and branches a year)
+      if (HX_RARE(buf.out_rare)) {  // (one test instead of ~25 pointer loads and branches a year)
       // (and inside: a bit of HxBuffers::out_mask0 per output instead of its pointer)
       // (in groups: a run that records one diagnostic skips the others a group at a time)
       unsigned long long om = buf.out_mask0;
@@ -1303,47 +1303,47 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           (1ull << HXO_GMST) | (1ull << HXO_FLUX_MIXED) | (1ull << HXO_FLUX_INTERIOR) | (1ull << HXO_C_HL) |
           (1ull << HXO_C_LL) | (1ull << HXO_C_IO) | (1ull << HXO_C_DO) | (1ull << HXO_PCO2_HL) |
           (1ull << HXO_PCO2_LL);
-      if (om & OM_G1) {
-      if ((om & (1ull << HXO_RF_TOT))) sto_(buf, HXO_RF_TOT, o, rf_tot);
-      if ((om & (1ull << HXO_RF_CO2))) sto_(buf, HXO_RF_CO2, o, rf_co2);
-      if ((om & (1ull << HXO_OCEAN_C))) sto_(buf, HXO_OCEAN_C, o, m.cDO + m.cIO + m.cLL + m.cHL);
-      if ((om & (1ull << HXO_HL_PH))) sto_(buf, HXO_HL_PH, o, -log10(m.hH));
-      if ((om & (1ull << HXO_LL_PH))) sto_(buf, HXO_LL_PH, o, -log10(m.hL));
-      if ((om & (1ull << HXO_ATMOS_C))) sto_(buf, HXO_ATMOS_C, o, m.atmos);
-      if ((om & (1ull << HXO_HEATFLUX))) sto_(buf, HXO_HEATFLUX, o, heatflux);
-      if ((om & (1ull << HXO_CH4))) sto_(buf, HXO_CH4, o, ch4);
-      if ((om & (1ull << HXO_O3))) sto_(buf, HXO_O3, o, o3);
-      if ((om & (1ull << HXO_EARTH_C))) sto_(buf, HXO_EARTH_C, o, m.earth);
-      if ((om & (1ull << HXO_NBP))) sto_(buf, HXO_NBP, o, m.nbp);
-      if ((om & (1ull << HXO_OCEAN_UPTAKE))) sto_(buf, HXO_OCEAN_UPTAKE, o, m.annualflux_sum);
-      if ((om & (1ull << HXO_NSTASH))) sto_(buf, HXO_NSTASH, o, (double)m.nstash);
-      if ((om & (1ull << HXO_NSTEPS))) sto_(buf, HXO_NSTEPS, o, (double)m.nsteps);
+      if (HX_RARE(om & OM_G1)) {
+      if (HX_RARE(om & (1ull << HXO_RF_TOT))) sto_(buf, HXO_RF_TOT, o, rf_tot);
+      if (HX_RARE(om & (1ull << HXO_RF_CO2))) sto_(buf, HXO_RF_CO2, o, rf_co2);
+      if (HX_RARE(om & (1ull << HXO_OCEAN_C))) sto_(buf, HXO_OCEAN_C, o, m.cDO + m.cIO + m.cLL + m.cHL);
+      if (HX_RARE(om & (1ull << HXO_HL_PH))) sto_(buf, HXO_HL_PH, o, -log10(m.hH));
+      if (HX_RARE(om & (1ull << HXO_LL_PH))) sto_(buf, HXO_LL_PH, o, -log10(m.hL));
+      if (HX_RARE(om & (1ull << HXO_ATMOS_C))) sto_(buf, HXO_ATMOS_C, o, m.atmos);
+      if (HX_RARE(om & (1ull << HXO_HEATFLUX))) sto_(buf, HXO_HEATFLUX, o, heatflux);
+      if (HX_RARE(om & (1ull << HXO_CH4))) sto_(buf, HXO_CH4, o, ch4);
+      if (HX_RARE(om & (1ull << HXO_O3))) sto_(buf, HXO_O3, o, o3);
+      if (HX_RARE(om & (1ull << HXO_EARTH_C))) sto_(buf, HXO_EARTH_C, o, m.earth);
+      if (HX_RARE(om & (1ull << HXO_NBP))) sto_(buf, HXO_NBP, o, m.nbp);
+      if (HX_RARE(om & (1ull << HXO_OCEAN_UPTAKE))) sto_(buf, HXO_OCEAN_UPTAKE, o, m.annualflux_sum);
+      if (HX_RARE(om & (1ull << HXO_NSTASH))) sto_(buf, HXO_NSTASH, o, (double)m.nstash);
+      if (HX_RARE(om & (1ull << HXO_NSTEPS))) sto_(buf, HXO_NSTEPS, o, (double)m.nsteps);
       }
-      if ((om & (1ull << HXO_PERMAFROST_C)) || (om & (1ull << HXO_VEG_C)) || (om & (1ull << HXO_DET_C)) ||
-          (om & (1ull << HXO_SOIL_C)) || (om & (1ull << HXO_THAWED_C))) {
+      if (HX_RARE(om & ((1ull << HXO_PERMAFROST_C) | (1ull << HXO_VEG_C) | (1ull << HXO_DET_C) |
+                        (1ull << HXO_SOIL_C) | (1ull << HXO_THAWED_C)))) {
         double v = 0, d = 0, s = 0, p = 0, th = 0;
 #pragma unroll hx_ur<B>()
         for (int b = 0; b < nbio<B>(m); ++b) { v += m.veg[b]; d += m.det[b]; s += m.soil[b];
                                        p += m.pf[b]; th += m.thawed[b]; }
-        if ((om & (1ull << HXO_PERMAFROST_C))) sto_(buf, HXO_PERMAFROST_C, o, p);
-        if ((om & (1ull << HXO_VEG_C))) sto_(buf, HXO_VEG_C, o, v);
-        if ((om & (1ull << HXO_DET_C))) sto_(buf, HXO_DET_C, o, d);
-        if ((om & (1ull << HXO_SOIL_C))) sto_(buf, HXO_SOIL_C, o, s);
-        if ((om & (1ull << HXO_THAWED_C))) sto_(buf, HXO_THAWED_C, o, th);
+        if (HX_RARE(om & (1ull << HXO_PERMAFROST_C))) sto_(buf, HXO_PERMAFROST_C, o, p);
+        if (HX_RARE(om & (1ull << HXO_VEG_C))) sto_(buf, HXO_VEG_C, o, v);
+        if (HX_RARE(om & (1ull << HXO_DET_C))) sto_(buf, HXO_DET_C, o, d);
+        if (HX_RARE(om & (1ull << HXO_SOIL_C))) sto_(buf, HXO_SOIL_C, o, s);
+        if (HX_RARE(om & (1ull << HXO_THAWED_C))) sto_(buf, HXO_THAWED_C, o, th);
       }
       if constexpr (CON) {  // diagnostics of the extended kernel
-      if (om & OM_G3) {
-      if ((om & (1ull << HXO_GMST))) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
-      if ((om & (1ull << HXO_FLUX_MIXED))) sto_(buf, HXO_FLUX_MIXED, o, flux_mixed);
-      if ((om & (1ull << HXO_FLUX_INTERIOR))) sto_(buf, HXO_FLUX_INTERIOR, o, flux_interior);
-      if ((om & (1ull << HXO_C_HL))) sto_(buf, HXO_C_HL, o, m.cHL);
-      if ((om & (1ull << HXO_C_LL))) sto_(buf, HXO_C_LL, o, m.cLL);
-      if ((om & (1ull << HXO_C_IO))) sto_(buf, HXO_C_IO, o, m.cIO);
-      if ((om & (1ull << HXO_C_DO))) sto_(buf, HXO_C_DO, o, m.cDO);
-      if ((om & (1ull << HXO_PCO2_HL))) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
-      if ((om & (1ull << HXO_PCO2_LL))) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
+      if (HX_RARE(om & OM_G3)) {
+      if (HX_RARE(om & (1ull << HXO_GMST))) sto_(buf, HXO_GMST, o, D_flnd * tl_new + (1.0 - D_flnd) * sst_new);
+      if (HX_RARE(om & (1ull << HXO_FLUX_MIXED))) sto_(buf, HXO_FLUX_MIXED, o, flux_mixed);
+      if (HX_RARE(om & (1ull << HXO_FLUX_INTERIOR))) sto_(buf, HXO_FLUX_INTERIOR, o, flux_interior);
+      if (HX_RARE(om & (1ull << HXO_C_HL))) sto_(buf, HXO_C_HL, o, m.cHL);
+      if (HX_RARE(om & (1ull << HXO_C_LL))) sto_(buf, HXO_C_LL, o, m.cLL);
+      if (HX_RARE(om & (1ull << HXO_C_IO))) sto_(buf, HXO_C_IO, o, m.cIO);
+      if (HX_RARE(om & (1ull << HXO_C_DO))) sto_(buf, HXO_C_DO, o, m.cDO);
+      if (HX_RARE(om & (1ull << HXO_PCO2_HL))) sto_(buf, HXO_PCO2_HL, o, m.pco2H);
+      if (HX_RARE(om & (1ull << HXO_PCO2_LL))) sto_(buf, HXO_PCO2_LL, o, m.pco2L);
       }
-      if (om & (1ull << HX_OM_BIOME_ANY)) {  // "<biome>.veg_c" ...: pools and factors of each biome
+      if (HX_RARE(om & (1ull << HX_OM_BIOME_ANY))) {  // "<biome>.veg_c" ...: pools and factors of each biome
         LandK<B> lkb;
         load_landk<B>(m, lkb);
 #pragma unroll hx_ur<B>()
@@ -1356,7 +1356,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
           putb(HXOB_TEMPFERTD, m.tempfertd[b]); putb(HXOB_TEMPFERTS, m.tempferts[b]);
         }
       }
-      if ((om & (1ull << HXO_RH_CH4)) || (om & (1ull << HXO_F_FROZEN))) {
+      if (HX_RARE(om & ((1ull << HXO_RH_CH4) | (1ull << HXO_F_FROZEN)))) {
         // record_state: RH_ch4 = rh_ftpa_ch4 of the year-end pools (simpleNbox.cpp:800-812);
         // f_frozen: permafrost-weighted mean over biomes, 1 without permafrost (:492-514)
         LandK<B> lk;
@@ -1368,8 +1368,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
 #pragma unroll hx_ur<B>()
           for (int b = 0; b < nbio<B>(m); ++b) ff += (m.pf[b] / ptot) * ffrozen_of<B>(m, b);
         } else ff = 1.0;
-        if ((om & (1ull << HXO_RH_CH4))) sto_(buf, HXO_RH_CH4, o, rch4);
-        if ((om & (1ull << HXO_F_FROZEN))) sto_(buf, HXO_F_FROZEN, o, ff);
+        if (HX_RARE(om & (1ull << HXO_RH_CH4))) sto_(buf, HXO_RH_CH4, o, rch4);
+        if (HX_RARE(om & (1ull << HXO_F_FROZEN))) sto_(buf, HXO_F_FROZEN, o, ff);
       }
       }
       }  // out_rare
@@ -1393,7 +1393,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         }
       }
       HX_STAMP(m, 14);    // outputs
-      if (buf.hist) {  // Core::reset(date) needs every component's state of every year
+      if (HX_RARE(buf.hist)) {  // Core::reset(date) needs every component's state of every year
         double *slab = buf.hist + (size_t)iy * (size_t)HX_NSTATE(nbio<B>(m)) * buf.npad;
         store_state<B>(buf, mem, m, slab);
         store_park_state<B>(buf, mem, m, slab);

@@ -7,7 +7,7 @@
 #include <stdint.h>
 
 #define HX_MAXB 4          // biome counts with a templated (fully unrolled) kernel: B = 1..4
-#define HX_BDYN 16         // more biomes, up to this many, run the looped kernels (template tag 0):
+#define HX_BDYN 32         // more biomes, up to this many, run the looped kernels (template tag 0):
                            // per-biome arrays in the LDS park, loops over the core's biome count
 #define HX_WAVE 64
 

@@ -45,7 +45,7 @@ const char *hx_last_error(void);
  * `scenario` is a Hector INI file (csv: tables resolved like the reference) or
  * a dense scenario pack (.hxs).  Creates an n_members ensemble on GPU `device`,
  * all members at the INI's parameter values; one biome "global", or the biomes the INI
- * defines with "<biome>.<variable>" keys (at most 16). */
+ * defines with "<biome>.<variable>" keys (at most 32; carbon tracking: 24). */
 int hx_newcore(const char *scenario, int n_members, int device, hx_core **out);
 
 /* The same ensemble over SEVERAL GPUs of the node.  The reference keeps many
@@ -155,8 +155,8 @@ int hx_split_biome_of(hx_core *core, const char *old_biome, int n_biomes,
 /* create_biome_impl / delete_biome_impl / rename_biome  (src/rcpp_hector.cpp:359-400;
  * SimpleNbox::createBiome / deleteBiome / renameBiome, src/simpleNbox.cpp:864-1060).  A created
  * biome has empty pools and npp_flux0 = 0 and the other parameters of the most recent biome
- * (set them with hx_setvar("<biome>.veg_c", ...), like R's create_biome does); at most 16 biomes
- * (1-8 run fully unrolled kernels, 9-16 kernels that loop over the biomes).
+ * (set them with hx_setvar("<biome>.veg_c", ...), like R's create_biome does); at most 32 biomes
+ * (1-8 run fully unrolled kernels, 9-32 kernels that loop over the biomes).
  * All three invalidate the run (spinup again), like any parameter change. */
 int hx_create_biome(hx_core *core, const char *biome);
 int hx_delete_biome(hx_core *core, const char *biome);

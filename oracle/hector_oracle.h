@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HXO_MAXB 16     /* max biomes */
+#define HXO_MAXB 32     /* max biomes */
 #define HXO_NHALO 26
 
 /* output variable ids: out[var * ns + (year - start)] */

@@ -12,7 +12,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 ORACLE_DIR = os.path.dirname(os.path.abspath(__file__))
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libhector_oracle.so")
-MAXB = 16
+MAXB = 32
 
 VARS = ["CO2_concentration", "global_tas", "RF_tot", "RF_CO2", "heatflux", "ocean_c", "HL_pH",
         "atmos_co2", "sst", "permafrost_c", "land_tas", "CH4_concentration", "N2O_concentration",

@@ -116,8 +116,8 @@ def split_of_one_of_several_checks(lib, oracle, **kw):
         hector_amd.split_biome(c, "a", ["x", "y"], fveg_c=[0.5, 0.6])
     with pytest.raises(E):
         hector_amd.split_biome(c, "a", ["x", "b1"])
-    with pytest.raises(E):   # would make seventeen biomes (limit: 16, tests/test_many_biomes.py)
-        hector_amd.split_biome(c, "a", ["n%d" % i for i in range(15)])
+    with pytest.raises(E):   # would make thirty-three biomes (limit: 32, tests/test_many_biomes.py)
+        hector_amd.split_biome(c, "a", ["n%d" % i for i in range(31)])
     return c
 
 

@@ -1,7 +1,8 @@
 """More than four biomes: the reference creates any number of biomes
 (src/simpleNbox.cpp:864-1124, biome_list.push_back at :928; tests/testthat/test_biome.R:127-300);
-1-4 run fully unrolled kernels, 5-16 the looped kernels (template tag HX_DYN: per-biome arrays
-in the LDS park, loops to the core's biome count).  Heterogeneous splits into 5, 8, 11 and 16
+1-8 run fully unrolled kernels, 9-32 the looped kernels (template tag HX_DYN: the biomes' pools
+in the LDS park, loops to the core's biome count; HX_BDYN = 32 since round 5 -- 17 to 32 biomes
+take 41-71 KB of LDS a wavefront, two wavefronts a CU).  Heterogeneous splits into 5 ... 32
 biomes -- unequal pool fractions, per-biome Q10 / warming factor / beta, per member -- against
 the oracle; the identical-split property; per-biome outputs; create / delete keep working."""
 import numpy as np
@@ -120,7 +121,7 @@ def unrolled_equals_looped(lib, monkeypatch, n, run_to, tol=1e-11, **kw):
 
 
 def test_many_biomes_vs_oracle(emul_lib, oracle, monkeypatch):
-    many_biome_checks(emul_lib, oracle, counts=(5, 8, 11), n=2, run_to=2100, allow_emulation=True)
+    many_biome_checks(emul_lib, oracle, counts=(5, 8, 11, 21), n=2, run_to=2100, allow_emulation=True)
     identical_split_equals_global(emul_lib, allow_emulation=True)
     unrolled_equals_looped(emul_lib, monkeypatch, 3, 1900, allow_emulation=True)
 
@@ -139,11 +140,21 @@ def test_many_biomes_api(emul_lib):
     t.split_biome(["a", "b", "c", "d", "e"]); t.setvar("trackingDate", [1800.0]); t.run(1810)
     v, f = t.tracking_data(0, (1800, 1810))
     assert v.shape == (11, 31) and abs(f.sum(axis=2) - 1.0).max() < 1e-12
+    # the caps: 32 biomes (HX_BDYN); carbon tracking up to 24 (128 pools = two mask words a pool)
+    big = hector_amd.Core(SCENARIO, 1, lib_path=emul_lib, allow_emulation=True)
+    big.split_biome(["n%02d" % i for i in range(32)])
+    with pytest.raises(hector_amd.HectorAmdError, match="at most 32 biomes"):
+        big.create_biome("one_more")
+    big.run(1760)
+    assert big.status()[0] == 0
+    big.setvar("trackingDate", [1750.0])
+    with pytest.raises(hector_amd.HectorAmdError, match="at most 24 biomes"):
+        big.reset(1745); big.run(1760)
 
 
 @pytest.mark.gpu
 def test_many_biomes_vs_oracle_on_gpu(hip_lib, oracle):
-    many_biome_checks(hip_lib, oracle, counts=(5, 6, 8, 9, 16), n=6, device=0)
+    many_biome_checks(hip_lib, oracle, counts=(5, 6, 8, 9, 16, 17, 32), n=6, device=0)
     identical_split_equals_global(hip_lib, device=0)
 
 
