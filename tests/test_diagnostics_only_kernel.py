@@ -17,6 +17,9 @@ DIAG = ["NPP", "RH", "rh_det", "rh_soil", "rh_ch4", "f_frozen", "atmos_c_residua
         "IO_ocean_c", "DO_ocean_c", "HL_downwelling", "HL_PCO2", "LL_PCO2", "HL_pH", "TAU_OH",
         "permafrost_c", "thawedp_c", "NBP", "RF_tot"]
 REL = 2e-9   # (two instantiations contract different multiply-adds: 7e-11 seen; identical step sequences are asserted)
+# air-sea fluxes are (CO2 - pCO2) x a large exchange coefficient: a 7e-11 difference in CO2 shows
+# as 1e-7 of the flux (2.3e-7 PgC/yr seen on the GPU); NBP is a small difference of NPP and RH
+FLUX = {v: 500.0 for v in ("HL_ocean_uptake", "LL_ocean_uptake", "ocean_uptake", "NBP")}
 
 
 def _run(lib, n, outs, monkeypatch, cons, biomes=1, two_wave=0, diff=False, scen=SCENARIO, lo=False, **kw):
@@ -62,7 +65,7 @@ def _check(lib, monkeypatch, n, tmp_path, **kw):
         assert np.array_equal(a["timesteps"], b["timesteps"])
         for v in a:
             scale = np.abs(b[v]).max() + 1e-30
-            assert np.abs(a[v] - b[v]).max() / scale < REL, (biomes, two_wave, diff, v)
+            assert np.abs(a[v] - b[v]).max() / scale < REL * FLUX.get(v, 1.0), (biomes, two_wave, diff, v)
     # the carbon cycle is the plain kernel's
     p, vp, _ = _run(lib, n, base, monkeypatch, False, **kw)
     d, vd, _ = _run(lib, n, base + ["NPP"], monkeypatch, False, **kw)
