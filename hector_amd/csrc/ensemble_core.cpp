@@ -1584,6 +1584,11 @@ bool EnsembleCore::predict_cost(const std::vector<int> &varying, std::vector<dou
 // tracking, at least hx_set_two_wave_from() members (default: more wavefronts than SIMDs).
 bool EnsembleCore::two_wave_expected() const {
   const int w2_from = two_wave_from_ < 0 ? simds_ * HX_WAVE + 1 : two_wave_from_;
+  // (members with their own ocean diffusivity: by default the one-wavefront kernel in two rounds --
+  // since round 5 it requests a member's kernel-table entries ahead of their use, which the
+  // two-wavefront flavour has no registers for: 131 072 such members 13.5 against 14.3 ms;
+  // hx_set_two_wave_from with an explicit size still takes the flavour)
+  if (two_wave_from_ < 0 && !row_uniform_[HXP_DIFF]) return false;
   return B_ == 1 && trk_iy() < 0 && !d_track_out_f_ && w2_from > 0 && n_ >= w2_from;
 }
 

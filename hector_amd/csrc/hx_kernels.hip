@@ -169,6 +169,61 @@ __device__ __forceinline__ void doeclim_pass_dev(const double *sst_hist,
     for (int j = 0; j < NA; ++j) { acc[j] = 0; acc2[j] = 0; }
     // window entry w of chunk i0 = Ker[(ns - (blk0 + j0) - 1) + i0 - 15 + w]
     const int k0 = ns - (blk0 + j0) - 1 - 15 + HX_KPAD;
+#ifndef HX_PASS_NO_HALVES
+    if constexpr (KERPM && NA == 16) {
+      // Per-member kernel tables, one wavefront per SIMD (round 5).  The window of a chunk of 16
+      // history years is 32 entries of THIS member's table -- vector loads -- of which the upper
+      // 16 are the next chunk's lower 16: the window moves through the table in HALVES of 16
+      // (half q = entries k0 + 16 q ... + 15; chunk c uses halves c / 16 and c / 16 + 1), each
+      // loaded once, and like the history itself one chunk AHEAD of its use -- the old form asked
+      // for all 32 right before the chunk's 256 multiply-adds, one exposed HBM latency per chunk.
+      // Four names in turn (P Q / Q R / R S / S P), so that no half is ever copied.
+      if (blk0 + j0 < ns) {
+        auto load_T = [&](double (&T)[16], int i0) {
+#pragma unroll
+          for (int ii = 0; ii < 16; ++ii) {
+            const int i = i0 + ii;
+            const double v = hist[(size_t)(i < ns ? i : ns - 1) * np];   // (rows >= hist_end may be stale)
+            T[ii] = (i < hist_end) ? v : 0.0;
+          }
+        };
+        auto load_H = [&](double (&H)[16], int q) {
+#pragma unroll
+          for (int x = 0; x < 16; ++x) H[x] = HX_GCD(ker)[(size_t)(k0 + 16 * q + x) * np + mem];
+        };
+        auto compute = [&](const double (&T)[16], const double (&lo)[16], const double (&hi)[16]) {
+#pragma unroll
+          for (int ii = 0; ii < 16; ++ii) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int w = 15 + ii - j, w2 = 16 + ii - j;
+              acc[j] += T[ii] * (w < 16 ? lo[w] : hi[w - 16]);
+              if (HF) acc2[j] += T[ii] * (w2 < 16 ? lo[w2] : hi[w2 - 16]);
+            }
+          }
+        };
+        double Ta[16], Tb[16], P[16], Q[16], R[16], S[16];
+        load_T(Ta, 0); load_H(P, 0); load_H(Q, 1);
+        for (int i0 = 0; i0 < hist_end; i0 += 64) {
+          const int q = i0 >> 4;
+          load_T(Tb, i0 + 16); load_H(R, q + 2);
+          compute(Ta, P, Q);
+          if (i0 + 16 < hist_end) {
+            load_T(Ta, i0 + 32); load_H(S, q + 3);
+            compute(Tb, Q, R);
+            if (i0 + 32 < hist_end) {
+              load_T(Tb, i0 + 48); load_H(P, q + 4);
+              compute(Ta, R, S);
+              if (i0 + 48 < hist_end) {
+                load_T(Ta, i0 + 64); load_H(Q, q + 5);
+                compute(Tb, S, P);
+              }
+            }
+          }
+        }
+      }
+    } else
+#endif
     if (blk0 + j0 < ns) {
       // software pipeline: the 16 loads of the next chunk are in flight while the
       // 256 FMAs of the current one execute
@@ -574,6 +629,18 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   // and the block's history partial sum -- and with one wavefront on the SIMD a load's latency is
   // waited out in full: they are requested a phase ahead, before the solver (pf_*).
   double pf_tl_old = 0.0, pf_dpart = 0.0;
+  // Per-member diffusivity: the in-block terms of the history sum multiply the block's SSTs with
+  // THIS member's kernel entries of lags 1 ... 32 -- rows of the [ns][npad] kernel table, vector
+  // loads where the shared table takes scalar ones, and a lone wavefront waited out one HBM
+  // latency per chunk of eight (2.5 a model year).  They are requested before the solver like the
+  // two values above and wait in registers (33 doubles; the KERPM kernels have them to spare):
+  // 65 536 members with their own diffusivity 8.56 -> see profiles/r05_variant_log.md 11.
+  constexpr bool KPF = KERPM && !hx_w2<B>() && hx_nbc<B>() >= 1 && hx_nbc<B>() <= 4;
+  [[maybe_unused]] double kpf[KPF ? HX_DBLK + 1 : 1];
+  if constexpr (KPF) {
+#pragma unroll
+    for (int r = 0; r <= HX_DBLK; ++r) kpf[r] = 0.0;   // (an entry not loaded yet multiplies a zero SST)
+  }
   if constexpr (!hx_w2<B>()) {
     const int iold0 = iy_from + 1 - 203;
     pf_tl_old = HX_GCD(args->buf.out[HXO_TLAND])[(size_t)(iold0 >= 1 ? iold0 : 0) * args->buf.npad + mem];
@@ -993,6 +1060,20 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
         pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iy - blk0) * buf.npad + mem];
         }
+        if constexpr (KPF) {  // this year's in-block kernel entries (chunks of eight, like their use)
+          const int jbp = newblk ? 0 : iy - blk0;
+          const int kqp = args->kc.ns - iy - 1 + HX_KPAD + (newblk ? 0 : blk0);
+#pragma unroll
+          for (int c = 0; c < HX_DBLK / 8; ++c) {
+            if (8 * c < jbp + (HF ? 1 : 0)) {   // (the heat-flux sum reads one entry further)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                if constexpr (hx_rowio<B>()) kpf[8 * c + r] = hx_ldm(HX_GCD(buf.ker) + (size_t)(kqp + 8 * c + r) * buf.npad, m.moff);
+                else kpf[8 * c + r] = HX_GCD(buf.ker)[(size_t)(kqp + 8 * c + r) * buf.npad + mem];
+              }
+            }
+          }
+        }
         hx_ccd shc = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
         yc4[0] = shc[HXSH_SQRT_N2O]; yc4[1] = shc[HXSH_RF_OTHER]; yc4[2] = shc[HXSH_RF_AERO]; yc4[3] = shc[HXSH_RF_VOL];
         load_year_a(iy + 1);
@@ -1192,13 +1273,30 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
               double K[8], K2[8];
 #pragma unroll
               for (int r = 0; r < 8; ++r) {
+                if constexpr (KPF) {
+                  K[r] = kpf[8 * c + r];
+                  K2[r] = want_hf ? kpf[8 * c + r + 1] : 0.0;
+                } else {
                 K[r] = ldk(kq + i0 + r);
                 K2[r] = want_hf ? ldk(kq + i0 + r + 1) : 0.0;
+                }
               }
 #pragma unroll
               for (int r = 0; r < 8; ++r) {
                 dpast += Tall[8 * c + r] * K[r];
                 if (want_hf) hint += Tall[8 * c + r] * K2[r];
+              }
+            }
+          }
+        } else if constexpr (KPF) {   // (one biome: the SSTs from the LDS tile, the entries from kpf)
+#pragma unroll
+          for (int c = 0; c < HX_DBLK / 8; ++c) {
+            if (c < nchunk) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const double t = s_tblk[8 * c + r][lane];   // (zeros from this year on)
+                dpast += t * kpf[8 * c + r];
+                if (want_hf) hint += t * kpf[8 * c + r + 1];
               }
             }
           }

@@ -16,10 +16,12 @@ DIAG = ["NPP", "RH", "rh_det", "rh_soil", "rh_ch4", "f_frozen", "atmos_c_residua
         "HL_ocean_uptake", "LL_ocean_uptake", "ocean_uptake", "HL_ocean_c", "LL_ocean_c",
         "IO_ocean_c", "DO_ocean_c", "HL_downwelling", "HL_PCO2", "LL_PCO2", "HL_pH", "TAU_OH",
         "permafrost_c", "thawedp_c", "NBP", "RF_tot"]
-REL = 2e-9   # (two instantiations contract different multiply-adds: 7e-11 seen; identical step sequences are asserted)
+REL = 2e-8   # (what tests/test_diagnostics.py holds every diagnostic to against the oracle: two instantiations
+             # contract different multiply-adds -- 7e-11 in CO2, 1.2e-8 in a box's pCO2, whose carbonate
+             # solve stops at that size; identical step sequences are asserted)
 # air-sea fluxes are (CO2 - pCO2) x a large exchange coefficient: a 7e-11 difference in CO2 shows
 # as 1e-7 of the flux (2.3e-7 PgC/yr seen on the GPU); NBP is a small difference of NPP and RH
-FLUX = {v: 500.0 for v in ("HL_ocean_uptake", "LL_ocean_uptake", "ocean_uptake", "NBP")}
+FLUX = {v: 50.0 for v in ("HL_ocean_uptake", "LL_ocean_uptake", "ocean_uptake", "NBP")}
 
 
 def _run(lib, n, outs, monkeypatch, cons, biomes=1, two_wave=0, diff=False, scen=SCENARIO, lo=False, **kw):
