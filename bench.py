@@ -53,6 +53,11 @@ Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
                    two-wavefront kernel's range; 131 072
                    members = configs[3]'s per-GPU share; 65 536 members x 4 biomes), 5 steps
                    each, timed the same way after the headline (N = 1 only)
+  workload_variants -- the headline ensemble with what users commonly add to it, timed the same
+                   way (N = 1 only; not BASELINE configurations): the NPP diagnostic recorded (the
+                   plain kernel + diagnostics instantiations), every member its own ocean heat
+                   diffusivity (per-member DOECLIM kernel tables: the history contraction on the
+                   vector ALU)
   cpu_baseline  -- the CPU oracle (a scalar C port of the reference loop, pinned to the
                    reference's golden trajectory) on a bounded sample of the same ensemble,
                    all host cores, 555-year loop only
@@ -251,11 +256,18 @@ def wave_time(core):
             "span_ms": float(w[:, 1].max() - w[:, 0].min())}
 
 
-def time_config(n, biomes, steps, warmup, device):
-    """One extra configuration, timed like the headline: -> dict for other_configs."""
+def time_config(n, biomes, steps, warmup, device, variant=None):
+    """One extra configuration, timed like the headline: -> dict for other_configs.
+    variant: None, "npp" (the NPP diagnostic recorded: the plain kernel + diagnostics family) or
+    "diff" (every member its own ocean heat diffusivity: per-member DOECLIM kernel tables)."""
     import numpy as np
     import torch
     core = make_core(n, biomes, 0, device)
+    if variant == "npp":
+        core.set_outputs(["CO2_concentration", "global_tas", "NPP"])
+    elif variant == "diff":
+        from hector_amd import ensemble
+        core.setvar("diff", 1.2 + 2.2 * ensemble.uniform01(np.arange(n, dtype=np.uint64), 5), "cm2/s")
     start, end = core.strtdate, core.enddate
     stats = torch.zeros((2, end - start + 1, 5), dtype=torch.float64, device="cuda:%d" % device)
 
@@ -284,6 +296,12 @@ def time_config(n, biomes, steps, warmup, device):
     core.shutdown()
     kernel_ms = float(np.mean(kms))
     rf = roofline_object(n, biomes, kernel_ms, which)
+    if variant:   # (no counter profile of these instantiations: time only)
+        return {"members": n, "biomes": biomes, "variant": {"npp": "NPP diagnostic recorded",
+                                                             "diff": "per-member ocean heat diffusivity"}[variant],
+                "steps": steps, "ms_per_step": elapsed / steps * 1e3, "kernel": which, "kernel_ms": kernel_ms,
+                "first_run_kernel_ms": first_ms, "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
+                "members_with_model_errors": bad}
     return {"members": n, "biomes": biomes, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
             "kernel": rf["kernel"], "kernel_ms": kernel_ms, "first_run_kernel_ms": first_ms,
             "lanes_ordered_by": lanes_by, "first_run_lanes_ordered_by": first_by,
@@ -687,6 +705,9 @@ def main():
                     continue
                 others.append(time_config(m2, b2, 5, 1, local_rank))
             out["other_configs"] = others
+            # the headline ensemble with what users commonly add to it (not BASELINE configurations)
+            out["workload_variants"] = [time_config(n, args.biomes, 5, 1, local_rank, variant=v)
+                                        for v in ("npp", "diff")] if args.biomes == 1 else []
             for o in others:   # (one biome: the ensemble sizes of the --gpus N series and configs[1])
                 if o["biomes"] == args.biomes:
                     out["value_per_gpu_workload"][str(o["members"])] = o["value"]
