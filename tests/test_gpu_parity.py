@@ -571,9 +571,9 @@ def test_stats_kernel_on_ragged_member_counts(hip_lib, n):
     assert np.array_equal(got[:, 3:], ref[:, 3:])
 
 
-def test_every_run_kernel_instantiation_launches_on_gpu(hip_lib, oracle):
+def test_every_run_kernel_instantiation_launches_on_gpu(hip_lib, oracle, monkeypatch):
     """hx_run_kernel has 38 instantiations (1-4 biomes and the looped kernel x heat-flux sum x
-    per-member DOECLIM kernel table x plain / extended / tracking).  Each is run here to 2300 on
+    per-member DOECLIM kernel table x plain / plain + diagnostics / extended / tracking).  Each is run here to 2300 on
     TWO wavefronts (128 members) holding the oracle's default member and two perturbed ones (one
     of them in the second wavefront), and compared with the oracle over the whole run -- the guard
     against the compiler: a build of one instantiation that misbehaves on the device (round 2 met
@@ -593,9 +593,14 @@ def test_every_run_kernel_instantiation_launches_on_gpu(hip_lib, oracle):
     base_diff = None
     for nb in (1, 2, 3, 4, 6):   # 6: the looped kernels (5-16 biomes), which carry no tracking
         for kpm in (False, True):
-            for mode in ("plain", "hf", "ext", "track"):
-                if nb > 4 and mode == "track":
+            for mode in ("plain", "hf", "diag", "ext", "track"):
+                if nb > 4 and mode in ("track", "diag"):   # (diagnostics-only family: 1-4 biomes)
                     continue
+                # "ext": the extended kernel proper, although only a diagnostic asks for it
+                if mode == "ext":
+                    monkeypatch.setenv("HECTOR_AMD_EXTENDED_CONS", "1")
+                else:
+                    monkeypatch.delenv("HECTOR_AMD_EXTENDED_CONS", raising=False)
                 c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
                 c.set_pair_kernel_limit(0)
                 if nb > 1:
@@ -612,13 +617,14 @@ def test_every_run_kernel_instantiation_launches_on_gpu(hip_lib, oracle):
                 outs = ["CO2_concentration", "global_tas", "timesteps"]
                 if mode == "hf":
                     outs.append("heatflux")
-                if mode == "ext":
+                if mode in ("ext", "diag"):
                     outs.append("NPP")
                 if mode == "track":
                     c.setvar("trackingDate", [1800.0])
                 c.set_outputs(outs)
                 c.run(2300)
                 assert c.last_run_kernel() == "run"
+                assert c.last_run_variant() == {"plain": 0, "hf": 0, "diag": -2, "ext": -1, "track": 2}[mode]
                 assert (c.status() == 0).all(), (nb, kpm, mode)
                 co2 = c.fetchvars("CO2_concentration", (1745, 2300))
                 tg = c.fetchvars("global_tas", (1745, 2300))
