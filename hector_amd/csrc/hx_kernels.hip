@@ -679,6 +679,25 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
   }
 #endif
 
+  // Two to four biomes (parked arrays, no table rows in scalar form): the biomes' warming factors
+  // and ln Q10 -- constants of the launch, and the only HBM values the year start asked for, one
+  // exposed round trip a model year -- are read once and stay in 2 x NB registers.
+#ifndef HX_NO_CWF
+  constexpr bool CWF = !hx_w2<B>() && !hx_tbl<B>() && hx_nbc<B>() >= 2 && hx_nbc<B>() <= 4;
+#else
+  constexpr bool CWF = false;
+#endif
+  // (The block's SSTs, which these kernels re-read from the output array every year, requested
+  // before the solver as well -- 64 more registers through the step loop -- lose 1.3 %:
+  // profiles/r05_variant_log.md 13.)
+  [[maybe_unused]] double c_wf[CWF ? hx_nbc<B>() : 1], c_lnq[CWF ? hx_nbc<B>() : 1];
+  if constexpr (CWF) {
+#pragma unroll
+    for (int b = 0; b < hx_nbc<B>(); ++b) {
+      c_wf[b] = ldp(args->buf, HXP_NGLOBAL + b * HXPB_N + HXPB_WF, mem);
+      c_lnq[b] = ldd(args->buf, HXD_NGLOBAL + b, mem);
+    }
+  }
   // Extended kernels: which constraints / per-member series / outputs exist -- HxConst::con_mask,
   // HxBuffers::ms_mask, ::out_mask0 -- read ONCE and kept in scalar registers (laundered through an
   // empty asm so that they stay values, not loads): a scalar load + test inside the year loop waits
@@ -789,7 +808,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
             if constexpr (hx_tbl<B>()) return w2_ld(buf.params, m.npad, row, m.moff);
             else return ldp(buf, row, mem);
           };
-          p_wf[b] = ldpm(pr + HXPB_WF);
+          if constexpr (CWF) p_wf[b] = c_wf[b];
+          else p_wf[b] = ldpm(pr + HXPB_WF);
           if (buf.uni_bio) {  // beta, permafrost mu/sigma uniform over members: scalar loads
             hx_ccd u = HX_CCD(buf.uparams) + pr;
             p_beta[b] = u[HXPB_BETA]; p_mu[b] = u[HXPB_PF_MU]; p_sigma[b] = u[HXPB_PF_SIGMA];
@@ -798,7 +818,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
             p_mu[b] = ldpm(pr + HXPB_PF_MU);
             p_sigma[b] = ldpm(pr + HXPB_PF_SIGMA);
           }
-          if constexpr (hx_tbl<B>()) p_lnq10[b] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
+          if constexpr (CWF) p_lnq10[b] = c_lnq[b];
+          else if constexpr (hx_tbl<B>()) p_lnq10[b] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
           else p_lnq10[b] = ldd(buf, HXD_NGLOBAL + b, mem);
           if (m.upar) {
             lk.fpf_static[b] = m.upar[pr + HXPB_FPF_STATIC];
