@@ -195,6 +195,93 @@ __device__ __forceinline__ void chunk_loop(int nb, L load, W work) {
     work(b0, v);
   }
 }
+// Round 5: the TABLE part of a chunk's values one chunk ahead.  A chunk's values come from three
+// places -- the LDS park (the pools: ~64 clocks), scalar loads (the biome constants every member
+// shares) and HBM rows (the thawed pool, tempferts, tempfertd, co2fert, f_new_thaw; the biome
+// constants when they differ between members) -- and a chunk's work ends in stores to such rows,
+// behind which the next chunk's loads queue (one counter, in order): the section clock put a
+// chunk of any of these loops at ~4.5 k ticks whatever it computed, two HBM round trips.  Only the
+// HBM part (5 to 11 doubles a biome, not the 15 of the attempt recorded above) is requested a
+// chunk ahead -- before the current chunk's stores -- and copied over when its turn comes; a
+// chunk's biomes are never the ones the previous chunk stores to (the tail's clamp stays inside
+// the last chunk).  -DHX_DYN_NO_AHEAD: the old form.
+struct BioTab {
+  double thw, tfs, tfd, co2f, fnt, k[6];
+};
+template <bool FLOWS>
+__device__ __forceinline__ void load_bio_tab(const Member<HX_DYN> &m, const LandK<HX_DYN> &lk, int b, BioTab &h) {
+  h.thw = m.thawed[b]; h.tfs = m.tempferts[b]; h.tfd = m.tempfertd[b]; h.co2f = m.co2fert[b];
+  if constexpr (FLOWS) h.fnt = m.f_new_thaw[b];
+  // (a zero the compiler takes for a vector value: left undefined in the uniform case, the slots --
+  // carried from one chunk to the next -- were assigned scalar registers, "illegal VGPR to SGPR copy")
+  double z = 0.0;
+#ifndef HX_HOST_EMULATION
+  asm("" : "+v"(z));
+#endif
+  if (!m.upar) {   // (the biome constants differ between members: rows of the parameter table)
+    // (the member's rows themselves, not ParamCol's choice between them and the uniform table)
+    const ParamCol &c = lk.npp0;
+    const int r = HXP_NGLOBAL + b * HXPB_N;
+    h.k[0] = w2_ld(c.par, c.npad, r + HXPB_NPP0, c.moff);
+    h.k[1] = w2_ld(c.par, c.npad, r + HXPB_FPF_STATIC, c.moff);
+    h.k[2] = w2_ld(c.par, c.npad, r + HXPB_RH_CH4_FRAC, c.moff);
+    if constexpr (FLOWS) {
+      h.k[3] = w2_ld(c.par, c.npad, r + HXPB_F_NPPV, c.moff);
+      h.k[4] = w2_ld(c.par, c.npad, r + HXPB_F_NPPD, c.moff);
+      h.k[5] = w2_ld(c.par, c.npad, r + HXPB_F_LITTERD, c.moff);
+    }
+  } else {
+    h.k[0] = h.k[1] = h.k[2] = z;
+    if constexpr (FLOWS) h.k[3] = h.k[4] = h.k[5] = z;
+  }
+  if constexpr (!FLOWS) { h.fnt = z; h.k[3] = h.k[4] = h.k[5] = z; }
+}
+template <bool FLOWS>
+__device__ __forceinline__ void load_bio_rest(const Member<HX_DYN> &m, const LandK<HX_DYN> &lk, int b,
+                                              const BioTab &h, BioIn &v) {
+  v.det = m.det[b]; v.soil = m.soil[b]; v.pf = m.pf[b]; v.thw = h.thw;
+  if constexpr (FLOWS) v.veg = m.veg[b];
+  v.tfs = h.tfs; v.tfd = h.tfd; v.co2f = h.co2f;
+  if constexpr (FLOWS) v.fnt = h.fnt;
+  if (m.upar) {   // (scalar loads from the uniform table)
+    hx_ccd u = m.upar + (HXP_NGLOBAL + b * HXPB_N);
+    v.npp0 = u[HXPB_NPP0]; v.fpf = u[HXPB_FPF_STATIC]; v.rch4 = u[HXPB_RH_CH4_FRAC];
+    if constexpr (FLOWS) { v.f_nppv = u[HXPB_F_NPPV]; v.f_nppd = u[HXPB_F_NPPD]; v.f_litterd = u[HXPB_F_LITTERD]; }
+  } else {
+    v.npp0 = h.k[0]; v.fpf = h.k[1]; v.rch4 = h.k[2];
+    if constexpr (FLOWS) { v.f_nppv = h.k[3]; v.f_nppd = h.k[4]; v.f_litterd = h.k[5]; }
+  }
+}
+template <bool FLOWS, class W>
+__device__ __forceinline__ void chunk_loop_bio(const Member<HX_DYN> &m, const LandK<HX_DYN> &lk, int nb, W work) {
+#ifdef HX_DYN_NO_AHEAD
+  chunk_loop<BioIn>(
+      nb,
+      [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
+#pragma unroll
+        for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<FLOWS>(m, lk, min(b0 + j, nb - 1), v[j]);
+      },
+      work);
+#else
+  BioTab nxt[HX_DYN_CHUNK];
+#pragma unroll
+  for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio_tab<FLOWS>(m, lk, min(j, nb - 1), nxt[j]);
+  for (int b0 = 0; b0 < nb; b0 += HX_DYN_CHUNK) {
+    BioTab cur[HX_DYN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < HX_DYN_CHUNK; ++j) cur[j] = nxt[j];
+    if (b0 + HX_DYN_CHUNK < nb) {
+#pragma unroll
+      for (int j = 0; j < HX_DYN_CHUNK; ++j)
+        load_bio_tab<FLOWS>(m, lk, min(b0 + HX_DYN_CHUNK + j, nb - 1), nxt[j]);
+    }
+    BioIn v[HX_DYN_CHUNK];
+#pragma unroll
+    for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio_rest<FLOWS>(m, lk, min(b0 + j, nb - 1), cur[j], v[j]);
+    work(b0, v);
+  }
+#endif
+}
 // the fluxes of one biome from its values (m_npp ... m_rh_tp_ch4 above, operation by operation)
 __device__ __forceinline__ double bio_npp(const BioIn &v, double adj) { return (v.npp0 * v.co2f) * adj; }
 __device__ __forceinline__ double bio_fda(const BioIn &v) { return (v.det * 0.25) * v.tfd; }
@@ -244,12 +331,8 @@ __device__ __forceinline__ void compute_flows_chunked(const Member<HX_DYN> &m, c
                                                       Flows &F) {
   flows_zero(F);
   const int nb = m.nb;
-  chunk_loop<BioIn>(
-      nb,
-      [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
-#pragma unroll
-        for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<true>(m, lk, min(b0 + j, nb - 1), v[j]);
-      },
+  chunk_loop_bio<true>(
+      m, lk, nb,
       [&](int b0, const BioIn (&v)[HX_DYN_CHUNK]) {
 #pragma unroll
         for (int j = 0; j < HX_DYN_CHUNK; ++j)
@@ -480,12 +563,8 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   const int NB = nbio<B>(m);
   [[maybe_unused]] double sp_rd = 0, sp_rs = 0, sp_rc = 0;  // spinup record: final_rh_detritus / _soil, thawed part
   if constexpr (B == HX_DYN) {   // (looped kernels: a chunk's values requested together, see load_bio)
-    chunk_loop<BioIn>(
-        NB,
-        [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
-#pragma unroll
-          for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<false>(m, lk, min(b0 + j, NB - 1), v[j]);
-        },
+    chunk_loop_bio<false>(
+        m, lk, NB,
         [&](int b0, const BioIn (&v)[HX_DYN_CHUNK]) {
 #pragma unroll
           for (int j = 0; j < HX_DYN_CHUNK; ++j) {
@@ -563,12 +642,8 @@ __device__ __forceinline__ void stash(Member<B> &m, double t, const double *y,
   [[maybe_unused]] Flows Fn;   // looped kernels: the next interval's land flows, from the new pools
   if constexpr (B == HX_DYN) {
     flows_zero(Fn);
-    chunk_loop<BioIn>(
-        NB,
-        [&](int b0, BioIn (&v)[HX_DYN_CHUNK]) {
-#pragma unroll
-          for (int j = 0; j < HX_DYN_CHUNK; ++j) load_bio<true>(m, lk, min(b0 + j, NB - 1), v[j]);
-        },
+    chunk_loop_bio<true>(
+        m, lk, NB,
         [&](int b0, const BioIn (&v)[HX_DYN_CHUNK]) {
 #pragma unroll
       for (int j = 0; j < HX_DYN_CHUNK; ++j) {

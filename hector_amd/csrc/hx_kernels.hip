@@ -997,21 +997,36 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         // fractions evaluated as batches (hx_dev_math.h), then stored (hx_dev_solver.h: load_bio)
         constexpr int CH = HX_DYN_CHUNK;
         const int nb = m.nb;
+        // (the chunk's table values one chunk ahead, like the solver's chunk loops: hx_dev_solver.h,
+        // chunk_loop_bio -- a chunk ends in stores to such rows)
+        struct ATab { double wf, lnq, beta, pmu, psg, ffz, tfl; };
+        auto load_atab = [&](int c0, ATab (&t)[CH]) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const int b = min(c0 + j, nb - 1);
+            const int pr = HXP_NGLOBAL + b * HXPB_N;
+            t[j].wf = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
+            t[j].lnq = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
+            t[j].beta = w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff);
+            t[j].pmu = w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
+            t[j].psg = w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
+            t[j].ffz = ffrozen_of<B>(m, b);
+            t[j].tfl = m.tempferts[b];
+          }
+        };
+        ATab anxt[CH];
+        load_atab(0, anxt);
         for (int b0 = 0; b0 < nb; b0 += CH) {
           double wf[CH], lnq[CH], beta[CH], pmu[CH], psg[CH], pfv[CH], ffz[CH], tfl[CH];
 #pragma unroll
           for (int j = 0; j < CH; ++j) {
-            const int b = min(b0 + j, nb - 1);
-            const int pr = HXP_NGLOBAL + b * HXPB_N;
-            wf[j] = w2_ld(buf.params, m.npad, pr + HXPB_WF, m.moff);
-            lnq[j] = w2_ld(buf.derived, m.npad, HXD_NGLOBAL + b, m.moff);
-            beta[j] = w2_ld(buf.params, m.npad, pr + HXPB_BETA, m.moff);
-            pmu[j] = w2_ld(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
-            psg[j] = w2_ld(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
-            pfv[j] = m.pf[b];
-            ffz[j] = ffrozen_of<B>(m, b);
-            tfl[j] = m.tempferts[b];
+            wf[j] = anxt[j].wf; lnq[j] = anxt[j].lnq; beta[j] = anxt[j].beta; pmu[j] = anxt[j].pmu;
+            psg[j] = anxt[j].psg; ffz[j] = anxt[j].ffz; tfl[j] = anxt[j].tfl;
+            pfv[j] = m.pf[min(b0 + j, nb - 1)];
           }
+#ifndef HX_DYN_NO_AHEAD_A
+          if (b0 + CH < nb) load_atab(b0 + CH, anxt);
+#endif
           double Tbc[CH], exc[2 * CH], lgc[CH], dfc[CH], ffc[CH];
 #pragma unroll
           for (int j = 0; j < CH; ++j) {
@@ -1040,6 +1055,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
               m.tempferts[b] = fmax(exc[2 * j + 1], last);
             }
           }
+#ifdef HX_DYN_NO_AHEAD_A
+          if (b0 + CH < nb) load_atab(b0 + CH, anxt);
+#endif
         }
       }
       // the frozen fractions of all biomes as one batch (hx_dev_math.h); a biome at or below
