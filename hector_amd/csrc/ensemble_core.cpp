@@ -1965,7 +1965,8 @@ void EnsembleCore::run(double runtodate) {
   if (con == -1 && con_mask == 0 && !getenv("HECTOR_AMD_EXTENDED_CONS")) {
     bool any_ms = false;
     for (int k = 0; k < HXM_N; ++k) if (d_mseries_[k]) any_ms = true;
-    if (!any_ms) con = -2;
+    // (built for one to four biomes and the two-wavefront flavour: hx_kernels.hip, launch_run_b)
+    if (!any_ms && B_ >= 1 && B_ <= 4) con = -2;
   }
   if (d_track_out_f_) {
     if (con_mask & (HXC_CO2 | HXC_NBP))
