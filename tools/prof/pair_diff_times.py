@@ -1,7 +1,13 @@
+"""Small ensembles on the pair kernel with per-member ocean diffusivity and / or the heat-flux sum:
+    python tools/prof/pair_diff_times.py [--lib=path]"""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import bench, hector_amd
 from hector_amd import ensemble
+libs = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--lib=")]
+if libs:   # an experiment build (gpuwork/)
+    _orig = hector_amd.Core
+    hector_amd.Core = lambda *a, **k: _orig(*a, **dict(k, lib_path=os.path.abspath(libs[0])))
 for n in (1024, 16384):
     for diff in (False, True):
         for hf in (False, True):
