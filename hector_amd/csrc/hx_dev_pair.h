@@ -437,34 +437,12 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
     double dpart_pf = 0, dpast_in = 0;
     [[maybe_unused]] double dpart2_pf = 0, hint_in = 0;
     bool sums_done = true;
-    // Members with their own diffusivity: the year's in-block kernel entries are rows of the
-    // member's table -- vector loads, one exposed HBM round trip per chunk of eight inside
-    // history_sums -- and are requested at the year start with the block's partial sum instead
-    // (33 registers on this side; hx_run_kernel's kpf, round 5).
-    [[maybe_unused]] double kpf[KERPM ? HX_DBLK + 1 : 1];
-    if constexpr (KERPM) {
-#pragma unroll
-      for (int r = 0; r <= HX_DBLK; ++r) kpf[r] = 0.0;
-    }
     auto history_sums = [&](int iy) {
       const int jb = iy - blk0;
       double acc = dpart_pf;
       [[maybe_unused]] double acc2 = dpart2_pf;
       const int kq = kc.ns - iy - 1 + HX_KPAD + (blk0 - 1);  // Ker index of slot 0 (year blk0 - 1)
       const int nchunk = (jb + 7) >> 3;
-      if constexpr (KERPM) {
-#pragma unroll
-        for (int cc = 0; cc < HX_DBLK / 8; ++cc) {
-          if (cc < nchunk) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const double t = (8 * cc + q < jb) ? s_tblk[8 * cc + q][lane] : 0.0;
-              acc += t * kpf[8 * cc + q];
-              if constexpr (HF) acc2 += t * kpf[8 * cc + q + 1];
-            }
-          }
-        }
-      } else
       for (int cc = 0; cc < nchunk; ++cc) {
         double T[8], K[8];
 #pragma unroll
@@ -549,17 +527,6 @@ __global__ __launch_bounds__(128) HX_PAIR_OCC void hx_pair_kernel(const HxArgs *
       if (blk0 < 0 || iy >= blk0 + HX_DBLK) blk0 = iy;
       dpart_pf = HX_GCD(buf.dpart)[(size_t)(iy - blk0) * np + mem];  // (the land side ran the pass last year end)
       if constexpr (HF) dpart2_pf = HX_GCD(buf.dpart2)[(size_t)(iy - blk0) * np + mem];
-      if constexpr (KERPM) {
-        const int jbp = iy - blk0;
-        const int kqp = kc.ns - iy - 1 + HX_KPAD + (blk0 - 1);
-#pragma unroll
-        for (int cc = 0; cc < HX_DBLK / 8; ++cc) {
-          if (8 * cc < jbp + (HF ? 1 : 0)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) kpf[8 * cc + q] = ldk(kqp + 8 * cc + q);
-          }
-        }
-      }
       sums_done = false;
       status |= (unsigned)s_yr[PY_STATUS1][lane];
       // the soil pool of the interval (this side integrates it: pair_attempt_zs), the three land
