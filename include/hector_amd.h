@@ -327,7 +327,9 @@ int hx_set_pair_kernel_limit(hx_core *core, int max_members);
  * constraints, land-ocean warming ratio and diagnostics -- except carbon tracking.
  * hx_set_two_wave_from: ensembles of at least min_members members use it (< 0: the default, one
  * more wavefront than the device has SIMDs; 0: never; the environment variable
- * HECTOR_AMD_TWO_WAVE_FROM sets the default of new cores).  hx_last_run_kernel then says "run2". */
+ * HECTOR_AMD_TWO_WAVE_FROM sets the default of new cores).  hx_last_run_kernel then says "run2".
+ * With the default (< 0) an ensemble whose members differ in ocean heat diffusivity stays on the
+ * one-wavefront kernel, which is the faster one for it (131 072 such members 13.5 against 14.3 ms). */
 int hx_set_two_wave_from(hx_core *core, int min_members);
 
 /* Core::outputEnabled (src/core.cpp:257-262, 688-695): 0 if the scenario's section of that component
