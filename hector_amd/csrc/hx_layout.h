@@ -209,7 +209,6 @@ struct HxBuffers {
   const double *ker;     // zero-padded DOECLIM kernel (32 in front, 64 behind): [ns+96] (shared diffusivity) or [ns+96][npad]
   const double *dpart;   // [HX_DBLK][npad] history partial sums of the current block
   const double *dpart2;  // same for the heat-flux diagnostic
-  double *out[HXO_NVAR]; // each [ns][npad] or nullptr
   double *hist;          // optional per-year state history [ns][HX_NSTATE(B)][npad] for reset(date)
   unsigned *hist_status; // ... and the members' status bits of every year [ns][npad]
   int n, npad, ker_per_member;
@@ -252,6 +251,8 @@ struct HxBuffers {
   // the constant 100 MHz clock (s_memrealtime): what the launch's tail looks like -- the launch
   // lasts as long as its last wavefront (hx_wave_clock)
   long long *wave_clk;
+  // (last: 396 pointers, see HxArgs)
+  double *out[HXO_NVAR]; // each [ns][npad] or nullptr
 };
 // rows of HxBuffers::spin_rec: the carbon-cycle variables of the stream, which are the ones that
 // move during the spinup
@@ -280,7 +281,13 @@ struct HxDiagArgs {
 
 // kernel arguments live in device memory (one copy per core) and are read through
 // wave-uniform scalar loads on demand -- passing them by value would pin ~110 SGPRs
+// (kc FIRST, and HxBuffers' big pointer tables last: a scalar load off a base the optimiser
+//  cannot see through -- the tableau, the batches' coefficient tables, the polynomial fits, all
+//  read through laundered offsets -- folds its constant offset into the instruction only below
+//  4 KB; with the per-biome output pointers of 32 biomes in front of them these tables sat beyond
+//  that, every such load got a 64-bit scalar add of its own and the plain kernel 70 more spilled
+//  scalars: 65 536 members 5.90 -> 6.04 ms.  In this order it has fewer of both than with 16.)
 struct HxArgs {
-  HxBuffers buf;
   HxConst kc;
+  HxBuffers buf;
 };
