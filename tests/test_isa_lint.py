@@ -158,3 +158,33 @@ def test_assembly_of_the_built_library_is_clean():
     k = text.index("_Z13hx_run_kernelILi101ELb0ELb0ELi0EEvPK6HxArgsii:")
     body = text[k:text.index(".Lfunc_end", k)]
     assert body.count("v_mfma_f64_16x16x4_f64 v[") >= 32 and "v_mfma_f64_16x16x4_f64 a[" not in body
+
+
+def test_static_figures_of_the_baseline_kernels_hold():
+    """Round 5: raising the biome limit moved the argument block's tables beyond the 4 KB a scalar
+    load folds into its offset and cost the headline kernel 2.4 % -- identical results, every box a
+    little different, so no test saw it; the compiler's own figures did (profiles/r05_variant_log.md
+    18: 53 -> 97 spilled scalars, 5 371 -> 5 533 instructions).  They are held here, with margin, for
+    the kernels of the BASELINE configurations: a change that moves them is looked at with
+    tools/isa_stats.py before it ships."""
+    files = glob.glob(os.path.join(ROOT, "hector_amd", "build", "hx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if not files:
+        import pytest
+        pytest.skip("no assembly in hector_amd/build (the library was not built in this tree)")
+    import isa_stats
+    kernels, meta = isa_stats.parse(files[0])
+    #                                         scratch, VGPRs <=, spilled SGPRs <=, static instructions <=
+    bounds = {"_Z13hx_run_kernelILi1ELb0ELb0ELi0EEvPK6HxArgsii": (0, 512, 60, 5450),      # configs[2]
+              "_Z13hx_run_kernelILi101ELb0ELb0ELi0EEvPK6HxArgsii": (0, 256, 30, 5750),    # configs[3]'s share
+              "_Z13hx_run_kernelILi4ELb0ELb0ELi0EEvPK6HxArgsii": (0, 512, 75, 7700),      # configs[4]
+              "_Z14hx_pair_kernelILb0ELb0ELb0ELi1EEvPK6HxArgsii": (0, 512, None, None)}   # configs[1]
+    for k, (scratch, vgpr, sspill, ninstr) in bounds.items():
+        assert k in meta, k
+        md = meta[k]
+        n = sum(isa_stats.hist(kernels[k]).values())
+        assert int(md["private_segment_fixed_size"]) == scratch, (k, md["private_segment_fixed_size"])
+        assert int(md["vgpr_count"]) <= vgpr, (k, md["vgpr_count"])
+        if sspill is not None:
+            assert int(md["sgpr_spill_count"]) <= sspill, (k, md["sgpr_spill_count"])
+        if ninstr is not None:
+            assert n <= ninstr, (k, n)
