@@ -13,6 +13,8 @@
 namespace host {  // shaped like inst/include/{imodel_component,message_data,unitval,core}.hpp
 struct unitval {
   double v = 0; std::string u;
+  unitval() {}
+  unitval(double val, const std::string &units) : v(val), u(units) {}
   double value() const { return v; }
   std::string unitsName() const { return u; }
 };
@@ -22,25 +24,31 @@ struct Core {
   void registerCapability(const std::string &name, const std::string &comp) { caps[name] = comp; }
 };
 struct message_data {
-  message_data() : date(Core::undefinedIndex()) {}
-  message_data(double d) : date(d) {}
-  message_data(double d, double value) : date(d), val(value) {}
-  double date; double val = 0;
+  // (the reference's constructors, inst/include/message_data.hpp:31-46, signature for signature:
+  // tests/test_adapter_interface_pin.py holds them against that header)
+  message_data() : date(Core::undefinedIndex()), isVal(false) {}
+  message_data(const double d) : date(d), isVal(false) {}
+  message_data(const std::string &value) : date(Core::undefinedIndex()), value_str(value), isVal(false) {}
+  message_data(const unitval &value) : date(Core::undefinedIndex()), value_unitval(value), isVal(true) {}
+  message_data(double d, const unitval &val) : date(d), value_unitval(val), isVal(true) {}
+  double date; std::string value_str; unitval value_unitval; bool isVal;
 };
 struct AVisitor {};
 struct IModelComponent {
   virtual ~IModelComponent() {}
   virtual std::string getComponentName() const = 0;
   virtual void init(Core *core) = 0;
-  virtual unitval sendMessage(const std::string &message, const std::string &datum,
+  virtual unitval sendMessage(const std::string &message,
+                              const std::string &datum,
                               const message_data info = message_data()) = 0;
-  virtual void setData(const std::string &varName, const message_data &data) = 0;
+  virtual void setData(const std::string &varName,
+                       const message_data &data) = 0;
   virtual void prepareToRun() = 0;
   virtual void run(const double runToDate) = 0;
-  virtual bool run_spinup(const int) { return true; }
+  virtual bool run_spinup(const int step) { return true; }
   virtual void reset(double time) = 0;
   virtual void shutDown() = 0;
-  virtual void accept(AVisitor *) = 0;
+  virtual void accept(AVisitor *visitor) = 0;
  private:
   virtual unitval getData(const std::string &varName, const double date) = 0;
 };
@@ -48,7 +56,7 @@ struct Traits {
   using Component = IModelComponent; using Core = host::Core; using unitval = host::unitval;
   using message_data = host::message_data; using Visitor = AVisitor;
   static double undefined_index() { return Core::undefinedIndex(); }
-  static double value_of(const message_data &d) { return d.val; }
+  static double value_of(const message_data &d) { return d.isVal ? d.value_unitval.v : std::atof(d.value_str.c_str()); }
   static unitval make(double v, const char *units) { unitval x; x.v = v; x.u = units ? units : ""; return x; }
   static void fail(const std::string &m) { throw std::runtime_error(m); }
 };
@@ -63,8 +71,8 @@ int main(int argc, char **argv) {
     c.init(&core);
     if (core.caps.count("CO2_concentration") == 0 || core.caps["global_tas"] != "hector-amd") return 3;
     comp.recordVariables({"CO2_concentration", "global_tas", "RF_tot"});
-    c.setData("S", host::message_data(host::Core::undefinedIndex(), 3.5));
-    for (int y = 2030; y <= 2060; ++y) c.setData("ffi_emissions", host::message_data((double)y, 4.0));
+    c.setData("S", host::message_data(host::Core::undefinedIndex(), host::unitval(3.5, "degC")));
+    for (int y = 2030; y <= 2060; ++y) c.setData("ffi_emissions", host::message_data((double)y, host::unitval(4.0, "Pg C/yr")));
     c.prepareToRun();
     for (int y = 1746; y <= 2100; ++y) {                   // Core::run, src/core.cpp:483-504
       c.run((double)y);
