@@ -145,6 +145,8 @@ def _declare(lib):
         "hx_lanes_calibrated": [P, c.POINTER(c.c_int)],
         "hx_lane_order_source": [P, c.POINTER(c.c_int)],
         "hx_set_cost_model": [P, c.c_int],
+        "hx_cost_models_export": [c.c_char_p, c.POINTER(c.c_int)],
+        "hx_cost_models_load": [c.c_char_p, c.POINTER(c.c_int)],
         "hx_enable_history": [P, c.c_int],
         "hx_enable_spinup_record": [P, c.c_int],
         "hx_spinup_record": [P, c.c_int, c.POINTER(c.POINTER(c.c_char_p)), c.POINTER(c.c_int), dp, c.c_int,
@@ -194,4 +196,5 @@ ABI_SYMBOLS = ["hx_backend", "hx_build_info", "hx_last_error", "hx_newcore", "hx
                "hx_last_run_ms", "hx_last_spinup_ms", "hx_stream", "hx_set_pair_kernel_limit", "hx_set_two_wave_from", "hx_wave_clock",
                "hx_last_run_kernel", "hx_last_run_variant", "hx_component_output", "hx_newcore_devices", "hx_shards",
                "hx_device_var_shard", "hx_stream_shard", "hx_comm_unique_id", "hx_comm_init_rank",
-               "hx_comm_info", "hx_ensemble_stats", "hx_set_lane_calibration", "hx_lanes_calibrated", "hx_lane_order_source", "hx_set_cost_model"]
+               "hx_comm_info", "hx_ensemble_stats", "hx_set_lane_calibration", "hx_lanes_calibrated", "hx_lane_order_source", "hx_set_cost_model",
+               "hx_cost_models_export", "hx_cost_models_load"]

@@ -5,6 +5,7 @@ Everything here is a thin ctypes veneer over the C ABI (include/hector_amd.h);
 the numerics live in the HIP kernels.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -412,6 +413,24 @@ def comm_unique_id(lib_path=None, allow_emulation=False):
     if lib.hx_comm_unique_id(buf) != 0:
         raise HectorAmdError(lib.hx_last_error().decode())
     return buf.raw
+
+
+def cost_models_export(path, lib_path=None, allow_emulation=False):
+    """Write every lane-cost model this process holds to `path` (hx_cost_models_export) -> count."""
+    lib = _lib.load(lib_path, allow_emulation)
+    n = ctypes.c_int(0)
+    if lib.hx_cost_models_export(os.fsencode(path), ctypes.byref(n)) != 0:
+        raise HectorAmdError(lib.hx_last_error().decode())
+    return n.value
+
+
+def cost_models_load(path, lib_path=None, allow_emulation=False):
+    """Add the lane-cost models of a file to the process's registry (hx_cost_models_load) -> count."""
+    lib = _lib.load(lib_path, allow_emulation)
+    n = ctypes.c_int(0)
+    if lib.hx_cost_models_load(os.fsencode(path), ctypes.byref(n)) != 0:
+        raise HectorAmdError(lib.hx_last_error().decode())
+    return n.value
 
 
 # R-style free functions

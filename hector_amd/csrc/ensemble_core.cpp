@@ -9,6 +9,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
+#include <fstream>
+#include <sstream>
+#include <string>
 #include <stdexcept>
 #include <map>
 #include <mutex>
@@ -1493,7 +1497,116 @@ uint64_t EnsembleCore::cost_model_key(const std::vector<int> &varying) const {
   mix(shared_.data(), shared_.size() * sizeof(double));
   mix(&B_, sizeof B_);
   for (int r : varying) mix(&r, sizeof r);
+  //  ... and what else shapes a member's schedule: the values of the rows every member
+  // shares, and which constraints the scenario / the members carry -- a model fitted to another
+  // workload of the same scenario is not applied to this one
+  const int cm = kc_.con_mask | member_con_mask_;
+  mix(&cm, sizeof cm);
+  for (int r = 0; r < HX_NPARAM(B_); ++r)
+    if (row_uniform_[r] && !params_[(size_t)r].empty()) mix(&params_[(size_t)r][0], sizeof(double));
   return h;
+}
+
+// ---- models that outlive the process -----------------------------------------------------------
+// A genuine one-shot run -- fresh process, one core -- has no earlier core to learn from.  The
+// registry is therefore seeded from a FILE of fitted models, one text record per model:
+//   model <key hex> <k> <cross> | rows ... | mean ... | sd ... | beta ...
+// read once per process, before the first lookup: $HECTOR_AMD_COST_MODELS if set, else
+// <directory of this library>/../data/cost_models.txt -- the models shipped with the scenarios
+// (tools/make_cost_models.py fits them on the GPU for the shipped scenarios' perturbed-parameter
+// ensembles and writes the file through hx_cost_models_export).  A record whose key matches no
+// core is never used; a model only orders lanes, results do not depend on it.
+namespace {
+std::once_flag g_cost_file_once;
+bool parse_cost_models(std::istream &in, std::map<uint64_t, CostModel> &out) {
+  std::string line;
+  bool any = false;
+  while (std::getline(in, line)) {
+    std::istringstream ls(line);
+    std::string tag, keyhex;
+    size_t k = 0; int cross = 0;
+    if (!(ls >> tag) || tag != "model") continue;
+    if (!(ls >> keyhex >> k >> cross) || k == 0 || k > 24) continue;
+    CostModel m;
+    m.cross = cross != 0;
+    const size_t nt = cost_terms(k, m.cross);
+    auto section = [&](const char *name, size_t n, auto &vec) {
+      std::string bar, nm;
+      if (!(ls >> bar >> nm) || bar != "|" || nm != name) return false;
+      vec.resize(n);
+      for (size_t i = 0; i < n; ++i) if (!(ls >> vec[i])) return false;
+      return true;
+    };
+    if (!section("rows", k, m.rows) || !section("mean", k, m.mean) || !section("sd", k, m.sd) ||
+        !section("beta", nt, m.beta)) continue;
+    bool ok = true;
+    for (double v : m.beta) ok = ok && std::isfinite(v);
+    for (double v : m.sd) ok = ok && std::isfinite(v) && v > 0;
+    if (!ok) continue;
+    out[std::strtoull(keyhex.c_str(), nullptr, 16)] = std::move(m);
+    any = true;
+  }
+  return any;
+}
+std::string default_cost_models_path() {
+  if (const char *e = std::getenv("HECTOR_AMD_COST_MODELS")) return e;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void *>(&default_cost_models_path), &info) && info.dli_fname) {
+    std::string lib = info.dli_fname;
+    const size_t sl = lib.rfind('/');
+    return (sl == std::string::npos ? std::string(".") : lib.substr(0, sl)) + "/../data/cost_models.txt";
+  }
+  return "";
+}
+void seed_cost_models_once() {
+  std::call_once(g_cost_file_once, [] {
+    const std::string path = default_cost_models_path();
+    if (path.empty()) return;
+    std::ifstream in(path);
+    if (!in) return;
+    std::map<uint64_t, CostModel> got;
+    if (!parse_cost_models(in, got)) return;
+    std::lock_guard<std::mutex> lk(g_cost_mu);
+    for (auto &kv : got) g_cost_models.emplace(kv.first, std::move(kv.second));   // (a fitted one stays)
+  });
+}
+}  // namespace
+
+int hx_cost_models_load_file(const char *path) {
+  std::ifstream in(path);
+  if (!in) return -1;
+  std::map<uint64_t, CostModel> got;
+  if (!parse_cost_models(in, got)) return 0;
+  std::lock_guard<std::mutex> lk(g_cost_mu);
+  int n = 0;
+  for (auto &kv : got) { g_cost_models[kv.first] = std::move(kv.second); ++n; }
+  return n;
+}
+
+int hx_cost_models_export_file(const char *path) {
+  std::ofstream out(path, std::ios::trunc);
+  if (!out) return -1;
+  out << "# hector_amd lane-cost models: cost ~ quadratic in the standardised varying parameter rows\n"
+         "# (EnsembleCore::fit_cost_model; written by hx_cost_models_export, read at first use)\n";
+  out.precision(17);
+  std::lock_guard<std::mutex> lk(g_cost_mu);
+  int n = 0;
+  for (const auto &kv : g_cost_models) {
+    const CostModel &m = kv.second;
+    char key[32];
+    std::snprintf(key, sizeof key, "%016llx", (unsigned long long)kv.first);
+    out << "model " << key << ' ' << m.rows.size() << ' ' << (m.cross ? 1 : 0) << " | rows";
+    for (int r : m.rows) out << ' ' << r;
+    out << " | mean";
+    for (double v : m.mean) out << ' ' << v;
+    out << " | sd";
+    for (double v : m.sd) out << ' ' << v;
+    out << " | beta";
+    for (double v : m.beta) out << ' ' << v;
+    out << '\n';
+    ++n;
+  }
+  return out ? n : -1;
 }
 
 // member_cost: [n_] measured cost per member (member order)
@@ -1559,6 +1672,7 @@ void EnsembleCore::fit_cost_model(const std::vector<double> &member_cost) {
 // core's scenario / biome count / varying rows
 bool EnsembleCore::predict_cost(const std::vector<int> &varying, std::vector<double> &out) const {
   if (!cost_model_ || varying.empty()) return false;
+  seed_cost_models_once();
   CostModel m;
   {
     std::lock_guard<std::mutex> lk(g_cost_mu);

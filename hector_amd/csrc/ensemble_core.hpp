@@ -18,6 +18,11 @@
 
 namespace hx {
 
+// The process-wide registry of lane-cost models (ensemble_core.cpp, fit_cost_model) to / from a
+// text file: -> number of models written / read, -1 if the file cannot be opened.
+int hx_cost_models_export_file(const char *path);
+int hx_cost_models_load_file(const char *path);
+
 class EnsembleCore {
  public:
   EnsembleCore(const std::string &scenario_path, int n_members, int device);

@@ -208,6 +208,20 @@ int hx_lane_order_source(hx_core *core, int *source) {
   HX_TRY(*source = core->core->lane_order_source())
 }
 int hx_set_cost_model(hx_core *core, int on) { HX_TRY(core->core->set_cost_model(on != 0)) }
+int hx_cost_models_export(const char *path, int *count) {
+  if (!path) return fail("null argument");
+  const int n = hx::hx_cost_models_export_file(path);
+  if (n < 0) return fail((std::string("hx_cost_models_export: cannot write ") + path).c_str());
+  if (count) *count = n;
+  return 0;
+}
+int hx_cost_models_load(const char *path, int *count) {
+  if (!path) return fail("null argument");
+  const int n = hx::hx_cost_models_load_file(path);
+  if (n < 0) return fail((std::string("hx_cost_models_load: cannot read ") + path).c_str());
+  if (count) *count = n;
+  return 0;
+}
 int hx_lanes_calibrated(hx_core *core, int *yes) {
   if (!yes) return fail("null argument");
   HX_TRY(*yes = core->core->lanes_calibrated() ? 1 : 0)

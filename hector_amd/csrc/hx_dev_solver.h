@@ -858,6 +858,24 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   constexpr double f2 = 1.0 / 5, f3 = 3.0 / 10, f4 = 4.0 / 5, f5 = 8.0 / 9;
 #endif
   constexpr double EPS = 2.220446049250313e-16;
+  // The three land pools of an attempt as TWO coefficient chains (round 6).  Within a stash
+  // interval vegetation, detritus and soil obey  dx_i/dt = c_i - r(t) x_i  with ONE loss rate r(t)
+  // = luc_e / (their sum), known at every stage time (see rhs); the equations do not couple.  A
+  // Runge-Kutta stage is an affine map of (x_i, c_i), the same map for the three pools: stage
+  // value  xt_l,i = a_l x_i + g_l (h c_i),  scaled derivative  H_l,i = -(h r_l) xt_l,i + h c_i.  So
+  // the dopri5 recursion runs ONCE on the coefficient pairs (a_l, g_l) instead of three times on
+  // the pools, and each pool takes its candidate, its error estimate and its first derivative
+  // from the final coefficients: x_i' = x_i + Pd x_i + Q (h c_i), xe_i = Ex x_i + Ec (h c_i).
+  // The g chain works on deviations Gd_l = -(h r_l) g_l from the rate-free scheme (whose stage
+  // coefficients are the nodes f_l and whose weights sum to 1 / 0 exactly), so nothing cancels.
+  // 90 operations where the three pool chains took 118; the pass carries the rate r(t) from
+  // attempt to attempt instead of three derivatives.  Same scheme, same step-size decisions;
+  // results within rounding of the pool-wise form (-DHX_NO_LAND2: that form, experiments).
+#if !defined(HX_NO_LAND2) && !defined(HX_NO_SCALED_STAGES) && !defined(HX_NO_RATE)
+  constexpr bool LAND2 = hx_zchain<CON, SPIN>();
+#else
+  constexpr bool LAND2 = false;
+#endif
 
   Interval K, K2s;
   Interval &K2 = hx_nbp<CON>() ? K2s : K;
@@ -911,6 +929,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     // A freshly constructed stepper evaluates the RHS once before its first step (FSAL starts
     // empty): here, ahead of the loop, for every lane -- only the lanes of this segment use it.
     rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt);
+    if constexpr (LAND2) dxdt[1] = hx_div1(m.luc_e, (y[1] + y[2]) + y[3]);   // (the loss rate itself: see LAND2)
     int fails = 0;
     bool stepping = seg;
     if constexpr (hx_w2<B>()) w2_park_out<B>(m);
@@ -959,7 +978,10 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           if (retry >= 8) { m.status |= HX_ERR_RETRIES; alive = false; stepping = false; }
           need = stepping && ((t + dtl) - m.ode_start) > m.max_ts;
         }
-        if (reload) { load_pools(true); rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt); }
+        if (reload) {
+          load_pools(true); rhs<B, SPIN, CON>(m, K, K2, yc, t, y, dxdt);
+          if constexpr (LAND2) dxdt[1] = hx_div1(m.luc_e, (y[1] + y[2]) + y[3]);
+        }
       }
       double k2[NP], k3[NP], k4[NP], k5[NP], k6[NP], xt[NP], xn[NP], dn[NP];
       // the land-use loss rates of the attempt's stage times (see rhs): five independent
@@ -1013,31 +1035,70 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           for (int i = 1; i <= 3; ++i) H[i] = fma(-hrj, x[i], cs[i]);
         };
         const double z1 = dxdt[4];
-        double H1[4];
-#pragma unroll
-        for (int i = 1; i <= 3; ++i) H1[i] = h * dxdt[i];
         const double Hz1 = fma(-hl, z1, ha);
         const double z2 = z1 + b21 * Hz1;
+        const double Hz2 = fma(-hl, z2, ha);
+        const double z3 = z1 + b31 * Hz1 + b32 * Hz2;
+        const double Hz3 = fma(-hl, z3, ha);
+        const double z4 = z1 + b41 * Hz1 + b42 * Hz2 + b43 * Hz3;
+        const double Hz4 = fma(-hl, z4, ha);
+        const double z5 = z1 + b51 * Hz1 + b52 * Hz2 + b53 * Hz3 + b54 * Hz4;
+        const double Hz5 = fma(-hl, z5, ha);
+        const double z6 = z1 + b61 * Hz1 + b62 * Hz2 + b63 * Hz3 + b64 * Hz4 + b65 * Hz5;
+        double H1[4], H7[4];
+        [[maybe_unused]] double l2_Ex = 0, l2_Ec = 0;
+        if constexpr (LAND2) {
+          // chain a (coefficient of x_i): a_1 = 1, A_l = -(h r_l) a_l
+          const double hr0 = h * dxdt[1];      // dxdt[1] carries the loss rate at (t, y)
+          const double A1 = -hr0;
+          const double a2 = fma(b21, A1, 1.0);
+          const double A2 = -hr[0] * a2;
+          const double a3 = 1.0 + b31 * A1 + b32 * A2;
+          const double A3 = -hr[1] * a3;
+          const double a4 = 1.0 + b41 * A1 + b42 * A2 + b43 * A3;
+          const double A4 = -hr[2] * a4;
+          const double a5 = 1.0 + b51 * A1 + b52 * A2 + b53 * A3 + b54 * A4;
+          const double A5 = -hr[3] * a5;
+          const double a6 = 1.0 + b61 * A1 + b62 * A2 + b63 * A3 + b64 * A4 + b65 * A5;
+          const double A6 = -hr[4] * a6;
+          const double Pd = c1 * A1 + c3 * A3 + c4 * A4 + c5 * A5 + c6 * A6;   // a_7 - 1
+          const double A7 = -hr[4] * (1.0 + Pd);
+          l2_Ex = dc1 * A1 + dc3 * A3 + dc4 * A4 + dc5 * A5 + dc6 * A6 + dc7 * A7;
+          // chain g (coefficient of h c_i): g_1 = 0, G_l = 1 + Gd_l, Gd_l = -(h r_l) g_l; the
+          // rate-free parts of the sums are the nodes f_l (Gd_1 = 0)
+          const double G2 = -hr[0] * f2;
+          const double g3 = fma(b32, G2, f3);
+          const double G3 = -hr[1] * g3;
+          const double g4 = f4 + b42 * G2 + b43 * G3;
+          const double G4 = -hr[2] * g4;
+          const double g5 = f5 + b52 * G2 + b53 * G3 + b54 * G4;
+          const double G5 = -hr[3] * g5;
+          const double g6 = 1.0 + b62 * G2 + b63 * G3 + b64 * G4 + b65 * G5;
+          const double G6 = -hr[4] * g6;
+          const double Q = 1.0 + (c3 * G3 + c4 * G4 + c5 * G5 + c6 * G6);       // g_7
+          const double G7 = -hr[4] * Q;
+          l2_Ec = dc3 * G3 + dc4 * G4 + dc5 * G5 + dc6 * G6 + dc7 * G7;
+#pragma unroll
+          for (int i = 1; i <= 3; ++i) {
+            xn[i] = fma(Pd, y[i], fma(Q, cs[i], y[i]));
+            H1[i] = fma(-hr0, y[i], cs[i]);      // the first stage's scaled derivative (error scale)
+          }
+          dn[1] = r5; dn[2] = 0.0; dn[3] = 0.0;  // (the rate at the candidate, for the next attempt)
+        } else {
+#pragma unroll
+        for (int i = 1; i <= 3; ++i) H1[i] = h * dxdt[i];
 #pragma unroll
         for (int i = 1; i <= 3; ++i) xt[i] = y[i] + b21 * H1[i];
         hland(xt, k2, hr[0]);
-        const double Hz2 = fma(-hl, z2, ha);
-        const double z3 = z1 + b31 * Hz1 + b32 * Hz2;
 #pragma unroll
         for (int i = 1; i <= 3; ++i) xt[i] = y[i] + b31 * H1[i] + b32 * k2[i];
         hland(xt, k3, hr[1]);
-        const double Hz3 = fma(-hl, z3, ha);
-        const double z4 = z1 + b41 * Hz1 + b42 * Hz2 + b43 * Hz3;
 #pragma unroll
         for (int i = 1; i <= 3; ++i) xt[i] = y[i] + b41 * H1[i] + b42 * k2[i] + b43 * k3[i];
         hland(xt, k4, hr[2]);
-        const double Hz4 = fma(-hl, z4, ha);
-        const double z5 = z1 + b51 * Hz1 + b52 * Hz2 + b53 * Hz3 + b54 * Hz4;
 #pragma unroll
         for (int i = 1; i <= 3; ++i) xt[i] = y[i] + b51 * H1[i] + b52 * k2[i] + b53 * k3[i] + b54 * k4[i];
         hland(xt, k5, hr[3]);
-        const double Hz5 = fma(-hl, z5, ha);
-        const double z6 = z1 + b61 * Hz1 + b62 * Hz2 + b63 * Hz3 + b64 * Hz4 + b65 * Hz5;
 #pragma unroll
         for (int i = 1; i <= 3; ++i)
           xt[i] = y[i] + b61 * H1[i] + b62 * k2[i] + b63 * k3[i] + b64 * k4[i] + b65 * k5[i];
@@ -1046,8 +1107,8 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         for (int i = 1; i <= 3; ++i)
           xn[i] = y[i] + c1 * H1[i] + c3 * k3[i] + c4 * k4[i] + c5 * k5[i] + c6 * k6[i];
         rhs_land<B>(m, K, xn, dn, r5);          // (unscaled: the next attempt's first derivative)
-        double H7[4];
         hland(xn, H7, hr[4]);
+        }
         // the pair from the stage fluxes
         const double Z = h * (c1 * z1 + c3 * z3 + c4 * z4 + c5 * z5 + c6 * z6);
         xn[0] = fma(h, K.Pn, y[0]) - Z;
@@ -1071,7 +1132,8 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         bool small = true;
 #pragma unroll
         for (int i = 1; i <= 3; ++i) {
-          xe3[i] = fabs(dc1 * H1[i] + dc3 * k3[i] + dc4 * k4[i] + dc5 * k5[i] + dc6 * k6[i] + dc7 * H7[i]);
+          if constexpr (LAND2) xe3[i] = fabs(fma(l2_Ex, y[i], l2_Ec * cs[i]));
+          else xe3[i] = fabs(dc1 * H1[i] + dc3 * k3[i] + dc4 * k4[i] + dc5 * k5[i] + dc6 * k6[i] + dc7 * H7[i]);
           d3[i] = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + fabs(H1[i]));
           small = small && (xe3[i] * qd <= qn * d3[i]);
         }

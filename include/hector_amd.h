@@ -213,6 +213,16 @@ int hx_lanes_calibrated(hx_core *core, int *yes);
  * Results do not depend on the order.  No counterpart in the reference. */
 int hx_lane_order_source(hx_core *core, int *source);
 int hx_set_cost_model(hx_core *core, int on);
+/* The registry as a file, so that a fresh process -- a genuine one-shot run -- starts with models:
+ * hx_cost_models_export writes every model the process holds (text, one record per model),
+ * hx_cost_models_load adds a file's models to the registry (count: how many).  Without either
+ * call the library reads $HECTOR_AMD_COST_MODELS, else <its directory>/../data/cost_models.txt
+ * -- the models shipped with the scenarios (tools/make_cost_models.py) -- once, before the first
+ * lookup.  A model is keyed on the scenario's per-year table, the biome count, the varying rows,
+ * the values of the uniform rows and the constraint mask; it only orders lanes.  No counterpart
+ * in the reference. */
+int hx_cost_models_export(const char *path, int *count);
+int hx_cost_models_load(const char *path, int *count);
 int hx_lane_of_member(hx_core *core, int *out /* n_members */);
 
 /* reset(core, date)  src/rcpp_hector.cpp:103-151 -> Core::reset src/core.cpp:511-549.

@@ -267,3 +267,64 @@ def test_hip_runtime_preload_checks_the_soname(hip_lib, monkeypatch, capsys):
                         lambda path, tags: {14: ["libamdhip64.so.6"]} if 14 in tags else {1: needed})
     _lib._share_torch_hip_runtime(hip_lib)
     assert loaded == [] and "not preloading" in capsys.readouterr().err
+
+
+def test_cost_models_persist_across_processes(emul_lib, tmp_path):
+    """VERDICT r5 item 2 / ADVICE r5: a genuine one-shot run -- a FRESH process, one core -- orders
+    its lanes by a cost model read from a file (hx_cost_models_export / $HECTOR_AMD_COST_MODELS,
+    by default the models shipped in hector_amd/data/cost_models.txt), not only by a model some
+    earlier core of the same process happened to fit.  And the key now holds the uniform rows'
+    values: the same scenario with another beta is another workload, no model."""
+    import subprocess
+    import sys
+    path = str(tmp_path / "models.txt")
+    prog = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import hector_amd
+from hector_amd import ensemble, core as core_mod
+kw = dict(lib_path=%(lib)r, allow_emulation=True)
+mode = sys.argv[1]
+if mode == "fit":
+    S, q = ensemble.ecs_q10(512)
+    a = hector_amd.Core(n_members=512, **kw)
+    a.setvar("S", S).setvar("q10_rh", q)
+    a.status()
+    assert a.lane_order_source() == "parameter key", a.lane_order_source()
+    a.run(2300); a.reset(1745)
+    assert core_mod.cost_models_export(%(path)r, **kw) == 1
+    print("fitted")
+else:
+    S, q = ensemble.ecs_q10(768, offset=9000)
+    b = hector_amd.Core(n_members=768, **kw)
+    b.setvar("S", S).setvar("q10_rh", q)
+    b.status()
+    print("first order:", b.lane_order_source())
+    d = hector_amd.Core(n_members=768, **kw)
+    d.setvar("S", S).setvar("q10_rh", q).setvar("beta", np.full(768, 0.5))
+    d.status()
+    print("other beta:", d.lane_order_source())
+    if mode == "load":       # the explicit call instead of the environment
+        assert core_mod.cost_models_load(%(path)r, **kw) == 1
+        e = hector_amd.Core(n_members=768, **kw)
+        e.setvar("S", S).setvar("q10_rh", q); e.status()
+        print("after load:", e.lane_order_source())
+''' % {"root": ROOT, "lib": emul_lib, "path": path}
+    env = dict(os.environ, HECTOR_AMD_SIMDS="2", HECTOR_AMD_COST_MODELS="")
+
+    def run(mode, **extra):
+        r = subprocess.run([sys.executable, "-c", prog, mode], env=dict(env, **extra), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+    assert "fitted" in run("fit")
+    text = open(path).read()
+    assert text.count("\nmodel ") == 1 and " | rows " in text and " | beta " in text
+    out = run("fresh", HECTOR_AMD_COST_MODELS=path)       # a fresh process, its first core
+    assert "first order: cost model" in out and "other beta: parameter key" in out
+    out = run("load")                                     # no file named: nothing until the explicit load
+    assert "first order: parameter key" in out and "after load: cost model" in out
+    # a damaged file is ignored, not fatal
+    open(path, "w").write("model zzzz 2 1 | rows 0 1 | mean 1 2\n")
+    assert "first order: parameter key" in run("fresh", HECTOR_AMD_COST_MODELS=path)

@@ -63,6 +63,9 @@ _Z6kernelv:
 BUG_AHEAD_OF_ELSE_HEAD = FINE_ELSE_HEAD.replace(
     ".LBB0_2:\n\ts_or_saveexec_b64 s[0:1], s[0:1]\n\tv_accvgpr_write_b32 a2, v162",
     ".LBB0_2:\n\tv_accvgpr_write_b32 a2, v162\n\ts_or_saveexec_b64 s[0:1], s[0:1]")
+# ... and an s_xor of ANOTHER pair does not close that window: the save stays suspect
+BUG_UNRELATED_XOR = FINE_ELSE_HEAD.replace("\ts_xor_b64 exec, exec, s[0:1]\n\tv_mov_b32_e32 v8, 0",
+                                           "\ts_xor_b64 exec, exec, s[4:5]\n\tv_mov_b32_e32 v8, 0")
 
 
 def _scan(text, tmp_path, name):
@@ -78,6 +81,8 @@ def test_lint_tells_a_lost_save_from_a_merge(tmp_path):
     assert _scan(FINE_MERGE, tmp_path, "fine2.s") == []
     assert _scan(FINE_ELSE_HEAD, tmp_path, "fine3.s") == []
     hits = _scan(BUG_AHEAD_OF_ELSE_HEAD, tmp_path, "bug2.s")
+    assert len(hits) == 1 and "a2, v162" in hits[0][3]
+    hits = _scan(BUG_UNRELATED_XOR, tmp_path, "bug3.s")
     assert len(hits) == 1 and "a2, v162" in hits[0][3]
 
 

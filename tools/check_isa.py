@@ -59,7 +59,8 @@ def scan(path):
     kernel, block = None, None
     stack = [set()]        # VGPRs written since each enclosing saveexec
     pend = []              # saves seen since the label of the current block
-    widened = False        # inside the full-mask window of an if / else join (see below)
+    widened = None         # inside the full-mask window of an if / else join: the SGPR pair its
+                           # s_or_saveexec saved (see below), else None
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+|hx_\w+):", l)
         if m:
@@ -67,7 +68,7 @@ def scan(path):
             continue
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
-            block, pend, widened = m.group(1), [], False
+            block, pend, widened = m.group(1), [], None
             continue
         s = l.strip()
         if not s or s[0] in ";.":
@@ -84,15 +85,18 @@ def scan(path):
             pend = []      # what follows belongs to the region opened here
             # (s_or_saveexec at the head of an else part: EXEC = then-lanes | else-lanes, the whole
             #  region's mask, until the s_xor that narrows it to the else lanes)
-            widened = op.startswith("s_or_saveexec")
+            # (the window closes only on the s_xor of THE SAME pair -- an unrelated
+            #  `s_xor_b64 exec, exec, sN` does not show that every lane of the region was active)
+            mm = re.match(r"s_or_saveexec_b64\s+(s\[\d+:\d+\])\s*,", s)
+            widened = mm.group(1) if mm else None
             continue
-        if widened and s.replace(" ", "").startswith("s_xor_b64exec,exec,"):
+        if widened and s.replace(" ", "") == "s_xor_b64exec,exec," + widened:
             # if / else: between `s_or_saveexec_b64 sX, sX` at the join label and this `s_xor_b64 exec,
             # exec, sX` every lane of the region is active -- a save there stores the value for all
             # of them, whichever way the block was reached (round 5: hx_run_kernel<looped, HF, KERPM,
             # NBP>, two spills of values from outside the NBP-constraint block, correct code)
             pend = []
-            widened = False
+            widened = None
             continue
         if s.replace(" ", "").startswith("s_or_b64exec,exec,"):
             inner = stack.pop() if len(stack) > 1 else set()
