@@ -42,10 +42,14 @@ Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
                    kernel on the core's stream, measured here.  With it: valu_active_frac
                    (same profile), traffic (HBM bytes per launch from the FETCH_SIZE /
                    WRITE_SIZE passes), hbm_measured_frac = traffic / kernel time / 8 TB/s,
-                   and hbm_yardstick -- the north star's "algorithmic bytes" figure (2 680 B
-                   per member-year, SURVEY.md 8d, x members x 555): a yardstick the kernel
-                   beats by design (block-causal DOECLIM pass, LDS-resident state), not a
-                   ceiling.  wave_time: how long the wavefronts of the last timed launch ran
+                   design_bytes_per_member_year -- THIS design's own byte model (design_bytes():
+                   4 output rows + the SST history once per 32-year block + partial sums,
+                   ~128 B) with traffic_over_design_bytes = traffic / it (~1: the kernel moves
+                   what it must and little else), and hbm_yardstick -- SURVEY.md 8(d)'s
+                   YEAR-STEPPED model (2 680 B per member-year: state round trip + history
+                   re-read every year), labelled as not this kernel: the kernel does not move
+                   those bytes by design, a frac above 1 there is no evidence of anything.
+                   kernel_ms_steps: min / median / max of the timed steps' kernel times.  wave_time: how long the wavefronts of the last timed launch ran
                    (the kernels' own s_memrealtime stamps, hx_wave_clock) -- mean, max and
                    max / mean: with one wavefront per SIMD the launch lasts as long as its
                    costliest wavefront.
@@ -58,6 +62,13 @@ Prints ONE JSON line on rank 0 (see the task contract) with three extra objects:
                    plain kernel + diagnostics instantiations), every member its own ocean heat
                    diffusivity (per-member DOECLIM kernel tables: the history contraction on the
                    vector ALU)
+  safe_build    -- kernel time of the same sources built WITHOUT the product's code-generation
+                   flags (libhector_amd_safe.so) at 65 536 and 131 072 members: what losing them
+                   would cost (N = 1 only)
+  first_run_*   -- the run kernel of a one-shot run (the first run of a fresh core: lanes by the
+                   shipped cost model where the order matters, launched behind the prewarm loop
+                   that keeps the chip's clocks up during upload and spinup) next to the steady
+                   state, and their ratio
   cpu_baseline  -- the CPU oracle (a scalar C port of the reference loop, pinned to the
                    reference's golden trajectory) on a bounded sample of the same ensemble,
                    all host cores, 555-year loop only
@@ -130,6 +141,30 @@ def pmc_entry(members, biomes):
     return None, True
 
 
+def design_bytes(members, biomes, kernel="run"):
+    """HBM bytes per member-year THIS design has to move ("the design's own byte
+    model") -- what `traffic` should be compared with, not SURVEY 8(d)'s year-stepped figure:
+      writes   4 output rows a year (SST and land temperature: the model's own histories; CO2 and
+               Tgav: the north star's outputs) = 32 B, + the block's 32 partial history sums,
+               written once per 32-year block = 8 B a year;
+      reads    the partial sum of the year (8 B), the land temperature leaving the 200-year Q10
+               window (8 B), and the SST history ONCE per 32-year block: block k reads its first
+               year index 1 + 32 k rows, sum over the 18 blocks of a 555-year run = 4 914 rows =
+               70.8 B a year;
+      entry / exit  the state table in and out once per launch: 16 (27 + 7 B) B / 555 years.
+    Kernels without the LDS tile of the block's SSTs (the two-wavefront flavour: 20 KB of LDS a
+    wavefront; several biomes: the tile's LDS holds the biome arrays) re-read the block's 32 SST
+    rows from the output array every year: + 256 B, most of which the L2 / MALL absorb."""
+    blocks = range(0, YEARS, 32)
+    hist_rows = sum(1 + b for b in blocks)                       # rows 0 .. blk0-1 of every block
+    parts = {"output_rows_written": 32.0, "partial_sums_written": 8.0, "partial_sum_read": 8.0,
+             "q10_window_read": 8.0, "sst_history_read_once_per_block": 8.0 * hist_rows / YEARS,
+             "state_in_and_out": 16.0 * (27 + 7 * biomes) / YEARS}
+    if kernel == "run2" or biomes != 1:
+        parts["block_ssts_reread_every_year"] = 256.0
+    return sum(parts.values()), parts
+
+
 def effective_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -179,12 +214,13 @@ def cpu_baseline(target_seconds=15.0, chunk=32):
     return n * YEARS / dt, dt, n, cores
 
 
-def make_core(n, biomes, offset, device, devices=None):
+def make_core(n, biomes, offset, device, devices=None, lib_path=None):
     """The synthetic perturbed-parameter ensemble of SURVEY.md 8(d) for members
     [offset, offset + n): ECS/Q10 (1 biome) or ECS + per-biome Q10 / warming factor (4)."""
     import hector_amd
     from hector_amd import ensemble
-    core = hector_amd.Core(n_members=n, device=device, devices=devices)
+    kw = {"lib_path": lib_path} if lib_path else {}
+    core = hector_amd.Core(n_members=n, device=device, devices=devices, **kw)
     if biomes == 1:
         S, q10 = ensemble.ecs_q10(n, offset=offset)
         core.setvar("S", S, "degC").setvar("q10_rh", q10, "(unitless)")
@@ -206,8 +242,12 @@ def roofline_object(members, biomes, kernel_ms, kernel="run"):
     alg_bytes = bpmy * members * YEARS  # per launch (one GPU)
     secs = kernel_ms * 1e-3
     yard = alg_bytes / secs / 1e9
+    dbytes, dparts = design_bytes(members, biomes, kernel)
     r = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VECTOR_PEAK / 1e12,
          "unit": "TFLOP/s", "frac": None, "traffic": None,
+         # this design's own byte model (design_bytes()): what `traffic` is held against
+         "design_bytes_per_member_year": dbytes, "design_bytes_parts": dparts,
+         "design_bytes_per_launch": dbytes * members * YEARS, "traffic_over_design_bytes": None,
          "kernel": ("hx_pair_kernel" if kernel == "pair" else
                     "hx_run_kernel<HX_B1W2> (two resident wavefronts per SIMD)" if kernel == "run2" else
                     "hx_run_kernel<%d>" % biomes),
@@ -223,6 +263,7 @@ def roofline_object(members, biomes, kernel_ms, kernel="run"):
         r["valu_active_frac"] = entry["valu_active_frac"]
         r["traffic"] = entry["traffic_bytes_per_launch"]
         r["hbm_measured_frac"] = entry["traffic_bytes_per_launch"] / secs / HBM_PEAK
+        r["traffic_over_design_bytes"] = entry["traffic_bytes_per_launch"] / (dbytes * members * YEARS)
         r["pmc_profile"] = entry["source"]
         r["pmc_profile_stale"] = stale
     r["formula"] = ("achieved = executed fp64 flops per launch (SQ_INSTS_VALU_FLOPS_FP64 x 64 lanes "
@@ -236,10 +277,20 @@ def roofline_object(members, biomes, kernel_ms, kernel="run"):
         "bound": "hbm", "achieved": yard, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": yard / (HBM_PEAK / 1e9), "algorithmic_bytes_per_member_year": bpmy,
         "algorithmic_bytes_per_launch": alg_bytes,
-        "note": "north-star yardstick (SURVEY 8d: yearly state round trip + yearly re-read of the "
-                "SST history); not a ceiling -- the block-causal DOECLIM pass reads the history "
-                "once per 32 years and the state lives in LDS, so the kernel moves ~7 % of it"}
+        "note": "SURVEY 8(d)'s YEAR-STEPPED byte model (state round trip through HBM every year + "
+                "the whole SST history re-read every year), NOT this kernel: the block-causal "
+                "DOECLIM pass reads the history once per 32 years and the state lives in "
+                "registers / LDS for the launch, so a frac above 1 here only says the kernel does "
+                "not move those bytes.  The figure to hold `traffic` against is "
+                "design_bytes_per_member_year (traffic_over_design_bytes)"}
     return r
+
+
+def spread(ms):
+    """min / median / max of the timed steps' kernel times (HIP events on the core's stream)."""
+    import numpy as np
+    a = np.asarray(ms, dtype=np.float64)
+    return {"n": int(a.size), "min": float(a.min()), "median": float(np.median(a)), "max": float(a.max())}
 
 
 def wave_time(core):
@@ -256,13 +307,13 @@ def wave_time(core):
             "span_ms": float(w[:, 1].max() - w[:, 0].min())}
 
 
-def time_config(n, biomes, steps, warmup, device, variant=None):
+def time_config(n, biomes, steps, warmup, device, variant=None, lib_path=None):
     """One extra configuration, timed like the headline: -> dict for other_configs.
     variant: None, "npp" (the NPP diagnostic recorded: the plain kernel + diagnostics family) or
     "diff" (every member its own ocean heat diffusivity: per-member DOECLIM kernel tables)."""
     import numpy as np
     import torch
-    core = make_core(n, biomes, 0, device)
+    core = make_core(n, biomes, 0, device, lib_path=lib_path)
     if variant == "npp":
         core.set_outputs(["CO2_concentration", "global_tas", "NPP"])
     elif variant == "diff":
@@ -281,6 +332,7 @@ def time_config(n, biomes, steps, warmup, device, variant=None):
     first_by = core.lane_order_source()               # (the cost model of an earlier core of this process, if any)
     core.run(end)                                     # lane calibration pass (see main) ...
     first_ms = core.last_run_ms()                     # ... and what a one-shot run of this core costs
+    first_pw = core.last_run_prewarmed()              # (launched behind the prewarm loop: hx_set_prewarm)
     core.reset(start); core.status()
     for _ in range(warmup):
         step()
@@ -296,6 +348,11 @@ def time_config(n, biomes, steps, warmup, device, variant=None):
     core.shutdown()
     kernel_ms = float(np.mean(kms))
     rf = roofline_object(n, biomes, kernel_ms, which)
+    if lib_path:  # (another build of the same sources: time only)
+        return {"members": n, "biomes": biomes, "steps": steps, "kernel": which, "kernel_ms": kernel_ms,
+                "kernel_ms_steps": spread(kms), "first_run_kernel_ms": first_ms,
+                "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
+                "members_with_model_errors": bad}
     if variant:   # (no counter profile of these instantiations: time only)
         return {"members": n, "biomes": biomes, "variant": {"npp": "NPP diagnostic recorded",
                                                              "diff": "per-member ocean heat diffusivity"}[variant],
@@ -303,12 +360,16 @@ def time_config(n, biomes, steps, warmup, device, variant=None):
                 "first_run_kernel_ms": first_ms, "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
                 "members_with_model_errors": bad}
     return {"members": n, "biomes": biomes, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-            "kernel": rf["kernel"], "kernel_ms": kernel_ms, "first_run_kernel_ms": first_ms,
+            "kernel": rf["kernel"], "kernel_ms": kernel_ms, "kernel_ms_steps": spread(kms),
+            "first_run_kernel_ms": first_ms, "first_run_over_steady": first_ms / kernel_ms,
+            "first_run_prewarmed": first_pw,
             "lanes_ordered_by": lanes_by, "first_run_lanes_ordered_by": first_by,
             "wave_max_over_mean": wt and wt["max_over_mean"], "wave_mean_ms": wt and wt["mean_ms"],
             "value": n * YEARS * steps / elapsed, "unit": "member-years/s",
             "members_with_model_errors": bad,
             "fp64_valu_frac": rf["frac"], "hbm_yardstick_frac": rf["hbm_yardstick"]["frac"],
+            "design_bytes_per_member_year": rf["design_bytes_per_member_year"],
+            "traffic_over_design_bytes": rf["traffic_over_design_bytes"],
             "pmc_profile_stale": rf.get("pmc_profile_stale")}
 
 
@@ -470,6 +531,7 @@ def run_workload(args, ctx, n, steps, warmup):
     first_by = core.lane_order_source()
     core.run(end)
     first_ms = core.last_run_ms()   # the one-shot run: lanes in the order a fresh core gives them
+    first_pw = core.last_run_prewarmed()
     core.reset(start)
     core.status()
     spin_ms = core.last_spinup_ms()
@@ -496,6 +558,8 @@ def run_workload(args, ctx, n, steps, warmup):
          "elapsed": float(t.item()),
          "kernel_ms": float(km[0].item()),   # slowest rank's (and slowest shard's) mean kernel time
          "first_run_kernel_ms": float(km[1].item()),   # ... and its first (one-shot) run's
+         "first_run_prewarmed": first_pw,
+         "kernel_ms_steps": spread(kern_ms),           # (this rank's)
          "bad": int((core.status() != 0).sum()),
          "stats_host": stats.cpu().numpy(),
          "which_kernel": core.last_run_kernel(),
@@ -611,7 +675,9 @@ def main():
     r = run_workload(args, ctx, n, args.steps, args.warmup)
     second = None
     if n_gpus > 1 and not args.members and not args.no_other_configs:
-        second = run_workload(args, ctx, 131072, max(5, args.steps // 2), 1)
+        # (timed like the headline -- the same steps and warmup -- so that the two
+        # workloads of a multi-GPU line are of equal standing)
+        second = run_workload(args, ctx, 131072, args.steps, args.warmup)
 
     failures = []
     if rank == 0:
@@ -642,12 +708,20 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            # which per-GPU workload `value` is: 2 = since round 5, BASELINE configs[2] (65 536
+            # members) on every GPU at every N, configs[3]'s shape beside it; lines of rounds 1-4
+            # (version 1) quoted 131 072 per GPU at N > 1 and are not comparable with these
+            "workload_version": 2,
+            "value_workload": "%d members per GPU" % n,
             "scaling_workload": "value: %d members on EVERY GPU at every N (one weak-scaling curve; "
                                 "N = 1 is BASELINE configs[2]); BASELINE configs[3]'s shape, 131 072 members "
                                 "per GPU = 1 048 576 at N = 8: value_per_gpu_workload['131072']" % n,
             "value_per_gpu_workload": {str(n): value},
             "first_run_kernel_ms": {str(n): r["first_run_kernel_ms"]},
+            "first_run_over_steady": {str(n): r["first_run_kernel_ms"] / kernel_ms},
+            "first_run_prewarmed": {str(n): r["first_run_prewarmed"]},
             "kernel_ms": {str(n): kernel_ms},
+            "kernel_ms_steps": r["kernel_ms_steps"],   # min / median / max of the timed steps (HIP events)
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -692,11 +766,15 @@ def main():
                 "collective_backend": backend2, "collective_world_size": cworld2,
                 "members_in_statistics": in2, "members_with_model_errors": second["bad"],
                 "first_run_kernel_ms": second["first_run_kernel_ms"],
+                "first_run_over_steady": second["first_run_kernel_ms"] / second["kernel_ms"],
+                "first_run_prewarmed": second["first_run_prewarmed"], "kernel_ms_steps": second["kernel_ms_steps"],
                 "lanes_ordered_by": second["lanes_by"], "first_run_lanes_ordered_by": second["first_run_lanes_by"],
                 "fp64_valu_frac": rf2["frac"], "pmc_profile_stale": rf2.get("pmc_profile_stale")}]
             k2 = str(second["n"])
             out["value_per_gpu_workload"][k2] = out["other_configs"][0]["value"]
             out["first_run_kernel_ms"][k2] = second["first_run_kernel_ms"]
+            out["first_run_over_steady"][k2] = second["first_run_kernel_ms"] / second["kernel_ms"]
+            out["first_run_prewarmed"][k2] = second["first_run_prewarmed"]
             out["kernel_ms"][k2] = second["kernel_ms"]
         if n_gpus == 1 and not args.no_other_configs:
             others = []
@@ -712,7 +790,24 @@ def main():
                 if o["biomes"] == args.biomes:
                     out["value_per_gpu_workload"][str(o["members"])] = o["value"]
                     out["first_run_kernel_ms"][str(o["members"])] = o["first_run_kernel_ms"]
+                    out["first_run_over_steady"][str(o["members"])] = o["first_run_over_steady"]
+                    out["first_run_prewarmed"][str(o["members"])] = o["first_run_prewarmed"]
                     out["kernel_ms"][str(o["members"])] = o["kernel_ms"]
+            # what losing the product's code-generation flags would cost: the same sources built with
+            # default code generation (`make safe`: no -disable-machine-licm, the carbonate restart
+            # in its select form), timed the same way
+            safe = os.path.join(ROOT, "hector_amd", "lib", "libhector_amd_safe.so")
+            if os.path.exists(safe):
+                try:
+                    sb = {str(m2): time_config(m2, 1, 3, 1, local_rank, lib_path=safe) for m2 in (65536, 131072)}
+                    for k2, v2 in sb.items():
+                        v2["over_product_build"] = v2["kernel_ms"] / out["kernel_ms"][k2] if k2 in out["kernel_ms"] else None
+                    out["safe_build"] = dict(sb, note="libhector_amd_safe.so: default code generation, "
+                                             "HX_CHEM_SELECT; kernel_ms against the product build's")
+                except Exception as e:   # a test-only artefact: its absence or failure is not the bench's
+                    out["safe_build"] = {"error": str(e)[:200]}
+            else:
+                out["safe_build"] = {"error": "hector_amd/lib/libhector_amd_safe.so not built (make -C hector_amd/csrc safe)"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             v, dt, ns, cores = cpu_baseline(args.cpu_seconds)
             out["cpu_baseline"] = {

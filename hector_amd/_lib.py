@@ -178,6 +178,8 @@ def _declare(lib):
         "hx_stream": [P, c.POINTER(P)],
         "hx_set_pair_kernel_limit": [P, c.c_int],
         "hx_set_two_wave_from": [P, c.c_int],
+        "hx_set_prewarm": [P, c.c_int],
+        "hx_last_run_prewarmed": [P, c.POINTER(c.c_int)],
         "hx_wave_clock": [P, c.c_int, c.POINTER(c.c_longlong), c.c_int, c.POINTER(c.c_int)],
         "hx_component_output": [P, c.c_char_p, c.POINTER(c.c_int)],
         "hx_last_run_kernel": [P, c.POINTER(c.c_char_p)],
@@ -197,4 +199,4 @@ ABI_SYMBOLS = ["hx_backend", "hx_build_info", "hx_last_error", "hx_newcore", "hx
                "hx_last_run_kernel", "hx_last_run_variant", "hx_component_output", "hx_newcore_devices", "hx_shards",
                "hx_device_var_shard", "hx_stream_shard", "hx_comm_unique_id", "hx_comm_init_rank",
                "hx_comm_info", "hx_ensemble_stats", "hx_set_lane_calibration", "hx_lanes_calibrated", "hx_lane_order_source", "hx_set_cost_model",
-               "hx_cost_models_export", "hx_cost_models_load"]
+               "hx_cost_models_export", "hx_cost_models_load", "hx_set_prewarm", "hx_last_run_prewarmed"]

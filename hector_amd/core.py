@@ -375,6 +375,17 @@ class Core:
         self._ck(self._lib.hx_set_two_wave_from(self._h, int(min_members)))
         return self
 
+    def set_prewarm(self, ms):
+        """Keep the chip's clocks up while run()'s preparation uploads and spins up after an idle
+        gap (hx_set_prewarm): at most `ms` milliseconds of a small busy loop, 0 = off."""
+        self._ck(self._lib.hx_set_prewarm(self._h, int(ms)))
+        return self
+
+    def last_run_prewarmed(self):
+        v = ctypes.c_int(0)
+        self._ck(self._lib.hx_last_run_prewarmed(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
     def last_run_kernel(self):
         """'run', 'run2' or 'pair': the kernel the last run() launched."""
         s = ctypes.c_char_p()

@@ -24,6 +24,8 @@ int hx_track_value_rows(int B);
 int hx_pair_available();
 hipError_t hx_launch_run_pair(const HxArgs *d_args, int npad, bool heatflux, bool kpm, int iy_from,
                               int iy_to, hipStream_t st, bool cons, int nbiome);
+hipError_t hx_launch_prewarm(const int *d_stop, long long max_ticks, double *d_sink, int waves,
+                             const double *mem, unsigned long long n_mem, hipStream_t st);
 hipError_t hx_launch_run(int B, const HxArgs *d_args, int npad, bool heatflux, bool kpm, int con,
                          int iy_from, int iy_to, hipStream_t st, bool two_wave, int cus);
 int hx_doeclim_block_years();
@@ -172,6 +174,7 @@ EnsembleCore::EnsembleCore(const std::string &scenario_path, int n_members, int 
   if (const char *e6 = std::getenv("HECTOR_AMD_COST_MODEL")) cost_model_ = std::atoi(e6) != 0;
   // (tests: the lane-order logic of a GPU with fewer SIMDs, so that small ensembles exercise it)
   if (const char *e7 = std::getenv("HECTOR_AMD_SIMDS")) simds_ = std::max(1, std::atoi(e7));
+  if (const char *e8 = std::getenv("HECTOR_AMD_PREWARM_MS")) prewarm_ms_ = std::max(0, std::atoi(e8));
   try {  // a constructor that throws gets no destructor: release the stream and events here
     check(hipEventCreate(&ev0_), "hipEventCreate");
     check(hipEventCreate(&ev1_), "hipEventCreate");
@@ -308,6 +311,9 @@ bool EnsembleCore::component_disabled(const std::string &section) const {
 }
 
 EnsembleCore::~EnsembleCore() {
+  if (prewarm_on_) (void)hipMemsetAsync(d_prewarm_, 1, 4, stream_);
+  if (aux_stream_) { (void)hipStreamSynchronize(aux_stream_); (void)hipStreamDestroy(aux_stream_); }
+  if (d_prewarm_) (void)hipFree(d_prewarm_);
   free_device();
   if (ev0_) (void)hipEventDestroy(ev0_);
   if (ev1_) (void)hipEventDestroy(ev1_);
@@ -1915,6 +1921,7 @@ void EnsembleCore::prepare() {
   check(hipSetDevice(device_), "hipSetDevice");
   StageClock clk;
   if (layout_dirty_) { alloc_device(); clk.lap("alloc_device"); }
+  if (shared_dirty_ || params_dirty_ || need_spinup_) prewarm_begin();
   if (shared_dirty_) {  // dated inputs changed: rebuild the per-year table
     build_shared();
     check(hipMemcpyAsync(d_shared_, shared_.data(), sizeof(double) * shared_.size(),
@@ -1961,6 +1968,9 @@ void EnsembleCore::prepare() {
     check(hipMemcpyAsync(d_status_, d_status_ + 2 * np, sizeof(unsigned) * np, hipMemcpyDeviceToDevice,
                          stream_), "restore status");
   } else {
+    // (an all-member spinup wants the SIMDs, and is itself full-chip work; experiments:
+    // HECTOR_AMD_PREWARM_STOP=spinup -- the loop ends ahead of a shared spinup too)
+    if (!uniform || std::getenv("HECTOR_AMD_PREWARM_STOP")) prewarm_end();
     check(hipEventRecord(ev0_, stream_), "event");
     check(hx_launch_spinup(B_, d_args_, uniform ? 1 : npad_, d_spin_steps_, stream_), "spinup");
     check(hx_launch_alk(d_args_, uniform ? 1 : npad_, stream_), "alkalinity tuning");
@@ -2041,6 +2051,46 @@ void EnsembleCore::reset(double date) {
   if (dirty_from_iy_ >= iy) dirty_from_iy_ = -1;
 }
 
+// ---- clocks up while the host prepares (hx_prewarm_kernel, hx_kernels.hip) -----------------------
+// Begun when prepare() finds an upload or a spinup to do (the GPU has been idle for a while and
+// will be for milliseconds more), ended by run() right ahead of the run kernel; bounded by
+// prewarm_ms_ on the device's own clock.  hx_set_prewarm / HECTOR_AMD_PREWARM_MS = 0: off.
+void EnsembleCore::prewarm_begin() {
+#ifndef HX_HOST_EMULATION
+  if (prewarm_ms_ <= 0 || prewarm_on_) return;
+  {  // only after an idle gap: a calibration loop's next iteration finds the clocks where it left them
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (last_gpu_activity_s_ >= 0 && now - last_gpu_activity_s_ < 0.005) return;
+  }
+  if (!aux_stream_) check(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking), "prewarm stream");
+  if (!d_prewarm_) check(hipMalloc((void **)&d_prewarm_, 64 + sizeof(double) * 1024), "prewarm flag");
+  check(hipMemsetAsync(d_prewarm_, 0, 64, aux_stream_), "prewarm flag");
+  // three small wavefronts a SIMD (16 registers each: every other launch still finds room; the
+  // spinup and alkalinity kernels raise their own priority in the instruction arbiter).  One a SIMD
+  // brings a 131 072-member first run to 1.06-1.09 of the steady state, three to 1.04
+  // (profiles/r06_one_shot_prewarm.txt)
+  int waves = 3 * simds_;
+  if (const char *e = std::getenv("HECTOR_AMD_PREWARM_WAVES")) waves = std::max(1, std::min(8 * simds_, std::atoi(e)));
+  // (experiments: HECTOR_AMD_PREWARM_MEM=1 -- the loop also sweeps the SST output array)
+  const bool sweep = std::getenv("HECTOR_AMD_PREWARM_MEM") && d_out_[HXO_SST];
+  check(hx_launch_prewarm(reinterpret_cast<const int *>(d_prewarm_), (long long)prewarm_ms_ * 100000ll,
+                          reinterpret_cast<double *>(d_prewarm_ + 64), waves,
+                          sweep ? d_out_[HXO_SST] : nullptr,
+                          sweep ? (unsigned long long)scen_.ns() * (unsigned long long)npad_ : 0ull, aux_stream_),
+        "prewarm kernel");
+  prewarm_on_ = true;
+#endif
+}
+// (on the core's stream: the flag rises when everything queued before it -- upload, spinup -- is done)
+void EnsembleCore::prewarm_end() {
+#ifndef HX_HOST_EMULATION
+  if (!prewarm_on_) return;
+  check(hipMemsetAsync(d_prewarm_, 1, 4, stream_), "prewarm stop");
+  prewarm_on_ = false;
+  last_run_prewarmed_ = true;
+#endif
+}
+
 void EnsembleCore::run(double runtodate) {
   prepare();
   if (runtodate < 0.0) runtodate = scen_.end;
@@ -2059,6 +2109,8 @@ void EnsembleCore::run(double runtodate) {
     check(hipMemsetAsync(d_cost_, 0, sizeof(double) * (size_t)npad_, stream_), "zero lane cost");
     cost_from_iy_ = 0;
   }
+  last_run_prewarmed_ = false;
+  prewarm_end();
   check(hipEventRecord(ev0_, stream_), "event");
   // one launch for the whole span: wavefronts are independent (each does its own DOECLIM
   // history pass every HX_DBLK years), so there is no global barrier to wait at
@@ -2133,6 +2185,7 @@ void EnsembleCore::run(double runtodate) {
 
 void EnsembleCore::sync() {
   check(hipStreamSynchronize(stream_), "stream sync");
+  last_gpu_activity_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   if (run_timed_) {
     float ms = 0;
     check(hipEventElapsedTime(&ms, ev0_, ev1_), "elapsed");

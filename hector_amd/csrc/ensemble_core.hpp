@@ -85,6 +85,12 @@ class EnsembleCore {
   // scenario table, biome count and varying rows, this process; ensemble_core.cpp: fit_cost_model)
   int lane_order_source() const { return lane_order_source_; }
   void set_cost_model(bool on) { cost_model_ = on; }
+  // the chip's clocks kept up while prepare() uploads and spins up after an idle gap, so that the
+  // run kernel behind it does not start at ramping clocks (ensemble_core.cpp: prewarm_begin);
+  // ms: the most the busy loop may last on the device's own clock, 0 = off
+  void set_prewarm(int ms) { prewarm_ms_ = ms < 0 ? 0 : (ms > 200 ? 200 : ms); }
+  int prewarm_ms() const { return prewarm_ms_; }
+  bool last_run_prewarmed() const { return last_run_prewarmed_; }
   // keep every year's component state in HBM (272 B per member-year for one biome) so that
   // reset(date) can go back to any computed year, like the reference's tseries records
   void enable_history(bool on);
@@ -251,6 +257,13 @@ class EnsembleCore {
   bool fetch_host(const std::string &capability, int year0, int year1, double *out_host);
   void compute_derived(const std::string &capability, int iy0, int ny);
   hipStream_t stream_ = nullptr;
+  hipStream_t aux_stream_ = nullptr;          // the prewarm loop's (non-blocking)
+  unsigned char *d_prewarm_ = nullptr;        // its stop flag (+ a sink)
+  int prewarm_ms_ = 50;
+  bool prewarm_on_ = false, last_run_prewarmed_ = false;
+  double last_gpu_activity_s_ = -1.0;         // host clock of the last launch / wait of this core
+  void prewarm_begin();
+  void prewarm_end();
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   bool run_timed_ = false;
   int pair_max_members_ = 32768;  // ensembles up to this size use the two-wavefront kernel (0: never)

@@ -389,6 +389,11 @@ int hx_component_output(hx_core *core, const char *component, int *enabled) {
 int hx_set_pair_kernel_limit(hx_core *core, int max_members) {
   HX_TRY(core->core->set_pair_kernel_limit(max_members))
 }
+int hx_set_prewarm(hx_core *core, int ms) { HX_TRY(core->core->set_prewarm(ms)) }
+int hx_last_run_prewarmed(hx_core *core, int *yes) {
+  if (!yes) return fail("null argument");
+  HX_TRY(*yes = core->core->last_run_prewarmed() ? 1 : 0)
+}
 int hx_set_two_wave_from(hx_core *core, int min_members) {
   HX_TRY(core->core->set_two_wave_from(min_members))
 }

@@ -286,6 +286,8 @@ int Fleet::spinup_record(int member, double *values, int max_steps) {
   return s.core->spinup_record(member - s.offset, values, max_steps);
 }
 void Fleet::set_pair_kernel_limit(int m) { HX_EACH(set_pair_kernel_limit(m)) }
+void Fleet::set_prewarm(int ms) { HX_EACH(set_prewarm(ms)) }
+bool Fleet::last_run_prewarmed() const { return shards_.front().core->last_run_prewarmed(); }
 void Fleet::set_two_wave_from(int m) { HX_EACH(set_two_wave_from(m)) }   // (members of a shard)
 void Fleet::setvar_dated(const std::string &cap, const int *years, const double *values, int n,
                          const char *units) {

@@ -96,6 +96,8 @@ class Fleet {
   hipStream_t stream(int shard_index = 0) const { return shards_[(size_t)shard_index].core->stream(); }
   void set_pair_kernel_limit(int max_members);
   void set_two_wave_from(int min_members);
+  void set_prewarm(int ms);
+  bool last_run_prewarmed() const;
 
   // ---- the collective -----------------------------------------------------------------------
   // Join a communicator of n_procs * n_shards() ranks; this process's shards are ranks

@@ -408,6 +408,11 @@ __global__ __launch_bounds__(64) void hx_spinup_kernel(const HxArgs *__restrict_
   const HxConst &kc = args->kc;
   const int mem = blockIdx.x * 64 + threadIdx.x;
   if (mem >= buf.npad) return;
+#ifndef HX_HOST_EMULATION
+  // (a chain of ~500 dependent solver steps, often on ONE wavefront: ahead of the prewarm loop's
+  // wavefronts -- hx_prewarm_kernel -- in the SIMD's instruction arbiter)
+  __builtin_amdgcn_s_setprio(3);
+#endif
   __shared__ double s_park_fixed[B == HX_DYN ? 1 : hx_npark<B>()][64];
   double (*s_park)[64] = (B == HX_DYN) ? hx_dyn_park : s_park_fixed;
   Member<B> m;
@@ -1760,6 +1765,9 @@ __global__ __launch_bounds__(256) void hx_doeclim_table_kernel(const double *dif
 // after the spinup kernel, and the run kernel finds the alkalinities in the state table.
 // ===========================================================================
 __global__ __launch_bounds__(64) void hx_alk_kernel(const HxArgs *__restrict__ args, int nmem) {
+#ifndef HX_HOST_EMULATION
+  __builtin_amdgcn_s_setprio(3);   // (see hx_spinup_kernel)
+#endif
   const int mem = blockIdx.x * 64 + threadIdx.x;
   if (mem >= nmem) return;
   const HxBuffers &buf = args->buf;
@@ -2252,6 +2260,40 @@ hipError_t hx_launch_unit_csys(int n, const double *Tc, const double *carbon, co
                                double inv_vol, double *out, hipStream_t st) {
   hipLaunchKernelGGL(hx_unit_csys_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, Tc, carbon, alk,
                      inv_vol, out);
+  return hipGetLastError();
+}
+// ---- the chip's clocks ahead of a one-shot run ---------------------------------------------------
+// A run kernel launched after an idle gap -- the first run of a fresh core: the host has just spent
+// 10-15 ms uploading and spinning up -- executes at ramping clocks: +6 % at 65 536 members, +11-15 %
+// on the two-wavefront kernel, and ~12 ms of full-chip work right before it removes most of that
+// (tools/prof/prewarm_curve.py, profiles/r06_prewarm_curve.txt).  This kernel is that work: one
+// small wavefront on some of the SIMDs (never all: a kernel that needs a whole SIMD's registers
+// must find one) multiplies and adds until the host raises `stop` (a memset on the core's stream,
+// right ahead of the run kernel) or its own deadline on the constant 100 MHz clock passes --
+// whichever comes first, so it cannot outlive its budget whatever the host does.
+__global__ __launch_bounds__(64) void hx_prewarm_kernel(const int *stop, long long max_ticks, double *sink,
+                                                         const double *mem, unsigned long long n_mem) {
+#ifndef HX_HOST_EMULATION
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  double a = 1.0 + 1e-9 * threadIdx.x, b = 0.999999, c = 1e-7, d = a, e = a + c, f = a - c, acc = 0.0;
+  unsigned long long pos = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 64;
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { a = fma(a, b, c); d = fma(d, b, c); e = fma(e, b, c); f = fma(f, b, c); }
+    if (n_mem) {   // (... and the memory system: a sweep over the arrays the run will write)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acc += __builtin_nontemporal_load(mem + pos % n_mem); pos += stride; }
+    }
+    if (__builtin_nontemporal_load(stop) != 0) break;
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
+  }
+  if (((a + d) + (e + f)) + acc == 12345.678) sink[blockIdx.x & 1023] = a;   // (keeps the arithmetic)
+#endif
+}
+hipError_t hx_launch_prewarm(const int *d_stop, long long max_ticks, double *d_sink, int waves,
+                             const double *mem, unsigned long long n_mem, hipStream_t st) {
+  hipLaunchKernelGGL(hx_prewarm_kernel, dim3(waves), dim3(64), 0, st, d_stop, max_ticks, d_sink, mem, n_mem);
   return hipGetLastError();
 }
 hipError_t hx_launch_diag(int kind, const HxDiagArgs &a, double *out, hipStream_t st) {

@@ -341,6 +341,16 @@ int hx_set_pair_kernel_limit(hx_core *core, int max_members);
  * With the default (< 0) an ensemble whose members differ in ocean heat diffusivity stays on the
  * one-wavefront kernel, which is the faster one for it (131 072 such members 13.5 against 14.3 ms). */
 int hx_set_two_wave_from(hx_core *core, int min_members);
+/* A run kernel launched after an idle gap -- the first run of a fresh core, behind 10-15 ms of
+ * upload and spinup -- executes at ramping clocks (+6 % at 65 536 members, +11-15 % at 131 072:
+ * profiles/r06_prewarm_curve.txt).  While hx_run's preparation uploads and spins up after such a
+ * gap, a busy loop of three small wavefronts a SIMD keeps the chip's clocks up; hx_run stops it right
+ * ahead of the run kernel, and it stops by itself after `ms` milliseconds of the device's own
+ * clock (default 50; 0: off; HECTOR_AMD_PREWARM_MS sets the default of new cores).
+ * hx_last_run_prewarmed: whether the last hx_run's kernel was launched behind it.  Results do
+ * not depend on it.  No counterpart in the reference. */
+int hx_set_prewarm(hx_core *core, int ms);
+int hx_last_run_prewarmed(hx_core *core, int *yes);
 
 /* Core::outputEnabled (src/core.cpp:257-262, 688-695): 0 if the scenario's section of that component
  * says output=0 -- the output stream visitor then leaves the component's rows out
