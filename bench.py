@@ -84,6 +84,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_MEMBER_YEAR = {1: 2680.0, 4: 3072.0}  # SURVEY.md 8(d) / BASELINE.md 4
+# SURVEY.md 8(d), "for context, flops": ~13.8 kflop-equivalent per member-year as the reference
+# executes it, ~9.6 k with warm-started Newton iterations (one biome)
+SURVEY_FLOPS_PER_MEMBER_YEAR = 9600.0
 HBM_PEAK = 8.0e12            # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK = 78.6e12   # fp64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 YEARS = 555
@@ -154,15 +157,20 @@ def design_bytes(members, biomes, kernel="run"):
       entry / exit  the state table in and out once per launch: 16 (27 + 7 B) B / 555 years.
     Kernels without the LDS tile of the block's SSTs (the two-wavefront flavour: 20 KB of LDS a
     wavefront; several biomes: the tile's LDS holds the biome arrays) re-read the block's 32 SST
-    rows from the output array every year: + 256 B, most of which the L2 / MALL absorb."""
+    rows from the output array every year: 256 B more of L2 traffic (`l2_reread_bytes`), which
+    reaches HBM only as far as the block's rows fall out of the L2 / MALL between two years -- not
+    at all for four biomes at 65 536 members (traffic / design 1.07), about half of it on the
+    two-wavefront flavour at 131 072 (2.05).  Small ensembles whose whole SST history stays in the
+    L2 (1 024 members: 4.5 MB) move LESS than this figure (0.40)."""
     blocks = range(0, YEARS, 32)
     hist_rows = sum(1 + b for b in blocks)                       # rows 0 .. blk0-1 of every block
     parts = {"output_rows_written": 32.0, "partial_sums_written": 8.0, "partial_sum_read": 8.0,
              "q10_window_read": 8.0, "sst_history_read_once_per_block": 8.0 * hist_rows / YEARS,
              "state_in_and_out": 16.0 * (27 + 7 * biomes) / YEARS}
+    total = sum(parts.values())
     if kernel == "run2" or biomes != 1:
-        parts["block_ssts_reread_every_year"] = 256.0
-    return sum(parts.values()), parts
+        parts["l2_reread_bytes_not_in_the_sum"] = 256.0
+    return total, parts
 
 
 def effective_cores():
@@ -273,6 +281,17 @@ def roofline_object(members, biomes, kernel_ms, kernel="run"):
                     "matrix pipe beside it: fp64_mfma_tflops = SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 / time); "
                     "hbm_measured_frac = PMC traffic "
                     "(2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s")
+    if biomes == 1:
+        yf = SURVEY_FLOPS_PER_MEMBER_YEAR * members * YEARS / secs / 1e12
+        r["flops_yardstick"] = {
+            "bound": "fp64-valu", "achieved": yf, "peak": FP64_VECTOR_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": yf / (FP64_VECTOR_PEAK / 1e12), "algorithmic_flops_per_member_year": SURVEY_FLOPS_PER_MEMBER_YEAR,
+            "note": "SURVEY 8(d)'s flop count of the algorithm AS THE REFERENCE EXECUTES IT (with warm-started "
+                    "Newton) over this run's time: a yardstick of the same kind as hbm_yardstick.  The "
+                    "kernels execute ~2.9 k flops per member-year, not 9.6 k -- the flux chain, scaled stages, "
+                    "coefficient chains, per-year polynomial constants and fitted equilibrium constants "
+                    "removed the rest -- so `frac` (EXECUTED flops) FALLS when such a step makes the kernel "
+                    "faster: round 6's coefficient chains took 8.5 % of the flops and ~2 % of the time"}
     r["hbm_yardstick"] = {
         "bound": "hbm", "achieved": yard, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": yard / (HBM_PEAK / 1e9), "algorithmic_bytes_per_member_year": bpmy,

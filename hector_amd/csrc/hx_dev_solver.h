@@ -814,6 +814,23 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
   // they are used), 12 % of the pass's instructions; five s_load_dwordx8/x16 a pass instead.
   // (-DHX_TAB_LITERALS: the old form, for experiment builds.)
   const double *T = kc.tab;
+#if defined(HX_TAB_HEAD_AHEAD) && !defined(HX_HOST_EMULATION) && !defined(HX_TOP_TESTED_LOOPS)
+  // (experiment: the tableau's first eight entries -- stages 2 to 4 -- requested at the END of the
+  // previous pass, behind the error norm, and carried over the back edge in 16 scalar registers: the
+  // head of a pass then does not wait for its first scalar load)
+  double T0[8];
+#define HX_TAB_HEAD() do { int o_ = 0; asm volatile("" : "+s"(o_)); const double *S_ = kc.tab + o_; \
+    _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) T0[k_] = S_[k_]; } while (0)
+#define b21 T0[0]
+#define f2 T0[1]
+#define b31 T0[2]
+#define b32 T0[3]
+#define f3 T0[4]
+#define b41 T0[5]
+#define b42 T0[6]
+#define b43 T0[7]
+#else
+#define HX_TAB_HEAD() do { } while (0)
 #define b21 T[0]
 #define f2 T[1]
 #define b31 T[2]
@@ -822,6 +839,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 #define b41 T[5]
 #define b42 T[6]
 #define b43 T[7]
+#endif
 #define f4 T[8]
 #define b51 T[9]
 #define b52 T[10]
@@ -932,6 +950,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
     if constexpr (LAND2) dxdt[1] = hx_div1(m.luc_e, (y[1] + y[2]) + y[3]);   // (the loss rate itself: see LAND2)
     int fails = 0;
     bool stepping = seg;
+    HX_TAB_HEAD();
     if constexpr (hx_w2<B>()) w2_park_out<B>(m);
     // One pass = one dopri5 attempt of every stepping lane.  The attempt itself is straight-line
     // code that ALL lanes execute (a lane that has reached its target computes on stale values
@@ -1035,48 +1054,57 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           for (int i = 1; i <= 3; ++i) H[i] = fma(-hrj, x[i], cs[i]);
         };
         const double z1 = dxdt[4];
-        const double Hz1 = fma(-hl, z1, ha);
-        const double z2 = z1 + b21 * Hz1;
-        const double Hz2 = fma(-hl, z2, ha);
-        const double z3 = z1 + b31 * Hz1 + b32 * Hz2;
-        const double Hz3 = fma(-hl, z3, ha);
-        const double z4 = z1 + b41 * Hz1 + b42 * Hz2 + b43 * Hz3;
-        const double Hz4 = fma(-hl, z4, ha);
-        const double z5 = z1 + b51 * Hz1 + b52 * Hz2 + b53 * Hz3 + b54 * Hz4;
-        const double Hz5 = fma(-hl, z5, ha);
-        const double z6 = z1 + b61 * Hz1 + b62 * Hz2 + b63 * Hz3 + b64 * Hz4 + b65 * Hz5;
         double H1[4], H7[4];
         [[maybe_unused]] double l2_Ex = 0, l2_Ec = 0;
+        [[maybe_unused]] double z3 = 0, z4 = 0, z5 = 0, z6 = 0;
         if constexpr (LAND2) {
-          // chain a (coefficient of x_i): a_1 = 1, A_l = -(h r_l) a_l
+          // STAGE by stage -- the flux chain z, chain a (coefficient of x_i: a_1 = 1, A_l = -(h r_l)
+          // a_l) and chain g (coefficient of h c_i: g_1 = 0, G_l = 1 + Gd_l, Gd_l = -(h r_l) g_l; the
+          // rate-free parts of its sums are the nodes f_l, Gd_1 = 0) side by side, so that every row
+          // of the tableau is used in ONE place (chain by chain its 30 scalars were wanted three
+          // times over: 54 spilled scalars against 37)
           const double hr0 = h * dxdt[1];      // dxdt[1] carries the loss rate at (t, y)
+          const double Hz1 = fma(-hl, z1, ha);
           const double A1 = -hr0;
+          // stage 2
+          const double z2 = z1 + b21 * Hz1;
           const double a2 = fma(b21, A1, 1.0);
+          const double Hz2 = fma(-hl, z2, ha);
           const double A2 = -hr[0] * a2;
-          const double a3 = 1.0 + b31 * A1 + b32 * A2;
-          const double A3 = -hr[1] * a3;
-          const double a4 = 1.0 + b41 * A1 + b42 * A2 + b43 * A3;
-          const double A4 = -hr[2] * a4;
-          const double a5 = 1.0 + b51 * A1 + b52 * A2 + b53 * A3 + b54 * A4;
-          const double A5 = -hr[3] * a5;
-          const double a6 = 1.0 + b61 * A1 + b62 * A2 + b63 * A3 + b64 * A4 + b65 * A5;
-          const double A6 = -hr[4] * a6;
-          const double Pd = c1 * A1 + c3 * A3 + c4 * A4 + c5 * A5 + c6 * A6;   // a_7 - 1
-          const double A7 = -hr[4] * (1.0 + Pd);
-          l2_Ex = dc1 * A1 + dc3 * A3 + dc4 * A4 + dc5 * A5 + dc6 * A6 + dc7 * A7;
-          // chain g (coefficient of h c_i): g_1 = 0, G_l = 1 + Gd_l, Gd_l = -(h r_l) g_l; the
-          // rate-free parts of the sums are the nodes f_l (Gd_1 = 0)
           const double G2 = -hr[0] * f2;
+          // stage 3
+          z3 = z1 + b31 * Hz1 + b32 * Hz2;
+          const double a3 = 1.0 + b31 * A1 + b32 * A2;
           const double g3 = fma(b32, G2, f3);
+          const double Hz3 = fma(-hl, z3, ha);
+          const double A3 = -hr[1] * a3;
           const double G3 = -hr[1] * g3;
+          // stage 4
+          z4 = z1 + b41 * Hz1 + b42 * Hz2 + b43 * Hz3;
+          const double a4 = 1.0 + b41 * A1 + b42 * A2 + b43 * A3;
           const double g4 = f4 + b42 * G2 + b43 * G3;
+          const double Hz4 = fma(-hl, z4, ha);
+          const double A4 = -hr[2] * a4;
           const double G4 = -hr[2] * g4;
+          // stage 5
+          z5 = z1 + b51 * Hz1 + b52 * Hz2 + b53 * Hz3 + b54 * Hz4;
+          const double a5 = 1.0 + b51 * A1 + b52 * A2 + b53 * A3 + b54 * A4;
           const double g5 = f5 + b52 * G2 + b53 * G3 + b54 * G4;
+          const double Hz5 = fma(-hl, z5, ha);
+          const double A5 = -hr[3] * a5;
           const double G5 = -hr[3] * g5;
+          // stage 6
+          z6 = z1 + b61 * Hz1 + b62 * Hz2 + b63 * Hz3 + b64 * Hz4 + b65 * Hz5;
+          const double a6 = 1.0 + b61 * A1 + b62 * A2 + b63 * A3 + b64 * A4 + b65 * A5;
           const double g6 = 1.0 + b62 * G2 + b63 * G3 + b64 * G4 + b65 * G5;
+          const double A6 = -hr[4] * a6;
           const double G6 = -hr[4] * g6;
-          const double Q = 1.0 + (c3 * G3 + c4 * G4 + c5 * G5 + c6 * G6);       // g_7
+          // the candidate: a_7 - 1, g_7
+          const double Pd = c1 * A1 + c3 * A3 + c4 * A4 + c5 * A5 + c6 * A6;
+          const double Q = 1.0 + (c3 * G3 + c4 * G4 + c5 * G5 + c6 * G6);
+          const double A7 = -hr[4] * (1.0 + Pd);
           const double G7 = -hr[4] * Q;
+          l2_Ex = dc1 * A1 + dc3 * A3 + dc4 * A4 + dc5 * A5 + dc6 * A6 + dc7 * A7;
           l2_Ec = dc3 * G3 + dc4 * G4 + dc5 * G5 + dc6 * G6 + dc7 * G7;
 #pragma unroll
           for (int i = 1; i <= 3; ++i) {
@@ -1085,6 +1113,16 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
           }
           dn[1] = r5; dn[2] = 0.0; dn[3] = 0.0;  // (the rate at the candidate, for the next attempt)
         } else {
+        const double Hz1 = fma(-hl, z1, ha);
+        const double z2 = z1 + b21 * Hz1;
+        const double Hz2 = fma(-hl, z2, ha);
+        z3 = z1 + b31 * Hz1 + b32 * Hz2;
+        const double Hz3 = fma(-hl, z3, ha);
+        z4 = z1 + b41 * Hz1 + b42 * Hz2 + b43 * Hz3;
+        const double Hz4 = fma(-hl, z4, ha);
+        z5 = z1 + b51 * Hz1 + b52 * Hz2 + b53 * Hz3 + b54 * Hz4;
+        const double Hz5 = fma(-hl, z5, ha);
+        z6 = z1 + b61 * Hz1 + b62 * Hz2 + b63 * Hz3 + b64 * Hz4 + b65 * Hz5;
 #pragma unroll
         for (int i = 1; i <= 3; ++i) H1[i] = h * dxdt[i];
 #pragma unroll
@@ -1272,6 +1310,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         err = fmax(err, hx_div(fabs(xe), d));
       }
       }
+      HX_TAB_HEAD();   // (experiment builds: the next pass's first rows)
       // increase_step: err < 0.5 -> dt *= 0.9 * max(err, 5^-5)^(-1/5)
       const double grow = 0.9 * pow_m15(fmax(0.00032, err));
       if (stepping) {

@@ -660,7 +660,40 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
     ya[4] = shn[HXSH_CH4N]; ya[5] = shn[HXSH_O3_NOX]; ya[6] = shn[HXSH_O3_CO]; ya[7] = shn[HXSH_O3_NMVOC];
     ya[8] = shn[HXSH_FFI]; ya[9] = shn[HXSH_DACCS]; ya[10] = shn[HXSH_LUC_E]; ya[11] = shn[HXSH_LUC_U];
   };
-  if constexpr (!hx_w2<B>()) load_year_a(iy_from + 1);
+  // Round 6: the year's 16 entries of the shared table are requested where they are used, in every
+  // kernel.  Requested ahead of the solver (round 2: one exposed scalar-load latency a phase less)
+  // their 32 scalar registers did not survive the step loop: the allocator moved them into the
+  // lanes of a spill VGPR and back -- 64 v_writelane / v_readlane a model year to save two ~55-clock
+  // waits.  Here: 42 -> 16 spilled scalars in the plain kernel, 65 536 members 5.78 -> 5.74 ms
+  // (profiles/r06_variant_log.md 8; -DHX_YA_PREFETCH: the old form).
+#ifndef HX_YA_PREFETCH
+  constexpr bool YAL = true;
+#else
+  constexpr bool YAL = hx_w2<B>();
+#endif
+  if constexpr (!YAL) load_year_a(iy_from + 1);
+  // Two-wavefront flavour (round 6): the build uses 227 of its 256 registers, so four values it
+  // re-read from the tables at every year start -- constants of the launch: end-of-spinup
+  // vegetation, both alkalinities, ln Q10 -- stay in eight of the spare ones, and the one value that
+  // does change, the land temperature leaving the Q10 window, is requested at the END of the
+  // previous year's phase C, ahead of the equilibrium-constant fit's 156 multiply-adds.  The year
+  // start then waits for no table trip at all.  (-DHX_W2_NO_KEEP: the round-4 form.)
+#ifndef HX_W2_NO_KEEP
+  constexpr bool W2K = hx_w2<B>();
+#else
+  constexpr bool W2K = false;
+#endif
+  [[maybe_unused]] double w2k_eos = 0, w2k_alkH = 0, w2k_alkL = 0, w2k_lnq = 0;
+  if constexpr (W2K) {
+    const HxBuffers &buf = args->buf;
+    HX_W2_LOCAL(m);
+    w2k_eos = w2_ld<true>(buf.state, m.npad, HXS_EOS_VEGC, m.moff);
+    w2k_alkH = w2_ld<true>(buf.state, m.npad, HXS_ALK_HL, m.moff);
+    w2k_alkL = w2_ld<true>(buf.state, m.npad, HXS_ALK_LL, m.moff);
+    w2k_lnq = w2_ld<true>(buf.derived, m.npad, HXD_NGLOBAL, m.moff);
+    const int iold0 = iy_from + 1 - 203;
+    pf_tl_old = hx_ldm<true>(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold0 >= 1 ? iold0 : 0) * buf.npad, m.moff);
+  }
   if constexpr (CON >= 2) m.trk_iy = args->kc.trk_iy;
   if constexpr (CON == 3) { m.trk_rec = s_trk_rec; m.trk_cmd = s_trk_cmd; }
   int cost_steps = 0, cost_stash = 0;  // this lane's solver work (the host's lane-ordering key)
@@ -744,9 +777,13 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       if constexpr (hx_tbl<B>() && !hx_w2<B>()) hx_tbl_local<B>(m);
       if constexpr (hx_w2<B>()) {   // values that live in the tables (hx_dev_member.h)
         HX_W2_LOCAL(m);
+        if constexpr (W2K) {
+          eos = w2k_eos; m.alkH = w2k_alkH; m.alkL = w2k_alkL;
+        } else {
         eos = w2_ld<true>(buf.state, m.npad, HXS_EOS_VEGC, m.moff);
         m.alkH = w2_ld<true>(buf.state, m.npad, HXS_ALK_HL, m.moff);
         m.alkL = w2_ld<true>(buf.state, m.npad, HXS_ALK_LL, m.moff);
+        }
       } else {
         eos = PKM(m, PK_EOS);
       }
@@ -769,13 +806,35 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       double twin = PKM(m, PK_TWIN);
       const double tl_m2 = PKM(m, PK_TL_M2);
       const int iold = iy - 203;
+      if constexpr (YAL && !hx_w2<B>()) load_year_a(iy);
       if constexpr (hx_w2<B>()) {
         // (two resident wavefronts hide a load's latency: nothing is requested a phase ahead, so
         // nothing waits in registers through the solver)
         load_year_a(iy);
+        if constexpr (!W2K)
         pf_tl_old = hx_ldm<true>(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold >= 1 ? iold : 0) * buf.npad, m.moff);
       }
       const double tl_old = pf_tl_old;
+#ifndef HX_PF_BEFORE_SOLVER
+      // Round 6: next year's window entry and this year's history partial sum are requested HERE, at
+      // the head of the year, not ahead of the solver.  They wait in registers through the solver
+      // either way -- but the allocator parks them in AGPRs when the step loop starts, a move that
+      // needs the value to have arrived: requested 86 instructions before it (the round-6 register
+      // allocation; 285 in round 5) the wavefront sat out most of an HBM round trip every year
+      // (tools/isa_sim.py: 933 of phase A's 7 382 clocks on that one s_waitcnt vmcnt).  From here
+      // they have all of phase A, ~4 000 clocks.
+      if constexpr (!hx_w2<B>()) {
+        const int iold1 = iy + 1 - 203;
+        const bool newblk_a = blk0 < 0 || iy >= blk_end;
+        if constexpr (hx_rowio<B>()) {
+          pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad, m.moff);
+          pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(newblk_a ? 0 : iy - blk0) * buf.npad, m.moff);
+        } else {
+          pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
+          pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk_a ? 0 : iy - blk0) * buf.npad + mem];
+        }
+      }
+#endif
       constexpr int NB = hx_nbc<B>();
       constexpr int SB = (B == HX_DYN) ? 1 : NB;  // (the looped kernels read these where they use them)
       double p_beta[SB], p_wf[SB], p_lnq10[SB], p_mu[SB], p_sigma[SB], s_ffrozen[SB];
@@ -797,7 +856,8 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
             p_mu[b] = w2_ld<true>(buf.params, m.npad, pr + HXPB_PF_MU, m.moff);
             p_sigma[b] = w2_ld<true>(buf.params, m.npad, pr + HXPB_PF_SIGMA, m.moff);
           }
-          p_lnq10[b] = w2_ld<true>(buf.derived, m.npad, HXD_NGLOBAL, m.moff);
+          if constexpr (W2K) p_lnq10[b] = w2k_lnq;
+          else p_lnq10[b] = w2_ld<true>(buf.derived, m.npad, HXD_NGLOBAL, m.moff);
           load_landk<B>(m, lk);
         } else if constexpr (B == 1) {
           constexpr int o = hx_pkb1<B>();
@@ -1095,8 +1155,9 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
     {
       if constexpr (!hx_w2<B>()) {  // next year's window entry, this year's history partial sum (see pf_* above)
         const HxBuffers &buf = args->buf;
-        const int iold1 = iy + 1 - 203;
         const bool newblk = blk0 < 0 || iy >= blk_end;  // (then the pass has not run yet)
+#ifdef HX_PF_BEFORE_SOLVER   // (the round-2 ... round-5 place of the two requests: experiments)
+        const int iold1 = iy + 1 - 203;
         if constexpr (hx_rowio<B>()) {
           pf_tl_old = hx_ldm(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad, m.moff);
           pf_dpart = hx_ldm(HX_GCD(buf.dpart) + (size_t)(newblk ? 0 : iy - blk0) * buf.npad, m.moff);
@@ -1104,6 +1165,7 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
         pf_tl_old = HX_GCD(buf.out[HXO_TLAND])[(size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad + mem];
         pf_dpart = HX_GCD(buf.dpart)[(size_t)(newblk ? 0 : iy - blk0) * buf.npad + mem];
         }
+#endif
         if constexpr (KPF) {  // this year's in-block kernel entries (chunks of eight, like their use)
           const int jbp = newblk ? 0 : iy - blk0;
           const int kqp = args->kc.ns - iy - 1 + HX_KPAD + (newblk ? 0 : blk0);
@@ -1118,9 +1180,11 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
             }
           }
         }
+        if constexpr (!YAL) {
         hx_ccd shc = HX_CCD(buf.shared) + (size_t)iy * HXSH_STRIDE;
         yc4[0] = shc[HXSH_SQRT_N2O]; yc4[1] = shc[HXSH_RF_OTHER]; yc4[2] = shc[HXSH_RF_AERO]; yc4[3] = shc[HXSH_RF_VOL];
         load_year_a(iy + 1);
+        }
       }
       const double year = (double)(args->kc.start_year + iy);
       HX_MASKS_LOCAL();
@@ -1196,11 +1260,17 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       // the history pass: a scalar row choice, the terms enter as 0 * Ker with no vector select)
       [[maybe_unused]] double Tall[HX_DBLK];
       if constexpr (TALL) {
+        // (round 6: requesting only the chunks of eight the year's sum will use -- a wave-uniform test
+        // per chunk -- makes every Tall entry a merge of "loaded" and "not": the two-wavefront flavour
+        // then needs 256 registers + 44 spilled to scratch instead of 237; profiles/r06_variant_log.md)
 #pragma unroll
         for (int r = 0; r < HX_DBLK; ++r) {
           const int i = blk0 + r;
           Tall[r] = hx_ldm<hx_w2<B>()>(HX_GCD(buf.out[HXO_SST]) + (size_t)(i < iy ? i : 0) * buf.npad, m.moff);
         }
+      }
+      if constexpr (YAL && !hx_w2<B>()) {
+        yc4[0] = sh[HXSH_SQRT_N2O]; yc4[1] = sh[HXSH_RF_OTHER]; yc4[2] = sh[HXSH_RF_AERO]; yc4[3] = sh[HXSH_RF_VOL];
       }
       if constexpr (hx_w2<B>()) {  // what the other kernels request ahead of the solver
         pf_dpart = hx_ldm<true>(HX_GCD(buf.dpart) + (size_t)(iy - blk0) * buf.npad, m.moff);
@@ -1411,6 +1481,10 @@ void hx_run_kernel(const HxArgs *__restrict__ args, int iy_from, int iy_to) {
       PKM(m, PK_TL_M1) = tl_seen;  // for the next year
       PKM(m, PK_TLAND) = tl_new;
       PKM(m, PK_SST) = sst_new;
+      if constexpr (W2K) {   // next year's Q10-window entry, ahead of the fit (see w2k_* above)
+        const int iold1 = iy + 1 - 203;
+        pf_tl_old = hx_ldm<true>(HX_GCD(buf.out[HXO_TLAND]) + (size_t)(iold1 >= 1 ? iold1 : 0) * buf.npad, m.moff);
+      }
 #ifdef HX_FIT_CARRIED
       if constexpr (FITC) chem_constants_fit(sst_new + 18 + (-16.4), sst_new + 18 + 2.9, kc.kfit, fitc);
 #endif

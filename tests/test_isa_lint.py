@@ -179,9 +179,11 @@ def test_static_figures_of_the_baseline_kernels_hold():
     import isa_stats
     kernels, meta = isa_stats.parse(files[0])
     #                                         scratch, VGPRs <=, spilled SGPRs <=, static instructions <=
-    bounds = {"_Z13hx_run_kernelILi1ELb0ELb0ELi0EEvPK6HxArgsii": (0, 512, 60, 5450),      # configs[2]
-              "_Z13hx_run_kernelILi101ELb0ELb0ELi0EEvPK6HxArgsii": (0, 256, 30, 5750),    # configs[3]'s share
-              "_Z13hx_run_kernelILi4ELb0ELb0ELi0EEvPK6HxArgsii": (0, 512, 75, 7700),      # configs[4]
+    # (round 6: 5 193 instructions / 16 spilled scalars, 5 605 / 8 at 237 registers, 7 436 / 27 --
+    #  the year's shared-table entries are no longer carried through the solver in scalar registers)
+    bounds = {"_Z13hx_run_kernelILi1ELb0ELb0ELi0EEvPK6HxArgsii": (0, 512, 30, 5300),      # configs[2]
+              "_Z13hx_run_kernelILi101ELb0ELb0ELi0EEvPK6HxArgsii": (0, 248, 20, 5700),    # configs[3]'s share
+              "_Z13hx_run_kernelILi4ELb0ELb0ELi0EEvPK6HxArgsii": (0, 512, 45, 7600),      # configs[4]
               "_Z14hx_pair_kernelILb0ELb0ELb0ELi1EEvPK6HxArgsii": (0, 512, None, None)}   # configs[1]
     for k, (scratch, vgpr, sspill, ninstr) in bounds.items():
         assert k in meta, k
