@@ -369,3 +369,47 @@ def test_wave_clock_and_cost_model_on_gpu(hip_lib, monkeypatch):
     assert np.array_equal(a.fetchvars("CO2_concentration", (1745, 2300)), ref)
     for x in (a, b, off, c):
         x.shutdown()
+
+
+@pytest.mark.gpu
+def test_prewarm_and_shipped_cost_model_on_gpu(hip_lib, monkeypatch):
+    """Round 6, the one-shot run: (i) the prewarm loop (hx_set_prewarm) that keeps the chip's clocks
+    up while run()'s preparation uploads and spins up is transparent -- bit-identical results with
+    and without it, hx_last_run_prewarmed says which launch was behind it, a second run of a warm
+    core is not; (ii) a core whose workload the SHIPPED models know (hector_amd/data/cost_models.txt:
+    SSP2-4.5, ECS x Q10) orders its lanes by the model from its first upload on, with no earlier
+    core to learn from (HECTOR_AMD_SIMDS: the lane-order logic of a GPU with 8 SIMDs), and one the
+    file does not know (another uniform beta: another key) keeps the parameter key."""
+    n = 4096
+    S, q = ensemble.ecs_q10(n)
+    res = {}
+    for ms in (0, 50):
+        c = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+        c.set_pair_kernel_limit(0).set_prewarm(ms)
+        c.setvar("S", S, "degC").setvar("q10_rh", q)
+        c.run(2300)
+        assert c.last_run_prewarmed() == (ms > 0)
+        res[ms] = (c.fetchvars("CO2_concentration", (1745, 2300)).copy(), c.fetchvars("global_tas", (1745, 2300)).copy())
+        assert (c.status() == 0).all()
+        c.reset(1745); c.run(2300)                 # a warm core, nothing to prepare: no loop
+        assert not c.last_run_prewarmed()
+        c.shutdown()
+    assert np.array_equal(res[0][0], res[50][0]) and np.array_equal(res[0][1], res[50][1])
+    models = os.path.join(os.path.dirname(os.path.dirname(hip_lib)), "data", "cost_models.txt")
+    assert os.path.exists(models) and open(models).read().count("\nmodel ") >= 9
+    monkeypatch.setenv("HECTOR_AMD_SIMDS", "8")
+    a = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    a.set_pair_kernel_limit(0)
+    a.setvar("S", S, "degC").setvar("q10_rh", q)
+    a.status()
+    assert a.lane_order_source() == "cost model"
+    a.run(2300)
+    cost = a.lane_of_member()
+    assert sorted(cost) == list(range(n))
+    assert np.array_equal(a.fetchvars("CO2_concentration", (1745, 2300)), res[0][0])   # whatever the order
+    b = hector_amd.Core(SCENARIO, n, device=0, lib_path=hip_lib)
+    b.set_pair_kernel_limit(0)
+    b.setvar("S", S, "degC").setvar("q10_rh", q).setvar("beta", np.full(n, 0.5))
+    b.status()
+    assert b.lane_order_source() == "parameter key"
+    a.shutdown(); b.shutdown()
