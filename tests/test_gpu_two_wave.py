@@ -403,7 +403,9 @@ def test_prewarm_and_shipped_cost_model_on_gpu(hip_lib, monkeypatch):
     a.setvar("S", S, "degC").setvar("q10_rh", q)
     a.status()
     assert a.lane_order_source() == "cost model"
+    a.set_two_wave_from(0)     # (the same kernel flavour as above: bit-identical whatever the lane order)
     a.run(2300)
+    assert a.last_run_kernel() == "run"
     cost = a.lane_of_member()
     assert sorted(cost) == list(range(n))
     assert np.array_equal(a.fetchvars("CO2_concentration", (1745, 2300)), res[0][0])   # whatever the order
