@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in "$@"; do
   set -- $cfg; M=$1; B=$2
   D=$R/gpurun_out/${TAG}_${M}x${B}; mkdir -p $D
-  ARGS="--members $M --biomes $B --no-cpu-baseline --no-other-configs"
+  ARGS="--members $M --biomes $B --no-cpu-baseline --no-other-configs --sustain 0"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o s -- python $R/bench.py --steps 5 --warmup 1 $ARGS > $D/bench_under_rocprof.json 2> $D/stats.err
   one() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $D/$1 -o p -- python $R/bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> $D/$1.err; }
   one fetch "FETCH_SIZE"
