@@ -335,7 +335,10 @@ def every_member(gpu, argv):
     for name in names:
         multi = name == "multi"
         n = 16384 if multi else 65536
-        scen = os.path.join(R, "hector_amd", "data", ("ssp245" if multi else name) + ".hxs")
+        scen_name = name
+        if "@" in name:     # "<scenario>@<members>": e.g. ssp585@131072, the two-wave flavour on another scenario
+            scen_name, n = name.split("@")[0], int(name.split("@")[1])
+        scen = os.path.join(R, "hector_amd", "data", ("ssp245" if multi else scen_name) + ".hxs")
         idx = np.arange(n, dtype=np.uint64)
         S, q10 = ensemble.ecs_q10(n)
         c = hector_amd.Core(scen, n, device=0)
@@ -398,7 +401,7 @@ def every_member(gpu, argv):
                  "oracle_moves_under_1e-13_noise_by": sens, "a_tie_the_oracle_does_not_pin": bool(tie)})
         rep["unexpected_members"] = unexpected
         os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
-        json.dump(rep, open(os.path.join(R, "gpurun_out", "parity_every_member_%s.json" % name), "w"), indent=1)
+        json.dump(rep, open(os.path.join(R, "gpurun_out", "parity_every_member_%s.json" % name.replace("@", "_")), "w"), indent=1)
         print(json.dumps(rep), flush=True)
         c.shutdown()
         assert unexpected == 0 and bad == int((oerr != 0).sum()), (name, unexpected, bad)
