@@ -1168,6 +1168,40 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
         // result does not depend on its neighbours.  (-DHX_LAND_QUOTIENTS: always divide.)
         double xe3[4], d3[4];
         bool small = true;
+#if !defined(HX_LAND_QUOTIENTS) && !defined(HX_NO_LAND_BOUND)
+        constexpr bool LBND = LAND2;
+#else
+        constexpr bool LBND = false;
+#endif
+        if constexpr (LBND) {
+          // (round 6) ... and with the coefficient chains the common case does not look at the pools
+          // one by one at all: |xe_i| = |Ex x_i + Ec (h c_i)| <= |Ex| max|x| + |Ec| max|h c|, and
+          // d_i >= eps_abs + eps_rel min|x|, so ONE comparison with a factor of two in hand (it
+          // covers every rounding of the two sides) implies the three exact ones -- thirteen
+          // operations instead of 24.  The embedded pair's order conditions make Ex and Ec
+          // rounding-sized (1e-17), the bound sits ten orders of magnitude below the flux chain's
+          // quotient; a lane it does not clear takes the exact tests below, so every lane's result
+          // is what the exact tests alone would give.
+          const double ymax = fmax(fmax(fabs(y[1]), fabs(y[2])), fabs(y[3]));
+          const double ymin = fmin(fmin(fabs(y[1]), fabs(y[2])), fabs(y[3]));
+          const double cmax = fmax(fmax(fabs(cs[1]), fabs(cs[2])), fabs(cs[3]));
+          const double bnd = fma(fabs(l2_Ex), ymax, fabs(l2_Ec) * cmax);
+          const double dlow = fma(kc.eps_rel, ymin, kc.eps_abs);
+          small = (bnd + bnd) * qd <= qn * dlow;
+          if (__builtin_expect(__any(!small), 0)) {
+            bool sm = true;
+#pragma unroll
+            for (int i = 1; i <= 3; ++i) {
+              xe3[i] = fabs(fma(l2_Ex, y[i], l2_Ec * cs[i]));
+              d3[i] = kc.eps_abs + kc.eps_rel * (fabs(y[i]) + fabs(H1[i]));
+              sm = sm && (xe3[i] * qd <= qn * d3[i]);
+            }
+            double el = err;
+#pragma unroll
+            for (int i = 1; i <= 3; ++i) el = fmax(el, hx_div(xe3[i], d3[i]));
+            err = (small || sm) ? err : el;
+          }
+        } else {
 #pragma unroll
         for (int i = 1; i <= 3; ++i) {
           if constexpr (LAND2) xe3[i] = fabs(fma(l2_Ex, y[i], l2_Ec * cs[i]));
@@ -1187,6 +1221,7 @@ __device__ __forceinline__ void solve_year(Member<B> &m, const HxConst &kc,
 #else
           err = el;
 #endif
+        }
         }
 #else
         // atmosphere + ocean as the flux chain z (see hx_zchain above); vegetation, detritus and
